@@ -1,0 +1,99 @@
+// C ABI of libcompressjs_amd.so (declared in include/compressjs_amd.h).
+#include "../../include/compressjs_amd.h"
+#include "cjs_common.h"
+#include "k1_bwt.h"
+#include <vector>
+#include <string.h>
+
+static int ensure_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CJS_E_NOGPU;
+    return CJS_OK;
+}
+
+// Cyclic BWT of several independent blocks (block i = T + i*cap, length nlen[i] <= cap).
+static int32_t bwt_batch_impl(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
+                              uint8_t* U, uint32_t* pidx, int reps, float* ms_out) {
+    if (!T || !U || !nlen || !pidx || nb == 0 || cap == 0 || cap > (1u << 20) - 1) return CJS_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    BatchGeom g = make_geom(nb, cap);
+    u32 max_n = 0;
+    std::vector<u8> text((size_t)nb * g.tstride, 0);
+    std::vector<u32> lens(nb);
+    for (u32 b = 0; b < nb; b++) {
+        const u32 n = nlen[b];
+        if (n > cap) return CJS_E_ARG;
+        lens[b] = n;
+        if (n > max_n) max_n = n;
+        u8* dst = text.data() + (size_t)b * g.tstride;
+        const u8* src = T + (size_t)b * cap;
+        if (n) {
+            memcpy(dst, src, n);
+            for (u32 i = 0; i < K1_TPAD; i++) dst[n + i] = dst[i % n] ;
+        }
+    }
+    // blocks of length 0/1 never reach the kernels (lib/BWT.js:376-379)
+    K1Buf B;
+    memset(&B, 0, sizeof B);
+    u8 *dT = nullptr, *dU = nullptr; u32 *dN = nullptr, *dP = nullptr; void* ws = nullptr;
+    const size_t wsb = k1_workspace_bytes(g);
+    hipStream_t st = nullptr;
+    hipError_t e;
+#define TRY(x) if ((e = (x)) != hipSuccess) { rc = CJS_E_HIP - (int)e; goto done; }
+    TRY(hipStreamCreate(&st));
+    TRY(hipMalloc((void**)&dT, text.size()));
+    TRY(hipMalloc((void**)&dU, (size_t)nb * g.stride));
+    TRY(hipMalloc((void**)&dN, nb * 4));
+    TRY(hipMalloc((void**)&dP, nb * 4));
+    TRY(hipMalloc(&ws, wsb));
+    TRY(hipMemcpyAsync(dT, text.data(), text.size(), hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(dN, lens.data(), nb * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemsetAsync(dP, 0, nb * 4, st));
+    k1_carve(B, g, ws);
+    B.T = dT; B.nlen = dN; B.U = dU; B.pidx = dP;
+    if (max_n >= 2) {
+        hipEvent_t e0, e1;
+        TRY(hipEventCreate(&e0)); TRY(hipEventCreate(&e1));
+        rc = k1_run(B, g, max_n, st);          // warm-up / the result
+        if (rc) goto done;
+        TRY(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; r++) { rc = k1_run(B, g, max_n, st); if (rc) goto done; }
+        TRY(hipEventRecord(e1, st));
+        TRY(hipStreamSynchronize(st));
+        float ms = 0.f;
+        TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (ms_out) *ms_out = reps > 0 ? ms / reps : 0.f;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    TRY(hipStreamSynchronize(st));
+    {
+        std::vector<u8> hu((size_t)nb * g.stride);
+        TRY(hipMemcpy(hu.data(), dU, hu.size(), hipMemcpyDeviceToHost));
+        TRY(hipMemcpy(pidx, dP, nb * 4, hipMemcpyDeviceToHost));
+        for (u32 b = 0; b < nb; b++) {
+            if (lens[b] >= 2) memcpy(U + (size_t)b * cap, hu.data() + (size_t)b * g.stride, lens[b]);
+            else { if (lens[b] == 1) U[(size_t)b * cap] = T[(size_t)b * cap]; pidx[b] = 0; }
+        }
+    }
+done:
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(dT); (void)hipFree(dU); (void)hipFree(dN); (void)hipFree(dP); (void)hipFree(ws);
+    return rc;
+#undef TRY
+}
+
+extern "C" int32_t cjs_bwt_cyclic_batch(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
+                                        uint8_t* U, uint32_t* pidx) {
+    return bwt_batch_impl(T, nlen, nb, cap, U, pidx, 0, nullptr);
+}
+// debug/bench helper: same, re-running the device pipeline `reps` times and reporting ms per run
+extern "C" int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
+                                          uint8_t* U, uint32_t* pidx, int reps, float* ms) {
+    return bwt_batch_impl(T, nlen, nb, cap, U, pidx, reps, ms);
+}
+
+extern "C" int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx) {
+    if (n == 0) { if (pidx) *pidx = 0; return CJS_OK; }
+    return cjs_bwt_cyclic_batch(T, &n, 1, n, U, pidx);
+}

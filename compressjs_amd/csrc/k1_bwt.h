@@ -1,0 +1,34 @@
+// K1: batched cyclic suffix sort + BWT (replaces BWT.bwtransform2, lib/BWT.js:372-417).
+#pragma once
+#include "cjs_common.h"
+
+#define K1_STAT_ACTIVE 0    // stats[0..31]  : unsorted-group starts entering round r
+#define K1_STAT_LARGE 32    // stats[32..63] : large groups registered in round r
+#define K1_STATS 64
+
+struct K1Buf {
+    const u8* T;      // [nb][tstride]  T_ext[i] = T[i mod n]
+    u32* SA;          // [nb][stride]   suffix array (result)
+    u32* SB;          // [nb][stride]   ping-pong
+    u32* ISA;         // [nb][stride]   rank (= position of the group head) of every rotation
+    u32* KA;          // [nb][stride]   keys of large groups (ping)
+    u32* KB;          // [nb][stride]   keys of large groups (pong)
+    u32* HC;          // [nb][hstride]  head bitmap, current
+    u32* HN;          // [nb][hstride]  head bitmap, next
+    u8* FC;           // [nb][htiles]   tile flags, current: bit0 = an unsorted group starts here,
+    u8* FN;           //                                     bit1 = holds a position of an unsorted group
+    const u32* nlen;  // [nb]           block lengths
+    u32* tileHist;    // [nb][rtiles][256]
+    u32* stats;       // [K1_STATS]
+    uint2* large;     // [largeCap]     (block, start position)
+    u32 largeCap;
+    u8* U;            // [nb][stride]   BWT output
+    u32* pidx;        // [nb]           origPtr
+};
+
+// bytes of workspace K1 needs for a batch geometry (everything except T, nlen, U, pidx)
+size_t k1_workspace_bytes(const BatchGeom& g);
+// carve the workspace; `ws` must be 256-byte aligned
+void k1_carve(K1Buf& B, const BatchGeom& g, void* ws);
+// enqueue the whole K1 pipeline on `stream`; max_n = largest block length in the batch
+int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);

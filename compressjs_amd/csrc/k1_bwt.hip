@@ -1,0 +1,653 @@
+// K1: batched cyclic suffix sort + BWT for gfx950 (wave64).
+//
+// Replaces BWT.bwtransform2 (lib/BWT.js:372-417), i.e. SA-IS on the doubled block plus the
+// gather of lib/BWT.js:407-414.  The reference's order is: rotations of the block sorted as
+// unsigned bytes, equal rotations by DESCENDING start index.  Any algorithm that
+// realises this total order yields identical bytes, so this file does not port SA-IS.  It runs,
+// for all blocks of a batch at once:
+//
+//   1. LSD radix sort of rotation indices by their first 8 bytes (8 stable 8-bit passes;
+//      per-tile LDS histograms, wave-ballot ranking, bucket scatter).
+//   2. Group refinement by prefix doubling (Larsson-Sadakane style, cyclic): positions of the
+//      suffix array that still tie form "groups" marked in a head bitmap; each round sorts every
+//      unsorted group by the rank of the rotation h positions ahead.  Groups of <= 2048 rotations
+//      are sorted inside LDS by the workgroup owning their first position; larger groups take a
+//      one-workgroup segmented radix sort through global memory.
+//   3. When h >= n the remaining ties are identical rotations: one more round keyed on the
+//      descending start index.
+//   4. U[j] = T[SA[j]-1 mod n], origPtr = position of rotation 0.
+//
+// All integer; no floating point anywhere.
+#include "k1_bwt.h"
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+// mask of lanes whose low `nbits` of d equal this lane's (and are valid)
+__device__ __forceinline__ u64 match_any(u32 d, int nbits, bool valid) {
+    u64 m = __ballot(valid);
+    for (int i = 0; i < nbits; i++) {
+        const bool bit = (d >> i) & 1u;
+        const u64 b = __ballot(bit);
+        m &= bit ? b : ~b;
+    }
+    return m;
+}
+
+// exclusive scan of 256 values held one per thread (threads 0..255 of the block); every thread
+// of the block must call it.  `sh` is a 256-entry LDS scratch.
+__device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* sh) {
+    const u32 tid = threadIdx.x;
+    if (tid < 256) sh[tid] = v;
+    __syncthreads();
+    for (u32 off = 1; off < 256; off <<= 1) {
+        u32 t = 0;
+        if (tid < 256 && tid >= off) t = sh[tid - off];
+        __syncthreads();
+        if (tid < 256) sh[tid] += t;
+        __syncthreads();
+    }
+    const u32 incl = tid < 256 ? sh[tid] : 0;
+    __syncthreads();
+    return incl - v;
+}
+
+__device__ __forceinline__ u64 load_key8(const u8* p) {
+    u64 k = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) k = (k << 8) | p[i];
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// init: stats, head bitmaps, tile flags
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.y;
+    const u32 n = B.nlen[b];
+    const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && gid < K1_STATS) B.stats[gid] = 0;
+    if (gid < g.hstride) {
+        const u32 lo = gid * 32u;
+        u32 w;
+        if (lo >= n) w = 0xFFFFFFFFu;
+        else if (lo + 32u > n) w = 0xFFFFFFFFu << (n - lo);
+        else w = 0u;
+        B.HN[(size_t)b * g.hstride + gid] = w;
+        if (gid == 0) w |= 1u;
+        B.HC[(size_t)b * g.hstride + gid] = w;
+    }
+    if (gid < g.htiles) {
+        B.FC[(size_t)b * g.htiles + gid] = (gid * K1_HT < n) ? 3 : 0;
+        B.FN[(size_t)b * g.htiles + gid] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// initial sort: one stable LSD pass on byte T[s + dpos]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1_hist(K1Buf B, BatchGeom g, const u32* in, int dpos, int first) {
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 n = B.nlen[b];
+    const u32 t0 = t * K1_RT;
+    if (t0 >= n) return;
+    __shared__ u32 wh[4][256];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    for (u32 i = tid; i < 1024; i += 256) (&wh[0][0])[i] = 0;
+    __syncthreads();
+    const u8* T = B.T + (size_t)b * g.tstride;
+    const u32* inb = in + (size_t)b * g.stride;
+#pragma unroll 4
+    for (int it = 0; it < 16; it++) {
+        const u32 j = t0 + w * 1024u + it * 64u + lane;
+        if (j < n) {
+            const u32 s = first ? j : inb[j];
+            atomicAdd(&wh[w][T[s + dpos]], 1u);
+        }
+    }
+    __syncthreads();
+    B.tileHist[((size_t)b * g.rtiles + t) * 256 + tid] = wh[0][tid] + wh[1][tid] + wh[2][tid] + wh[3][tid];
+}
+
+// per block: turn per-tile digit counts into global start offsets (digit-major, tile-minor)
+__global__ __launch_bounds__(1024) void k1_scan(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.x;
+    const u32 n = B.nlen[b];
+    const u32 nt = (n + K1_RT - 1) / K1_RT;
+    __shared__ u32 part[4][256];
+    __shared__ u32 sh[256];
+    const u32 tid = threadIdx.x, q = tid >> 8, d = tid & 255u;
+    const u32 per = (nt + 3) / 4;
+    const u32 tlo = q * per < nt ? q * per : nt;
+    const u32 thi = tlo + per < nt ? tlo + per : nt;
+    u32* hist = B.tileHist + (size_t)b * g.rtiles * 256;
+    u32 sum = 0;
+#pragma unroll 8
+    for (u32 t = tlo; t < thi; t++) sum += hist[(size_t)t * 256 + d];
+    part[q][d] = sum;
+    __syncthreads();
+    const u32 tot = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+    const u32 excl = block_excl_scan_256(tot, sh);     // threads >= 256 pass a dummy copy; only tid<256 lands in sh
+    __shared__ u32 dbase[256];
+    if (tid < 256) dbase[tid] = excl;
+    __syncthreads();
+    u32 run = dbase[d];
+    for (u32 qq = 0; qq < q; qq++) run += part[qq][d];
+    for (u32 t = tlo; t < thi; t++) {
+        const u32 c = hist[(size_t)t * 256 + d];
+        hist[(size_t)t * 256 + d] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u32* in, u32* out, int dpos, int first) {
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 n = B.nlen[b];
+    const u32 t0 = t * K1_RT;
+    if (t0 >= n) return;
+    __shared__ u32 wh[4][256];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    for (u32 i = tid; i < 1024; i += 256) (&wh[0][0])[i] = 0;
+    __syncthreads();
+    const u8* T = B.T + (size_t)b * g.tstride;
+    const u32* inb = in + (size_t)b * g.stride;
+    u32* outb = out + (size_t)b * g.stride;
+    u32 sv[16], dv[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const u32 j = t0 + w * 1024u + it * 64u + lane;
+        u32 s = 0, d = 0;
+        if (j < n) {
+            s = first ? j : inb[j];
+            d = T[s + dpos];
+            atomicAdd(&wh[w][d], 1u);
+        }
+        sv[it] = s;
+        dv[it] = d;
+    }
+    __syncthreads();
+    {
+        u32 o = B.tileHist[((size_t)b * g.rtiles + t) * 256 + tid];
+#pragma unroll
+        for (int ww = 0; ww < 4; ww++) {
+            const u32 c = wh[ww][tid];
+            wh[ww][tid] = o;
+            o += c;
+        }
+    }
+    __syncthreads();
+    const u64 lt = lanemask_lt();
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+        const u32 j = t0 + w * 1024u + it * 64u + lane;
+        const bool valid = j < n;
+        const u32 d = dv[it];
+        const u64 m = match_any(d, 8, valid);
+        const u32 rank = (u32)__popcll(m & lt), cnt = (u32)__popcll(m);
+        const u32 base = valid ? wh[w][d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wh[w][d] = base + cnt;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) outb[base + rank] = sv[it];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// group heads after the 8-byte sort
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 n = B.nlen[b];
+    const u32 base = t * K1_HT;
+    if (base >= n) return;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u8* T = B.T + (size_t)b * g.tstride;
+    const u32* SA = B.SA + (size_t)b * g.stride;
+    u32* HN = B.HN + (size_t)b * g.hstride;
+    for (int it = 0; it < 8; it++) {
+        const u32 p = base + w * 512u + it * 64u + lane;
+        bool head = true;
+        if (p < n && p > 0) head = load_key8(T + SA[p]) != load_key8(T + SA[p - 1]);
+        const u64 bal = __ballot(head);
+        if (lane == 0) {
+            HN[(p >> 5)] = (u32)bal;
+            HN[(p >> 5) + 1] = (u32)(bal >> 32);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rank update: ISA[SA[p]] = position of p's group head under HN, for every p that was in an
+// unsorted group under HC.  Also produces next round's tile flags and active-group count.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int slot_out) {
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 n = B.nlen[b];
+    const u32 base = t * K1_HT;
+    if (base >= n) return;
+    const size_t fidx = (size_t)b * g.htiles + t;
+    if (!(B.FC[fidx] & 2)) {
+        if (threadIdx.x == 0) B.FN[fidx] = 0;
+        return;
+    }
+    __shared__ u32 hc[66], hn[66];
+    __shared__ int prevh[64];
+    __shared__ int inHead;
+    __shared__ u32 red[2];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32* HC = B.HC + (size_t)b * g.hstride;
+    const u32* HN = B.HN + (size_t)b * g.hstride;
+    if (tid < 66) {
+        hc[tid] = HC[(base >> 5) + tid];
+        hn[tid] = HN[(base >> 5) + tid];
+    }
+    if (tid == 0) { red[0] = 0; red[1] = 0; }
+    __syncthreads();
+    if (w == 0) {
+        const u32 word = hn[lane];
+        int v = word ? (int)(lane * 32u + 31u - (u32)__clz((int)word)) : -1;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(v, (unsigned)off);
+            if ((int)lane >= off) v = v > u ? v : u;
+        }
+        int ex = __shfl_up(v, 1u);
+        if (lane == 0) ex = -1;
+        prevh[lane] = ex;
+        int found = 0;
+        if (!(hn[0] & 1u)) {
+            found = -1;
+            for (int iter = 0; found < 0; iter++) {
+                const int wi = (int)(base >> 5) - 1 - (int)lane - 64 * iter;
+                const u32 wd = wi >= 0 ? HN[wi] : 0u;
+                const u64 bal = __ballot(wd != 0u);
+                if (bal) {
+                    const int src = __ffsll((long long)bal) - 1;
+                    const int pos = wi * 32 + 31 - __clz((int)wd);
+                    found = __shfl(pos, src);
+                }
+            }
+        }
+        if (lane == 0) inHead = found;
+    }
+    __syncthreads();
+    const u32* SA = B.SA + (size_t)b * g.stride;
+    u32* ISA = B.ISA + (size_t)b * g.stride;
+    u32 nstart = 0, nact = 0;
+    for (int it = 0; it < 8; it++) {
+        const u32 q = w * 512u + it * 64u + lane;
+        const u32 p = base + q;
+        const u32 cb = (hc[q >> 5] >> (q & 31u)) & 1u, cn = (hc[(q + 1) >> 5] >> ((q + 1) & 31u)) & 1u;
+        const u32 nb = (hn[q >> 5] >> (q & 31u)) & 1u, nn = (hn[(q + 1) >> 5] >> ((q + 1) & 31u)) & 1u;
+        const bool in = p < n;
+        if (in && !(cb && cn)) {
+            const u32 wq = q >> 5;
+            const u32 mask = hn[wq] & (0xFFFFFFFFu >> (31u - (q & 31u)));
+            u32 r;
+            if (mask) r = base + wq * 32u + 31u - (u32)__clz((int)mask);
+            else if (prevh[wq] >= 0) r = base + (u32)prevh[wq];
+            else r = (u32)inHead;
+            ISA[SA[p]] = r;
+        }
+        if (in && !(nb && nn)) nact++;
+        if (in && nb && !nn) nstart++;
+    }
+    if (nact) atomicAdd(&red[1], nact);
+    if (nstart) atomicAdd(&red[0], nstart);
+    __syncthreads();
+    if (tid == 0) {
+        B.FN[fidx] = (u8)((red[0] ? 1 : 0) | (red[1] ? 2 : 0));
+        if (red[0]) atomicAdd(&B.stats[K1_STAT_ACTIVE + slot_out], red[0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// refinement of groups of <= K1_HT rotations, in LDS
+// mode 0: key = ISA[(s + h) mod n]        mode 1: key = n - 1 - s (identical rotations)
+// ---------------------------------------------------------------------------------------------
+#define K1_INF (1 << 30)
+
+struct PosClass {
+    int head;   // window-relative position of the group head (-1: before the window)
+    int endp;   // window-relative position of the next head (K1_INF: beyond the window)
+    bool is_head;
+};
+
+__device__ __forceinline__ PosClass classify(const u32* hw, const int* prevh, const int* nexth, u32 q) {
+    PosClass c;
+    const u32 wq = q >> 5, bq = q & 31u;
+    const u32 word = hw[wq];
+    const u32 low = word & (0xFFFFFFFFu >> (31u - bq));
+    c.head = low ? (int)(wq * 32u + 31u - (u32)__clz((int)low)) : prevh[wq];
+    const u32 high = bq == 31u ? 0u : (word & (0xFFFFFFFEu << bq));
+    c.endp = high ? (int)(wq * 32u + (u32)__ffs((int)high) - 1u) : nexth[wq];
+    c.is_head = (word >> bq) & 1u;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, int mode, int round) {
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 n = B.nlen[b];
+    const u32 base = t * K1_HT;
+    if (base >= n) return;
+    if (!(B.FC[(size_t)b * g.htiles + t] & 1)) return;
+    __shared__ u32 hw[132];
+    __shared__ int prevh[132], nexth[132];
+    __shared__ u32 ck[K1_WIN], cv[K1_WIN];
+    __shared__ u16 cp[K1_WIN], csz[K1_WIN];
+    __shared__ u32 wtot[4];
+    __shared__ u32 maxg;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32* HC = B.HC + (size_t)b * g.hstride;
+    u32* HN = B.HN + (size_t)b * g.hstride;
+    u32* SA = B.SA + (size_t)b * g.stride;
+    const u32* ISA = B.ISA + (size_t)b * g.stride;
+    const u32 wbase = base >> 5;
+    if (tid < 130) hw[tid] = HC[wbase + tid];
+    if (tid == 0) maxg = 0;
+    __syncthreads();
+    if (tid < 130) {
+        int pv = -1;
+        for (int i = (int)tid - 1; i >= 0; i--) {
+            const u32 wd = hw[i];
+            if (wd) { pv = i * 32 + 31 - __clz((int)wd); break; }
+        }
+        prevh[tid] = pv;
+        int nx = K1_INF;
+        for (int i = (int)tid + 1; i < 130; i++) {
+            const u32 wd = hw[i];
+            if (wd) { nx = i * 32 + __ffs((int)wd) - 1; break; }
+        }
+        nexth[tid] = nx;
+    }
+    __syncthreads();
+    const u64 lt = lanemask_lt();
+    // pass 1: count owned positions per wave, register large groups
+    u32 cnt = 0;
+    for (int it = 0; it < 16; it++) {
+        const u32 q = w * 1024u + it * 64u + lane;
+        const PosClass c = classify(hw, prevh, nexth, q);
+        const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
+        const bool owned = c.head >= 0 && c.head < K1_HT && size >= 2 && size <= K1_HT && base + q < n;
+        if (c.is_head && q < K1_HT && base + q < n && size > K1_HT) {
+            const u32 idx = atomicAdd(&B.stats[K1_STAT_LARGE + round], 1u);
+            if (idx < B.largeCap) B.large[idx] = make_uint2(b, base + q);
+        }
+        cnt += (u32)__popcll(__ballot(owned));
+    }
+    if (lane == 0) wtot[w] = cnt;
+    __syncthreads();
+    u32 wavebase = 0;
+    for (u32 i = 0; i < w; i++) wavebase += wtot[i];
+    const u32 m = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (m == 0) return;
+    // pass 2: gather keys of owned positions into the compact arrays
+    const u32 hm = h % n;
+    u32 run = wavebase;
+    for (int it = 0; it < 16; it++) {
+        const u32 q = w * 1024u + it * 64u + lane;
+        const PosClass c = classify(hw, prevh, nexth, q);
+        const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
+        const bool owned = c.head >= 0 && c.head < K1_HT && size >= 2 && size <= K1_HT && base + q < n;
+        const u64 bal = __ballot(owned);
+        if (owned) {
+            const u32 e = run + (u32)__popcll(bal & lt);
+            const u32 s = SA[base + q];
+            u32 k;
+            if (mode == 0) {
+                u32 x = s + hm;
+                if (x >= n) x -= n;
+                k = ISA[x];
+            } else {
+                k = n - 1u - s;
+            }
+            ck[e] = ((u32)c.head << 20) | k;
+            cv[e] = s;
+            cp[e] = (u16)q;
+            csz[e] = (u16)size;
+            if (c.is_head) atomicMax(&maxg, (u32)size);
+        }
+        run += (u32)__popcll(bal);
+    }
+    __syncthreads();
+    if (maxg <= 32u) {
+        // enumeration sort inside each (small) group
+        u32 nk[16], nv[16], ns[16];
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const u32 e = tid + (u32)it * 256u;
+            ns[it] = 0xFFFFFFFFu;
+            if (e < m) {
+                const u32 key = ck[e];
+                const u32 gs = e - ((u32)cp[e] - (key >> 20));
+                const u32 ge = gs + csz[e];
+                u32 r = 0;
+                for (u32 j = gs; j < ge; j++) {
+                    const u32 kj = ck[j];
+                    r += (kj < key || (kj == key && j < e)) ? 1u : 0u;
+                }
+                nk[it] = key; nv[it] = cv[e]; ns[it] = gs + r;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 16; it++)
+            if (ns[it] != 0xFFFFFFFFu) { ck[ns[it]] = nk[it]; cv[ns[it]] = nv[it]; }
+        __syncthreads();
+    } else {
+        u32 M = 64;
+        while (M < m) M <<= 1;
+        for (u32 e = m + tid; e < M; e += 256) { ck[e] = 0xFFFFFFFFu; cv[e] = 0; }
+        __syncthreads();
+        for (u32 k = 2; k <= M; k <<= 1) {
+            for (u32 j = k >> 1; j > 0; j >>= 1) {
+                for (u32 i = tid; i < (M >> 1); i += 256) {
+                    const u32 lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                    const u32 hi = lo | j;
+                    const bool up = (lo & k) == 0;
+                    const u32 a = ck[lo], c2 = ck[hi];
+                    if ((a > c2) == up) {
+                        ck[lo] = c2; ck[hi] = a;
+                        const u32 va = cv[lo]; cv[lo] = cv[hi]; cv[hi] = va;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // write back + new heads
+    for (u32 e = tid; e < m; e += 256) {
+        const u32 q = cp[e];
+        const u32 p = base + q;
+        SA[p] = cv[e];
+        const bool newhead = (e == 0) || (ck[e] != ck[e - 1]);
+        const bool cur = (hw[q >> 5] >> (q & 31u)) & 1u;
+        if (newhead && !cur) atomicOr(&HN[p >> 5], 1u << (p & 31u));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// groups of > K1_HT rotations: one 1024-thread workgroup per group, 3 stable 7-bit LSD passes
+// through global memory (keys < 2^20)
+// ---------------------------------------------------------------------------------------------
+__device__ void seg_radix_pass(const u32* srcK, const u32* srcV, u32* dstK, u32* dstV, u32 L, u32 shift,
+                               u32 (*wh)[128], u32* dtot) {
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    for (u32 i = tid; i < 2048; i += 1024) (&wh[0][0])[i] = 0;
+    __syncthreads();
+    const u32 chunk = (((L + 15u) / 16u) + 63u) & ~63u;
+    const u32 lo = w * chunk < L ? w * chunk : L;
+    const u32 hi = lo + chunk < L ? lo + chunk : L;
+    for (u32 i = lo + lane; i < hi; i += 64) atomicAdd(&wh[w][(srcK[i] >> shift) & 127u], 1u);
+    __syncthreads();
+    if (tid < 128) {
+        u32 run = 0;
+        for (int ww = 0; ww < 16; ww++) { const u32 c = wh[ww][tid]; wh[ww][tid] = run; run += c; }
+        dtot[tid] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (int d = 0; d < 128; d++) { const u32 c = dtot[d]; dtot[d] = run; run += c; }
+    }
+    __syncthreads();
+    for (u32 e = tid; e < 2048; e += 1024) wh[e >> 7][e & 127u] += dtot[e & 127u];
+    __syncthreads();
+    const u64 lt = lanemask_lt();
+    for (u32 i0 = lo; i0 < hi; i0 += 64) {
+        const u32 i = i0 + lane;
+        const bool valid = i < hi;
+        const u32 k = valid ? srcK[i] : 0u, v = valid ? srcV[i] : 0u;
+        const u32 d = (k >> shift) & 127u;
+        const u64 m = match_any(d, 7, valid);
+        const u32 rank = (u32)__popcll(m & lt), cnt = (u32)__popcll(m);
+        const u32 base = valid ? wh[w][d] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wh[w][d] = base + cnt;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) { dstK[base + rank] = k; dstV[base + rank] = v; }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void k1_sort_large(K1Buf B, BatchGeom g, u32 h, int mode, int round) {
+    __shared__ u32 wh[16][128];
+    __shared__ u32 dtot[128];
+    __shared__ u32 s_end;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    u32 nl = B.stats[K1_STAT_LARGE + round];
+    if (nl > B.largeCap) nl = B.largeCap;
+    for (u32 gi = blockIdx.x; gi < nl; gi += gridDim.x) {
+        const u32 b = B.large[gi].x, start = B.large[gi].y;
+        const u32 n = B.nlen[b];
+        const u32* HC = B.HC + (size_t)b * g.hstride;
+        u32* HN = B.HN + (size_t)b * g.hstride;
+        if (w == 0) {
+            const u32 pos0 = start + 1u;
+            const u32 wi0 = pos0 >> 5;
+            int found = -1;
+            for (int iter = 0; found < 0; iter++) {
+                const u32 wi = wi0 + lane + 64u * (u32)iter;
+                u32 wd = wi < g.hstride ? HC[wi] : 0xFFFFFFFFu;
+                if (iter == 0 && lane == 0) wd &= 0xFFFFFFFFu << (pos0 & 31u);
+                const u64 bal = __ballot(wd != 0u);
+                if (bal) {
+                    const int src = __ffsll((long long)bal) - 1;
+                    const int pos = (int)(wi * 32u) + __ffs((int)wd) - 1;
+                    found = __shfl(pos, src);
+                }
+            }
+            if (lane == 0) s_end = (u32)found;
+        }
+        __syncthreads();
+        const u32 L = s_end - start;
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32* SB = B.SB + (size_t)b * g.stride + start;
+        u32* KA = B.KA + (size_t)b * g.stride + start;
+        u32* KB = B.KB + (size_t)b * g.stride + start;
+        const u32* ISA = B.ISA + (size_t)b * g.stride;
+        const u32 hm = h % n;
+        for (u32 i = tid; i < L; i += 1024) {
+            const u32 s = SA[i];
+            u32 k;
+            if (mode == 0) {
+                u32 x = s + hm;
+                if (x >= n) x -= n;
+                k = ISA[x];
+            } else {
+                k = n - 1u - s;
+            }
+            SB[i] = s;
+            KB[i] = k;
+        }
+        __syncthreads();
+        seg_radix_pass(KB, SB, KA, SA, L, 0, wh, dtot);
+        seg_radix_pass(KA, SA, KB, SB, L, 7, wh, dtot);
+        seg_radix_pass(KB, SB, KA, SA, L, 14, wh, dtot);
+        for (u32 i = tid + 1; i < L; i += 1024)
+            if (KA[i] != KA[i - 1]) atomicOr(&HN[(start + i) >> 5], 1u << ((start + i) & 31u));
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BWT gather (lib/BWT.js:407-414)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.y;
+    const u32 n = B.nlen[b];
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const u8* T = B.T + (size_t)b * g.tstride;
+    const u32 s = B.SA[(size_t)b * g.stride + p];
+    B.U[(size_t)b * g.stride + p] = T[s == 0 ? n - 1 : s - 1];
+    if (s == 0) B.pidx[b] = p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t k1_workspace_bytes(const BatchGeom& g) {
+    const size_t e = (size_t)g.nb * g.stride;
+    size_t tot = 0;
+    tot += 5 * al256(e * 4);                                   // SA SB ISA KA KB
+    tot += 2 * al256((size_t)g.nb * g.hstride * 4);            // HC HN
+    tot += 2 * al256((size_t)g.nb * g.htiles);                 // FC FN
+    tot += al256((size_t)g.nb * g.rtiles * 256 * 4);           // tileHist
+    tot += al256(K1_STATS * 4);
+    tot += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
+    return tot;
+}
+
+void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
+    char* p = (char*)ws;
+    const size_t e = (size_t)g.nb * g.stride;
+    B.SA = (u32*)p; p += al256(e * 4);
+    B.SB = (u32*)p; p += al256(e * 4);
+    B.ISA = (u32*)p; p += al256(e * 4);
+    B.KA = (u32*)p; p += al256(e * 4);
+    B.KB = (u32*)p; p += al256(e * 4);
+    B.HC = (u32*)p; p += al256((size_t)g.nb * g.hstride * 4);
+    B.HN = (u32*)p; p += al256((size_t)g.nb * g.hstride * 4);
+    B.FC = (u8*)p; p += al256((size_t)g.nb * g.htiles);
+    B.FN = (u8*)p; p += al256((size_t)g.nb * g.htiles);
+    B.tileHist = (u32*)p; p += al256((size_t)g.nb * g.rtiles * 256 * 4);
+    B.stats = (u32*)p; p += al256(K1_STATS * 4);
+    B.large = (uint2*)p;
+    B.largeCap = g.nb * (g.htiles + 1);
+}
+
+int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
+    const dim3 gridR(g.rtiles, g.nb), gridH(g.htiles, g.nb);
+    const u32 initx = (g.hstride + 255) / 256;
+    hipLaunchKernelGGL(k1_init, dim3(initx, g.nb), dim3(256), 0, stream, B, g);
+    // 8 LSD passes, last byte first; results alternate SB, SA, ... and end in SA
+    for (int p = 0; p < 8; p++) {
+        const int dpos = 7 - p;
+        const u32* in = (p & 1) ? B.SB : B.SA;
+        u32* out = (p & 1) ? B.SA : B.SB;
+        hipLaunchKernelGGL(k1_hist, gridR, dim3(256), 0, stream, B, g, in, dpos, p == 0 ? 1 : 0);
+        hipLaunchKernelGGL(k1_scan, dim3(g.nb), dim3(1024), 0, stream, B, g);
+        hipLaunchKernelGGL(k1_scatter, gridR, dim3(256), 0, stream, B, g, in, out, dpos, p == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k1_init_heads, gridH, dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, 0);
+    { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
+    const size_t hbytes = (size_t)g.nb * g.hstride * 4;
+    int round = 0;
+    const u32 large_grid = g.nb * 4 < 1024 ? (g.nb * 4 < 64 ? 64 : g.nb * 4) : 1024;
+    for (u64 h = 8;; h <<= 1) {
+        const int mode = h >= max_n ? 1 : 0;      // last round: identical rotations by descending index
+        HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k1_refine, gridH, dim3(256), 0, stream, B, g, (u32)h, mode, round);
+        hipLaunchKernelGGL(k1_sort_large, dim3(large_grid), dim3(1024), 0, stream, B, g, (u32)h, mode, round);
+        hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, round + 1);
+        { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
+        round++;
+        if (mode == 1) break;
+    }
+    hipLaunchKernelGGL(k1_finish, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
