@@ -2,6 +2,7 @@
 #include "../../include/compressjs_amd.h"
 #include "cjs_common.h"
 #include "k1_bwt.h"
+#include "pipeline.h"
 #include <vector>
 #include <string.h>
 
@@ -96,4 +97,59 @@ extern "C" int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen
 extern "C" int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx) {
     if (n == 0) { if (pidx) *pidx = 0; return CJS_OK; }
     return cjs_bwt_cyclic_batch(T, &n, 1, n, U, pidx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// debug / test entry: run the block stages on host-supplied RLE1 blocks and copy every
+// intermediate array back, so tests can compare stage by stage with the oracle.
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
+                                        int upto, cjs_dbg_stage_out* o) {
+    if (!T || !nlen || !o || nb == 0 || cap == 0 || cap > (1u << 20) - 1) return CJS_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    BatchGeom g = make_geom(nb, cap);
+    u32 max_n = 0;
+    std::vector<u8> text((size_t)nb * g.tstride, 0);
+    for (u32 b = 0; b < nb; b++) {
+        const u32 n = nlen[b];
+        if (n > cap || n == 0) return CJS_E_ARG;
+        if (n > max_n) max_n = n;
+        u8* dst = text.data() + (size_t)b * g.tstride;
+        memcpy(dst, T + (size_t)b * cap, n);
+        for (u32 i = 0; i < K1_TPAD; i++) dst[n + i] = dst[i % n];
+    }
+    void* ws = nullptr;
+    hipStream_t st = nullptr;
+    hipError_t e;
+    Pipe P;
+#define TRY(x) if ((e = (x)) != hipSuccess) { rc = CJS_E_HIP - (int)e; goto done; }
+    TRY(hipStreamCreate(&st));
+    TRY(hipMalloc(&ws, pipe_bytes(g)));
+    pipe_carve(P, g, ws);
+    TRY(hipMemcpyAsync(P.T, text.data(), text.size(), hipMemcpyHostToDevice, st));
+    TRY(hipMemcpyAsync(P.nlen, nlen, nb * 4, hipMemcpyHostToDevice, st));
+    TRY(hipMemsetAsync(P.pidx, 0, nb * 4, st));
+    rc = pipe_run_block_stages(P, max_n, st, upto);
+    if (rc) goto done;
+    TRY(hipStreamSynchronize(st));
+#define BACK2D(dst, src, rowbytes, srcpitch, dstpitch)                                            \
+    if (dst) for (u32 b = 0; b < nb; b++)                                                        \
+        TRY(hipMemcpy((char*)(dst) + (size_t)b * (dstpitch), (const char*)(src) + (size_t)b * (srcpitch), \
+                      (rowbytes), hipMemcpyDeviceToHost));
+    BACK2D(o->U, P.U, max_n, g.stride, cap);
+    BACK2D(o->pidx, P.pidx, 4, 4, 4);
+    if (upto >= 2) {
+        BACK2D(o->A, P.A, ((size_t)max_n + 1) * 2, (size_t)g.stride * 2, ((size_t)cap + 1) * 2);
+        BACK2D(o->pos, P.pos, 4, 4, 4);
+        BACK2D(o->alpha, P.alpha, 4, 4, 4);
+        BACK2D(o->freq, P.freq, 258 * 4, K2_FREQ_PITCH * 4, 258 * 4);
+        BACK2D(o->used, P.used, 32, 32, 32);
+    }
+done:
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(ws);
+    return rc;
+#undef TRY
+#undef BACK2D
 }

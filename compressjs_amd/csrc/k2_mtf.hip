@@ -1,0 +1,312 @@
+// K2: symbol map + move-to-front + zero-run (RLE2) coding + symbol frequencies, for gfx950.
+//
+// Replaces lib/Bzip2.js:743-815 (used-symbol map, linear-search MTF, RUNA/RUNB run coding,
+// freq[]).  The reference walks U serially with one 256-entry list; here the work is expressed
+// per RUN of equal bytes in U (a run contributes one non-zero MTF index for its first byte, the
+// rest of the run are zeros):
+//
+//   k2_count / k2_scan_tiles / k2_compact : run heads of U -> (symbol, position) arrays, and the
+//       256-bit used-symbol set.
+//   k2_lastocc / k2_lastscan : for every 1024-run segment, the index of the last run of each
+//       symbol before the segment (symbols not seen yet get "virtual" positions -1-rank, which
+//       reproduces the initial list M = used bytes ascending, lib/Bzip2.js:773-776).
+//   k2_mtf : MTF index of a run head = number of symbols whose last occurrence is later than the
+//       previous occurrence of the head's own symbol.  One wave per segment, 64 run heads per
+//       step; last occurrences inside the step come from wave ballots, older ones from a
+//       per-lane register table (4 symbols per lane), read with v_readlane.
+//   k2_symcount / k2_scan_syms / k2_emit : each run emits (index+1 if index>0) followed by the
+//       bijective base-2 digits of its zero count (lib/Bzip2.js:783-794); exclusive scan gives
+//       the output offsets; freq[] by LDS histogram.  EOB appended (lib/Bzip2.js:813-814).
+#include "pipeline.h"
+
+__device__ __forceinline__ u32 popc_below(const u32* used8, u32 s) {
+    u32 r = 0;
+    for (u32 w = 0; w < (s >> 5); w++) r += (u32)__popc(used8[w]);
+    if (s & 31u) r += (u32)__popc(used8[s >> 5] & ((1u << (s & 31u)) - 1u));
+    return r;
+}
+
+// ---- run heads -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k2_count(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 n = P.nlen[b];
+    const u32 t0 = t * K1_RT;
+    if (t0 >= n) { if (threadIdx.x == 0) P.tileCnt[(size_t)b * g.rtiles + t] = 0; return; }
+    __shared__ u32 usedw[8];
+    __shared__ u32 cnt;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    if (tid < 8) usedw[tid] = 0;
+    if (tid == 8) cnt = 0;
+    __syncthreads();
+    const u8* U = P.U + (size_t)b * g.stride;
+    u32 c = 0;
+    for (int it = 0; it < 16; it++) {
+        const u32 i = t0 + w * 1024u + it * 64u + lane;
+        bool head = false;
+        if (i < n) {
+            const u32 s = U[i];
+            head = (i == 0) || (U[i - 1] != s);
+            if (head) atomicOr(&usedw[s >> 5], 1u << (s & 31u));
+        }
+        c += (u32)__popcll(__ballot(head));
+    }
+    if (lane == 0) atomicAdd(&cnt, c);
+    __syncthreads();
+    if (tid < 8 && usedw[tid]) atomicOr(&P.used[(size_t)b * 8 + tid], usedw[tid]);
+    if (tid == 0) P.tileCnt[(size_t)b * g.rtiles + t] = cnt;
+}
+
+// per block: exclusive scan of a per-tile count array (<= 256 tiles); total -> tot[b]
+__global__ __launch_bounds__(256) void k2_scan_tiles(Pipe P, u32* cnt, u32* tot, int finish_runs) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.x, tid = threadIdx.x;
+    __shared__ u32 sh[256];
+    __shared__ u32 carry;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < g.rtiles; t0 += 256) {
+        const u32 t = t0 + tid;
+        const u32 v = t < g.rtiles ? cnt[(size_t)b * g.rtiles + t] : 0;
+        const u32 ex = block_excl_scan_256(v, sh);
+        const u32 base = carry;
+        if (t < g.rtiles) cnt[(size_t)b * g.rtiles + t] = base + ex;
+        __syncthreads();
+        if (tid == 255) carry = base + ex + v;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        tot[b] = carry + (finish_runs ? 0u : 1u);     // symbol totals include the EOB
+        if (finish_runs) {
+            const u32 n = P.nlen[b];
+            P.RHpos[(size_t)b * (g.stride + 1) + carry] = n;    // sentinel: end of the last run
+            u32 a = 0;
+            for (int k = 0; k < 8; k++) a += (u32)__popc(P.used[(size_t)b * 8 + k]);
+            P.alpha[b] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k2_compact(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 n = P.nlen[b];
+    const u32 t0 = t * K1_RT;
+    if (t0 >= n) return;
+    __shared__ u32 wtot[4];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u8* U = P.U + (size_t)b * g.stride;
+    u32 c = 0;
+    for (int it = 0; it < 16; it++) {
+        const u32 i = t0 + w * 1024u + it * 64u + lane;
+        const bool head = i < n && (i == 0 || U[i - 1] != U[i]);
+        c += (u32)__popcll(__ballot(head));
+    }
+    if (lane == 0) wtot[w] = c;
+    __syncthreads();
+    u32 run = P.tileCnt[(size_t)b * g.rtiles + t];
+    for (u32 i = 0; i < w; i++) run += wtot[i];
+    const u64 lt = lanemask_lt();
+    u8* RHsym = P.RHsym + (size_t)b * g.stride;
+    u32* RHpos = P.RHpos + (size_t)b * (g.stride + 1);
+    for (int it = 0; it < 16; it++) {
+        const u32 i = t0 + w * 1024u + it * 64u + lane;
+        const u32 s = i < n ? U[i] : 0u;
+        const bool head = i < n && (i == 0 || U[i - 1] != s);
+        const u64 bal = __ballot(head);
+        if (head) {
+            const u32 r = run + (u32)__popcll(bal & lt);
+            RHsym[r] = (u8)s;
+            RHpos[r] = i;
+        }
+        run += (u32)__popcll(bal);
+    }
+}
+
+// ---- last-occurrence tables ------------------------------------------------------------------
+#define K2_NONE (-0x40000000)
+
+__global__ __launch_bounds__(256) void k2_lastocc(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y, seg = blockIdx.x;
+    const u32 nr = P.nruns[b];
+    if (seg * K2_SEG >= nr) return;
+    __shared__ int last[256];
+    const u32 tid = threadIdx.x;
+    last[tid] = K2_NONE;
+    __syncthreads();
+    const u8* RHsym = P.RHsym + (size_t)b * g.stride;
+    for (int k = 0; k < 4; k++) {
+        const u32 r = seg * K2_SEG + k * 256u + tid;
+        if (r < nr) atomicMax(&last[RHsym[r]], (int)r);
+    }
+    __syncthreads();
+    P.Ltab[((size_t)b * P.segs + seg) * 256 + tid] = last[tid];
+}
+
+__global__ __launch_bounds__(256) void k2_lastscan(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.x, s = threadIdx.x;
+    const u32 nr = P.nruns[b];
+    const u32 nseg = (nr + K2_SEG - 1) / K2_SEG;
+    const u32* used8 = P.used + (size_t)b * 8;
+    const bool isused = (used8[s >> 5] >> (s & 31u)) & 1u;
+    int cur = isused ? -1 - (int)popc_below(used8, s) : K2_NONE;
+    int* L = P.Ltab + (size_t)b * P.segs * 256 + s;
+#pragma unroll 4
+    for (u32 sg = 0; sg < nseg; sg++) {
+        const int v = L[(size_t)sg * 256];
+        L[(size_t)sg * 256] = cur;
+        cur = cur > v ? cur : v;
+    }
+}
+
+// ---- MTF index of every run head ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32 seg = blockIdx.x * 4u + w;
+    const u32 nr = P.nruns[b];
+    // whole waves leave together; no block-level barrier below
+    if (seg * K2_SEG >= nr) return;
+    const int* L = P.Ltab + ((size_t)b * P.segs + seg) * 256;
+    int Lr[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) Lr[k] = L[k * 64 + lane];
+    const u32* used8 = P.used + (size_t)b * 8;
+    u64 usedw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) usedw[k] = (u64)used8[2 * k] | ((u64)used8[2 * k + 1] << 32);
+    const u8* RHsym = P.RHsym + (size_t)b * g.stride;
+    u8* J = P.J + (size_t)b * g.stride;
+    const u64 lt = lanemask_lt();
+    for (int it = 0; it < 16; it++) {
+        const int base = (int)(seg * K2_SEG + it * 64u);
+        if ((u32)base >= nr) break;                       // wave-uniform
+        const u32 r = (u32)base + lane;
+        const bool valid = r < nr;
+        const u32 c = valid ? RHsym[r] : 0x1FFu;
+        // previous occurrence of my own symbol
+        const u64 own = match_any(c, 9, valid) & lt;
+        int p;
+        {
+            const int l0 = __shfl(Lr[0], (int)(c & 63u));
+            const int l1 = __shfl(Lr[1], (int)(c & 63u));
+            const int l2 = __shfl(Lr[2], (int)(c & 63u));
+            const int l3 = __shfl(Lr[3], (int)(c & 63u));
+            const u32 k = (c >> 6) & 3u;
+            const int lsel = k == 0 ? l0 : k == 1 ? l1 : k == 2 ? l2 : l3;
+            p = own ? base + 63 - __clzll((long long)own) : lsel;
+        }
+        u32 idx = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u64 um = usedw[k];
+            while (um) {                                   // wave-uniform loop over used symbols
+                const int sl = __ffsll((long long)um) - 1;
+                um &= um - 1;
+                const u32 s = (u32)(k * 64 + sl);
+                const u64 ms = __ballot(c == s);
+                const int Ls = __builtin_amdgcn_readlane(Lr[k], sl);
+                const u64 mlt = ms & lt;
+                const int Lsi = mlt ? base + 63 - __clzll((long long)mlt) : Ls;
+                idx += (Lsi > p) ? 1u : 0u;
+                if (ms && (int)lane == sl) Lr[k] = base + 63 - __clzll((long long)ms);
+            }
+        }
+        if (valid) J[r] = (u8)idx;
+    }
+}
+
+// ---- RLE2 symbol counts, offsets, emission ---------------------------------------------------
+__device__ __forceinline__ u32 run_symbols(u32 j, u32 len, u32& zeros) {
+    zeros = len - (j ? 1u : 0u);
+    const u32 nd = zeros ? 31u - (u32)__clz((int)(zeros + 1u)) : 0u;
+    return (j ? 1u : 0u) + nd;
+}
+
+__global__ __launch_bounds__(256) void k2_symcount(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 nr = P.nruns[b];
+    const u32 t0 = t * K1_RT;
+    if (t0 >= nr) { if (threadIdx.x == 0) P.symCnt[(size_t)b * g.rtiles + t] = 0; return; }
+    __shared__ u32 tot;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    const u8* J = P.J + (size_t)b * g.stride;
+    const u32* RHpos = P.RHpos + (size_t)b * (g.stride + 1);
+    u32 c = 0;
+    for (int k = 0; k < 16; k++) {
+        const u32 r = t0 + k * 256u + threadIdx.x;
+        if (r < nr) { u32 z; c += run_symbols(J[r], RHpos[r + 1] - RHpos[r], z); }
+    }
+    atomicAdd(&tot, c);
+    __syncthreads();
+    if (threadIdx.x == 0) P.symCnt[(size_t)b * g.rtiles + t] = tot;
+}
+
+__global__ __launch_bounds__(256) void k2_emit(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 nr = P.nruns[b];
+    const u32 t0 = t * K1_RT;
+    if (t0 >= nr) return;
+    __shared__ u32 sh[256];
+    __shared__ u32 hist[260];
+    const u32 tid = threadIdx.x;
+    for (u32 i = tid; i < 260; i += 256) hist[i] = 0;
+    const u8* J = P.J + (size_t)b * g.stride;
+    const u32* RHpos = P.RHpos + (size_t)b * (g.stride + 1);
+    u16* A = P.A + (size_t)b * g.stride;
+    // thread owns 16 consecutive runs
+    const u32 r0 = t0 + tid * 16u;
+    u32 mine = 0;
+    for (int k = 0; k < 16; k++) {
+        const u32 r = r0 + k;
+        if (r < nr) { u32 z; mine += run_symbols(J[r], RHpos[r + 1] - RHpos[r], z); }
+    }
+    u32 off = P.symCnt[(size_t)b * g.rtiles + t] + block_excl_scan_256(mine, sh);
+    for (int k = 0; k < 16; k++) {
+        const u32 r = r0 + k;
+        if (r >= nr) break;
+        const u32 j = J[r];
+        u32 z;
+        run_symbols(j, RHpos[r + 1] - RHpos[r], z);
+        if (j) { A[off++] = (u16)(j + 1u); atomicAdd(&hist[j + 1u], 1u); }
+        while (z) {                                   // lib/Bzip2.js:783-794
+            if (z & 1u) { A[off++] = 0; atomicAdd(&hist[0], 1u); z -= 1u; }
+            else { A[off++] = 1; atomicAdd(&hist[1], 1u); z -= 2u; }
+            z >>= 1;
+        }
+        if (r == nr - 1) {                            // end of block symbol, lib/Bzip2.js:814
+            const u32 eob = P.alpha[b] + 1u;
+            A[off++] = (u16)eob;
+            atomicAdd(&hist[eob], 1u);
+        }
+    }
+    __syncthreads();
+    u32* freq = P.freq + (size_t)b * K2_FREQ_PITCH;
+    for (u32 i = tid; i < 260; i += 256) if (hist[i]) atomicAdd(&freq[i], hist[i]);
+}
+
+int k2_run(Pipe P, u32 max_n, hipStream_t stream) {
+    const BatchGeom g = P.g;
+    const u32 tiles = (max_n + K1_RT - 1) / K1_RT;
+    const u32 segs = (max_n + K2_SEG - 1) / K2_SEG;
+    const dim3 gridT(tiles, g.nb);
+    HIP_CHECK_RET(hipMemsetAsync(P.used, 0, (size_t)g.nb * 8 * 4, stream));
+    HIP_CHECK_RET(hipMemsetAsync(P.freq, 0, (size_t)g.nb * K2_FREQ_PITCH * 4, stream));
+    hipLaunchKernelGGL(k2_count, dim3(g.rtiles, g.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k2_scan_tiles, dim3(g.nb), dim3(256), 0, stream, P, P.tileCnt, P.nruns, 1);
+    hipLaunchKernelGGL(k2_compact, gridT, dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k2_lastocc, dim3(segs, g.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k2_lastscan, dim3(g.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k2_mtf, dim3((segs + 3) / 4, g.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k2_symcount, dim3(g.rtiles, g.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k2_scan_tiles, dim3(g.nb), dim3(256), 0, stream, P, P.symCnt, P.pos, 0);
+    hipLaunchKernelGGL(k2_emit, gridT, dim3(256), 0, stream, P);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}

@@ -1,0 +1,57 @@
+// Device-side view of one batch of bzip2 blocks moving through K0..K5.
+#pragma once
+#include "cjs_common.h"
+#include "devutil.h"
+#include "k1_bwt.h"
+
+#define K2_SEG 1024          // run heads per MTF segment (one wave)
+#define K2_FREQ_PITCH 260    // u32 per block in freq[]
+#define CJS_MAX_SYMS 258     // lib/Bzip2.js:41
+#define CJS_MAX_GROUPS 6     // lib/Bzip2.js:45
+#define CJS_GROUP 50         // lib/Bzip2.js:46
+#define CJS_MAX_BITS 20      // lib/Bzip2.js:40
+#define CJS_LEN_PITCH 264    // bytes per table in lens[], u32 per table in codes[]
+
+struct Pipe {
+    BatchGeom g;
+    u32 segs;          // stride / K2_SEG
+    // ---- block text (K0 output / K1 input)
+    u8* T;             // [nb][tstride]  T_ext
+    u32* nlen;         // [nb]
+    u32* crc;          // [nb]           block CRCs
+    // ---- K1
+    K1Buf k1;
+    u8* U;             // [nb][stride]
+    u32* pidx;         // [nb]
+    // ---- K2
+    u32* used;         // [nb][8]        256-bit used-symbol set
+    u32* alpha;        // [nb]           alphabetSize
+    u32* nruns;        // [nb]
+    u32* tileCnt;      // [nb][rtiles]
+    u32* symCnt;       // [nb][rtiles]
+    u8* RHsym;         // [nb][stride]
+    u32* RHpos;        // [nb][stride+1]
+    int* Ltab;         // [nb][segs][256]
+    u8* J;             // [nb][stride]
+    u16* A;            // [nb][stride]   MTF/RLE2 symbols incl. EOB
+    u32* pos;          // [nb]           number of symbols in A
+    u32* freq;         // [nb][K2_FREQ_PITCH]
+    // ---- K3/K4
+    u8* sel;           // [nb][selPitch] selectors
+    u32 selPitch;
+    u8* lens;          // [nb][6][CJS_LEN_PITCH]
+    u32* codes;        // [nb][6][CJS_LEN_PITCH]
+    u32* ngroups;      // [nb]
+    u32* nsel;         // [nb]
+    // ---- K5
+    u32* blkBits;      // [nb][stride/..]  (see k5_pack.hip)
+    u64* bitlen;       // [nb]           bits of the encoded block
+    u64* bitoff;       // [nb+1]         exclusive scan of bitlen (+ stream header)
+    u32* outw;         // packed per-block bit streams, pitch outPitch u32 words
+    u32 outPitch;
+};
+
+int k2_run(Pipe P, u32 max_n, hipStream_t stream);
+size_t pipe_bytes(const BatchGeom& g);
+void pipe_carve(Pipe& P, const BatchGeom& g, void* base);
+int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto);

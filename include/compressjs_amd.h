@@ -14,6 +14,28 @@ int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx)
 int32_t cjs_bwt_cyclic_batch(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                              uint8_t* U, uint32_t* pidx);
 
+/* ---- debug/test entry points (not part of the drop-in surface) ------------------------------ */
+typedef struct cjs_dbg_stage_out {   /* every pointer may be NULL; pitches in elements */
+    uint8_t* U;          /* [nb][cap]        BWT output                           */
+    uint32_t* pidx;      /* [nb]                                                   */
+    uint16_t* A;         /* [nb][cap+1]      MTF/RLE2 symbols incl. EOB            */
+    uint32_t* pos;       /* [nb]                                                   */
+    uint32_t* alpha;     /* [nb]             alphabetSize                          */
+    uint32_t* freq;      /* [nb][258]                                              */
+    uint32_t* used;      /* [nb][8]          256-bit used-symbol set               */
+    uint8_t* sel;        /* [nb][(cap+1)/50+2]                                     */
+    uint8_t* lens;       /* [nb][6][258]                                           */
+    uint32_t* ngroups;   /* [nb]                                                   */
+    uint32_t* nsel;      /* [nb]                                                   */
+    uint64_t* bitlen;    /* [nb]                                                   */
+    uint8_t* bits;       /* [nb][bits_pitch] packed block bit streams              */
+    uint64_t bits_pitch;
+} cjs_dbg_stage_out;
+int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
+                               uint8_t* U, uint32_t* pidx, int reps, float* ms);
+int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
+                             int upto, cjs_dbg_stage_out* out);
+
 #ifdef __cplusplus
 }
 #endif

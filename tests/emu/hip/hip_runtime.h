@@ -221,3 +221,8 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
 static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
+template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return emu_shfl_(v, lane); }
+template <class T> static inline T __builtin_amdgcn_readfirstlane(T v) {
+    unsigned long long act = __ballot(1);
+    return emu_shfl_(v, __builtin_ctzll(act));
+}
