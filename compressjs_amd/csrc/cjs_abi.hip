@@ -105,6 +105,7 @@ extern "C" int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint
 // ---------------------------------------------------------------------------------------------
 extern "C" int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                                         int upto, cjs_dbg_stage_out* o) {
+    void* dout = nullptr;
     if (!T || !nlen || !o || nb == 0 || cap == 0 || cap > (1u << 20) - 1) return CJS_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -130,8 +131,18 @@ extern "C" int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, 
     TRY(hipMemcpyAsync(P.T, text.data(), text.size(), hipMemcpyHostToDevice, st));
     TRY(hipMemcpyAsync(P.nlen, nlen, nb * 4, hipMemcpyHostToDevice, st));
     TRY(hipMemsetAsync(P.pidx, 0, nb * 4, st));
+    if (o->crc_in) { TRY(hipMemcpyAsync(P.crc, o->crc_in, nb * 4, hipMemcpyHostToDevice, st)); }
+    else { TRY(hipMemsetAsync(P.crc, 0, nb * 4, st)); }
+    if (upto >= 5) {
+        P.outCapBytes = ((size_t)nb * ((size_t)cap * 2 + 8192) + 4096 + 255) & ~(size_t)255;
+        TRY(hipMalloc(&dout, P.outCapBytes));
+        P.out = (u32*)dout;
+        rc = k5_stream_begin(P, o->level ? o->level : 9, st);
+        if (rc) goto done;
+    }
     rc = pipe_run_block_stages(P, max_n, st, upto);
     if (rc) goto done;
+    if (upto >= 5) { rc = k5_stream_end(P, st); if (rc) goto done; }
     TRY(hipStreamSynchronize(st));
 #define BACK2D(dst, src, rowbytes, srcpitch, dstpitch)                                            \
     if (dst) for (u32 b = 0; b < nb; b++)                                                        \
@@ -146,9 +157,29 @@ extern "C" int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, 
         BACK2D(o->freq, P.freq, 258 * 4, K2_FREQ_PITCH * 4, 258 * 4);
         BACK2D(o->used, P.used, 32, 32, 32);
     }
+    if (upto >= 3) {
+        BACK2D(o->sel, P.sel, (max_n + 1) / 50 + 2, P.selPitch, (cap + 1) / 50 + 2);
+        for (int t = 0; t < 6; t++) {
+            BACK2D(o->lens ? o->lens + t * 258 : nullptr, P.lens + t * CJS_LEN_PITCH, 258,
+                   CJS_MAX_GROUPS * CJS_LEN_PITCH, 6 * 258);
+        }
+        BACK2D(o->ngroups, P.ngroups, 4, 4, 4);
+        BACK2D(o->nsel, P.nsel, 4, 4, 4);
+    }
+    if (upto >= 5) {
+        BACK2D(o->bitlen, P.bitlen, 8, 8, 8);
+        StreamState hs;
+        TRY(hipMemcpy(&hs, P.ss, sizeof hs, hipMemcpyDeviceToHost));
+        if (hs.overflow) { rc = CJS_E_NOSPACE; goto done; }
+        o->stream_bytes = (hs.bits + 7) >> 3;
+        if (o->stream && o->stream_cap >= o->stream_bytes) {
+            TRY(hipMemcpy(o->stream, P.out, o->stream_bytes, hipMemcpyDeviceToHost));
+        }
+    }
 done:
     if (st) (void)hipStreamDestroy(st);
     (void)hipFree(ws);
+    (void)hipFree(dout);
     return rc;
 #undef TRY
 #undef BACK2D

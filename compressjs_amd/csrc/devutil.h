@@ -31,3 +31,33 @@ __device__ __forceinline__ u32 block_excl_scan_256(u32 v, u32* sh) {
     return incl - v;
 }
 
+
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
+    const u32 lane = threadIdx.x & 63u;
+    for (u32 off = 1; off < 64; off <<= 1) {
+        const u32 u = __shfl_up(v, off);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
+// exclusive scan over the (up to 1024) threads of a block; every thread must call it.
+// `sh` needs 20 u32 of LDS.  *total receives the block-wide sum.
+__device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* sh, u32* total) {
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32 nw = (blockDim.x + 63u) >> 6;
+    const u32 incl = wave_incl_scan_u32(v);
+    if (lane == 63u) sh[w] = incl;
+    __syncthreads();
+    if (w == 0) {
+        const u32 t = lane < nw ? sh[lane] : 0u;
+        const u32 ti = wave_incl_scan_u32(t);
+        if (lane < nw) sh[lane] = ti - t;
+        if (lane == 63u) sh[17] = ti;
+    }
+    __syncthreads();
+    const u32 r = sh[w] + incl - v;
+    *total = sh[17];
+    __syncthreads();
+    return r;
+}

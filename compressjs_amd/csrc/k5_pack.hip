@@ -1,0 +1,390 @@
+// K5: block header / selector / code-length-table emission, Huffman bit packing, and stream
+// assembly at bit granularity, for gfx950.
+//
+// Replaces the serial bit-at-a-time writer of the reference:
+//   compressBlock header + tables   lib/Bzip2.js:740-741, 749-758, 847-867, StaticHuffman.emit :610-629
+//   data emission                   lib/Bzip2.js:869-874, StaticHuffman.encode :631-633
+//   stream framing                  lib/Bzip2.js:903-906, 917-919, 925-927
+//   BitStream.writeBits/flush       lib/BitStream.js:52-73, 93-105 (MSB first, zero padded)
+//
+//   k5_header    one workgroup per block builds the header bits in LDS (selectors: parallel MTF over
+//                <= 6 tables + unary codes; tables: per-symbol delta codes + scan) -> hdr[b], hbits[b]
+//   k5_lensum    code bits per 4096-symbol tile
+//   k5_blockscan per block: tile offsets; across blocks: absolute bit offsets, combined CRC
+//   k5_pack      every thread packs 16 consecutive symbols into 32-bit words and ORs them into the
+//                stream at its absolute bit position; tile 0 also shifts the header in.
+// The stream buffer is kept as big-endian 32-bit words stored byte-swapped, i.e. memory order is
+// already the .bz2 byte order.  It must be zero before the first k5_pack of a stream.
+#include "pipeline.h"
+
+__device__ __forceinline__ u32 bswap32(u32 v) {
+    return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24);
+}
+
+// OR `nbits` (<= 32) of `value` into an MSB-first bit array of 32-bit words at bit position `pos`.
+__device__ __forceinline__ void put_bits_lds(u32* words, u32 pos, u32 nbits, u32 value) {
+    if (nbits == 0) return;
+    const u32 wi = pos >> 5, sh = pos & 31u;
+    const u64 v = ((u64)value << (64u - nbits)) >> sh;        // left-aligned in 64 bits, then shifted
+    atomicOr(&words[wi], (u32)(v >> 32));
+    const u32 lo = (u32)v;
+    if (lo) atomicOr(&words[wi + 1], lo);
+}
+
+// 6-entry MTF list packed 4 bits per entry (entry 0 in the low nibble)
+__device__ __forceinline__ u32 mtf6_index(u32 list, u32 s) {
+    u32 j = 0;
+    while (((list >> (4u * j)) & 15u) != s) j++;
+    return j;
+}
+__device__ __forceinline__ u32 mtf6_front(u32 list, u32 j, u32 s) {
+    const u32 lowmask = (1u << (4u * j)) - 1u;                 // entries 0..j-1
+    const u32 keep = list & ~((lowmask << 4) | 15u);           // entries above j
+    return keep | ((list & lowmask) << 4) | s;
+}
+
+__global__ __launch_bounds__(256) void k5_header(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.x;
+    const u32 n = P.nlen[b];
+    const u32 tid = threadIdx.x;
+    if (n == 0) { if (tid == 0) P.hbits[b] = 0; return; }
+    __shared__ u32 hw[K5_HDR_WORDS];
+    __shared__ u32 sh[256];
+    __shared__ int lastT[6][256];
+    __shared__ u32 s_cursor;
+    for (u32 i = tid; i < K5_HDR_WORDS; i += 256) hw[i] = 0;
+    __syncthreads();
+    const u32 alpha = P.alpha[b], G = P.ngroups[b], nSel = P.nsel[b];
+    const int S = (int)alpha + 2;
+    const u8* sel = P.sel + (size_t)b * P.selPitch;
+    if (tid == 0) {
+        // magic, CRC (lib/Bzip2.js:918-919); randomised bit + origPtr (:740-741)
+        put_bits_lds(hw, 0, 24, 0x314159u);
+        put_bits_lds(hw, 24, 24, 0x265359u);
+        put_bits_lds(hw, 48, 32, P.crc[b]);
+        put_bits_lds(hw, 80, 1, 0);
+        put_bits_lds(hw, 81, 24, P.pidx[b]);
+        // used map (:749-758): bit i of the 16-bit map = any of bytes 16i..16i+15 used
+        const u32* used8 = P.used + (size_t)b * 8;
+        u32 cur = 105, map = 0;
+        for (int i = 0; i < 16; i++) {
+            const u32 r = (used8[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;
+            if (r) map |= 1u << (15 - i);
+        }
+        put_bits_lds(hw, cur, 16, map);
+        cur += 16;
+        for (int i = 0; i < 16; i++) {
+            const u32 r = (used8[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu;   // bit j = byte 16i+j used
+            if (r) {
+                u32 rev = 0;                                   // written MSB first: j = 0 first
+                for (int j = 0; j < 16; j++) if (r & (1u << j)) rev |= 1u << (15 - j);
+                put_bits_lds(hw, cur, 16, rev);
+                cur += 16;
+            }
+        }
+        put_bits_lds(hw, cur, 3, G);                          // :847
+        put_bits_lds(hw, cur + 3, 15, nSel);                  // :849
+        s_cursor = cur + 18;
+    }
+    __syncthreads();
+    u32 cursor = s_cursor;
+    // ---- selectors, MTF over the table numbers, unary (:850-862)
+    if (alpha >= G) {
+        const u32 chunk = (nSel + 255u) / 256u;
+        const u32 lo = tid * chunk < nSel ? tid * chunk : nSel;
+        const u32 hi = lo + chunk < nSel ? lo + chunk : nSel;
+        int lastp[6];
+#pragma unroll
+        for (int t = 0; t < 6; t++) lastp[t] = K5_NONE;
+        for (u32 i = lo; i < hi; i++) {
+            const u32 s = sel[i];
+#pragma unroll
+            for (int t = 0; t < 6; t++) if (s == (u32)t) lastp[t] = (int)i;
+        }
+#pragma unroll
+        for (int t = 0; t < 6; t++) lastT[t][tid] = lastp[t];
+        __syncthreads();
+        if (tid < 6) {                                        // exclusive running max per table
+            int cur = -1 - (int)tid;                          // initial list 0,1,2,... (:850)
+            for (int k = 0; k < 256; k++) {
+                const int v = lastT[tid][k];
+                lastT[tid][k] = cur;
+                cur = cur > v ? cur : v;
+            }
+        }
+        __syncthreads();
+        // list at the start of my chunk: tables ordered by last occurrence, most recent first
+        u32 list = 0;
+        {
+            int Ls[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) Ls[t] = lastT[t][tid];
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                u32 r = 0;
+#pragma unroll
+                for (int u = 0; u < 6; u++) r += (Ls[u] > Ls[t]) ? 1u : 0u;   // all distinct
+                list |= (u32)t << (4u * r);
+            }
+        }
+        const u32 list0 = list;
+        u32 bits = 0;
+        for (u32 i = lo; i < hi; i++) {
+            const u32 s = sel[i];
+            const u32 j = mtf6_index(list, s);
+            list = mtf6_front(list, j, s);
+            bits += j + 1u;
+        }
+        u32 off = cursor + block_excl_scan_256(bits, sh);
+        list = list0;
+        for (u32 i = lo; i < hi; i++) {
+            const u32 s = sel[i];
+            const u32 j = mtf6_index(list, s);
+            list = mtf6_front(list, j, s);
+            put_bits_lds(hw, off, j + 1u, ((1u << j) - 1u) << 1);
+            off += j + 1u;
+        }
+        __syncthreads();
+        if (tid == 255) s_cursor = off;
+        __syncthreads();
+        cursor = s_cursor;
+    } else {
+        // The reference reuses its Uint8Array M of length alphabetSize here; with fewer than G
+        // slots, stores past the end are dropped and loads past the end never match.  Mirrored
+        // serially (tiny alphabets only).
+        if (tid == 0) {
+            int M[6];
+            const int mlen = (int)alpha;
+            for (int i = 0; i < mlen; i++) M[i] = i;
+            u32 off = cursor;
+            for (u32 i = 0; i < nSel; i++) {
+                const int s = sel[i];
+                int j;
+                for (j = 0; j < (int)G; j++) if (j < mlen && M[j] == s) break;
+                const int src = j < mlen ? M[j] : 0;
+                for (int k = j; k > 0; k--) if (k < mlen) M[k] = M[k - 1];
+                if (mlen > 0) M[0] = src;
+                put_bits_lds(hw, off, (u32)j + 1u, ((1u << j) - 1u) << 1);
+                off += (u32)j + 1u;
+            }
+            s_cursor = off;
+        }
+        __syncthreads();
+        cursor = s_cursor;
+    }
+    // ---- code-length tables (StaticHuffman.emit :610-629): 5 bits, then per symbol delta codes
+    for (u32 t = 0; t < G; t++) {
+        const u8* lens = P.lens + ((size_t)b * CJS_MAX_GROUPS + t) * CJS_LEN_PITCH;
+        if (tid == 0) put_bits_lds(hw, cursor, 5, lens[0]);
+        // thread owns symbols 2*tid and 2*tid+1
+        u32 nb0 = 0, nb1 = 0;
+        const int i0 = 2 * (int)tid, i1 = i0 + 1;
+        int l0 = 0, lp0 = 0, l1 = 0;
+        if (i0 < S) { l0 = lens[i0]; lp0 = i0 ? lens[i0 - 1] : l0; nb0 = 2u * (u32)(l0 > lp0 ? l0 - lp0 : lp0 - l0) + 1u; }
+        if (i1 < S) { l1 = lens[i1]; nb1 = 2u * (u32)(l1 > l0 ? l1 - l0 : l0 - l1) + 1u; }
+        u32 off = cursor + 5u + block_excl_scan_256(nb0 + nb1, sh);
+        if (i0 < S) {
+            const u32 val = lp0 < l0 ? 2u : 3u;
+            for (u32 d = 0; d + 1u < nb0; d += 2u) put_bits_lds(hw, off + d, 2, val);
+            off += nb0;                                       // terminating 0 bit is already there
+        }
+        if (i1 < S) {
+            const u32 val = l0 < l1 ? 2u : 3u;
+            for (u32 d = 0; d + 1u < nb1; d += 2u) put_bits_lds(hw, off + d, 2, val);
+            off += nb1;
+        }
+        __syncthreads();
+        if (tid == 255) s_cursor = off;                       // thread 255 owns nothing: off = end
+        __syncthreads();
+        cursor = s_cursor;
+    }
+    const u32 nw = (cursor + 31u) >> 5;
+    u32* out = P.hdr + (size_t)b * K5_HDR_WORDS;
+    for (u32 i = tid; i < nw; i += 256) out[i] = hw[i];
+    if (tid == 0) P.hbits[b] = cursor;
+}
+
+// selector of symbol i inside a tile: staged table of the tile's selectors
+__global__ __launch_bounds__(256) void k5_lensum(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 pos = P.nlen[b] ? P.pos[b] : 0u;
+    const u32 t0 = t * K1_RT;
+    if (t0 >= pos) { if (threadIdx.x == 0) P.tileBits[(size_t)b * g.rtiles + t] = 0; return; }
+    __shared__ u8 lens[CJS_MAX_GROUPS][CJS_LEN_PITCH];
+    __shared__ u32 tot;
+    const u32 tid = threadIdx.x;
+    const u32 G = P.ngroups[b];
+    for (u32 i = tid; i < G * CJS_LEN_PITCH; i += 256)
+        (&lens[0][0])[i] = P.lens[(size_t)b * CJS_MAX_GROUPS * CJS_LEN_PITCH + i];
+    if (tid == 0) tot = 0;
+    __syncthreads();
+    const u16* A = P.A + (size_t)b * g.stride;
+    const u8* sel = P.sel + (size_t)b * P.selPitch;
+    u32 c = 0;
+    for (int k = 0; k < 16; k++) {
+        const u32 i = t0 + k * 256u + tid;
+        if (i < pos) c += lens[sel[i / CJS_GROUP]][A[i]];
+    }
+    atomicAdd(&tot, c);
+    __syncthreads();
+    if (tid == 0) P.tileBits[(size_t)b * g.rtiles + t] = tot;
+}
+
+// per block: exclusive scan of tileBits with the header length as base -> bitlen[b]
+__global__ __launch_bounds__(256) void k5_tilescan(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.x, tid = threadIdx.x;
+    __shared__ u32 sh[256];
+    __shared__ u32 carry;
+    if (tid == 0) carry = P.nlen[b] ? P.hbits[b] : 0u;
+    __syncthreads();
+    u32* cnt = P.tileBits + (size_t)b * g.rtiles;
+    for (u32 t0 = 0; t0 < g.rtiles; t0 += 256) {
+        const u32 t = t0 + tid;
+        const u32 v = t < g.rtiles ? cnt[t] : 0;
+        const u32 ex = block_excl_scan_256(v, sh);
+        const u32 base = carry;
+        if (t < g.rtiles) cnt[t] = base + ex;
+        __syncthreads();
+        if (tid == 255) carry = base + ex + v;
+        __syncthreads();
+    }
+    if (tid == 0) P.bitlen[b] = carry;
+}
+
+// across the blocks of the batch: absolute bit offsets and the combined CRC (lib/Bzip2.js:917)
+__global__ __launch_bounds__(64) void k5_blockscan(Pipe P) {
+    if (threadIdx.x != 0) return;
+    u64 bits = P.ss->bits;
+    u32 crc = P.ss->crc;
+    for (u32 b = 0; b < P.g.nb; b++) {
+        P.bitoff[b] = bits;
+        if (P.nlen[b]) {
+            bits += P.bitlen[b];
+            crc = ((crc << 1) | (crc >> 31)) ^ P.crc[b];
+        }
+    }
+    if (((bits + 80u + 7u) >> 3) + 8u > P.outCapBytes) P.ss->overflow = 1;
+    P.ss->bits = bits;
+    P.ss->crc = crc;
+}
+
+__device__ __forceinline__ void or_word(u32* out, u64 wi, u32 word) {
+    if (word) atomicOr(&out[wi], bswap32(word));
+}
+
+__global__ __launch_bounds__(256) void k5_pack(Pipe P) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    if (P.nlen[b] == 0 || P.ss->overflow) return;
+    const u32 pos = P.pos[b];
+    const u32 t0 = t * K1_RT;
+    const u32 tid = threadIdx.x;
+    const u64 boff = P.bitoff[b];
+    if (t == 0) {
+        // shift the header into the stream
+        const u32 hb = P.hbits[b];
+        const u32 nw = (hb + 31u) >> 5;
+        const u32* hdr = P.hdr + (size_t)b * K5_HDR_WORDS;
+        const u32 s = (u32)(boff & 31u);
+        const u64 w0 = boff >> 5;
+        for (u32 k = tid; k <= nw; k += 256) {
+            const u32 cur = k < nw ? hdr[k] : 0u;
+            const u32 prev = k > 0 ? hdr[k - 1] : 0u;
+            const u32 v = s ? ((prev << (32u - s)) | (cur >> s)) : cur;
+            or_word(P.out, w0 + k, v);
+        }
+    }
+    if (t0 >= pos) return;
+    __shared__ u8 lens[CJS_MAX_GROUPS][CJS_LEN_PITCH];
+    __shared__ u32 codes[CJS_MAX_GROUPS][CJS_LEN_PITCH];
+    __shared__ u32 sh[256];
+    const u32 G = P.ngroups[b];
+    for (u32 i = tid; i < G * CJS_LEN_PITCH; i += 256) {
+        (&lens[0][0])[i] = P.lens[(size_t)b * CJS_MAX_GROUPS * CJS_LEN_PITCH + i];
+        (&codes[0][0])[i] = P.codes[(size_t)b * CJS_MAX_GROUPS * CJS_LEN_PITCH + i];
+    }
+    __syncthreads();
+    const u16* A = P.A + (size_t)b * g.stride;
+    const u8* sel = P.sel + (size_t)b * P.selPitch;
+    const u32 i0 = t0 + tid * 16u;
+    u32 mine = 0;
+    for (int k = 0; k < 16; k++) {
+        const u32 i = i0 + k;
+        if (i < pos) mine += lens[sel[i / CJS_GROUP]][A[i]];
+    }
+    const u32 ex = block_excl_scan_256(mine, sh);
+    if (i0 >= pos) return;
+    const u64 bitpos = boff + P.tileBits[(size_t)b * g.rtiles + t] + ex;
+    u64 wi = bitpos >> 5;
+    u32 nacc = (u32)(bitpos & 31u);        // bits of the current word that belong to earlier symbols
+    u64 acc = 0;
+    for (int k = 0; k < 16; k++) {
+        const u32 i = i0 + k;
+        if (i >= pos) break;
+        const u32 gsel = sel[i / CJS_GROUP], sym = A[i];
+        const u32 l = lens[gsel][sym];
+        acc = (acc << l) | codes[gsel][sym];
+        nacc += l;
+        if (nacc >= 32u) {
+            nacc -= 32u;
+            or_word(P.out, wi, (u32)(acc >> nacc));
+            wi++;
+            acc &= (1ull << nacc) - 1ull;
+        }
+    }
+    if (nacc) or_word(P.out, wi, (u32)(acc << (32u - nacc)));
+}
+
+// 'B','Z','h','0'+level (lib/Bzip2.js:903-906); resets the running stream state
+__global__ void k5_begin(Pipe P, int level) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        P.out[0] = bswap32(0x425A6800u | (u32)('0' + level));
+        P.ss->bits = 32;
+        P.ss->crc = 0;
+        P.ss->overflow = 0;
+    }
+}
+// end-of-stream magic + combined CRC (lib/Bzip2.js:925-927); zero padding is already there
+__global__ void k5_end(Pipe P) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || P.ss->overflow) return;
+    const u64 pos = P.ss->bits;
+    const u32 parts[3] = {0x177245u, 0x385090u, P.ss->crc};
+    const u32 nb[3] = {24, 24, 32};
+    u64 p = pos;
+    for (int k = 0; k < 3; k++) {
+        const u32 sh = (u32)(p & 31u);
+        const u64 v = ((u64)parts[k] << (64u - nb[k])) >> sh;
+        or_word(P.out, p >> 5, (u32)(v >> 32));
+        or_word(P.out, (p >> 5) + 1, (u32)v);
+        p += nb[k];
+    }
+    P.ss->bits = p;
+}
+
+int k5_stream_begin(Pipe P, int level, hipStream_t stream) {
+    HIP_CHECK_RET(hipMemsetAsync(P.out, 0, P.outCapBytes, stream));
+    hipLaunchKernelGGL(k5_begin, dim3(1), dim3(64), 0, stream, P, level);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
+int k5_stream_end(Pipe P, hipStream_t stream) {
+    hipLaunchKernelGGL(k5_end, dim3(1), dim3(64), 0, stream, P);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
+int k5_run(Pipe P, u32 max_n, hipStream_t stream) {
+    const BatchGeom g = P.g;
+    const u32 tiles = (max_n + 1 + K1_RT - 1) / K1_RT;
+    hipLaunchKernelGGL(k5_header, dim3(g.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k5_lensum, dim3(g.rtiles, g.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k5_tilescan, dim3(g.nb), dim3(256), 0, stream, P);
+    hipLaunchKernelGGL(k5_blockscan, dim3(1), dim3(64), 0, stream, P);
+    hipLaunchKernelGGL(k5_pack, dim3(tiles, g.nb), dim3(256), 0, stream, P);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}

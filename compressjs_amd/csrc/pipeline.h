@@ -12,6 +12,15 @@
 #define CJS_MAX_BITS 20      // lib/Bzip2.js:40
 #define CJS_LEN_PITCH 264    // bytes per table in lens[], u32 per table in codes[]
 
+#define K5_NONE (-0x40000000)
+#define K5_HDR_WORDS 6144     // >= worst-case header: 18001 selectors x 6 bits + 6 tables x 10067 bits
+
+struct StreamState {
+    u64 bits;          // bits written so far (next block starts here)
+    u32 crc;           // combined CRC so far (lib/Bzip2.js:917)
+    u32 overflow;      // set when the stream would not fit outCapBytes
+};
+
 struct Pipe {
     BatchGeom g;
     u32 segs;          // stride / K2_SEG
@@ -43,15 +52,23 @@ struct Pipe {
     u32* codes;        // [nb][6][CJS_LEN_PITCH]
     u32* ngroups;      // [nb]
     u32* nsel;         // [nb]
+    u16* selCost;      // [nb][selPitch] best cost of every 50-symbol group (optimiser scratch)
     // ---- K5
-    u32* blkBits;      // [nb][stride/..]  (see k5_pack.hip)
+    u32* hdr;          // [nb][K5_HDR_WORDS] block header bits (magic .. code-length tables)
+    u32* hbits;        // [nb]           header length in bits
+    u32* tileBits;     // [nb][rtiles]   code bits per 4096-symbol tile -> exclusive offsets
     u64* bitlen;       // [nb]           bits of the encoded block
-    u64* bitoff;       // [nb+1]         exclusive scan of bitlen (+ stream header)
-    u32* outw;         // packed per-block bit streams, pitch outPitch u32 words
-    u32 outPitch;
+    u64* bitoff;       // [nb]           absolute bit offset of the block in the stream
+    StreamState* ss;   // running stream state (bit cursor, combined CRC), device resident
+    u32* out;          // the .bz2 stream being assembled (byte order = memory order)
+    u64 outCapBytes;
 };
 
 int k2_run(Pipe P, u32 max_n, hipStream_t stream);
+int k34_run(Pipe P, hipStream_t stream);
+int k5_run(Pipe P, u32 max_n, hipStream_t stream);
+int k5_stream_begin(Pipe P, int level, hipStream_t stream);
+int k5_stream_end(Pipe P, hipStream_t stream);
 size_t pipe_bytes(const BatchGeom& g);
 void pipe_carve(Pipe& P, const BatchGeom& g, void* base);
 int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto);

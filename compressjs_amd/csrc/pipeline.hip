@@ -21,6 +21,10 @@ size_t pipe_bytes(const BatchGeom& g) {
     tot += al256((size_t)g.nb * selPitch);                  // selectors
     tot += al256((size_t)g.nb * CJS_MAX_GROUPS * CJS_LEN_PITCH);       // lens
     tot += al256((size_t)g.nb * CJS_MAX_GROUPS * CJS_LEN_PITCH * 4);   // codes
+    tot += al256((size_t)g.nb * selPitch * 2);              // selCost
+    tot += al256((size_t)g.nb * K5_HDR_WORDS * 4);          // hdr
+    tot += al256((size_t)g.nb * g.rtiles * 4);              // tileBits
+    tot += 4 * al256((size_t)g.nb * 8);                     // hbits bitlen bitoff ss
     tot += k1_workspace_bytes(g);
     return tot;
 }
@@ -56,6 +60,11 @@ void pipe_carve(Pipe& P, const BatchGeom& g, void* base) {
     TAKE(sel, u8*, (size_t)g.nb * P.selPitch);
     TAKE(lens, u8*, (size_t)g.nb * CJS_MAX_GROUPS * CJS_LEN_PITCH);
     TAKE(codes, u32*, (size_t)g.nb * CJS_MAX_GROUPS * CJS_LEN_PITCH * 4);
+    TAKE(selCost, u16*, (size_t)g.nb * P.selPitch * 2);
+    TAKE(hdr, u32*, (size_t)g.nb * K5_HDR_WORDS * 4);
+    TAKE(tileBits, u32*, (size_t)g.nb * g.rtiles * 4);
+    TAKE(hbits, u32*, (size_t)g.nb * 4);
+    TAKE(ss, StreamState*, sizeof(StreamState));
 #undef TAKE
     p = (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255);
     k1_carve(P.k1, g, p);
@@ -70,5 +79,7 @@ int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto) {
     if (rc || upto <= 1) return rc;
     rc = k2_run(P, max_n, stream);
     if (rc || upto <= 2) return rc;
-    return rc;
+    rc = k34_run(P, stream);
+    if (rc || upto <= 4) return rc;
+    return k5_run(P, max_n, stream);
 }

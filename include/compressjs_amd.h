@@ -28,8 +28,11 @@ typedef struct cjs_dbg_stage_out {   /* every pointer may be NULL; pitches in el
     uint32_t* ngroups;   /* [nb]                                                   */
     uint32_t* nsel;      /* [nb]                                                   */
     uint64_t* bitlen;    /* [nb]                                                   */
-    uint8_t* bits;       /* [nb][bits_pitch] packed block bit streams              */
-    uint64_t bits_pitch;
+    const uint32_t* crc_in; /* [nb] block CRCs to put in the headers (K0 is bypassed here) */
+    int32_t level;       /* level digit for the stream header                      */
+    uint8_t* stream;     /* whole .bz2 stream of the batch (header, blocks, trailer) */
+    uint64_t stream_cap;
+    uint64_t stream_bytes; /* out */
 } cjs_dbg_stage_out;
 int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                                uint8_t* U, uint32_t* pidx, int reps, float* ms);

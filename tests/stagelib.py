@@ -17,8 +17,9 @@ class StageOut(C.Structure):
     _fields_ = [("U", C.c_void_p), ("pidx", C.c_void_p), ("A", C.c_void_p), ("pos", C.c_void_p),
                 ("alpha", C.c_void_p), ("freq", C.c_void_p), ("used", C.c_void_p),
                 ("sel", C.c_void_p), ("lens", C.c_void_p), ("ngroups", C.c_void_p),
-                ("nsel", C.c_void_p), ("bitlen", C.c_void_p), ("bits", C.c_void_p),
-                ("bits_pitch", C.c_uint64)]
+                ("nsel", C.c_void_p), ("bitlen", C.c_void_p), ("crc_in", C.c_void_p),
+                ("level", C.c_int32), ("stream", C.c_void_p), ("stream_cap", C.c_uint64),
+                ("stream_bytes", C.c_uint64)]
 
 
 def build_emu():
@@ -41,7 +42,7 @@ def load(which: str):
     return L
 
 
-def block_stages(L, blocks, cap: int, upto: int = 5):
+def block_stages(L, blocks, cap: int, upto: int = 5, crcs=None, level: int = 9):
     """Run the device block stages on a list of RLE1 blocks (uint8 arrays, each <= cap)."""
     nb = len(blocks)
     T = np.zeros(nb * cap, dtype=np.uint8)
@@ -50,18 +51,23 @@ def block_stages(L, blocks, cap: int, upto: int = 5):
         T[i * cap:i * cap + b.size] = b
         nl[i] = b.size
     selp = (cap + 1) // 50 + 2
-    bits_pitch = (cap * 2 + 8192 + 7) & ~7
+    stream_cap = nb * (cap * 2 + 8192) + 4096
     arrs = dict(U=np.zeros(nb * cap, np.uint8), pidx=np.zeros(nb, np.uint32),
                 A=np.zeros(nb * (cap + 1), np.uint16), pos=np.zeros(nb, np.uint32),
                 alpha=np.zeros(nb, np.uint32), freq=np.zeros(nb * 258, np.uint32),
                 used=np.zeros(nb * 8, np.uint32), sel=np.zeros(nb * selp, np.uint8),
                 lens=np.zeros(nb * 6 * 258, np.uint8), ngroups=np.zeros(nb, np.uint32),
                 nsel=np.zeros(nb, np.uint32), bitlen=np.zeros(nb, np.uint64),
-                bits=np.zeros(nb * bits_pitch, np.uint8))
+                stream=np.zeros(stream_cap, np.uint8))
     o = StageOut()
     for k, a in arrs.items():
         setattr(o, k, a.ctypes.data)
-    o.bits_pitch = bits_pitch
+    o.stream_cap = stream_cap
+    o.level = level
+    crc_arr = None
+    if crcs is not None:
+        crc_arr = np.ascontiguousarray(crcs, dtype=np.uint32)
+        o.crc_in = crc_arr.ctypes.data
     rc = L.cjs_dbg_block_stages(T.ctypes.data, nl.ctypes.data, nb, cap, upto, C.byref(o))
     if rc != 0:
         raise RuntimeError("cjs_dbg_block_stages rc=%d" % rc)
@@ -76,8 +82,8 @@ def block_stages(L, blocks, cap: int, upto: int = 5):
                         used=arrs["used"][i * 8:(i + 1) * 8],
                         selectors=arrs["sel"][i * selp:i * selp + nsel],
                         lens=arrs["lens"][i * 6 * 258:(i + 1) * 6 * 258].reshape(6, 258),
-                        ngroups=int(arrs["ngroups"][i]), nsel=nsel, bitlen=int(arrs["bitlen"][i]),
-                        bits=arrs["bits"][i * bits_pitch:(i + 1) * bits_pitch]))
+                        ngroups=int(arrs["ngroups"][i]), nsel=nsel, bitlen=int(arrs["bitlen"][i])))
+    out[0]["stream"] = arrs["stream"][:int(o.stream_bytes)].tobytes()
     return out
 
 
