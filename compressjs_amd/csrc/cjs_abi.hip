@@ -184,3 +184,156 @@ done:
 #undef TRY
 #undef BACK2D
 }
+
+// =============================================================================================
+// Product entry points
+// =============================================================================================
+struct cjs_ctx {
+    int device;
+    hipStream_t stream;
+    u32 batch_blocks;          // blocks per batch the workspace is sized for
+    void* ws;                  // block-pipeline workspace (level-9 geometry)
+    size_t ws_bytes;
+    void* k0ws;                // K0 workspace (grows with the input length)
+    size_t k0ws_bytes;
+    void* din;  size_t din_bytes;      // staging for the host-buffer entry point
+    void* dout; size_t dout_bytes;
+    hipEvent_t ev0, ev1;
+    float last_ms;             // device time of the last compress call (HIP events on ctx->stream)
+    u32 last_blocks;
+    // optional per-kernel timing of the dominant kernel (bench.py roofline leg)
+    K1Prof prof;
+};
+
+extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
+    if (ensure_device()) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    cjs_ctx* c = new cjs_ctx();
+    memset(c, 0, sizeof *c);
+    c->device = device;
+    c->batch_blocks = batch_blocks ? batch_blocks : 128;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
+    BatchGeom g = make_geom(c->batch_blocks, 9u * 100000u - 19u);
+    c->ws_bytes = pipe_bytes(g);
+    if (hipMalloc(&c->ws, c->ws_bytes) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    return c;
+}
+
+extern "C" void cjs_destroy(cjs_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->ws); (void)hipFree(c->k0ws); (void)hipFree(c->din); (void)hipFree(c->dout);
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    k1_prof_destroy(c->prof);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int64_t cjs_bz2_compress_bound(uint64_t in_len) {
+    // RLE1 expands by at most 5/4, Huffman codes are at most 20 bits per symbol; headers per block
+    return (int64_t)(in_len + in_len / 2 + (in_len / 100000 + 2) * 24576 + 4096);
+}
+
+static int grow(void** p, size_t* have, size_t need) {
+    if (*have >= need) return CJS_OK;
+    (void)hipFree(*p);
+    *p = nullptr; *have = 0;
+    need = (need + (1u << 20)) & ~(size_t)((1u << 20) - 1);
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) return CJS_E_HIP - (int)e;
+    *have = need;
+    return CJS_OK;
+}
+
+extern "C" int64_t cjs_bz2_compress_device(cjs_ctx* c, const void* d_in, uint64_t in_len, int level,
+                                           void* d_out, uint64_t out_cap) {
+    if (!c || (!d_in && in_len) || !d_out) return CJS_E_ARG;
+    if (level < 1 || level > 9) return CJS_E_LEVEL;                  // lib/Bzip2.js:888-890
+    if (out_cap < 64 || ((uintptr_t)d_out & 3)) return CJS_E_ARG;
+    hipError_t e;
+    int rc;
+#define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
+    TRYR(hipSetDevice(c->device));
+    const u32 cap = (u32)level * 100000u - 19u;                      // lib/Bzip2.js:892-900
+    hipStream_t st = c->stream;
+    rc = grow(&c->k0ws, &c->k0ws_bytes, k0_bytes(in_len, cap));
+    if (rc) return rc;
+    K0Buf K;
+    k0_carve(K, (const u8*)d_in, in_len, cap, c->k0ws);
+    BatchGeom g = make_geom(c->batch_blocks, cap);
+    Pipe P;
+    pipe_carve(P, g, c->ws);
+    P.out = (u32*)d_out;
+    P.outCapBytes = out_cap & ~(uint64_t)3;
+    P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
+    TRYR(hipEventRecord(c->ev0, st));
+    rc = k0_prepass(K, cap, st);
+    if (rc) return rc;
+    rc = k5_stream_begin(P, level, st);
+    if (rc) return rc;
+    u32 nblocks = 0;
+    TRYR(hipMemcpyAsync(&nblocks, K.nBlocks, 4, hipMemcpyDeviceToHost, st));
+    TRYR(hipStreamSynchronize(st));
+    for (u32 first = 0; first < nblocks; first += c->batch_blocks) {
+        const u32 nb = nblocks - first < c->batch_blocks ? nblocks - first : c->batch_blocks;
+        P.g.nb = nb;
+        P.k1.largeCap = nb * (g.htiles + 1);
+        rc = k0_batch(K, P, first, cap, st);
+        if (rc) return rc;
+        rc = pipe_run_block_stages(P, cap, st, 5);
+        if (rc) return rc;
+    }
+    rc = k5_stream_end(P, st);
+    if (rc) return rc;
+    TRYR(hipEventRecord(c->ev1, st));
+    StreamState hs;
+    TRYR(hipMemcpyAsync(&hs, P.ss, sizeof hs, hipMemcpyDeviceToHost, st));
+    TRYR(hipStreamSynchronize(st));
+    TRYR(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    c->last_blocks = nblocks;
+    if (hs.overflow) return CJS_E_NOSPACE;
+    return (int64_t)((hs.bits + 7) >> 3);
+#undef TRYR
+}
+
+extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
+                                    uint64_t out_cap) {
+    if (!c || (!in && in_len) || !out) return CJS_E_ARG;
+    if (level < 1 || level > 9) return CJS_E_LEVEL;
+    hipError_t e;
+#define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
+    TRYR(hipSetDevice(c->device));
+    const uint64_t need = (uint64_t)cjs_bz2_compress_bound(in_len);
+    int rc = grow(&c->din, &c->din_bytes, in_len + 64);
+    if (rc) return rc;
+    rc = grow(&c->dout, &c->dout_bytes, need);
+    if (rc) return rc;
+    if (in_len) TRYR(hipMemcpyAsync(c->din, in, in_len, hipMemcpyHostToDevice, c->stream));
+    const int64_t n = cjs_bz2_compress_device(c, c->din, in_len, level, c->dout, c->dout_bytes);
+    if (n < 0) return n;
+    if ((uint64_t)n > out_cap) return CJS_E_NOSPACE;
+    TRYR(hipMemcpy(out, c->dout, (size_t)n, hipMemcpyDeviceToHost));
+    return n;
+#undef TRYR
+}
+
+extern "C" float cjs_last_device_ms(const cjs_ctx* c) { return c ? c->last_ms : 0.f; }
+extern "C" uint32_t cjs_last_block_count(const cjs_ctx* c) { return c ? c->last_blocks : 0; }
+extern "C" void* cjs_stream(const cjs_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// Per-kernel timing of the K1 radix scatter (the dominant kernel) with HIP events on the
+// library's own stream, for bench.py's roofline leg.
+extern "C" int32_t cjs_profile_enable(cjs_ctx* c, int on) {
+    if (!c) return CJS_E_ARG;
+    return k1_prof_enable(c->prof, on);
+}
+extern "C" int32_t cjs_profile_read(cjs_ctx* c, float* total_ms, uint32_t* launches, uint64_t* elements) {
+    if (!c) return CJS_E_ARG;
+    u64 el = 0;
+    const int rc = k1_prof_read(c->prof, total_ms, launches, &el);
+    if (elements) *elements = el;
+    return rc;
+}

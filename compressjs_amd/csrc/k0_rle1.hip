@@ -1,0 +1,549 @@
+// K0: RLE1 + input-dependent block splitting + per-block CRC, for gfx950.
+//
+// Replaces readBlock (lib/Bzip2.js:636-667) and CRC32.updateCRC (lib/CRC32.js:72-103, table
+// :37-70).  The reference reads one byte at a time into a block of capacity
+// cap = level*100000-19 with per-block run state; semantics distilled in SURVEY.md 9.1:
+//   * a run of equal input bytes is cut into sub-runs of 255: 4 literals + one count byte
+//     (0..251); the count byte is appended as soon as the 4th literal is stored, unless that
+//     literal filled the block; a block that fills on the count byte leaves it at 0;
+//   * every block starts a fresh run, even in the middle of an input run.
+//
+// Per input byte j with k = j - max(run start, block start) and sub = k mod 255, the byte
+// contributes c = 1 (sub < 3), 2 (sub == 3: literal + count byte) or 0 (absorbed) output bytes.
+// With C(i) = sum_{j<i} c(j) over UNCUT runs (a device-wide scan over 4096-byte tiles), the
+// output position of any byte of a block is a difference of C values plus a closed-form
+// correction g() for the one run the block start may cut.  Block boundaries form a serial chain
+// (k0_chain, one workgroup, ~10 us per block); everything else is parallel:
+//
+//   k0_tile_last / scan(max)  -> run start of every tile's first byte
+//   k0_tile_cost / scan(sum)  -> Ctile[t] = C(4096 t)
+//   k0_chain                  -> (start, end, length, correction) of every block of the input
+//   k0_materialize            -> T (RLE1 output) of the blocks of one batch
+//   k0_pad                    -> T_ext wrap-around padding
+//   k0_crc                    -> CRC of the input bytes each block consumed: 256 independent
+//                                table-driven streams per block, combined with x^(8m) mod P.
+#include "pipeline.h"
+
+#define K0_TILE 4096
+#define K0_NONE 0ull          // boundary positions are stored +1 so that 0 means "none"
+
+__device__ __forceinline__ u32 k0_g(u64 k) {          // output bytes before the k-th byte of a fresh run
+    const u64 q = k / 255u;
+    const u32 r = (u32)(k - q * 255u);
+    return (u32)(5u * q) + (r < 4u ? r : 5u);
+}
+__device__ __forceinline__ u32 k0_c(u64 k) {
+    const u32 sub = (u32)(k % 255u);
+    return sub < 3u ? 1u : (sub == 3u ? 2u : 0u);
+}
+
+// ---- per-tile: last run boundary (position j with j == 0 or in[j] != in[j-1]), stored +1 -------
+__global__ __launch_bounds__(256) void k0_tile_last(K0Buf K) {
+    const u64 t = blockIdx.x;
+    const u64 t0 = t * K0_TILE;
+    __shared__ unsigned long long last;
+    if (threadIdx.x == 0) last = K0_NONE;
+    __syncthreads();
+    u64 mine = K0_NONE;
+    for (int k = 0; k < 16; k++) {
+        const u64 j = t0 + (u64)k * 256u + threadIdx.x;
+        if (j < K.in_len && (j == 0 || K.in[j] != K.in[j - 1])) mine = j + 1;
+    }
+    if (mine != K0_NONE) atomicMax(&last, (unsigned long long)mine);
+    __syncthreads();
+    if (threadIdx.x == 0) K.tileA[t] = last;
+}
+
+// ---- generic 3-phase exclusive scan over u64 (sum or max), chunk = 1024 elements ------------------
+template <bool MAX>
+__device__ __forceinline__ u64 scan_op(u64 a, u64 b) { return MAX ? (a > b ? a : b) : a + b; }
+
+template <bool MAX>
+__global__ __launch_bounds__(256) void k0_scan_local(u64* data, u64* chunkTot, u64 n) {
+    __shared__ u64 sh[256];
+    const u64 c0 = (u64)blockIdx.x * 1024u;
+    const u32 tid = threadIdx.x;
+    u64 v[4], run = 0;
+    for (int k = 0; k < 4; k++) {
+        const u64 i = c0 + tid * 4u + k;
+        v[k] = i < n ? data[i] : 0;
+    }
+    u64 tot = 0;
+    for (int k = 0; k < 4; k++) tot = scan_op<MAX>(tot, v[k]);
+    sh[tid] = tot;
+    __syncthreads();
+    for (u32 off = 1; off < 256; off <<= 1) {
+        u64 tv = 0;
+        if (tid >= off) tv = sh[tid - off];
+        __syncthreads();
+        if (tid >= off) sh[tid] = scan_op<MAX>(sh[tid], tv);
+        __syncthreads();
+    }
+    run = tid ? sh[tid - 1] : 0;
+    for (int k = 0; k < 4; k++) {
+        const u64 i = c0 + tid * 4u + k;
+        if (i < n) data[i] = run;
+        run = scan_op<MAX>(run, v[k]);
+    }
+    if (tid == 255) chunkTot[blockIdx.x] = sh[255];
+}
+
+template <bool MAX>
+__global__ __launch_bounds__(1024) void k0_scan_chunks(u64* chunkTot, u64 nchunks, u64* total) {
+    __shared__ u64 sh[1024];
+    __shared__ u64 carry;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (u64 c0 = 0; c0 < nchunks; c0 += 1024) {
+        const u64 i = c0 + tid;
+        const u64 v = i < nchunks ? chunkTot[i] : 0;
+        sh[tid] = v;
+        __syncthreads();
+        for (u32 off = 1; off < 1024; off <<= 1) {
+            u64 tv = 0;
+            if (tid >= off) tv = sh[tid - off];
+            __syncthreads();
+            if (tid >= off) sh[tid] = scan_op<MAX>(sh[tid], tv);
+            __syncthreads();
+        }
+        const u64 ex = scan_op<MAX>(carry, tid ? sh[tid - 1] : 0);
+        if (i < nchunks) chunkTot[i] = ex;
+        __syncthreads();
+        if (tid == 1023) carry = scan_op<MAX>(carry, sh[1023]);
+        __syncthreads();
+    }
+    if (tid == 0 && total) *total = carry;
+}
+
+template <bool MAX>
+__global__ __launch_bounds__(256) void k0_scan_apply(u64* data, const u64* chunkTot, u64 n) {
+    const u64 c0 = (u64)blockIdx.x * 1024u;
+    const u64 base = chunkTot[blockIdx.x];
+    for (int k = 0; k < 4; k++) {
+        const u64 i = c0 + (u64)k * 256u + threadIdx.x;
+        if (i < n) data[i] = scan_op<MAX>(base, data[i]);
+    }
+}
+
+// ---- in-tile helper: every thread owns 16 consecutive bytes of tile t ----------------------------
+// Returns, for the thread's first byte, the start of its run (global, uncut), given the tile's
+// incoming run start rs_in.  `sh` is 256 u64 of LDS.  Also returns the bytes in b[16].
+__device__ __forceinline__ u64 tile_runstarts(const K0Buf& K, u64 t, u64 rs_in, u8* b, u64* sh) {
+    const u32 tid = threadIdx.x;
+    const u64 j0 = t * K0_TILE + tid * 16u;
+    u64 lastb = K0_NONE;
+    u8 prev = 0;
+    if (j0 > 0 && j0 - 1 < K.in_len) prev = K.in[j0 - 1];
+    for (int k = 0; k < 16; k++) {
+        const u64 j = j0 + k;
+        b[k] = j < K.in_len ? K.in[j] : 0;
+        if (j < K.in_len && (j == 0 || b[k] != (k ? b[k - 1] : prev))) lastb = j + 1;
+    }
+    sh[tid] = lastb;
+    __syncthreads();
+    for (u32 off = 1; off < 256; off <<= 1) {
+        u64 tv = 0;
+        if (tid >= off) tv = sh[tid - off];
+        __syncthreads();
+        if (tid >= off && tv > sh[tid]) sh[tid] = tv;
+        __syncthreads();
+    }
+    const u64 before = tid ? sh[tid - 1] : K0_NONE;       // last boundary (+1) in earlier threads' bytes
+    __syncthreads();
+    return before != K0_NONE ? before - 1 : rs_in;
+}
+
+// ---- per-tile cost with uncut runs ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k0_tile_cost(K0Buf K) {
+    const u64 t = blockIdx.x;
+    __shared__ u64 sh[256];
+    __shared__ u32 tot;
+    if (threadIdx.x == 0) tot = 0;
+    u8 b[16];
+    const u64 rsin_raw = K.tileA[t];                        // exclusive max-scan: last boundary (+1) before the tile
+    const u64 rs_in = rsin_raw != K0_NONE ? rsin_raw - 1 : 0;
+    u64 rs = tile_runstarts(K, t, rs_in, b, sh);
+    const u64 j0 = t * K0_TILE + threadIdx.x * 16u;
+    u32 c = 0;
+    for (int k = 0; k < 16; k++) {
+        const u64 j = j0 + k;
+        if (j >= K.in_len) break;
+        if (k == 0 ? (j == 0 || K.in[j - 1] != b[0]) : (b[k] != b[k - 1])) rs = j;
+        c += k0_c(j - rs);
+    }
+    atomicAdd(&tot, c);
+    __syncthreads();
+    if (threadIdx.x == 0) K.tileC[t] = tot;
+}
+
+// ---- C(i) for an arbitrary position; workgroup-cooperative (256 threads), all threads get it ---
+__device__ u64 k0_evalC(const K0Buf& K, u64 i, u64* sh, u32* sh32) {
+    if (i >= K.in_len) return K.tileC[K.ntiles];           // total
+    const u64 t = i / K0_TILE;
+    const u64 rsin_raw = K.tileA[t];
+    const u64 rs_in = rsin_raw != K0_NONE ? rsin_raw - 1 : 0;
+    u8 b[16];
+    u64 rs = tile_runstarts(K, t, rs_in, b, sh);
+    const u64 j0 = t * K0_TILE + threadIdx.x * 16u;
+    if (threadIdx.x == 0) sh32[0] = 0;
+    __syncthreads();
+    u32 c = 0;
+    for (int k = 0; k < 16; k++) {
+        const u64 j = j0 + k;
+        if (j >= i) break;
+        if (k == 0 ? (j == 0 || K.in[j - 1] != b[0]) : (b[k] != b[k - 1])) rs = j;
+        c += k0_c(j - rs);
+    }
+    if (c) atomicAdd(&sh32[0], c);
+    __syncthreads();
+    const u64 r = K.tileC[t] + sh32[0];
+    __syncthreads();
+    return r;
+}
+
+// smallest i in (from, in_len] with C(i) >= target, or in_len+1 when the total is below target
+__device__ u64 k0_searchC(const K0Buf& K, u64 target, u64 from, u64* sh, u32* sh32) {
+    const u32 tid = threadIdx.x;
+    u64 lo = from / K0_TILE, hi = K.ntiles;                // tiles [lo, hi); Ctile[lo] <= C(from) < target
+    while (hi - lo > 256) {
+        const u64 step = (hi - lo + 255) / 256;
+        const u64 p = lo + (u64)tid * step;
+        if (tid == 0) sh32[0] = 0;
+        __syncthreads();
+        if (p < hi && K.tileC[p] < target) atomicAdd(&sh32[0], 1u);
+        __syncthreads();
+        const u32 cnt = sh32[0];                          // >= 1 because Ctile[lo] < target
+        __syncthreads();
+        const u64 nlo = lo + (u64)(cnt - 1) * step;
+        hi = nlo + step < hi ? nlo + step : hi;
+        lo = nlo;
+    }
+    if (tid == 0) sh32[0] = 0;
+    __syncthreads();
+    if (lo + tid < hi && K.tileC[lo + tid] < target) atomicAdd(&sh32[0], 1u);
+    __syncthreads();
+    const u64 t = lo + sh32[0] - 1;
+    __syncthreads();
+    // inside tile t
+    const u64 rsin_raw = K.tileA[t];
+    const u64 rs_in = rsin_raw != K0_NONE ? rsin_raw - 1 : 0;
+    u8 b[16];
+    u64 rs = tile_runstarts(K, t, rs_in, b, sh);
+    const u64 j0 = t * K0_TILE + tid * 16u;
+    u32 cs[16], mine = 0;
+    for (int k = 0; k < 16; k++) {
+        const u64 j = j0 + k;
+        cs[k] = 0;
+        if (j >= K.in_len) continue;
+        if (k == 0 ? (j == 0 || K.in[j - 1] != b[0]) : (b[k] != b[k - 1])) rs = j;
+        cs[k] = k0_c(j - rs);
+        mine += cs[k];
+    }
+    // exclusive scan of `mine` over the 256 threads
+    u32* s32 = (u32*)sh;
+    s32[tid] = mine;
+    __syncthreads();
+    for (u32 off = 1; off < 256; off <<= 1) {
+        u32 tv = 0;
+        if (tid >= off) tv = s32[tid - off];
+        __syncthreads();
+        if (tid >= off) s32[tid] += tv;
+        __syncthreads();
+    }
+    u64 run = K.tileC[t] + (tid ? s32[tid - 1] : 0);
+    __syncthreads();
+    unsigned long long* best = (unsigned long long*)sh;
+    if (tid == 0) best[0] = ~0ull;
+    __syncthreads();
+    for (int k = 0; k < 16; k++) {
+        const u64 j = j0 + k;
+        if (j >= K.in_len) break;
+        run += cs[k];
+        if (run >= target && j + 1 > from) { atomicMin(&best[0], (unsigned long long)(j + 1)); break; }
+    }
+    __syncthreads();
+    const u64 r = best[0];
+    __syncthreads();
+    return r == ~0ull ? K.in_len + 1 : r;
+}
+
+// first position > s whose byte differs from in[s] (the end of s's run), or in_len
+__device__ u64 k0_run_end(const K0Buf& K, u64 s, u64* sh) {
+    const u32 tid = threadIdx.x;
+    const u8 c = K.in[s];
+    unsigned long long* best = (unsigned long long*)sh;
+    u64 t = s / K0_TILE;
+    for (;;) {
+        if (tid == 0) best[0] = ~0ull;
+        __syncthreads();
+        const u64 j0 = t * K0_TILE + tid * 16u;
+        for (int k = 0; k < 16; k++) {
+            const u64 j = j0 + k;
+            if (j > s && j < K.in_len && K.in[j] != c) { atomicMin(&best[0], (unsigned long long)j); break; }
+        }
+        __syncthreads();
+        const u64 r = best[0];
+        __syncthreads();
+        if (r != ~0ull) return r;
+        // skip tiles that contain no boundary at all
+        t++;
+        for (;;) {
+            if (t >= K.ntiles) return K.in_len;
+            if (tid == 0) best[0] = ~0ull;
+            __syncthreads();
+            const u64 tt = t + tid;
+            // tileB[tt] = last boundary (+1) inside tile tt (unscanned copy)
+            if (tt < K.ntiles && K.tileB[tt] != K0_NONE) atomicMin(&best[0], (unsigned long long)tt);
+            __syncthreads();
+            const u64 ft = best[0];
+            __syncthreads();
+            if (ft != ~0ull) { t = ft; break; }
+            t += 256;
+        }
+    }
+}
+
+// ---- the serial chain over blocks -----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k0_chain(K0Buf K, u32 cap) {
+    __shared__ u64 sh[256];
+    __shared__ u32 sh32[4];
+    u64 s = 0;
+    u32 kb = 0;
+    while (s < K.in_len && kb < K.maxBlocks) {
+        const bool cut = s > 0 && K.in[s - 1] == K.in[s];
+        u64 e = s, adj = 0, re = s;
+        u32 n = 0;
+        bool done = false;
+        u64 pre = 0, cbase = 0;
+        if (cut) {
+            re = k0_run_end(K, s, sh);
+            const u64 L = re - s;
+            const u64 gL = k0_g(L);
+            if (gL >= cap) {
+                // the block ends inside the cut run: smallest k with g(k) >= cap
+                const u32 q = cap / 5u, rem = cap % 5u;
+                const u64 k = (u64)q * 255u + (rem == 0 ? 0u : (rem <= 3u ? rem : 4u));
+                e = s + k;
+                const u32 gk = k0_g(k);
+                n = gk < cap ? gk : cap;
+                adj = 0;
+                re = e;                                   // all of the block lies in the closed-form region
+                done = true;
+            } else if (re >= K.in_len) {                  // the cut run reaches EOF without filling the block
+                e = K.in_len;
+                n = (u32)gL;
+                re = e;
+                done = true;
+            } else {
+                pre = gL;
+            }
+        }
+        if (!done) {
+            cbase = k0_evalC(K, re, sh, sh32);            // == C(s) when not cut
+            adj = cbase - pre;                            // OB_s(i) = C(i) - adj for i >= re
+            const u64 target = adj + cap;
+            e = k0_searchC(K, target, re, sh, sh32);
+            if (e > K.in_len) {                           // EOF before the block filled
+                e = K.in_len;
+                n = (u32)(K.tileC[K.ntiles] - adj);
+            } else {
+                const u64 ob = k0_evalC(K, e, sh, sh32) - adj;
+                n = ob < cap ? (u32)ob : cap;
+            }
+        }
+        if (threadIdx.x == 0) {
+            K.blkStart[kb] = s;
+            K.blkEnd[kb] = e;
+            K.blkN[kb] = n;
+            K.blkAdj[kb] = adj;
+            K.blkRe[kb] = re;
+        }
+        kb++;
+        s = e;
+        if (n < cap) break;                               // lib/Bzip2.js:922
+    }
+    if (threadIdx.x == 0) *K.nBlocks = kb;
+}
+
+// ---- RLE1 output of the blocks of one batch ---------------------------------------------------------
+__global__ __launch_bounds__(256) void k0_materialize(K0Buf K, Pipe P, u32 first_block, u32 cap) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.y;
+    const u32 kb = first_block + b;
+    const u32 tid = threadIdx.x;
+    if (kb >= *K.nBlocks) { if (blockIdx.x == 0 && tid == 0) P.nlen[b] = 0; return; }
+    __shared__ u64 sh[256];
+    const u64 s = K.blkStart[kb], e = K.blkEnd[kb], adj = K.blkAdj[kb], re = K.blkRe[kb];
+    const u32 n = K.blkN[kb];
+    if (blockIdx.x == 0 && tid == 0) P.nlen[b] = n;
+    u8* T = P.T + (size_t)b * g.tstride;
+    const u64 tfirst = s / K0_TILE, tlast = (e - 1) / K0_TILE;
+    for (u64 t = tfirst + blockIdx.x; t <= tlast; t += gridDim.x) {
+        const u64 rsin_raw = K.tileA[t];
+        const u64 rs_in = rsin_raw != K0_NONE ? rsin_raw - 1 : 0;
+        u8 by[16];
+        u64 rs = tile_runstarts(K, t, rs_in, by, sh);
+        const u64 j0 = t * K0_TILE + tid * 16u;
+        // output position of the thread's first byte
+        u32 cs[16], mine = 0;
+        for (int k = 0; k < 16; k++) {
+            const u64 j = j0 + k;
+            cs[k] = 0;
+            if (j >= K.in_len) continue;
+            if (k == 0 ? (j == 0 || K.in[j - 1] != by[0]) : (by[k] != by[k - 1])) rs = j;
+            const u64 rss = rs > s ? rs : s;              // the block start cuts the run
+            if (j >= s && j < e) { cs[k] = k0_c(j - rss); mine += cs[k]; }
+        }
+        u32* s32 = (u32*)sh;
+        s32[tid] = mine;
+        __syncthreads();
+        for (u32 off = 1; off < 256; off <<= 1) {
+            u32 tv = 0;
+            if (tid >= off) tv = s32[tid - off];
+            __syncthreads();
+            if (tid >= off) s32[tid] += tv;
+            __syncthreads();
+        }
+        const u32 excl = tid ? s32[tid - 1] : 0;
+        __syncthreads();
+        // output bytes before the first in-block byte of this tile
+        const u64 tb = t * K0_TILE > s ? t * K0_TILE : s;
+        const u64 ob0 = tb <= re ? (u64)k0_g(tb - s) : K.tileC[t] - adj;   // tb > re implies tile-aligned tb
+        u64 ob = ob0 + excl;
+        for (int k = 0; k < 16; k++) {
+            const u64 j = j0 + k;
+            if (j < s || j >= e || j >= K.in_len) continue;
+            if (cs[k]) {
+                if (ob < n) T[ob] = by[k];
+                if (cs[k] == 2 && ob + 1 < n) {
+                    // count byte: equal bytes that follow inside the block, at most 251
+                    u32 cntv = 0;
+                    for (u64 q = j + 1; q < e && cntv < 251u && K.in[q] == by[k]; q++) cntv++;
+                    T[ob + 1] = (u8)cntv;
+                }
+                ob += cs[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k0_pad(Pipe P) {
+    const u32 b = blockIdx.x;
+    const u32 n = P.nlen[b];
+    if (n == 0) return;
+    u8* T = P.T + (size_t)b * P.g.tstride;
+    T[n + threadIdx.x] = T[threadIdx.x % n];
+}
+
+// ---- CRC -----------------------------------------------------------------------------------------------
+#define CRC_POLY 0x04c11db7u
+__device__ __forceinline__ u32 gf_mul(u32 a, u32 b) {    // a*b mod P over GF(2), P = x^32 + CRC_POLY
+    u32 r = 0;
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r & 0x80000000u) ? CRC_POLY : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+// v * x^(8*m) mod P using pw[k] = x^(8*2^k) mod P
+__device__ __forceinline__ u32 gf_shift(u32 v, u64 m, const u32* pw) {
+    for (int k = 0; m; k++, m >>= 1) if (m & 1u) v = gf_mul(v, pw[k]);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
+    const u32 b = blockIdx.x, kb = first_block + b, tid = threadIdx.x;
+    if (kb >= *K.nBlocks) return;
+    __shared__ u32 tab[256];
+    __shared__ u32 pw[40];
+    __shared__ u32 acc;
+    {   // lib/CRC32.js:37-70
+        u32 c = tid << 24;
+        for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : (c << 1);
+        tab[tid] = c;
+    }
+    if (tid == 0) {
+        acc = 0;
+        u32 p = 0x100u;                                   // x^8
+        for (int k = 0; k < 40; k++) { pw[k] = p; p = gf_mul(p, p); }
+    }
+    __syncthreads();
+    const u64 s = K.blkStart[kb], e = K.blkEnd[kb], len = e - s;
+    const u64 per = (len + 255) / 256;
+    const u64 lo = s + (u64)tid * per < e ? s + (u64)tid * per : e;
+    const u64 hi = lo + per < e ? lo + per : e;
+    u32 crc = 0;                                          // raw remainder (init 0)
+    for (u64 j = lo; j < hi; j++) crc = (crc << 8) ^ tab[((crc >> 24) ^ K.in[j]) & 0xffu];
+    if (hi > lo) {
+        crc = gf_shift(crc, e - hi, pw);
+        atomicXor(&acc, crc);
+    }
+    __syncthreads();
+    if (tid == 0) P.crc[b] = ~(acc ^ gf_shift(0xffffffffu, len, pw));
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+size_t k0_bytes(u64 in_len, u32 cap) {
+    const u64 ntiles = (in_len + K0_TILE - 1) / K0_TILE;
+    const u64 nchunks = (ntiles + 1 + 1023) / 1024;
+    const u64 maxBlocks = in_len / (cap / 2 + 1) + 2;     // > worst-case number of blocks
+    size_t tot = 0;
+    tot += 3 * (((ntiles + 2) * 8 + 255) & ~(size_t)255);
+    tot += ((nchunks + 1) * 8 + 255) & ~(size_t)255;
+    tot += 4 * ((maxBlocks * 8 + 255) & ~(size_t)255) + ((maxBlocks * 4 + 255) & ~(size_t)255) + 256;
+    return tot;
+}
+
+void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws) {
+    K.in = d_in;
+    K.in_len = in_len;
+    K.ntiles = (in_len + K0_TILE - 1) / K0_TILE;
+    K.nchunks = (K.ntiles + 1 + 1023) / 1024;
+    K.maxBlocks = (u32)(in_len / (cap / 2 + 1) + 2);
+    char* p = (char*)ws;
+    const size_t ta = ((K.ntiles + 2) * 8 + 255) & ~(size_t)255;
+    K.tileA = (u64*)p; p += ta;
+    K.tileB = (u64*)p; p += ta;
+    K.tileC = (u64*)p; p += ta;
+    K.chunk = (u64*)p; p += ((K.nchunks + 1) * 8 + 255) & ~(size_t)255;
+    const size_t bb = ((size_t)K.maxBlocks * 8 + 255) & ~(size_t)255;
+    K.blkStart = (u64*)p; p += bb;
+    K.blkEnd = (u64*)p; p += bb;
+    K.blkAdj = (u64*)p; p += bb;
+    K.blkRe = (u64*)p; p += bb;
+    K.blkN = (u32*)p; p += ((size_t)K.maxBlocks * 4 + 255) & ~(size_t)255;
+    K.nBlocks = (u32*)p;
+}
+
+// whole-input pre-pass: tile scans + block chain.  After it *K.nBlocks and blk* are valid.
+int k0_prepass(K0Buf K, u32 cap, hipStream_t stream) {
+    if (K.in_len == 0) {
+        HIP_CHECK_RET(hipMemsetAsync(K.nBlocks, 0, 4, stream));
+        return CJS_OK;
+    }
+    const u32 nt = (u32)K.ntiles, nc = (u32)K.nchunks;
+    hipLaunchKernelGGL(k0_tile_last, dim3(nt), dim3(256), 0, stream, K);
+    HIP_CHECK_RET(hipMemcpyAsync(K.tileB, K.tileA, K.ntiles * 8, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(k0_scan_local<true>, dim3(nc), dim3(256), 0, stream, K.tileA, K.chunk, K.ntiles);
+    hipLaunchKernelGGL(k0_scan_chunks<true>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, (u64*)nullptr);
+    hipLaunchKernelGGL(k0_scan_apply<true>, dim3(nc), dim3(256), 0, stream, K.tileA, (const u64*)K.chunk, K.ntiles);
+    hipLaunchKernelGGL(k0_tile_cost, dim3(nt), dim3(256), 0, stream, K);
+    hipLaunchKernelGGL(k0_scan_local<false>, dim3(nc), dim3(256), 0, stream, K.tileC, K.chunk, K.ntiles);
+    hipLaunchKernelGGL(k0_scan_chunks<false>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, K.tileC + K.ntiles);
+    hipLaunchKernelGGL(k0_scan_apply<false>, dim3(nc), dim3(256), 0, stream, K.tileC, (const u64*)K.chunk, K.ntiles);
+    hipLaunchKernelGGL(k0_chain, dim3(1), dim3(256), 0, stream, K, cap);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
+// RLE1 text + CRC of blocks [first_block, first_block + P.g.nb) into the batch P
+int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream) {
+    const u32 gx = cap / K0_TILE + 2;
+    hipLaunchKernelGGL(k0_materialize, dim3(gx, P.g.nb), dim3(256), 0, stream, K, P, first_block, cap);
+    hipLaunchKernelGGL(k0_pad, dim3(P.g.nb), dim3(64), 0, stream, P);
+    hipLaunchKernelGGL(k0_crc, dim3(P.g.nb), dim3(256), 0, stream, K, P, first_block);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}

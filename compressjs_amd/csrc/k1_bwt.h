@@ -6,7 +6,20 @@
 #define K1_STAT_LARGE 32    // stats[32..63] : large groups registered in round r
 #define K1_STATS 64
 
+// HIP-event timing of one kernel's launches (k1_scatter), filled by k1_run when enabled.
+#define K1_PROF_MAX 4096
+struct K1Prof {
+    int enabled;
+    u32 used;                 // event pairs recorded since the last read
+    u64 elements;             // elements those launches processed
+    hipEvent_t* ev;           // [2*K1_PROF_MAX]
+};
+int k1_prof_enable(K1Prof& p, int on);
+int k1_prof_read(K1Prof& p, float* total_ms, u32* launches, u64* elements);
+void k1_prof_destroy(K1Prof& p);
+
 struct K1Buf {
+    K1Prof* prof;     // optional
     const u8* T;      // [nb][tstride]  T_ext[i] = T[i mod n]
     u32* SA;          // [nb][stride]   suffix array (result)
     u32* SB;          // [nb][stride]   ping-pong

@@ -601,7 +601,15 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         u32* out = (p & 1) ? B.SA : B.SB;
         hipLaunchKernelGGL(k1_hist, gridR, dim3(256), 0, stream, B, g, in, dpos, p == 0 ? 1 : 0);
         hipLaunchKernelGGL(k1_scan, dim3(g.nb), dim3(1024), 0, stream, B, g);
+        K1Prof* pr = B.prof;
+        const bool timed = pr && pr->enabled && pr->used < K1_PROF_MAX;
+        if (timed) (void)hipEventRecord(pr->ev[2 * pr->used], stream);
         hipLaunchKernelGGL(k1_scatter, gridR, dim3(256), 0, stream, B, g, in, out, dpos, p == 0 ? 1 : 0);
+        if (timed) {
+            (void)hipEventRecord(pr->ev[2 * pr->used + 1], stream);
+            pr->used++;
+            pr->elements += (u64)g.nb * max_n;
+        }
     }
     hipLaunchKernelGGL(k1_init_heads, gridH, dim3(256), 0, stream, B, g);
     hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, 0);
@@ -622,4 +630,37 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     hipLaunchKernelGGL(k1_finish, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
+}
+
+int k1_prof_enable(K1Prof& p, int on) {
+    if (on && !p.ev) {
+        p.ev = new hipEvent_t[2 * K1_PROF_MAX];
+        for (int i = 0; i < 2 * K1_PROF_MAX; i++) HIP_CHECK_RET(hipEventCreate(&p.ev[i]));
+    }
+    p.enabled = on;
+    p.used = 0;
+    p.elements = 0;
+    return CJS_OK;
+}
+int k1_prof_read(K1Prof& p, float* total_ms, u32* launches, u64* elements) {
+    float tot = 0.f;
+    for (u32 i = 0; i < p.used; i++) {
+        float ms = 0.f;
+        HIP_CHECK_RET(hipEventSynchronize(p.ev[2 * i + 1]));
+        HIP_CHECK_RET(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = p.used;
+    if (elements) *elements = p.elements;
+    p.used = 0;
+    p.elements = 0;
+    return CJS_OK;
+}
+void k1_prof_destroy(K1Prof& p) {
+    if (p.ev) {
+        for (int i = 0; i < 2 * K1_PROF_MAX; i++) (void)hipEventDestroy(p.ev[i]);
+        delete[] p.ev;
+        p.ev = nullptr;
+    }
 }

@@ -64,11 +64,34 @@ struct Pipe {
     u64 outCapBytes;
 };
 
+// K0 (whole-input pre-pass) ----------------------------------------------------------------------
+struct K0Buf {
+    const u8* in;      // input bytes (device)
+    u64 in_len;
+    u64 ntiles;        // 4096-byte tiles
+    u64 nchunks;       // scan chunks of 1024 tiles
+    u32 maxBlocks;
+    u64* tileA;        // [ntiles+2] last run boundary (+1) before the tile   (exclusive max-scan)
+    u64* tileB;        // [ntiles+2] last run boundary (+1) inside the tile
+    u64* tileC;        // [ntiles+2] C(4096 t): RLE1 output bytes before the tile with uncut runs; [ntiles] = total
+    u64* chunk;        // [nchunks+1] scan scratch
+    u64* blkStart;     // [maxBlocks] first input byte of block k
+    u64* blkEnd;       // [maxBlocks] one past its last input byte
+    u64* blkAdj;       // [maxBlocks] output position of input byte i >= blkRe is C(i) - blkAdj
+    u64* blkRe;        // [maxBlocks] end of the run the block start cuts (== blkStart if none)
+    u32* blkN;         // [maxBlocks] block length after RLE1
+    u32* nBlocks;      // [1]
+};
+size_t k0_bytes(u64 in_len, u32 cap);
+void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws);
+int k0_prepass(K0Buf K, u32 cap, hipStream_t stream);
+
 int k2_run(Pipe P, u32 max_n, hipStream_t stream);
 int k34_run(Pipe P, hipStream_t stream);
 int k5_run(Pipe P, u32 max_n, hipStream_t stream);
 int k5_stream_begin(Pipe P, int level, hipStream_t stream);
 int k5_stream_end(Pipe P, hipStream_t stream);
+int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream);
 size_t pipe_bytes(const BatchGeom& g);
 void pipe_carve(Pipe& P, const BatchGeom& g, void* base);
 int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto);

@@ -8,6 +8,38 @@
 extern "C" {
 #endif
 
+/* Opaque per-GPU context: one HIP stream + the HBM workspace for `batch_blocks` bzip2 blocks in
+ * flight (about 31 B per block byte; 128 blocks of 900 kB = 3.6 GB).  Not thread safe; one
+ * context per thread/GPU.  Returns NULL when no MI355X is visible (there is no CPU path). */
+typedef struct cjs_ctx cjs_ctx;
+cjs_ctx* cjs_create(int device, uint32_t batch_blocks);
+void cjs_destroy(cjs_ctx* ctx);
+
+/* Upper bound of the .bz2 size for in_len input bytes (any level). */
+int64_t cjs_bz2_compress_bound(uint64_t in_len);
+
+/* = Bzip2.compressFile(input, null, level)            (reference: lib/Bzip2.js:879-929)
+ * Host buffers in, complete .bz2 stream out.  Returns the number of bytes written, or < 0:
+ *   CJS_E_LEVEL (-20) 'Invalid block size multiplier' (lib/Bzip2.js:888-890),
+ *   CJS_E_NOSPACE (-21) out_cap too small, CJS_E_ARG (-22), CJS_E_NOGPU (-23), -100-hipError_t. */
+int64_t cjs_bz2_compress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
+                         uint64_t out_cap);
+/* The same with input and output resident in HBM (device pointers, d_out 4-byte aligned). */
+int64_t cjs_bz2_compress_device(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level, void* d_out,
+                                uint64_t out_cap);
+/* Device time (HIP events on the context's stream) and block count of the last compress call. */
+float cjs_last_device_ms(const cjs_ctx* ctx);
+uint32_t cjs_last_block_count(const cjs_ctx* ctx);
+void* cjs_stream(const cjs_ctx* ctx);   /* the hipStream_t the library launches on */
+/* HIP-event timing of every launch of the dominant kernel (K1 radix scatter). */
+int32_t cjs_profile_enable(cjs_ctx* ctx, int on);
+int32_t cjs_profile_read(cjs_ctx* ctx, float* total_ms, uint32_t* launches, uint64_t* elements);
+
+#define CJS_E_LEVEL (-20)
+#define CJS_E_NOSPACE (-21)
+#define CJS_E_ARG (-22)
+#define CJS_E_NOGPU (-23)
+
 /* = BWT.bwtransform2(T, U, n, 256) -> pidx            (reference: lib/BWT.js:372-417) */
 int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx);
 /* the same for nb independent blocks laid out at a fixed pitch `cap` (host pointers) */
