@@ -1,5 +1,7 @@
-"""Loader of the HIP shared library.  There is NO CPU fallback: if the library is missing or no
-MI355X is visible the product raises."""
+"""Loader of the HIP shared library (C ABI in include/compressjs_amd.h).
+
+There is NO CPU fallback: if libcompressjs_amd.so is missing, or no MI355X is visible, every
+product entry point raises."""
 from __future__ import annotations
 
 import ctypes as C
@@ -8,6 +10,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcompressjs_amd.so")
 _lib = None
+
+# every symbol include/compressjs_amd.h declares (tests check the .so exports all of them)
+SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_bz2_compress_bound", "cjs_bz2_compress",
+           "cjs_bz2_compress_device", "cjs_bz2_plan", "cjs_bz2_encode_blocks",
+           "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
+           "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch",
+           "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages"]
 
 
 class CompressjsAmdError(RuntimeError):
@@ -23,25 +32,55 @@ def load(path: str | None = None):
     if not os.path.exists(p):
         raise CompressjsAmdError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(there is no CPU fallback)" % p)
+            "(the product has no CPU fallback)" % p)
     L = C.CDLL(p)
-    vp, u32p = C.c_void_p, C.POINTER(C.c_uint32)
+    vp = C.c_void_p
+    L.cjs_create.restype = vp
+    L.cjs_create.argtypes = [C.c_int, C.c_uint32]
+    L.cjs_destroy.restype = None
+    L.cjs_destroy.argtypes = [vp]
+    L.cjs_bz2_compress_bound.restype = C.c_int64
+    L.cjs_bz2_compress_bound.argtypes = [C.c_uint64]
+    L.cjs_bz2_compress.restype = C.c_int64
+    L.cjs_bz2_compress.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64]
+    L.cjs_bz2_compress_device.restype = C.c_int64
+    L.cjs_bz2_compress_device.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64]
+    L.cjs_bz2_plan.restype = C.c_int64
+    L.cjs_bz2_plan.argtypes = [vp, vp, C.c_uint64, C.c_int]
+    L.cjs_bz2_encode_blocks.restype = C.c_int64
+    L.cjs_bz2_encode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint64,
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.cjs_last_device_ms.restype = C.c_float
+    L.cjs_last_device_ms.argtypes = [vp]
+    L.cjs_last_block_count.restype = C.c_uint32
+    L.cjs_last_block_count.argtypes = [vp]
+    L.cjs_stream.restype = vp
+    L.cjs_stream.argtypes = [vp]
+    L.cjs_profile_enable.restype = C.c_int32
+    L.cjs_profile_enable.argtypes = [vp, C.c_int]
+    L.cjs_profile_read.restype = C.c_int32
+    L.cjs_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32),
+                                   C.POINTER(C.c_uint64)]
     L.cjs_bwt_cyclic.restype = C.c_int32
-    L.cjs_bwt_cyclic.argtypes = [vp, vp, C.c_uint32, u32p]
+    L.cjs_bwt_cyclic.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.cjs_bwt_cyclic_batch.restype = C.c_int32
     L.cjs_bwt_cyclic_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     L.cjs_dbg_bwt_batch_time.restype = C.c_int32
-    L.cjs_dbg_bwt_batch_time.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int, C.POINTER(C.c_float)]
+    L.cjs_dbg_bwt_batch_time.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int,
+                                         C.POINTER(C.c_float)]
     if path is None:
         _lib = L
     return L
 
 
-def check(rc: int, what: str = "call"):
+def check(rc: int, what: str = "call") -> int:
+    """Map negative C-ABI codes to the exceptions the reference raises."""
     if rc >= 0:
         return rc
     if rc == -20:
-        raise ValueError("Invalid block size multiplier")
+        raise ValueError("Invalid block size multiplier")          # lib/Bzip2.js:888-890
+    if rc == -21:
+        raise CompressjsAmdError("%s: output buffer too small" % what)
     if rc == -23:
         raise CompressjsAmdError("%s: no HIP device visible (the product has no CPU path)" % what)
     if rc <= -100:

@@ -1,0 +1,177 @@
+"""Host-side mirror of the reference's module API for the bzip2 path.
+
+    compressjs.Bzip2.compressFile(input, [output], [level])      lib/Bzip2.js:879-929
+    compressjs.BWT.bwtransform2(T, U, n, [k]) -> pidx            lib/BWT.js:372-417
+
+with the input/output coercions of lib/Util.js:9-103 translated to Python objects.  The primary
+host binding for the reference's own language is js/ (N-API); this module is the same thin layer
+for Python callers, bench.py and the tests.  Every call goes through the C ABI
+(include/compressjs_amd.h) into the HIP kernels; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+EOF_BYTE = -1          # Stream.EOF (lib/Stream.js)
+
+
+class Context:
+    """One GPU context (cjs_ctx): HIP stream + HBM workspace for `batch_blocks` blocks."""
+
+    def __init__(self, device: int = 0, batch_blocks: int = 128):
+        self.L = _lib.load()
+        self.h = self.L.cjs_create(device, batch_blocks)
+        if not self.h:
+            raise _lib.CompressjsAmdError(
+                "cjs_create failed: no MI355X visible or out of HBM (the product has no CPU path)")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cjs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # host buffers -------------------------------------------------------------------------
+    def compress(self, data: np.ndarray, level: int = 9) -> bytes:
+        d = np.ascontiguousarray(data, dtype=np.uint8)
+        cap = int(self.L.cjs_bz2_compress_bound(d.size))
+        out = np.empty(cap, dtype=np.uint8)
+        n = self.L.cjs_bz2_compress(self.h, d.ctypes.data, d.size, int(level), out.ctypes.data, cap)
+        _lib.check(n, "cjs_bz2_compress")
+        return out[:n].tobytes()
+
+    # device-resident (torch tensors on this context's GPU) ----------------------------------
+    def compress_device(self, d_in, d_out, level: int = 9) -> int:
+        """d_in / d_out: torch uint8 CUDA tensors.  Returns the number of bytes written."""
+        n = self.L.cjs_bz2_compress_device(self.h, d_in.data_ptr(), d_in.numel(), int(level),
+                                           d_out.data_ptr(), d_out.numel())
+        return _lib.check(n, "cjs_bz2_compress_device")
+
+    def plan(self, d_in, level: int = 9) -> int:
+        """RLE1/block-split pre-pass over the whole input; returns the number of blocks."""
+        return _lib.check(self.L.cjs_bz2_plan(self.h, d_in.data_ptr(), d_in.numel(), int(level)),
+                          "cjs_bz2_plan")
+
+    def encode_blocks(self, first: int, count: int, d_seg):
+        """Encode blocks [first, first+count) of the planned input into d_seg (bit 0 aligned).
+        Returns (bits, crc_fold, n_blocks)."""
+        fold, cnt = C.c_uint32(0), C.c_uint32(0)
+        bits = self.L.cjs_bz2_encode_blocks(self.h, first, count, d_seg.data_ptr(), d_seg.numel(),
+                                            C.byref(fold), C.byref(cnt))
+        _lib.check(bits, "cjs_bz2_encode_blocks")
+        return int(bits), int(fold.value), int(cnt.value)
+
+    @property
+    def last_device_ms(self) -> float:
+        return float(self.L.cjs_last_device_ms(self.h))
+
+    @property
+    def last_block_count(self) -> int:
+        return int(self.L.cjs_last_block_count(self.h))
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0, 32)
+    return _default_ctx
+
+
+def _coerce_input(inp) -> np.ndarray:
+    """Util.coerceInputStream (lib/Util.js:9-29): buffers are used as they are, stream objects
+    are drained through readByte() until it returns -1."""
+    if hasattr(inp, "readByte"):
+        buf = bytearray()
+        while True:
+            b = inp.readByte()
+            if b == EOF_BYTE:
+                break
+            buf.append(b & 0xFF)
+        return np.frombuffer(bytes(buf), dtype=np.uint8)
+    if isinstance(inp, np.ndarray):
+        return np.ascontiguousarray(inp, dtype=np.uint8)
+    if isinstance(inp, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(inp), dtype=np.uint8)
+    return np.asarray(list(inp), dtype=np.uint8)
+
+
+def _deliver(data: bytes, output):
+    """Util.coerceOutputStream (lib/Util.js:85-103): None -> exact-length bytes; object with
+    writeByte -> bytes pushed one at a time and the object returned; int -> expected size;
+    writable buffer -> filled, size must match."""
+    if output is None or output is False:
+        return data
+    if hasattr(output, "writeByte"):
+        for b in data:
+            output.writeByte(b)
+        if hasattr(output, "flush"):
+            output.flush()
+        return output
+    if isinstance(output, int):
+        if output != len(data):
+            raise TypeError("outputsize does not match decoded input")    # lib/Util.js:69-71
+        return data
+    mv = memoryview(output)
+    if len(mv) != len(data):
+        raise TypeError("outputsize does not match decoded input")
+    mv[:] = data
+    return output
+
+
+class Bzip2:
+    """compressjs.Bzip2 (lib/Bzip2.js:878-933), compress side on MI355X."""
+
+    @staticmethod
+    def compressFile(inStream, outStream=None, props=None):
+        level = 9
+        if isinstance(props, (int, float)) and not isinstance(props, bool):   # lib/Bzip2.js:884-887
+            level = props
+        if level < 1 or level > 9 or level != int(level):
+            raise ValueError("Invalid block size multiplier")                  # :888-890
+        data = _coerce_input(inStream)
+        return _deliver(default_context().compress(data, int(level)), outStream)
+
+    @staticmethod
+    def decompressFile(inStream, outStream=None, multistream=False):
+        """Decoding is fully determined by the format; it is not on the accelerated path yet
+        (SURVEY.md 8f-1).  Delegates to the interpreter's libbz2 binding."""
+        import bz2
+        data = _coerce_input(inStream).tobytes()
+        try:
+            if multistream:
+                out = bz2.decompress(data)
+            else:
+                d = bz2.BZ2Decompressor()
+                out = d.decompress(data)
+        except (OSError, ValueError) as ex:
+            err = TypeError("Data integrity error")
+            err.errorCode = -5
+            raise err from ex
+        return _deliver(out, outStream)
+
+
+class BWT:
+    """compressjs.BWT (lib/BWT.js:302-419): the cyclic transform used by bzip2."""
+
+    @staticmethod
+    def bwtransform2(T, U, n, alphabetSize=256):
+        t = np.ascontiguousarray(np.asarray(T)[:n], dtype=np.uint8)
+        u = np.zeros(max(n, 1), dtype=np.uint8)
+        p = C.c_uint32(0)
+        _lib.check(_lib.load().cjs_bwt_cyclic(t.ctypes.data, u.ctypes.data, n, C.byref(p)),
+                   "cjs_bwt_cyclic")
+        U[:n] = u[:n] if isinstance(U, np.ndarray) else bytes(u[:n])
+        return int(p.value)

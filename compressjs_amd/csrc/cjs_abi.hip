@@ -203,6 +203,10 @@ struct cjs_ctx {
     u32 last_blocks;
     // optional per-kernel timing of the dominant kernel (bench.py roofline leg)
     K1Prof prof;
+    // state of cjs_bz2_plan
+    K0Buf plan;
+    int plan_level;
+    u32 plan_blocks;
 };
 
 extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
@@ -317,6 +321,75 @@ extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_l
     if ((uint64_t)n > out_cap) return CJS_E_NOSPACE;
     TRYR(hipMemcpy(out, c->dout, (size_t)n, hipMemcpyDeviceToHost));
     return n;
+#undef TRYR
+}
+
+// ---- sharded encoding (multi-GPU): plan once, then encode a block range bit-aligned at 0 ----------
+// cjs_bz2_plan runs the K0 pre-pass over the whole input (kept in the context) and returns the
+// number of bzip2 blocks.  cjs_bz2_encode_blocks encodes blocks [first, first+count) into d_seg
+// WITHOUT stream header/trailer, first block starting at bit 0; returns the number of bits and the
+// partial combined-CRC fold  P = XOR_i rotl^(count-1-i)(crc_i)  so that the caller can chain
+// S' = rotl^count(S) ^ P across shards (lib/Bzip2.js:917 is linear over GF(2)).
+extern "C" int64_t cjs_bz2_plan(cjs_ctx* c, const void* d_in, uint64_t in_len, int level) {
+    if (!c || (!d_in && in_len)) return CJS_E_ARG;
+    if (level < 1 || level > 9) return CJS_E_LEVEL;
+    hipError_t e;
+#define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
+    TRYR(hipSetDevice(c->device));
+    const u32 cap = (u32)level * 100000u - 19u;
+    int rc = grow(&c->k0ws, &c->k0ws_bytes, k0_bytes(in_len, cap));
+    if (rc) return rc;
+    k0_carve(c->plan, (const u8*)d_in, in_len, cap, c->k0ws);
+    c->plan_level = level;
+    rc = k0_prepass(c->plan, cap, c->stream);
+    if (rc) return rc;
+    u32 nblocks = 0;
+    TRYR(hipMemcpyAsync(&nblocks, c->plan.nBlocks, 4, hipMemcpyDeviceToHost, c->stream));
+    TRYR(hipStreamSynchronize(c->stream));
+    c->plan_blocks = nblocks;
+    return (int64_t)nblocks;
+#undef TRYR
+}
+
+extern "C" int64_t cjs_bz2_encode_blocks(cjs_ctx* c, uint32_t first, uint32_t count, void* d_seg,
+                                         uint64_t seg_cap, uint32_t* crc_fold, uint32_t* n_done) {
+    if (!c || !d_seg || !c->plan_level || ((uintptr_t)d_seg & 3) || seg_cap < 64) return CJS_E_ARG;
+    if (first > c->plan_blocks) return CJS_E_ARG;
+    if (first + count > c->plan_blocks) count = c->plan_blocks - first;
+    hipError_t e;
+    int rc;
+#define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
+    TRYR(hipSetDevice(c->device));
+    const u32 cap = (u32)c->plan_level * 100000u - 19u;
+    hipStream_t st = c->stream;
+    BatchGeom g = make_geom(c->batch_blocks, cap);
+    Pipe P;
+    pipe_carve(P, g, c->ws);
+    P.out = (u32*)d_seg;
+    P.outCapBytes = seg_cap & ~(uint64_t)3;
+    P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
+    TRYR(hipEventRecord(c->ev0, st));
+    rc = k5_stream_begin(P, -1, st);                 // level < 0: no "BZh" header, cursor at bit 0
+    if (rc) return rc;
+    for (u32 f = first; f < first + count; f += c->batch_blocks) {
+        const u32 nb = first + count - f < c->batch_blocks ? first + count - f : c->batch_blocks;
+        P.g.nb = nb;
+        P.k1.largeCap = nb * (g.htiles + 1);
+        rc = k0_batch(c->plan, P, f, cap, st);
+        if (rc) return rc;
+        rc = pipe_run_block_stages(P, cap, st, 5);
+        if (rc) return rc;
+    }
+    TRYR(hipEventRecord(c->ev1, st));
+    StreamState hs;
+    TRYR(hipMemcpyAsync(&hs, P.ss, sizeof hs, hipMemcpyDeviceToHost, st));
+    TRYR(hipStreamSynchronize(st));
+    TRYR(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    c->last_blocks = count;
+    if (hs.overflow) return CJS_E_NOSPACE;
+    if (crc_fold) *crc_fold = hs.crc;                // k5 folded from 0: exactly P
+    if (n_done) *n_done = count;
+    return (int64_t)hs.bits;
 #undef TRYR
 }
 

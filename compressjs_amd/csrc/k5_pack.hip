@@ -341,8 +341,8 @@ __global__ __launch_bounds__(256) void k5_pack(Pipe P) {
 // 'B','Z','h','0'+level (lib/Bzip2.js:903-906); resets the running stream state
 __global__ void k5_begin(Pipe P, int level) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        P.out[0] = bswap32(0x425A6800u | (u32)('0' + level));
-        P.ss->bits = 32;
+        if (level > 0) P.out[0] = bswap32(0x425A6800u | (u32)('0' + level));
+        P.ss->bits = level > 0 ? 32 : 0;              // level <= 0: bare block segment (sharded encode)
         P.ss->crc = 0;
         P.ss->overflow = 0;
     }

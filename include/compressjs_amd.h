@@ -27,6 +27,15 @@ int64_t cjs_bz2_compress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int l
 /* The same with input and output resident in HBM (device pointers, d_out 4-byte aligned). */
 int64_t cjs_bz2_compress_device(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level, void* d_out,
                                 uint64_t out_cap);
+/* Sharded encoding for multi-GPU runs (blocks are independent once the RLE1 split is known):
+ * cjs_bz2_plan   = the readBlock chain of lib/Bzip2.js:913-922 over the whole (device) input;
+ *                  returns the number of blocks and keeps the split in the context.
+ * cjs_bz2_encode_blocks = compressBlock (lib/Bzip2.js:735-876) for blocks [first, first+count):
+ *                  bare bit stream in d_seg starting at bit 0 (no "BZh" header, no trailer);
+ *                  returns its length in BITS; *crc_fold = XOR_i rotl^(count-1-i)(blockCRC_i). */
+int64_t cjs_bz2_plan(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level);
+int64_t cjs_bz2_encode_blocks(cjs_ctx* ctx, uint32_t first, uint32_t count, void* d_seg,
+                              uint64_t seg_cap, uint32_t* crc_fold, uint32_t* n_done);
 /* Device time (HIP events on the context's stream) and block count of the last compress call. */
 float cjs_last_device_ms(const cjs_ctx* ctx);
 uint32_t cjs_last_block_count(const cjs_ctx* ctx);

@@ -1,0 +1,64 @@
+"""world_size-2 test of the multi-GPU sharding logic (compressjs_amd/dist.py) on CPU: gloo
+backend, kernels through the CPU logic-debug build.  The assembled stream must equal the
+single-process stream bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import stagelib
+    from compressjs_amd import _lib, synth
+    from compressjs_amd.bzip2 import Context
+    from compressjs_amd.dist import sharded_compress
+    _lib._lib = _lib.load(stagelib.EMU_SO)          # CPU logic-debug build stands in for the GPU
+    ctx = Context(0, 2)
+    data = np.concatenate([synth.text_like(230000, 21), synth.runs_mixed(40000, 2)])
+    d_in = torch.from_numpy(data.copy())
+    out = sharded_compress(ctx, d_in, 1)
+    if rank == 0:
+        q.put(out.numpy().tobytes())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_stream_equals_reference_stream():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stagelib
+    stagelib.build_emu()
+    import oracle
+    from compressjs_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    data = np.concatenate([synth.text_like(230000, 21), synth.runs_mixed(40000, 2)])
+    assert got == oracle.bz2_compress(data, 1)
+
+
+def test_shift_and_trailer_helpers():
+    from compressjs_amd.dist import shift_bits, trailer_bytes, _rotl32
+    seg = torch.tensor([0b10110011, 0b01010101], dtype=torch.uint8)
+    assert shift_bits(seg, 2, 0).tolist() == [0b10110011, 0b01010101, 0]
+    assert shift_bits(seg, 2, 3).tolist() == [0b00010110, 0b01101010, 0b10100000]
+    off, tb, total = trailer_bytes(32, 0)
+    assert off == 4 and total == 14 and tb == bytes.fromhex("17724538509000000000")
+    assert _rotl32(0x80000001, 1) == 0x00000003

@@ -1,0 +1,50 @@
+"""Host-side mirror of the reference API (no GPU needed for these checks) and the C-ABI library's
+export table."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from compressjs_amd import Bzip2, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_invalid_block_size_multiplier_message():
+    for lv in (0, 10, -1, 2.5):
+        with pytest.raises(ValueError, match="Invalid block size multiplier"):   # lib/Bzip2.js:888-890
+            Bzip2.compressFile(b"abc", None, lv)
+
+
+def test_library_exports_every_declared_symbol():
+    """The HIP library must load on a GPU-less machine and export all of include/*.h."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libcompressjs_amd.so not built (run __graft_entry__.build())")
+    hdr = open(os.path.join(ROOT, "include", "compressjs_amd.h")).read()
+    declared = set(re.findall(r"\b(cjs_[a-z0-9_]+)\s*\(", hdr))
+    L = C.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared >= set(_lib.SYMBOLS)
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    if not os.path.exists(_lib.LIB_PATH):
+        with pytest.raises(_lib.CompressjsAmdError):
+            Bzip2.compressFile(b"abc")
+        return
+    with pytest.raises(_lib.CompressjsAmdError, match="no CPU path"):
+        Bzip2.compressFile(b"abc")
+
+
+def test_product_never_imports_the_oracle():
+    pk = os.path.join(ROOT, "compressjs_amd")
+    for dp, _, fs in os.walk(pk):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cc", ".js")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert "import oracle" not in src and "oracle/" not in src.replace("the oracle", ""), f
