@@ -1,0 +1,130 @@
+// N-API addon: the thin binding between Node.js and the C ABI of libcompressjs_amd.so
+// (include/compressjs_amd.h).  Built by plain g++ (no node-gyp): see __graft_entry__.build_addon().
+//
+//   compress(input: Buffer|Uint8Array, level: number) -> Buffer      = Bzip2.compressFile hot path
+//   bwtransform2(T: Uint8Array, U: Uint8Array, n: number) -> pidx     = BWT.bwtransform2
+//
+// The shared library is dlopen()ed at require() time from ../compressjs_amd/ (or
+// $COMPRESSJS_AMD_LIB); a missing library or a missing GPU surfaces as a thrown Error -- there is
+// no JavaScript/CPU fallback for the accelerated path.
+#include <node_api.h>
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+
+typedef struct cjs_ctx cjs_ctx;
+static cjs_ctx* (*p_create)(int, uint32_t);
+static void (*p_destroy)(cjs_ctx*);
+static int64_t (*p_bound)(uint64_t);
+static int64_t (*p_compress)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t);
+static int32_t (*p_bwt)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
+static void* g_lib;
+static cjs_ctx* g_ctx;
+static std::string g_err;
+
+static bool load_lib(const char* path) {
+    if (g_lib) return true;
+    g_lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!g_lib) { g_err = dlerror(); return false; }
+    p_create = (cjs_ctx * (*)(int, uint32_t)) dlsym(g_lib, "cjs_create");
+    p_destroy = (void (*)(cjs_ctx*))dlsym(g_lib, "cjs_destroy");
+    p_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bz2_compress_bound");
+    p_compress = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bz2_compress");
+    p_bwt = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t*))dlsym(g_lib, "cjs_bwt_cyclic");
+    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt) { g_err = "missing symbols"; return false; }
+    return true;
+}
+
+static napi_value throw_code(napi_env env, int64_t rc, const char* what) {
+    char msg[160];
+    if (rc == -20) snprintf(msg, sizeof msg, "Invalid block size multiplier");      // lib/Bzip2.js:889
+    else if (rc == -23) snprintf(msg, sizeof msg, "%s: no HIP device visible (compressjs_amd has no CPU path)", what);
+    else snprintf(msg, sizeof msg, "%s failed with code %lld", what, (long long)rc);
+    napi_throw_error(env, nullptr, msg);
+    return nullptr;
+}
+
+static bool get_bytes(napi_env env, napi_value v, uint8_t** data, size_t* len) {
+    bool is = false;
+    if (napi_is_buffer(env, v, &is) == napi_ok && is)
+        return napi_get_buffer_info(env, v, (void**)data, len) == napi_ok;
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type t; napi_value ab; size_t off;
+        if (napi_get_typedarray_info(env, v, &t, len, (void**)data, &ab, &off) != napi_ok) return false;
+        return t == napi_uint8_array || t == napi_int8_array || t == napi_uint8_clamped_array;
+    }
+    return false;
+}
+
+static napi_value Load(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    char path[4096]; size_t n = 0;
+    napi_get_value_string_utf8(env, argv[0], path, sizeof path, &n);
+    napi_value r;
+    napi_get_boolean(env, load_lib(path), &r);
+    return r;
+}
+
+static napi_value LastError(napi_env env, napi_callback_info) {
+    napi_value r;
+    napi_create_string_utf8(env, g_err.c_str(), NAPI_AUTO_LENGTH, &r);
+    return r;
+}
+
+static bool ensure_ctx(napi_env env) {
+    if (!g_lib) { napi_throw_error(env, nullptr, ("libcompressjs_amd.so not loaded: " + g_err).c_str()); return false; }
+    if (!g_ctx) g_ctx = p_create(0, 32);
+    if (!g_ctx) { throw_code(env, -23, "cjs_create"); return false; }
+    return true;
+}
+
+static napi_value Compress(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t* in; size_t len;
+    if (argc < 2 || !get_bytes(env, argv[0], &in, &len)) { napi_throw_type_error(env, nullptr, "compress(bytes, level)"); return nullptr; }
+    int32_t level = 9;
+    napi_get_value_int32(env, argv[1], &level);
+    if (level < 1 || level > 9) return throw_code(env, -20, "compress");
+    if (!ensure_ctx(env)) return nullptr;
+    const uint64_t cap = (uint64_t)p_bound(len);
+    uint8_t* tmp = (uint8_t*)malloc(cap);
+    if (!tmp) { napi_throw_error(env, nullptr, "out of memory"); return nullptr; }
+    const int64_t n = p_compress(g_ctx, in, len, level, tmp, cap);
+    if (n < 0) { free(tmp); return throw_code(env, n, "cjs_bz2_compress"); }
+    napi_value out; void* dst;
+    napi_create_buffer_copy(env, (size_t)n, tmp, &dst, &out);
+    free(tmp);
+    return out;
+}
+
+static napi_value Bwt2(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t *T, *U; size_t tl, ul; uint32_t n = 0;
+    if (argc < 3 || !get_bytes(env, argv[0], &T, &tl) || !get_bytes(env, argv[1], &U, &ul)) { napi_throw_type_error(env, nullptr, "bwtransform2(T, U, n)"); return nullptr; }
+    napi_get_value_uint32(env, argv[2], &n);
+    if (n > tl || n > ul) { napi_throw_range_error(env, nullptr, "n exceeds the arrays"); return nullptr; }
+    if (!g_lib) { napi_throw_error(env, nullptr, "libcompressjs_amd.so not loaded"); return nullptr; }
+    uint32_t pidx = 0;
+    const int32_t rc = p_bwt(T, U, n, &pidx);
+    if (rc < 0) return throw_code(env, rc, "cjs_bwt_cyclic");
+    napi_value r;
+    napi_create_uint32(env, pidx, &r);
+    return r;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+    napi_property_descriptor d[] = {
+        {"load", nullptr, Load, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"lastError", nullptr, LastError, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"compress", nullptr, Compress, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"bwtransform2", nullptr, Bwt2, nullptr, nullptr, nullptr, napi_default, nullptr},
+    };
+    napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
+    return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -1,0 +1,91 @@
+// Drop-in module for the bzip2 path of cscott/compressjs: same export shape as the reference's
+// main.js:4-28 for the functions on the accelerated path.
+//
+//   Bzip2.compressFile(input, [output], [level])   -> MI355X (N-API addon -> C ABI -> HIP kernels)
+//   BWT.bwtransform2(T, U, n, [alphabetSize])       -> MI355X
+//   everything else (decompressFile, decompressBlock, table, the other 12 codecs)
+//       -> delegated unchanged to an installed reference package (require('compressjs')), when
+//          there is one; otherwise those properties throw.  Decoding is format-determined and is
+//          listed as the next row to accelerate (SURVEY.md 8f-1).
+'use strict';
+var path = require('path');
+var addon = require(path.join(__dirname, '..', 'build', 'compressjs_amd.node'));
+var libPath = process.env.COMPRESSJS_AMD_LIB ||
+    path.join(__dirname, '..', 'compressjs_amd', 'libcompressjs_amd.so');
+var loaded = addon.load(libPath);
+
+var reference = null;
+try { reference = require(process.env.COMPRESSJS_REFERENCE || 'compressjs'); } catch (e) { reference = null; }
+
+var EOF = -1; // Stream.EOF (lib/Stream.js)
+
+// Util.coerceInputStream (lib/Util.js:9-29): buffers as they are; stream objects drained via readByte()
+function inputBytes(input) {
+  if (input && typeof input.readByte === 'function') {
+    var chunks = [], b;
+    while ((b = input.readByte()) !== EOF) chunks.push(b & 0xFF);
+    return Buffer.from(chunks);
+  }
+  if (Buffer.isBuffer(input)) return input;
+  if (input instanceof Uint8Array) return Buffer.from(input.buffer, input.byteOffset, input.length);
+  return Buffer.from(input); // plain Array of byte values
+}
+
+// Util.coerceOutputStream (lib/Util.js:85-103)
+function deliver(bytes, output) {
+  if (!output) return new Uint8Array(bytes.buffer, bytes.byteOffset, bytes.length).slice();
+  if (typeof output === 'object' && typeof output.writeByte === 'function') {
+    for (var i = 0; i < bytes.length; i++) output.writeByte(bytes[i]);
+    if (output.flush) output.flush();
+    return output;
+  }
+  var buf = (typeof output === 'number') ? new Uint8Array(output) : output;
+  if (buf.length !== bytes.length) throw new TypeError('outputsize does not match decoded input');
+  for (var j = 0; j < bytes.length; j++) buf[j] = bytes[j];
+  return buf;
+}
+
+function need() {
+  if (!loaded) throw new Error('compressjs_amd: ' + libPath + ' could not be loaded (' + addon.lastError() +
+                               '); build it with __graft_entry__.build(). There is no JavaScript fallback for the accelerated path.');
+}
+
+var Bzip2 = Object.create(null);
+Bzip2.compressFile = function(inStream, outStream, props) {          // lib/Bzip2.js:879
+  var level = 9;
+  if (typeof props === 'number') level = props;
+  if (level < 1 || level > 9) throw new Error('Invalid block size multiplier');   // :888-890
+  need();
+  return deliver(addon.compress(inputBytes(inStream), level), outStream);
+};
+['decompressFile', 'decompressBlock', 'table'].forEach(function(k) {
+  Bzip2[k] = function() {
+    if (!reference) throw new Error('Bzip2.' + k + ' is not on the accelerated path yet; install the reference package (compressjs) to delegate it');
+    return reference.Bzip2[k].apply(reference.Bzip2, arguments);
+  };
+});
+
+var BWT = Object.create(null);
+BWT.bwtransform2 = function(T, U, n, alphabetSize) {                  // lib/BWT.js:372
+  if (alphabetSize && alphabetSize > 256) {
+    if (reference) return reference.BWT.bwtransform2(T, U, n, alphabetSize);
+    throw new Error('only byte alphabets are accelerated');
+  }
+  need();
+  var t = inputBytes(T), u = Buffer.alloc(Math.max(n, 1));
+  var pidx = addon.bwtransform2(t, u, n);
+  for (var i = 0; i < n; i++) U[i] = u[i];
+  return pidx;
+};
+['suffixsort', 'bwtransform', 'unbwtransform'].forEach(function(k) {
+  BWT[k] = function() {
+    if (!reference) throw new Error('BWT.' + k + ' is not on the accelerated path yet');
+    return reference.BWT[k].apply(reference.BWT, arguments);
+  };
+});
+
+var out = { version: '0.1.0-mi355x', Bzip2: Object.freeze(Bzip2), BWT: Object.freeze(BWT) };
+if (reference) {
+  Object.keys(reference).forEach(function(k) { if (!(k in out)) out[k] = reference[k]; });
+}
+module.exports = Object.freeze(out);

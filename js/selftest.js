@@ -1,0 +1,22 @@
+// node js/selftest.js <golden.json> : compresses a few deterministic inputs through the drop-in
+// module and prints sha256 digests as JSON (compared by tests/test_gpu_js.py with the golden file).
+'use strict';
+var crypto = require('crypto');
+var cjs = require('./index.js');
+function sha(b) { return crypto.createHash('sha256').update(Buffer.from(b)).digest('hex'); }
+var res = {};
+res.a1000 = sha(cjs.Bzip2.compressFile(Buffer.alloc(1000, 'a'), null, 9));
+res.empty = sha(cjs.Bzip2.compressFile(Buffer.alloc(0)));
+var all = Buffer.alloc(256 * 40); for (var i = 0; i < all.length; i++) all[i] = i & 255;
+res.bytes40 = sha(cjs.Bzip2.compressFile(all, null, 9));
+// LCG(250000, 7) of SURVEY.md 8c
+var n = 250000, s = 7, lcg = Buffer.alloc(n);
+for (var k = 0; k < n; k++) { s = (Math.imul(s, 1664525) + 1013904223) >>> 0; lcg[k] = 32 + ((s >>> 16) % 95); }
+res.lcg250000 = sha(cjs.Bzip2.compressFile(lcg, null, 1));
+var U = Buffer.alloc(7);
+res.bwt = [cjs.BWT.bwtransform2(Buffer.from('bcababa'), U, 7, 256), U.toString('ascii')];
+var sink = { bytes: [], writeByte: function(b) { this.bytes.push(b); } };
+cjs.Bzip2.compressFile({ data: Buffer.from('hello hello hello'), i: 0, readByte: function() { return this.i < this.data.length ? this.data[this.i++] : -1; } }, sink, 9);
+res.stream_len = sink.bytes.length;
+try { cjs.Bzip2.compressFile(Buffer.from('x'), null, 0); res.badlevel = 'no throw'; } catch (e) { res.badlevel = e.message; }
+console.log(JSON.stringify(res));

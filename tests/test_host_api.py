@@ -48,3 +48,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cc", ".js")):
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert "import oracle" not in src and "oracle/" not in src.replace("the oracle", ""), f
+
+
+def test_node_dropin_loads_and_fails_loudly_without_gpu():
+    import shutil
+    import subprocess
+    import torch
+    if torch.cuda.is_available() or shutil.which("node") is None:
+        pytest.skip("needs node and no GPU")
+    if not os.path.exists(os.path.join(ROOT, "build", "compressjs_amd.node")):
+        pytest.skip("addon not built")
+    js = ("var c=require('./js');"
+          "try{c.Bzip2.compressFile(Buffer.from('abc'));console.log('NOTHROW')}catch(e){console.log('E1:'+e.message)}"
+          "try{c.Bzip2.compressFile(Buffer.from('abc'),null,0)}catch(e){console.log('E2:'+e.message)}")
+    out = subprocess.check_output(["node", "-e", js], cwd=ROOT).decode()
+    assert "no CPU path" in out and "E2:Invalid block size multiplier" in out and "NOTHROW" not in out
