@@ -33,6 +33,13 @@ def load(path: str | None = None):
         raise CompressjsAmdError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the product has no CPU fallback)" % p)
+    # PyTorch-ROCm bundles its own HIP runtime (same SONAME as /opt/rocm's).  Two runtimes in one
+    # process cannot both own the GPU, so when torch is installed let it load its copy first; the
+    # dynamic loader then binds this library to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
     L = C.CDLL(p)
     vp = C.c_void_p
     L.cjs_create.restype = vp

@@ -56,9 +56,20 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// initial sort: one stable LSD pass on byte T[s + dpos]
+// initial sort by the first 8 bytes: LSD radix over (key32, index) pairs, 8-bit digits.
+//   stage 1 (passes 0-3): key = bytes 4..7 of the rotation, computed from T with coalesced loads;
+//   the scatter of pass 3 re-keys every element with bytes 0..3 (the only random gather of T);
+//   stage 2 (passes 4-7): the same four digit passes on the new key.
+// Each pass = k1_hist (per-tile digit counts) -> k1_scan -> k1_scatter.  The scatter ranks
+// elements with wave ballots (stable), stages the tile in LDS in digit order and writes each
+// digit's run to global memory with consecutive lanes on consecutive addresses.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k1_hist(K1Buf B, BatchGeom g, const u32* in, int dpos, int first) {
+__device__ __forceinline__ u32 load_be32(const u8* p) {
+    return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k1_hist(K1Buf B, BatchGeom g, const u32* keys, int shift) {
     const u32 b = blockIdx.y, t = blockIdx.x;
     const u32 n = B.nlen[b];
     const u32 t0 = t * K1_RT;
@@ -68,13 +79,13 @@ __global__ __launch_bounds__(256) void k1_hist(K1Buf B, BatchGeom g, const u32* 
     for (u32 i = tid; i < 1024; i += 256) (&wh[0][0])[i] = 0;
     __syncthreads();
     const u8* T = B.T + (size_t)b * g.tstride;
-    const u32* inb = in + (size_t)b * g.stride;
+    const u32* kb = keys + (size_t)b * g.stride;
 #pragma unroll 4
     for (int it = 0; it < 16; it++) {
         const u32 j = t0 + w * 1024u + it * 64u + lane;
         if (j < n) {
-            const u32 s = first ? j : inb[j];
-            atomicAdd(&wh[w][T[s + dpos]], 1u);
+            const u32 key = FIRST ? load_be32(T + j + 4) : kb[j];
+            atomicAdd(&wh[w][(key >> shift) & 255u], 1u);
         }
     }
     __syncthreads();
@@ -112,55 +123,81 @@ __global__ __launch_bounds__(1024) void k1_scan(K1Buf B, BatchGeom g) {
     }
 }
 
-__global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u32* in, u32* out, int dpos, int first) {
+template <bool FIRST, bool REKEY>
+__global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u32* kin, const u32* vin, u32* kout,
+                                                  u32* vout, int shift) {
     const u32 b = blockIdx.y, t = blockIdx.x;
     const u32 n = B.nlen[b];
     const u32 t0 = t * K1_RT;
     if (t0 >= n) return;
     __shared__ u32 wh[4][256];
+    __shared__ u32 dstart[256], gbase[256], sh[256];
+    __shared__ u32 lk[K1_RT], lv[K1_RT];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     for (u32 i = tid; i < 1024; i += 256) (&wh[0][0])[i] = 0;
     __syncthreads();
     const u8* T = B.T + (size_t)b * g.tstride;
-    const u32* inb = in + (size_t)b * g.stride;
-    u32* outb = out + (size_t)b * g.stride;
-    u32 sv[16], dv[16];
+    const u32* kb = kin + (size_t)b * g.stride;
+    const u32* vb = vin + (size_t)b * g.stride;
+    u32 kv[16], vv[16];
 #pragma unroll
     for (int it = 0; it < 16; it++) {
         const u32 j = t0 + w * 1024u + it * 64u + lane;
-        u32 s = 0, d = 0;
+        u32 key = 0, val = 0;
         if (j < n) {
-            s = first ? j : inb[j];
-            d = T[s + dpos];
-            atomicAdd(&wh[w][d], 1u);
+            key = FIRST ? load_be32(T + j + 4) : kb[j];
+            val = FIRST ? j : vb[j];
+            atomicAdd(&wh[w][(key >> shift) & 255u], 1u);
         }
-        sv[it] = s;
-        dv[it] = d;
+        kv[it] = key;
+        vv[it] = val;
     }
     __syncthreads();
+    u32 total;
     {
-        u32 o = B.tileHist[((size_t)b * g.rtiles + t) * 256 + tid];
+        u32 o = 0;
 #pragma unroll
         for (int ww = 0; ww < 4; ww++) {
             const u32 c = wh[ww][tid];
-            wh[ww][tid] = o;
+            wh[ww][tid] = o;                      // offset of wave ww inside digit `tid` of this tile
             o += c;
         }
+        total = o;
+        gbase[tid] = B.tileHist[((size_t)b * g.rtiles + t) * 256 + tid];
     }
+    const u32 ds = block_excl_scan_256(total, sh);
+    dstart[tid] = ds;
     __syncthreads();
     const u64 lt = lanemask_lt();
 #pragma unroll
     for (int it = 0; it < 16; it++) {
         const u32 j = t0 + w * 1024u + it * 64u + lane;
         const bool valid = j < n;
-        const u32 d = dv[it];
+        const u32 d = (kv[it] >> shift) & 255u;
         const u64 m = match_any(d, 8, valid);
         const u32 rank = (u32)__popcll(m & lt), cnt = (u32)__popcll(m);
         const u32 base = valid ? wh[w][d] : 0u;
         __builtin_amdgcn_wave_barrier();
         if (valid && rank == 0) wh[w][d] = base + cnt;
         __builtin_amdgcn_wave_barrier();
-        if (valid) outb[base + rank] = sv[it];
+        if (valid) {
+            const u32 lp = dstart[d] + base + rank;
+            lk[lp] = kv[it];
+            lv[lp] = vv[it];
+        }
+    }
+    __syncthreads();
+    const u32 cntv = n - t0 < K1_RT ? n - t0 : K1_RT;
+    u32* ko = kout + (size_t)b * g.stride;
+    u32* vo = vout + (size_t)b * g.stride;
+    for (u32 i = tid; i < cntv; i += 256) {
+        u32 key = lk[i];
+        const u32 val = lv[i];
+        const u32 d = (key >> shift) & 255u;
+        const u32 gp = gbase[d] + (i - dstart[d]);
+        if (REKEY) key = load_be32(T + val);
+        ko[gp] = key;
+        vo[gp] = val;
     }
 }
 
@@ -175,11 +212,16 @@ __global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32* SA = B.SA + (size_t)b * g.stride;
+    const u32* KH = B.KA + (size_t)b * g.stride;     // bytes 0..3 of every rotation, in SA order
     u32* HN = B.HN + (size_t)b * g.hstride;
     for (int it = 0; it < 8; it++) {
         const u32 p = base + w * 512u + it * 64u + lane;
+        u32 hi = 0, lo = 0;
+        if (p < n) { hi = KH[p]; lo = load_be32(T + SA[p] + 4); }
+        u32 phi = __shfl_up(hi, 1u), plo = __shfl_up(lo, 1u);
+        if (lane == 0 && p > 0 && p < n) { phi = KH[p - 1]; plo = load_be32(T + SA[p - 1] + 4); }
         bool head = true;
-        if (p < n && p > 0) head = load_key8(T + SA[p]) != load_key8(T + SA[p - 1]);
+        if (p < n && p > 0) head = (hi != phi) || (lo != plo);
         const u64 bal = __ballot(head);
         if (lane == 0) {
             HN[(p >> 5)] = (u32)bal;
@@ -594,17 +636,22 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const dim3 gridR(g.rtiles, g.nb), gridH(g.htiles, g.nb);
     const u32 initx = (g.hstride + 255) / 256;
     hipLaunchKernelGGL(k1_init, dim3(initx, g.nb), dim3(256), 0, stream, B, g);
-    // 8 LSD passes, last byte first; results alternate SB, SA, ... and end in SA
+    // 8 LSD passes over (key, index) pairs; buffers alternate (KB,SB), (KA,SA), ... and end in (KA,SA)
     for (int p = 0; p < 8; p++) {
-        const int dpos = 7 - p;
-        const u32* in = (p & 1) ? B.SB : B.SA;
-        u32* out = (p & 1) ? B.SA : B.SB;
-        hipLaunchKernelGGL(k1_hist, gridR, dim3(256), 0, stream, B, g, in, dpos, p == 0 ? 1 : 0);
+        const u32* kin = (p & 1) ? B.KB : B.KA;
+        const u32* vin = (p & 1) ? B.SB : B.SA;
+        u32* kout = (p & 1) ? B.KA : B.KB;
+        u32* vout = (p & 1) ? B.SA : B.SB;
+        const int shift = 8 * (p & 3);
+        if (p == 0) hipLaunchKernelGGL(k1_hist<true>, gridR, dim3(256), 0, stream, B, g, kin, shift);
+        else hipLaunchKernelGGL(k1_hist<false>, gridR, dim3(256), 0, stream, B, g, kin, shift);
         hipLaunchKernelGGL(k1_scan, dim3(g.nb), dim3(1024), 0, stream, B, g);
         K1Prof* pr = B.prof;
         const bool timed = pr && pr->enabled && pr->used < K1_PROF_MAX;
         if (timed) (void)hipEventRecord(pr->ev[2 * pr->used], stream);
-        hipLaunchKernelGGL(k1_scatter, gridR, dim3(256), 0, stream, B, g, in, out, dpos, p == 0 ? 1 : 0);
+        if (p == 0) hipLaunchKernelGGL((k1_scatter<true, false>), gridR, dim3(256), 0, stream, B, g, kin, vin, kout, vout, shift);
+        else if (p == 3) hipLaunchKernelGGL((k1_scatter<false, true>), gridR, dim3(256), 0, stream, B, g, kin, vin, kout, vout, shift);
+        else hipLaunchKernelGGL((k1_scatter<false, false>), gridR, dim3(256), 0, stream, B, g, kin, vin, kout, vout, shift);
         if (timed) {
             (void)hipEventRecord(pr->ev[2 * pr->used + 1], stream);
             pr->used++;

@@ -35,6 +35,8 @@ def build_emu():
 
 def load(which: str):
     path = build_emu() if which == "emu" else REAL_SO
+    if which != "emu":
+        import torch  # noqa: F401  (one HIP runtime per process: see compressjs_amd/_lib.py)
     L = C.CDLL(path)
     L.cjs_dbg_block_stages.restype = C.c_int32
     L.cjs_dbg_block_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int,
