@@ -203,7 +203,7 @@ __device__ u64 k0_evalC(const K0Buf& K, u64 i, u64* sh, u32* sh32) {
 }
 
 // smallest i in (from, in_len] with C(i) >= target, or in_len+1 when the total is below target
-__device__ u64 k0_searchC(const K0Buf& K, u64 target, u64 from, u64* sh, u32* sh32) {
+__device__ u64 k0_searchC(const K0Buf& K, u64 target, u64 from, u64* sh, u32* sh32, u64* c_at) {
     const u32 tid = threadIdx.x;
     u64 lo = from / K0_TILE, hi = K.ntiles;                // tiles [lo, hi); Ctile[lo] <= C(from) < target
     while (hi - lo > 256) {
@@ -256,14 +256,22 @@ __device__ u64 k0_searchC(const K0Buf& K, u64 target, u64 from, u64* sh, u32* sh
     unsigned long long* best = (unsigned long long*)sh;
     if (tid == 0) best[0] = ~0ull;
     __syncthreads();
+    u64 myhit = ~0ull, myrun = 0;
     for (int k = 0; k < 16; k++) {
         const u64 j = j0 + k;
         if (j >= K.in_len) break;
         run += cs[k];
-        if (run >= target && j + 1 > from) { atomicMin(&best[0], (unsigned long long)(j + 1)); break; }
+        if (run >= target && j + 1 > from) {
+            myhit = j + 1; myrun = run;
+            atomicMin(&best[0], (unsigned long long)(j + 1));
+            break;
+        }
     }
     __syncthreads();
     const u64 r = best[0];
+    if (r != ~0ull && myhit == r) best[1] = myrun;        // C(r), published by the thread that found it
+    __syncthreads();
+    *c_at = best[1];
     __syncthreads();
     return r == ~0ull ? K.in_len + 1 : r;
 }
@@ -308,7 +316,8 @@ __device__ u64 k0_run_end(const K0Buf& K, u64 s, u64* sh) {
 __global__ __launch_bounds__(256) void k0_chain(K0Buf K, u32 cap) {
     __shared__ u64 sh[256];
     __shared__ u32 sh32[4];
-    u64 s = 0;
+    u64 s = 0, cnext = 0;
+    bool have_cnext = true;                               // C(0) = 0
     u32 kb = 0;
     while (s < K.in_len && kb < K.maxBlocks) {
         const bool cut = s > 0 && K.in[s - 1] == K.in[s];
@@ -340,17 +349,24 @@ __global__ __launch_bounds__(256) void k0_chain(K0Buf K, u32 cap) {
             }
         }
         if (!done) {
-            cbase = k0_evalC(K, re, sh, sh32);            // == C(s) when not cut
+            // C(re); when the block start cuts no run this is C(s) = C(previous block's end)
+            cbase = (!cut && have_cnext) ? cnext : k0_evalC(K, re, sh, sh32);
             adj = cbase - pre;                            // OB_s(i) = C(i) - adj for i >= re
             const u64 target = adj + cap;
-            e = k0_searchC(K, target, re, sh, sh32);
+            u64 ce = 0;
+            e = k0_searchC(K, target, re, sh, sh32, &ce);
             if (e > K.in_len) {                           // EOF before the block filled
                 e = K.in_len;
                 n = (u32)(K.tileC[K.ntiles] - adj);
+                have_cnext = false;
             } else {
-                const u64 ob = k0_evalC(K, e, sh, sh32) - adj;
+                const u64 ob = ce - adj;
                 n = ob < cap ? (u32)ob : cap;
+                cnext = ce;
+                have_cnext = true;
             }
+        } else {
+            have_cnext = false;
         }
         if (threadIdx.x == 0) {
             K.blkStart[kb] = s;

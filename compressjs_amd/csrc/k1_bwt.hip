@@ -234,8 +234,7 @@ __global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g) {
 // rank update: ISA[SA[p]] = position of p's group head under HN, for every p that was in an
 // unsorted group under HC.  Also produces next round's tile flags and active-group count.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int slot_out) {
-    const u32 b = blockIdx.y, t = blockIdx.x;
+__device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeom& g, int slot_out, u32 b, u32 t) {
     const u32 n = B.nlen[b];
     const u32 base = t * K1_HT;
     if (base >= n) return;
@@ -244,14 +243,14 @@ __global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int
         if (threadIdx.x == 0) B.FN[fidx] = 0;
         return;
     }
-    __shared__ u32 hc[66], hn[66];
+    __shared__ u32 hc[68], hn[68];
     __shared__ int prevh[64];
     __shared__ int inHead;
     __shared__ u32 red[2];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* HC = B.HC + (size_t)b * g.hstride;
     const u32* HN = B.HN + (size_t)b * g.hstride;
-    if (tid < 66) {
+    if (tid < 68) {
         hc[tid] = HC[(base >> 5) + tid];
         hn[tid] = HN[(base >> 5) + tid];
     }
@@ -288,12 +287,23 @@ __global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int
     u32* ISA = B.ISA + (size_t)b * g.stride;
     u32 nstart = 0, nact = 0;
     for (int it = 0; it < 8; it++) {
-        const u32 q = w * 512u + it * 64u + lane;
+        const u32 q0 = w * 512u + it * 64u;
+        // 64 positions at once (wave-uniform): heads of this chunk and of the positions after them
+        const u32 wi = q0 >> 5;
+        const u64 c64 = (u64)hc[wi] | ((u64)hc[wi + 1] << 32);
+        const u64 cnx = (c64 >> 1) | ((u64)(hc[wi + 2] & 1u) << 63);
+        const u64 n64 = (u64)hn[wi] | ((u64)hn[wi + 1] << 32);
+        const u64 nnx = (n64 >> 1) | ((u64)(hn[wi + 2] & 1u) << 63);
+        // bits of positions >= n are all set, so they never count as unsorted
+        if (lane == 0) {
+            nact += (u32)__popcll(~(n64 & nnx));
+            nstart += (u32)__popcll(n64 & ~nnx);
+        }
+        const u64 actc = ~(c64 & cnx);
+        if (actc == 0) continue;                                      // wave-uniform
+        const u32 q = q0 + lane;
         const u32 p = base + q;
-        const u32 cb = (hc[q >> 5] >> (q & 31u)) & 1u, cn = (hc[(q + 1) >> 5] >> ((q + 1) & 31u)) & 1u;
-        const u32 nb = (hn[q >> 5] >> (q & 31u)) & 1u, nn = (hn[(q + 1) >> 5] >> ((q + 1) & 31u)) & 1u;
-        const bool in = p < n;
-        if (in && !(cb && cn)) {
+        if ((actc >> lane) & 1u) {
             const u32 wq = q >> 5;
             const u32 mask = hn[wq] & (0xFFFFFFFFu >> (31u - (q & 31u)));
             u32 r;
@@ -302,8 +312,6 @@ __global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int
             else r = (u32)inHead;
             ISA[SA[p]] = r;
         }
-        if (in && !(nb && nn)) nact++;
-        if (in && nb && !nn) nstart++;
     }
     if (nact) atomicAdd(&red[1], nact);
     if (nstart) atomicAdd(&red[0], nstart);
@@ -312,6 +320,12 @@ __global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int
         B.FN[fidx] = (u8)((red[0] ? 1 : 0) | (red[1] ? 2 : 0));
         if (red[0]) atomicAdd(&B.stats[K1_STAT_ACTIVE + slot_out], red[0]);
     }
+}
+
+// (a persistent 8-per-CU grid walking the tiles was measured 2x SLOWER than one workgroup per
+// tile for k1_refine and 12 % slower here: per-tile cost varies too much for static striding)
+__global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int slot_out) {
+    update_ranks_tile(B, g, slot_out, blockIdx.y, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,8 +352,27 @@ __device__ __forceinline__ PosClass classify(const u32* hw, const int* prevh, co
     return c;
 }
 
-__global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, int mode, int round) {
-    const u32 b = blockIdx.y, t = blockIdx.x;
+// true when none of the 64 positions starting at window position q0 (a multiple of 64) belongs to
+// an unsorted group: every position is a head and so is its successor.  Wave-uniform.
+__device__ __forceinline__ bool chunk_all_sorted(const u32* hw, u32 q0) {
+    const u32 wi = q0 >> 5;
+    const u64 m = (u64)hw[wi] | ((u64)hw[wi + 1] << 32);
+    const u64 nx = (m >> 1) | ((u64)(hw[wi + 2] & 1u) << 63);
+    return (m & nx) == ~0ull;
+}
+
+// ascending compare-exchange of LDS pairs (key, value)
+__device__ __forceinline__ void cmpx(u32* ck, u32* cv, u32 lo, u32 hi) {
+    const u32 a = ck[lo], c2 = ck[hi];
+    if (a > c2) {
+        ck[lo] = c2; ck[hi] = a;
+        const u32 va = cv[lo]; cv[lo] = cv[hi]; cv[hi] = va;
+    }
+}
+
+#define K1_SMALL 64        // groups up to this size: enumeration sort; larger (<= K1_HT): bitonic
+
+__device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, u32 h, int mode, int round, u32 b, u32 t) {
     const u32 n = B.nlen[b];
     const u32 base = t * K1_HT;
     if (base >= n) return;
@@ -349,7 +382,8 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
     __shared__ u32 ck[K1_WIN], cv[K1_WIN];
     __shared__ u16 cp[K1_WIN], csz[K1_WIN];
     __shared__ u32 wtot[4];
-    __shared__ u32 maxg;
+    __shared__ u32 biglist[64];
+    __shared__ u32 nbig;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* HC = B.HC + (size_t)b * g.hstride;
     u32* HN = B.HN + (size_t)b * g.hstride;
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
     const u32* ISA = B.ISA + (size_t)b * g.stride;
     const u32 wbase = base >> 5;
     if (tid < 130) hw[tid] = HC[wbase + tid];
-    if (tid == 0) maxg = 0;
+    if (tid == 0) nbig = 0;
     __syncthreads();
     if (tid < 130) {
         int pv = -1;
@@ -378,7 +412,9 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
     // pass 1: count owned positions per wave, register large groups
     u32 cnt = 0;
     for (int it = 0; it < 16; it++) {
-        const u32 q = w * 1024u + it * 64u + lane;
+        const u32 q0 = w * 1024u + it * 64u;
+        if (chunk_all_sorted(hw, q0)) continue;                       // wave-uniform
+        const u32 q = q0 + lane;
         const PosClass c = classify(hw, prevh, nexth, q);
         const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
         const bool owned = c.head >= 0 && c.head < K1_HT && size >= 2 && size <= K1_HT && base + q < n;
@@ -398,7 +434,9 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
     const u32 hm = h % n;
     u32 run = wavebase;
     for (int it = 0; it < 16; it++) {
-        const u32 q = w * 1024u + it * 64u + lane;
+        const u32 q0 = w * 1024u + it * 64u;
+        if (chunk_all_sorted(hw, q0)) continue;
+        const u32 q = q0 + lane;
         const PosClass c = classify(hw, prevh, nexth, q);
         const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
         const bool owned = c.head >= 0 && c.head < K1_HT && size >= 2 && size <= K1_HT && base + q < n;
@@ -418,19 +456,22 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
             cv[e] = s;
             cp[e] = (u16)q;
             csz[e] = (u16)size;
-            if (c.is_head) atomicMax(&maxg, (u32)size);
+            if (c.is_head && size > K1_SMALL) {
+                const u32 bi = atomicAdd(&nbig, 1u);
+                biglist[bi] = e | ((u32)size << 16);
+            }
         }
         run += (u32)__popcll(bal);
     }
     __syncthreads();
-    if (maxg <= 32u) {
-        // enumeration sort inside each (small) group
+    {
+        // enumeration sort inside every small group (<= K1_SMALL elements)
         u32 nk[16], nv[16], ns[16];
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const u32 e = tid + (u32)it * 256u;
             ns[it] = 0xFFFFFFFFu;
-            if (e < m) {
+            if (e < m && csz[e] <= K1_SMALL) {
                 const u32 key = ck[e];
                 const u32 gs = e - ((u32)cp[e] - (key >> 20));
                 const u32 ge = gs + csz[e];
@@ -447,22 +488,29 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
         for (int it = 0; it < 16; it++)
             if (ns[it] != 0xFFFFFFFFu) { ck[ns[it]] = nk[it]; cv[ns[it]] = nv[it]; }
         __syncthreads();
-    } else {
-        u32 M = 64;
-        while (M < m) M <<= 1;
-        for (u32 e = m + tid; e < M; e += 256) { ck[e] = 0xFFFFFFFFu; cv[e] = 0; }
-        __syncthreads();
+    }
+    // bigger groups: in-place bitonic network for arbitrary length (flip + half-cleaners, all
+    // ascending; pairs whose upper index falls beyond the group are skipped)
+    const u32 nb = nbig;
+    for (u32 gi = 0; gi < nb; gi++) {
+        const u32 e0 = biglist[gi] & 0xFFFFu, sz = biglist[gi] >> 16;
+        u32* gk = ck + e0;
+        u32* gv = cv + e0;
+        u32 M = 128;
+        while (M < sz) M <<= 1;
         for (u32 k = 2; k <= M; k <<= 1) {
-            for (u32 j = k >> 1; j > 0; j >>= 1) {
+            const u32 hk = k >> 1;
+            for (u32 i = tid; i < (M >> 1); i += 256) {
+                const u32 blk = i / hk, off = i - blk * hk;
+                const u32 lo = blk * k + off, hi = blk * k + (k - 1u - off);
+                if (hi < sz) cmpx(gk, gv, lo, hi);
+            }
+            __syncthreads();
+            for (u32 j = k >> 2; j > 0; j >>= 1) {
                 for (u32 i = tid; i < (M >> 1); i += 256) {
                     const u32 lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
                     const u32 hi = lo | j;
-                    const bool up = (lo & k) == 0;
-                    const u32 a = ck[lo], c2 = ck[hi];
-                    if ((a > c2) == up) {
-                        ck[lo] = c2; ck[hi] = a;
-                        const u32 va = cv[lo]; cv[lo] = cv[hi]; cv[hi] = va;
-                    }
+                    if (hi < sz) cmpx(gk, gv, lo, hi);
                 }
                 __syncthreads();
             }
@@ -477,6 +525,10 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
         const bool cur = (hw[q >> 5] >> (q & 31u)) & 1u;
         if (newhead && !cur) atomicOr(&HN[p >> 5], 1u << (p & 31u));
     }
+}
+
+__global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, int mode, int round) {
+    refine_tile(B, g, h, mode, round, blockIdx.y, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
