@@ -16,7 +16,8 @@ SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_bz2_compress_bound", "cjs_bz2_compr
            "cjs_bz2_compress_device", "cjs_bz2_plan", "cjs_bz2_encode_blocks",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
            "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch",
-           "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages"]
+           "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages", "cjs_dbg_k1_sparse_rounds",
+           "cjs_dbg_k1_rounds"]
 
 
 class CompressjsAmdError(RuntimeError):

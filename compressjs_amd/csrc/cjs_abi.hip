@@ -5,6 +5,7 @@
 #include "pipeline.h"
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 
 static int ensure_device() {
     int n = 0;
@@ -188,12 +189,23 @@ done:
 // =============================================================================================
 // Product entry points
 // =============================================================================================
+#define CJS_NSTREAMS 4       // sub-batches in flight: latency-bound stages of one sub-batch
+                             // (Huffman optimiser, scans, sparse sort rounds) overlap the
+                             // bandwidth-bound stages of the others
+
 struct cjs_ctx {
     int device;
-    hipStream_t stream;
-    u32 batch_blocks;          // blocks per batch the workspace is sized for
-    void* ws;                  // block-pipeline workspace (level-9 geometry)
+    hipStream_t stream;        // stream 0: pre-pass, framing, timing events
+    hipStream_t sub[CJS_NSTREAMS];
+    hipEvent_t evReady;        // pre-pass + output zeroing done
+    hipEvent_t evScan[CJS_NSTREAMS];   // k5_blockscan of the last sub-batch issued on that stream
+    hipEvent_t evDone[CJS_NSTREAMS];   // everything issued on that stream
+    u32 nstreams;              // streams in use (<= CJS_NSTREAMS; env CJS_STREAMS overrides)
+    u32 batch_blocks;          // blocks in flight over all streams
+    u32 sub_blocks;            // blocks per sub-batch
+    void* ws[CJS_NSTREAMS];    // block-pipeline workspaces (level-9 geometry)
     size_t ws_bytes;
+    StreamState* d_ss;         // stream cursor + combined CRC, shared by all sub-batches
     void* k0ws;                // K0 workspace (grows with the input length)
     size_t k0ws_bytes;
     void* din;  size_t din_bytes;      // staging for the host-buffer entry point
@@ -209,6 +221,8 @@ struct cjs_ctx {
     u32 plan_blocks;
 };
 
+extern "C" void cjs_destroy(cjs_ctx* c);
+
 extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
     if (ensure_device()) return nullptr;
     if (hipSetDevice(device) != hipSuccess) return nullptr;
@@ -216,23 +230,44 @@ extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
     memset(c, 0, sizeof *c);
     c->device = device;
     c->batch_blocks = batch_blocks ? batch_blocks : 128;
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return nullptr; }
-    BatchGeom g = make_geom(c->batch_blocks, 9u * 100000u - 19u);
+    c->nstreams = 1;            // measured: 1 stream 25.8 ms, 2 streams 27.9 ms per 10^8 B (host read-backs in K1 serialise)
+    if (const char* ev = getenv("CJS_STREAMS")) {
+        const int v = atoi(ev);
+        if (v >= 1 && v <= CJS_NSTREAMS) c->nstreams = (u32)v;
+    }
+    c->sub_blocks = (c->batch_blocks + c->nstreams - 1) / c->nstreams;
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+    BatchGeom g = make_geom(c->sub_blocks, 9u * 100000u - 19u);
     c->ws_bytes = pipe_bytes(g);
-    if (hipMalloc(&c->ws, c->ws_bytes) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
-    (void)hipEventCreate(&c->ev0);
-    (void)hipEventCreate(&c->ev1);
+    for (u32 i = 0; ok && i < c->nstreams; i++) {
+        ok = ok && hipStreamCreate(&c->sub[i]) == hipSuccess;
+        ok = ok && hipMalloc(&c->ws[i], c->ws_bytes) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->evScan[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&c->evReady, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_ss, 256) == hipSuccess;
+    ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
+    if (!ok) { cjs_destroy(c); return nullptr; }
     return c;
 }
 
 extern "C" void cjs_destroy(cjs_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(c->ws); (void)hipFree(c->k0ws); (void)hipFree(c->din); (void)hipFree(c->dout);
-    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < CJS_NSTREAMS; i++) {
+        (void)hipFree(c->ws[i]);
+        if (c->evScan[i]) (void)hipEventDestroy(c->evScan[i]);
+        if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]);
+        if (c->sub[i]) (void)hipStreamDestroy(c->sub[i]);
+    }
+    (void)hipFree(c->d_ss); (void)hipFree(c->k0ws); (void)hipFree(c->din); (void)hipFree(c->dout);
+    if (c->evReady) (void)hipEventDestroy(c->evReady);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
     k1_prof_destroy(c->prof);
-    (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -252,6 +287,39 @@ static int grow(void** p, size_t* have, size_t need) {
     return CJS_OK;
 }
 
+// Issue blocks [first, first+count) of the planned input K as sub-batches round-robin over the
+// context's streams.  Stream 0 must already hold the pre-pass + output zeroing (evReady).
+static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 count, void* d_out, uint64_t out_cap) {
+    BatchGeom g = make_geom(c->sub_blocks, cap);
+    hipEvent_t prevScan = nullptr;
+    bool used[CJS_NSTREAMS] = {false, false, false, false};
+    u32 j = 0;
+    for (u32 f = first; f < first + count; f += c->sub_blocks, j++) {
+        const u32 si = j % c->nstreams;
+        hipStream_t st = c->sub[si];
+        const u32 nb = first + count - f < c->sub_blocks ? first + count - f : c->sub_blocks;
+        Pipe P;
+        pipe_carve(P, g, c->ws[si]);
+        P.ss = c->d_ss;
+        P.out = (u32*)d_out;
+        P.outCapBytes = out_cap & ~(uint64_t)3;
+        P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
+        P.g.nb = nb;
+        P.k1.largeCap = nb * (g.htiles + 1);
+        if (!used[si]) { HIP_CHECK_RET(hipStreamWaitEvent(st, c->evReady, 0)); used[si] = true; }
+        int rc = k0_batch(K, P, f, cap, st);
+        if (rc) return rc;
+        rc = pipe_run_block_stages(P, cap, st, 5, prevScan, c->evScan[si]);
+        if (rc) return rc;
+        prevScan = c->evScan[si];
+    }
+    for (int i = 0; i < CJS_NSTREAMS; i++) if (used[i]) {
+        HIP_CHECK_RET(hipEventRecord(c->evDone[i], c->sub[i]));
+        HIP_CHECK_RET(hipStreamWaitEvent(c->stream, c->evDone[i], 0));
+    }
+    return CJS_OK;
+}
+
 extern "C" int64_t cjs_bz2_compress_device(cjs_ctx* c, const void* d_in, uint64_t in_len, int level,
                                            void* d_out, uint64_t out_cap) {
     if (!c || (!d_in && in_len) || !d_out) return CJS_E_ARG;
@@ -267,34 +335,27 @@ extern "C" int64_t cjs_bz2_compress_device(cjs_ctx* c, const void* d_in, uint64_
     if (rc) return rc;
     K0Buf K;
     k0_carve(K, (const u8*)d_in, in_len, cap, c->k0ws);
-    BatchGeom g = make_geom(c->batch_blocks, cap);
-    Pipe P;
-    pipe_carve(P, g, c->ws);
-    P.out = (u32*)d_out;
-    P.outCapBytes = out_cap & ~(uint64_t)3;
-    P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
+    Pipe P0;
+    memset(&P0, 0, sizeof P0);
+    P0.ss = c->d_ss;
+    P0.out = (u32*)d_out;
+    P0.outCapBytes = out_cap & ~(uint64_t)3;
     TRYR(hipEventRecord(c->ev0, st));
     rc = k0_prepass(K, cap, st);
     if (rc) return rc;
-    rc = k5_stream_begin(P, level, st);
+    rc = k5_stream_begin(P0, level, st);
     if (rc) return rc;
+    TRYR(hipEventRecord(c->evReady, st));
     u32 nblocks = 0;
     TRYR(hipMemcpyAsync(&nblocks, K.nBlocks, 4, hipMemcpyDeviceToHost, st));
     TRYR(hipStreamSynchronize(st));
-    for (u32 first = 0; first < nblocks; first += c->batch_blocks) {
-        const u32 nb = nblocks - first < c->batch_blocks ? nblocks - first : c->batch_blocks;
-        P.g.nb = nb;
-        P.k1.largeCap = nb * (g.htiles + 1);
-        rc = k0_batch(K, P, first, cap, st);
-        if (rc) return rc;
-        rc = pipe_run_block_stages(P, cap, st, 5);
-        if (rc) return rc;
-    }
-    rc = k5_stream_end(P, st);
+    rc = issue_blocks(c, K, cap, 0, nblocks, d_out, out_cap);
+    if (rc) return rc;
+    rc = k5_stream_end(P0, st);
     if (rc) return rc;
     TRYR(hipEventRecord(c->ev1, st));
     StreamState hs;
-    TRYR(hipMemcpyAsync(&hs, P.ss, sizeof hs, hipMemcpyDeviceToHost, st));
+    TRYR(hipMemcpyAsync(&hs, c->d_ss, sizeof hs, hipMemcpyDeviceToHost, st));
     TRYR(hipStreamSynchronize(st));
     TRYR(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
     c->last_blocks = nblocks;
@@ -362,27 +423,20 @@ extern "C" int64_t cjs_bz2_encode_blocks(cjs_ctx* c, uint32_t first, uint32_t co
     TRYR(hipSetDevice(c->device));
     const u32 cap = (u32)c->plan_level * 100000u - 19u;
     hipStream_t st = c->stream;
-    BatchGeom g = make_geom(c->batch_blocks, cap);
-    Pipe P;
-    pipe_carve(P, g, c->ws);
-    P.out = (u32*)d_seg;
-    P.outCapBytes = seg_cap & ~(uint64_t)3;
-    P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
+    Pipe P0;
+    memset(&P0, 0, sizeof P0);
+    P0.ss = c->d_ss;
+    P0.out = (u32*)d_seg;
+    P0.outCapBytes = seg_cap & ~(uint64_t)3;
     TRYR(hipEventRecord(c->ev0, st));
-    rc = k5_stream_begin(P, -1, st);                 // level < 0: no "BZh" header, cursor at bit 0
+    rc = k5_stream_begin(P0, -1, st);                // level < 0: no "BZh" header, cursor at bit 0
     if (rc) return rc;
-    for (u32 f = first; f < first + count; f += c->batch_blocks) {
-        const u32 nb = first + count - f < c->batch_blocks ? first + count - f : c->batch_blocks;
-        P.g.nb = nb;
-        P.k1.largeCap = nb * (g.htiles + 1);
-        rc = k0_batch(c->plan, P, f, cap, st);
-        if (rc) return rc;
-        rc = pipe_run_block_stages(P, cap, st, 5);
-        if (rc) return rc;
-    }
+    TRYR(hipEventRecord(c->evReady, st));
+    rc = issue_blocks(c, c->plan, cap, first, count, d_seg, seg_cap);
+    if (rc) return rc;
     TRYR(hipEventRecord(c->ev1, st));
     StreamState hs;
-    TRYR(hipMemcpyAsync(&hs, P.ss, sizeof hs, hipMemcpyDeviceToHost, st));
+    TRYR(hipMemcpyAsync(&hs, c->d_ss, sizeof hs, hipMemcpyDeviceToHost, st));
     TRYR(hipStreamSynchronize(st));
     TRYR(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
     c->last_blocks = count;

@@ -20,6 +20,7 @@
 // All integer; no floating point anywhere.
 #include "k1_bwt.h"
 #include "devutil.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -319,6 +320,7 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
     if (tid == 0) {
         B.FN[fidx] = (u8)((red[0] ? 1 : 0) | (red[1] ? 2 : 0));
         if (red[0]) atomicAdd(&B.stats[K1_STAT_ACTIVE + slot_out], red[0]);
+        if (red[1]) atomicAdd(&B.stats[K1_STAT_ACTPOS + slot_out], red[1]);
     }
 }
 
@@ -636,6 +638,329 @@ __global__ __launch_bounds__(1024) void k1_sort_large(K1Buf B, BatchGeom g, u32 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sparse phase.  Once few positions remain unsorted, a round costs what the unsorted groups cost:
+// groups are kept as descriptors (block, start, length) in device lists; a wave sorts one group of
+// <= 64 rotations in registers, a workgroup one group of <= K1_MED_MAX in LDS.  New ranks go to
+// R (= SB) and are copied into ISA by k1_sp_update after every group of the round has read its
+// keys.  The head bitmaps are not maintained any more.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 sp_desc(u32 b, u32 start, u32 len) {
+    return ((u64)b << 52) | ((u64)start << 26) | (u64)len;
+}
+#define SP_B(d) ((u32)((d) >> 52))
+#define SP_START(d) ((u32)(((d) >> 26) & 0x3FFFFFFu))
+#define SP_LEN(d) ((u32)((d) & 0x3FFFFFFu))
+#define SP_TINY 8u
+
+// Append one descriptor per lane with pred set: ONE atomic per wave and class (the lists' counters
+// are single words; per-lane atomics on them saturate at ~90 per microsecond).  Must be called by
+// all lanes of the wave (wave-uniform control flow).
+__device__ __forceinline__ void sp_append_class(u64* list, u32* counter, u32 cap, bool pred, u64 d) {
+    const u64 m = __ballot(pred);
+    if (m == 0) return;                                          // wave-uniform
+    const int leader = __ffsll((long long)m) - 1;
+    u32 base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, (u32)__popcll(m));
+    base = __shfl(base, leader);
+    if (pred) {
+        const u32 idx = base + (u32)__popcll(m & lanemask_lt());
+        if (idx < cap) list[idx] = d;
+    }
+}
+__device__ __forceinline__ void sp_append(const K1Buf& B, int parity, bool pred, u32 b, u32 start, u32 len) {
+    const u64 d = sp_desc(b, start, len);
+    u32* c = B.stats + K1_STAT_LIST + parity * 3;
+    sp_append_class(B.listT[parity], c + 0, B.listTCap, pred && len <= SP_TINY, d);
+    sp_append_class(B.listS[parity], c + 1, B.listSCap, pred && len > SP_TINY && len <= 64u, d);
+    sp_append_class(B.listM[parity], c + 2, B.listMCap, pred && len > 64u && len <= K1_MED_MAX, d);
+    const u64 big = __ballot(pred && len > K1_MED_MAX);
+    if (big && (threadIdx.x & 63u) == 0) atomicAdd(&B.stats[K1_STAT_LIST + 6], (u32)__popcll(big));
+}
+
+// one descriptor per unsorted group of the current head bitmap (run once, at the switch).
+// Descriptors are staged in LDS per size class; one global atomic per class and workgroup.
+__global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.y, t = blockIdx.x;
+    const u32 n = B.nlen[b];
+    const u32 base = t * K1_HT;
+    if (base >= n) return;
+    if (!(B.FC[(size_t)b * g.htiles + t] & 1)) return;
+    __shared__ u32 hw[132];
+    __shared__ int nexth[132];
+    __shared__ u64 stT[K1_HT / 2], stS[K1_HT / 8], stM[K1_HT / 64];
+    __shared__ u32 cntc[4], basec[3];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32* HC = B.HC + (size_t)b * g.hstride;
+    if (tid < 130) hw[tid] = HC[(base >> 5) + tid];
+    if (tid < 4) cntc[tid] = 0;
+    __syncthreads();
+    if (tid < 130) {
+        int nx = K1_INF;
+        for (int i = (int)tid + 1; i < 130; i++) {
+            const u32 wd = hw[i];
+            if (wd) { nx = i * 32 + __ffs((int)wd) - 1; break; }
+        }
+        nexth[tid] = nx;
+    }
+    __syncthreads();
+    for (int it = 0; it < 8; it++) {
+        const u32 q0 = w * 512u + it * 64u;
+        if (chunk_all_sorted(hw, q0)) continue;                  // wave-uniform
+        const u32 q = q0 + lane;
+        const u32 wq = q >> 5, bq = q & 31u;
+        const u32 word = hw[wq];
+        const bool is_head = (word >> bq) & 1u;
+        const u32 high = bq == 31u ? 0u : (word & (0xFFFFFFFEu << bq));
+        int endp = high ? (int)(wq * 32u + (u32)__ffs((int)high) - 1u) : nexth[wq];
+        const bool starts = is_head && base + q < n && endp != (int)q + 1;
+        if (!starts) continue;
+        if (endp >= K1_INF) {
+            // longer than the window: find the next head in the global bitmap
+            u32 wi = (base >> 5) + 130u;
+            u32 wd = 0;
+            while (wi < g.hstride && (wd = HC[wi]) == 0u) wi++;
+            endp = (int)(wi * 32u + (u32)__ffs((int)wd) - 1u) - (int)base;
+        }
+        const u32 len = (u32)endp - q;
+        const u64 d = sp_desc(b, base + q, len);
+        if (len <= SP_TINY) stT[atomicAdd(&cntc[0], 1u)] = d;
+        else if (len <= 64u) stS[atomicAdd(&cntc[1], 1u)] = d;
+        else if (len <= K1_MED_MAX) stM[atomicAdd(&cntc[2], 1u)] = d;
+        else atomicAdd(&cntc[3], 1u);
+    }
+    __syncthreads();
+    if (tid < 3 && cntc[tid]) basec[tid] = atomicAdd(&B.stats[K1_STAT_LIST + tid], cntc[tid]);
+    if (tid == 3 && cntc[3]) atomicAdd(&B.stats[K1_STAT_LIST + 6], cntc[3]);
+    __syncthreads();
+    for (u32 i = tid; i < cntc[0]; i += 256) if (basec[0] + i < B.listTCap) B.listT[0][basec[0] + i] = stT[i];
+    for (u32 i = tid; i < cntc[1]; i += 256) if (basec[1] + i < B.listSCap) B.listS[0][basec[1] + i] = stS[i];
+    for (u32 i = tid; i < cntc[2]; i += 256) if (basec[2] + i < B.listMCap) B.listM[0][basec[2] + i] = stM[i];
+}
+
+__device__ __forceinline__ u32 sp_key(const K1Buf& B, const BatchGeom& g, u32 b, u32 n, u32 s, u32 hm, int mode) {
+    if (mode) return n - 1u - s;
+    u32 x = s + hm;
+    if (x >= n) x -= n;
+    return B.ISA[(size_t)b * g.stride + x];
+}
+
+// groups of <= 8 rotations: one LANE each.  Keys and values live in registers; an 8-input
+// odd-even merge network (19 compare-exchanges) sorts them, absent slots carry key 0xFFFFFFFF.
+#define SP_CX(i, j) { const bool sw = k##i > k##j; const u32 tk = sw ? k##j : k##i, tv = sw ? v##j : v##i; \
+                      k##j = sw ? k##i : k##j; v##j = sw ? v##i : v##j; k##i = tk; v##i = tv; }
+__global__ __launch_bounds__(256) void k1_sp_tiny(K1Buf B, BatchGeom g, u32 h, int mode, int parity) {
+    u32 cnt = B.stats[K1_STAT_LIST + parity * 3 + 0];
+    if (cnt > B.listTCap) cnt = B.listTCap;
+    const u32 nthreads = gridDim.x * 256u;
+    const u32 rounds = (cnt + nthreads - 1u) / nthreads;        // uniform trip count: appends are wave-wide
+    for (u32 r = 0; r < rounds; r++) {
+        const u32 gi = r * nthreads + blockIdx.x * 256u + threadIdx.x;
+        const bool act = gi < cnt;
+        const u64 d = act ? B.listT[parity][gi] : 0ull;
+        const u32 b = SP_B(d), start = SP_START(d), len = act ? SP_LEN(d) : 0u;
+        const u32 n = act ? B.nlen[b] : 1u;
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32* R = B.SB + (size_t)b * g.stride + start;
+        const u32 hm = h % n;
+        u32 k0 = ~0u, k1 = ~0u, k2 = ~0u, k3 = ~0u, k4 = ~0u, k5 = ~0u, k6 = ~0u, k7 = ~0u;
+        u32 v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0;
+#define SP_LD(i) if (len > i) { v##i = SA[i]; k##i = sp_key(B, g, b, n, v##i, hm, mode); }
+        SP_LD(0) SP_LD(1) SP_LD(2) SP_LD(3) SP_LD(4) SP_LD(5) SP_LD(6) SP_LD(7)
+#undef SP_LD
+        SP_CX(0, 1) SP_CX(2, 3) SP_CX(4, 5) SP_CX(6, 7)
+        SP_CX(0, 2) SP_CX(1, 3) SP_CX(4, 6) SP_CX(5, 7)
+        SP_CX(1, 2) SP_CX(5, 6)
+        SP_CX(0, 4) SP_CX(1, 5) SP_CX(2, 6) SP_CX(3, 7)
+        SP_CX(2, 4) SP_CX(3, 5)
+        SP_CX(1, 2) SP_CX(3, 4) SP_CX(5, 6)
+        // write back, ranks, and the sub-groups that are still tied (at most 4)
+        u32 hp = 0, sub0 = 0, sub1 = 0, sub2 = 0, sub3 = 0, nsub = 0;
+#define SP_ST(i, kprev) if (len > i) { \
+            if (i > 0 && k##i != kprev) { \
+                if (i - hp >= 2u) { const u32 e = hp | ((i - hp) << 8); \
+                    if (nsub == 0) sub0 = e; else if (nsub == 1) sub1 = e; else if (nsub == 2) sub2 = e; else sub3 = e; nsub++; } \
+                hp = i; } \
+            SA[i] = v##i; R[i] = start + hp; }
+        SP_ST(0, 0u) SP_ST(1, k0) SP_ST(2, k1) SP_ST(3, k2) SP_ST(4, k3) SP_ST(5, k4) SP_ST(6, k5) SP_ST(7, k6)
+#undef SP_ST
+        if (len - hp >= 2u && len > 0) {
+            const u32 e = hp | ((len - hp) << 8);
+            if (nsub == 0) sub0 = e; else if (nsub == 1) sub1 = e; else if (nsub == 2) sub2 = e; else sub3 = e;
+            nsub++;
+        }
+        // wave-aggregated append of up to 4 descriptors per lane
+        const u32 incl = wave_incl_scan_u32(nsub);
+        const u32 tot = __shfl(incl, 63);
+        if (tot) {
+            u32 basev = 0;
+            if ((threadIdx.x & 63u) == 63u) basev = atomicAdd(&B.stats[K1_STAT_LIST + (parity ^ 1) * 3 + 0], tot);
+            basev = __shfl(basev, 63);
+            u32 o = basev + incl - nsub;
+            u64* L = B.listT[parity ^ 1];
+            if (nsub > 0 && o < B.listTCap) L[o] = sp_desc(b, start + (sub0 & 255u), sub0 >> 8);
+            if (nsub > 1 && o + 1 < B.listTCap) L[o + 1] = sp_desc(b, start + (sub1 & 255u), sub1 >> 8);
+            if (nsub > 2 && o + 2 < B.listTCap) L[o + 2] = sp_desc(b, start + (sub2 & 255u), sub2 >> 8);
+            if (nsub > 3 && o + 3 < B.listTCap) L[o + 3] = sp_desc(b, start + (sub3 & 255u), sub3 >> 8);
+        }
+    }
+}
+#undef SP_CX
+
+// groups of 9..64 rotations: one wave each, persistent grid
+__global__ __launch_bounds__(256) void k1_sp_small(K1Buf B, BatchGeom g, u32 h, int mode, int parity) {
+    __shared__ u32 sk[4][64];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    u32 cnt = B.stats[K1_STAT_LIST + parity * 3 + 1];
+    if (cnt > B.listSCap) cnt = B.listSCap;
+    const u32 nwaves = gridDim.x * 4u;
+    const u64 lt = lanemask_lt();
+    for (u32 gi = blockIdx.x * 4u + w; gi < cnt; gi += nwaves) {
+        const u64 d = B.listS[parity][gi];
+        const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
+        const u32 n = B.nlen[b];
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32* R = B.SB + (size_t)b * g.stride + start;
+        const bool act = lane < len;
+        const u32 s = act ? SA[lane] : 0u;
+        const u32 k = act ? sp_key(B, g, b, n, s, h % n, mode) : 0xFFFFFFFFu;
+        u32 rank = 0;
+        for (u32 j = 0; j < len; j++) {                        // wave-uniform trip count
+            const u32 kj = __builtin_amdgcn_readlane(k, (int)j);
+            rank += (kj < k || (kj == k && j < lane)) ? 1u : 0u;
+        }
+        if (act) { SA[rank] = s; sk[w][rank] = k; }
+        __builtin_amdgcn_wave_barrier();
+        const u32 mk = act ? sk[w][lane] : 0u;                 // key of the element now at position lane
+        const u32 pk = (act && lane > 0) ? sk[w][lane - 1] : 0u;
+        __builtin_amdgcn_wave_barrier();
+        const bool head = act && (lane == 0 || mk != pk);
+        const u64 hm64 = __ballot(head);
+        u32 sublen = 0;
+        if (act) {
+            const u64 below = hm64 & (lt | (1ull << lane));
+            const u32 hp = 63u - (u32)__clzll((long long)below);
+            R[lane] = start + hp;
+            if (head) {
+                const u64 above = hm64 & ~(lt | (1ull << lane));
+                const u32 nxt = above ? (u32)__ffsll((long long)above) - 1u : len;
+                sublen = nxt - lane;
+            }
+        }
+        sp_append(B, parity ^ 1, sublen >= 2u, b, start + lane, sublen);
+    }
+}
+
+// groups of 65..K1_MED_MAX rotations: one workgroup each, persistent grid
+__global__ __launch_bounds__(256) void k1_sp_medium(K1Buf B, BatchGeom g, u32 h, int mode, int parity) {
+    __shared__ u32 ck[K1_MED_MAX], cv[K1_MED_MAX];
+    __shared__ u32 hb[K1_MED_MAX / 32 + 2];
+    const u32 tid = threadIdx.x;
+    u32 cnt = B.stats[K1_STAT_LIST + parity * 3 + 2];
+    if (cnt > B.listMCap) cnt = B.listMCap;
+    for (u32 gi = blockIdx.x; gi < cnt; gi += gridDim.x) {
+        const u64 d = B.listM[parity][gi];
+        const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
+        const u32 n = B.nlen[b];
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32* R = B.SB + (size_t)b * g.stride + start;
+        const u32 hmod = h % n;
+        for (u32 i = tid; i < len; i += 256) {
+            const u32 s = SA[i];
+            cv[i] = s;
+            ck[i] = sp_key(B, g, b, n, s, hmod, mode);
+        }
+        for (u32 i = tid; i < K1_MED_MAX / 32 + 2; i += 256) hb[i] = 0;
+        __syncthreads();
+        u32 M = 128;
+        while (M < len) M <<= 1;
+        for (u32 k = 2; k <= M; k <<= 1) {
+            const u32 hk = k >> 1;
+            for (u32 i = tid; i < (M >> 1); i += 256) {
+                const u32 blk = i / hk, off = i - blk * hk;
+                const u32 lo = blk * k + off, hi = blk * k + (k - 1u - off);
+                if (hi < len) cmpx(ck, cv, lo, hi);
+            }
+            __syncthreads();
+            for (u32 j = k >> 2; j > 0; j >>= 1) {
+                for (u32 i = tid; i < (M >> 1); i += 256) {
+                    const u32 lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                    const u32 hi = lo | j;
+                    if (hi < len) cmpx(ck, cv, lo, hi);
+                }
+                __syncthreads();
+            }
+        }
+        // heads of the sorted group -> LDS bitmap (bit len is a sentinel head)
+        for (u32 i = tid; i <= len; i += 256) {
+            const bool head = i == 0 || i == len || ck[i] != ck[i - 1];
+            if (head) atomicOr(&hb[i >> 5], 1u << (i & 31u));
+        }
+        __syncthreads();
+        for (u32 i0 = 0; i0 < len; i0 += 256) {                // uniform trip count (wave-wide appends)
+            const u32 i = i0 + tid;
+            u32 sublen = 0;
+            if (i < len) {
+                SA[i] = cv[i];
+                u32 wi = i >> 5;                               // last head <= i
+                u32 m = hb[wi] & (0xFFFFFFFFu >> (31u - (i & 31u)));
+                while (!m) m = hb[--wi];
+                const u32 hp = wi * 32u + 31u - (u32)__clz((int)m);
+                R[i] = start + hp;
+                if (hp == i) {                                 // next head > i
+                    u32 wj = i >> 5;
+                    u32 mm = (i & 31u) == 31u ? 0u : (hb[wj] & (0xFFFFFFFEu << (i & 31u)));
+                    while (!mm) mm = hb[++wj];
+                    sublen = wj * 32u + (u32)__ffs((int)mm) - 1u - i;
+                }
+            }
+            sp_append(B, parity ^ 1, sublen >= 2u, b, start + i, sublen);
+        }
+        __syncthreads();
+    }
+}
+
+// ISA[SA[p]] = R[p] for every position of the groups of this round
+__global__ __launch_bounds__(256) void k1_sp_update(K1Buf B, BatchGeom g, int parity) {
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32* c = B.stats + K1_STAT_LIST + parity * 3;
+    const u32 ct = c[0] < B.listTCap ? c[0] : B.listTCap;
+    const u32 cs = c[1] < B.listSCap ? c[1] : B.listSCap;
+    const u32 cm = c[2] < B.listMCap ? c[2] : B.listMCap;
+    for (u32 gi = blockIdx.x * 256u + tid; gi < ct; gi += gridDim.x * 256u) {
+        const u64 d = B.listT[parity][gi];
+        const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
+        const size_t o = (size_t)b * g.stride + start;
+        for (u32 i = 0; i < len; i++) B.ISA[(size_t)b * g.stride + B.SA[o + i]] = B.SB[o + i];
+    }
+    const u32 nwaves = gridDim.x * 4u;
+    for (u32 gi = blockIdx.x * 4u + w; gi < cs; gi += nwaves) {
+        const u64 d = B.listS[parity][gi];
+        const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
+        if (lane < len) {
+            const size_t o = (size_t)b * g.stride + start + lane;
+            B.ISA[(size_t)b * g.stride + B.SA[o]] = B.SB[o];
+        }
+    }
+    for (u32 gi = blockIdx.x; gi < cm; gi += gridDim.x) {
+        const u64 d = B.listM[parity][gi];
+        const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
+        for (u32 i = tid; i < len; i += 256) {
+            const size_t o = (size_t)b * g.stride + start + i;
+            B.ISA[(size_t)b * g.stride + B.SA[o]] = B.SB[o];
+        }
+    }
+}
+
+__global__ void k1_sp_reset(K1Buf B, int parity) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        B.stats[K1_STAT_LIST + parity * 3 + 0] = 0;
+        B.stats[K1_STAT_LIST + parity * 3 + 1] = 0;
+        B.stats[K1_STAT_LIST + parity * 3 + 2] = 0;
+        B.stats[K1_STAT_LIST + 6] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // BWT gather (lib/BWT.js:407-414)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g) {
@@ -663,6 +988,9 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += al256((size_t)g.nb * g.rtiles * 256 * 4);           // tileHist
     tot += al256(K1_STATS * 4);
     tot += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
+    tot += 2 * al256((size_t)g.nb * (g.stride / 2) * 8);       // listT cur/next
+    tot += 2 * al256((size_t)g.nb * (g.stride / 8) * 8);       // listS cur/next
+    tot += 2 * al256((size_t)g.nb * (g.stride / 64) * 8);      // listM cur/next
     return tot;
 }
 
@@ -680,11 +1008,25 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.FN = (u8*)p; p += al256((size_t)g.nb * g.htiles);
     B.tileHist = (u32*)p; p += al256((size_t)g.nb * g.rtiles * 256 * 4);
     B.stats = (u32*)p; p += al256(K1_STATS * 4);
-    B.large = (uint2*)p;
+    B.large = (uint2*)p; p += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     B.largeCap = g.nb * (g.htiles + 1);
+    B.listTCap = g.nb * (g.stride / 2);
+    B.listSCap = g.nb * (g.stride / 8);
+    B.listMCap = g.nb * (g.stride / 64);
+    B.listT[0] = (u64*)p; p += al256((size_t)B.listTCap * 8);
+    B.listT[1] = (u64*)p; p += al256((size_t)B.listTCap * 8);
+    B.listS[0] = (u64*)p; p += al256((size_t)B.listSCap * 8);
+    B.listS[1] = (u64*)p; p += al256((size_t)B.listSCap * 8);
+    B.listM[0] = (u64*)p; p += al256((size_t)B.listMCap * 8);
+    B.listM[1] = (u64*)p;
 }
 
+static int g_k1_last_sparse_rounds = 0, g_k1_last_rounds = 0;
+extern "C" int cjs_dbg_k1_sparse_rounds() { return g_k1_last_sparse_rounds; }
+extern "C" int cjs_dbg_k1_rounds() { return g_k1_last_rounds; }
+
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
+    int sparse_rounds = 0;
     const dim3 gridR(g.rtiles, g.nb), gridH(g.htiles, g.nb);
     const u32 initx = (g.hstride + 255) / 256;
     hipLaunchKernelGGL(k1_init, dim3(initx, g.nb), dim3(256), 0, stream, B, g);
@@ -716,16 +1058,51 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const size_t hbytes = (size_t)g.nb * g.hstride * 4;
     int round = 0;
     const u32 large_grid = g.nb * 4 < 1024 ? (g.nb * 4 < 64 ? 64 : g.nb * 4) : 1024;
+    bool sparse = false;
+    int parity = 0, retry_at = 0;
+    const u64 total_n = (u64)g.nb * max_n;
+    static const u64 sparse_min = []() -> u64 {              // tests lower this to reach the sparse phase
+        const char* e = getenv("CJS_SPARSE_MIN");
+        return e ? (u64)strtoull(e, nullptr, 10) : (u64)(1u << 20);
+    }();
     for (u64 h = 8;; h <<= 1) {
         const int mode = h >= max_n ? 1 : 0;      // last round: identical rotations by descending index
-        HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(k1_refine, gridH, dim3(256), 0, stream, B, g, (u32)h, mode, round);
-        hipLaunchKernelGGL(k1_sort_large, dim3(large_grid), dim3(1024), 0, stream, B, g, (u32)h, mode, round);
-        hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, round + 1);
-        { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
+        if (!sparse) {
+            HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
+            hipLaunchKernelGGL(k1_refine, gridH, dim3(256), 0, stream, B, g, (u32)h, mode, round);
+            hipLaunchKernelGGL(k1_sort_large, dim3(large_grid), dim3(1024), 0, stream, B, g, (u32)h, mode, round);
+            hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, round + 1);
+            { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
+            if (mode == 0 && round >= retry_at && total_n >= sparse_min) {
+                // how much is still unsorted?  (one small read-back; worth it: a sparse round costs
+                // microseconds, a tile round a fixed ~0.7 ms per 10^8 positions)
+                u32 hs[K1_STATS];
+                HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats, sizeof hs, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK_RET(hipStreamSynchronize(stream));
+                const u64 actpos = hs[K1_STAT_ACTPOS + round + 1];
+                if (actpos == 0) { round++; break; }           // everything sorted: no tie round needed
+                if (actpos * 8 < total_n) {
+                    hipLaunchKernelGGL(k1_build_list, gridH, dim3(256), 0, stream, B, g);
+                    HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats, sizeof hs, hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK_RET(hipStreamSynchronize(stream));
+                    if (hs[K1_STAT_LIST + 6] == 0) { sparse = true; parity = 0; }
+                    else { hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0); retry_at = round + 3; }
+                }
+            }
+        } else {
+            hipLaunchKernelGGL(k1_sp_tiny, dim3(1024), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
+            hipLaunchKernelGGL(k1_sp_small, dim3(2048), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
+            hipLaunchKernelGGL(k1_sp_medium, dim3(512), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
+            hipLaunchKernelGGL(k1_sp_update, dim3(1024), dim3(256), 0, stream, B, g, parity);
+            hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, parity);
+            parity ^= 1;
+            sparse_rounds++;
+        }
         round++;
         if (mode == 1) break;
     }
+    g_k1_last_sparse_rounds = sparse_rounds;
+    g_k1_last_rounds = round;
     hipLaunchKernelGGL(k1_finish, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;

@@ -88,10 +88,11 @@ int k0_prepass(K0Buf K, u32 cap, hipStream_t stream);
 
 int k2_run(Pipe P, u32 max_n, hipStream_t stream);
 int k34_run(Pipe P, hipStream_t stream);
-int k5_run(Pipe P, u32 max_n, hipStream_t stream);
+int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after = nullptr, hipEvent_t done = nullptr);
 int k5_stream_begin(Pipe P, int level, hipStream_t stream);
 int k5_stream_end(Pipe P, hipStream_t stream);
 int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream);
 size_t pipe_bytes(const BatchGeom& g);
 void pipe_carve(Pipe& P, const BatchGeom& g, void* base);
-int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto);
+int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto, hipEvent_t after = nullptr,
+                          hipEvent_t done = nullptr);

@@ -74,12 +74,12 @@ void pipe_carve(Pipe& P, const BatchGeom& g, void* base) {
     P.k1.pidx = P.pidx;
 }
 
-int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto) {
+int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto, hipEvent_t after, hipEvent_t done) {
     int rc = k1_run(P.k1, P.g, max_n, stream);
     if (rc || upto <= 1) return rc;
     rc = k2_run(P, max_n, stream);
     if (rc || upto <= 2) return rc;
     rc = k34_run(P, stream);
     if (rc || upto <= 4) return rc;
-    return k5_run(P, max_n, stream);
+    return k5_run(P, max_n, stream, after, done);
 }

@@ -77,6 +77,8 @@ typedef struct cjs_dbg_stage_out {   /* every pointer may be NULL; pitches in el
 } cjs_dbg_stage_out;
 int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                                uint8_t* U, uint32_t* pidx, int reps, float* ms);
+int cjs_dbg_k1_sparse_rounds(void);   /* rounds of the last K1 run that used the sparse phase */
+int cjs_dbg_k1_rounds(void);
 int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                              int upto, cjs_dbg_stage_out* out);
 

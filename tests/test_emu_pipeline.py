@@ -106,3 +106,32 @@ def test_invalid_level_code(emu_ctx):
     out = np.zeros(256, np.uint8)
     assert L.cjs_bz2_compress(h, d.ctypes.data, 4, 0, out.ctypes.data, 256) == -20
     assert L.cjs_bz2_compress(h, d.ctypes.data, 4, 10, out.ctypes.data, 256) == -20
+
+
+def test_sparse_phase_of_suffix_sort():
+    """K1 switches to list-driven rounds when few positions remain unsorted (normally only for
+    >= 2^20 positions); force it on a small input in a fresh process and compare with the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle, stagelib
+from compressjs_amd import synth
+L = C.CDLL(stagelib.build_emu())
+L.cjs_bwt_cyclic.restype = C.c_int32
+L.cjs_bwt_cyclic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+passage = synth.text_like(700, 3)
+d = np.concatenate([synth.text_like(20000, 1), passage, synth.text_like(15000, 2), passage,
+                    synth.runs_mixed(3000, 1), passage, synth.text_like(9000, 4)])
+u = np.zeros(d.size, np.uint8); p = C.c_uint32(0)
+assert L.cjs_bwt_cyclic(d.ctypes.data, u.ctypes.data, d.size, C.byref(p)) == 0
+uo, po = oracle.bwt_cyclic(d)
+assert p.value == po and (u == uo).all()
+assert L.cjs_dbg_k1_sparse_rounds() >= 3, L.cjs_dbg_k1_sparse_rounds()
+print("ok", L.cjs_dbg_k1_rounds(), L.cjs_dbg_k1_sparse_rounds())
+''' % (stagelib.ROOT, os.path.join(stagelib.ROOT, "tests"))
+    env = dict(os.environ, CJS_SPARSE_MIN="100")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600)
+    assert out.decode().startswith("ok")
