@@ -109,6 +109,45 @@ __device__ void huff_build_wave(const u32* freq, int S, u8* lens, int* keys, int
     __builtin_amdgcn_wave_barrier();
 }
 
+// LDS plan (static, < 64 KB): the 50 KB staging area for the symbol walks is time-shared with the
+// table-build scratch (keys, arr) and the cost histogram, which are never live at the same time.
+#define K34_STAGE_WORDS 800          // 32 groups x 50 symbols x 2 B per wave
+#define K34_GROUPS_PER_CHUNK 32
+
+// Walk every 50-symbol group of A: each wave stages 32 groups (1600 symbols) with coalesced
+// 4-byte loads, then lanes 0..31 read their own group back (stride 25 words: conflict free).
+// `body(gi, sym)` is called for every symbol of group gi by the lane that owns it.
+template <class Body, class Done>
+__device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32* stage_w, Body body, Done done) {
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32* Aw = (const u32*)A;
+    const u32 nchunks = (nSel + K34_GROUPS_PER_CHUNK - 1) / K34_GROUPS_PER_CHUNK;
+    for (u32 c = w; c < nchunks; c += 16) {
+        const u32 g0 = c * K34_GROUPS_PER_CHUNK;
+        const u32 sym0 = g0 * CJS_GROUP;
+        const u32 nsym = pos - sym0 < 1600u ? pos - sym0 : 1600u;
+        const u32 nwords = (nsym + 1u) >> 1;
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const u32 j = lane + 64u * (u32)k;
+            if (j < nwords) stage_w[j] = Aw[(sym0 >> 1) + j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const u32 gi = g0 + lane;
+        if (lane < K34_GROUPS_PER_CHUNK && gi < nSel) {
+            const u32 cnt = pos - gi * CJS_GROUP < CJS_GROUP ? pos - gi * CJS_GROUP : CJS_GROUP;
+            const u32* gw = stage_w + lane * 25u;
+            for (u32 k = 0; k < cnt; k += 2) {
+                const u32 wd = gw[k >> 1];
+                body(gi, wd & 0xFFFFu);
+                if (k + 1 < cnt) body(gi, wd >> 16);
+            }
+            done(gi);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
     const BatchGeom g = P.g;
     const u32 b = blockIdx.x;
@@ -123,15 +162,17 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
     u8* sel = P.sel + (size_t)b * P.selPitch;
     u16* cost = P.selCost + (size_t)b * P.selPitch;
 
+    __shared__ u32 pool[16 * K34_STAGE_WORDS];
     __shared__ u8 lens[CJS_MAX_GROUPS][HB_PITCH];
     __shared__ u32 fr[CJS_MAX_GROUPS][HB_PITCH];
-    __shared__ int keys[CJS_MAX_GROUPS][HB_PITCH];
-    __shared__ int arr[CJS_MAX_GROUPS][HB_PITCH];
     __shared__ u64 lens64[HB_PITCH];
     __shared__ u32 cnt[8];
-    __shared__ u32 chist[1024];
     __shared__ u32 scan_sh[20];
     __shared__ u32 s_which, s_cstar, s_keep;
+    u32* stage_w = pool + w * K34_STAGE_WORDS;
+    int (*keys)[HB_PITCH] = (int (*)[HB_PITCH])pool;                                   // [6][264]
+    int (*arr)[HB_PITCH] = (int (*)[HB_PITCH])(pool + CJS_MAX_GROUPS * HB_PITCH);      // [6][264]
+    u32* chist = pool + 2 * CJS_MAX_GROUPS * HB_PITCH;                                 // [1024]
 
     const u32* gfreq = P.freq + (size_t)b * K2_FREQ_PITCH;
     for (u32 i = tid; i < (u32)S; i += 1024) { fr[0][i] = gfreq[i]; fr[1][i] = 1; }   // :835-837
@@ -148,20 +189,23 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
         }
         __syncthreads();
         // assignSelectors :671-684
-        for (u32 gi = tid; gi < nSel; gi += 1024) {
-            const u32 start = gi * CJS_GROUP;
-            const u32 end = start + CJS_GROUP < pos ? start + CJS_GROUP : pos;
+        {
             u64 acc = 0;
-            for (u32 i = start; i < end; i++) acc += lens64[A[i]];
-            u32 best = 0, bc = (u32)(acc & 1023u);
-            for (int t = 1; t < G; t++) {
-                const u32 c = (u32)((acc >> (10 * t)) & 1023u);
-                if (c < bc) { best = (u32)t; bc = c; }
-            }
-            sel[gi] = (u8)best;
-            cost[gi] = (u16)bc;
+            walk_groups(A, pos, nSel, stage_w,
+                [&](u32, u32 sym) { acc += lens64[sym]; },
+                [&](u32 gi) {
+                    u32 best = 0, bc = (u32)(acc & 1023u);
+                    for (int t = 1; t < G; t++) {
+                        const u32 c = (u32)((acc >> (10 * t)) & 1023u);
+                        if (c < bc) { best = (u32)t; bc = c; }
+                    }
+                    sel[gi] = (u8)best;
+                    cost[gi] = (u16)bc;
+                    acc = 0;
+                });
         }
         if (G >= target) break;
+        __syncthreads();                                  // staging area is reused as chist below
         if (tid < 8) cnt[tid] = 0;
         chist[tid] = 0;
         __syncthreads();
@@ -185,7 +229,7 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
                 if (lower + chist[c] > half) break;
                 lower += chist[c];
             }
-            s_cstar = c;                                  // 1024 when m == 0 (nothing moves)
+            s_cstar = c;
             s_keep = half - lower;
         }
         __syncthreads();
@@ -208,12 +252,9 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
         G++;
         for (u32 i = tid; i < (u32)(CJS_MAX_GROUPS * HB_PITCH); i += 1024) (&fr[0][0])[i] = 0;
         __syncthreads();
-        for (u32 gi = tid; gi < nSel; gi += 1024) {       // recount :717-727
-            u32* f = fr[sel[gi]];
-            const u32 start = gi * CJS_GROUP;
-            const u32 end = start + CJS_GROUP < pos ? start + CJS_GROUP : pos;
-            for (u32 i = start; i < end; i++) atomicAdd(&f[A[i]], 1u);
-        }
+        walk_groups(A, pos, nSel, stage_w,                 // recount :717-727
+            [&](u32 gi, u32 sym) { atomicAdd(&fr[sel[gi]][sym], 1u); },
+            [&](u32) {});
         __syncthreads();
     }
     __syncthreads();
