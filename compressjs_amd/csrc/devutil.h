@@ -61,3 +61,18 @@ __device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* sh, u32* total) 
     __syncthreads();
     return r;
 }
+
+
+// XCD-aware (block, tile) mapping for grids launched as dim3(tiles, round_up(nb, 8)).
+// The dispatcher places consecutive workgroup ids round-robin on the 8 XCDs (observed, used for
+// speed only): with this remap all tiles of one bzip2 block run on the same XCD, so the block's
+// text, suffix array and rank array stay in that XCD's 4 MB L2 while its random gathers and
+// scatters are in flight.  Returns false for the padding workgroups.
+__device__ __forceinline__ bool xcd_block_tile(u32 nb, u32& b, u32& t) {
+    const u32 T = gridDim.x;
+    const u32 L = blockIdx.x + T * blockIdx.y;
+    const u32 xcd = L & 7u, r = L >> 3;
+    t = r % T;
+    b = xcd + 8u * (r / T);
+    return b < nb;
+}

@@ -20,7 +20,7 @@
 //   k0_chain                  -> (start, end, length, correction) of every block of the input
 //   k0_materialize            -> T (RLE1 output) of the blocks of one batch
 //   k0_pad                    -> T_ext wrap-around padding
-//   k0_crc                    -> CRC of the input bytes each block consumed: 256 independent
+//   k0_crc                    -> CRC of the input bytes each block consumed: 1024 independent
 //                                table-driven streams per block, combined with x^(8m) mod P.
 #include "pipeline.h"
 
@@ -469,13 +469,13 @@ __device__ __forceinline__ u32 gf_shift(u32 v, u64 m, const u32* pw) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
+__global__ __launch_bounds__(1024) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
     const u32 b = blockIdx.x, kb = first_block + b, tid = threadIdx.x;
     if (kb >= *K.nBlocks) return;
     __shared__ u32 tab[256];
     __shared__ u32 pw[40];
     __shared__ u32 acc;
-    {   // lib/CRC32.js:37-70
+    if (tid < 256) {   // lib/CRC32.js:37-70
         u32 c = tid << 24;
         for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : (c << 1);
         tab[tid] = c;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k0_crc(K0Buf K, Pipe P, u32 first_block) 
     }
     __syncthreads();
     const u64 s = K.blkStart[kb], e = K.blkEnd[kb], len = e - s;
-    const u64 per = (len + 255) / 256;
+    const u64 per = (len + 1023) / 1024;
     const u64 lo = s + (u64)tid * per < e ? s + (u64)tid * per : e;
     const u64 hi = lo + per < e ? lo + per : e;
     u32 crc = 0;                                          // raw remainder (init 0)
@@ -559,7 +559,7 @@ int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream) {
     const u32 gx = cap / K0_TILE + 2;
     hipLaunchKernelGGL(k0_materialize, dim3(gx, P.g.nb), dim3(256), 0, stream, K, P, first_block, cap);
     hipLaunchKernelGGL(k0_pad, dim3(P.g.nb), dim3(64), 0, stream, P);
-    hipLaunchKernelGGL(k0_crc, dim3(P.g.nb), dim3(256), 0, stream, K, P, first_block);
+    hipLaunchKernelGGL(k0_crc, dim3(P.g.nb), dim3(1024), 0, stream, K, P, first_block);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -5,7 +5,7 @@
 #define K1_STAT_ACTIVE 0    // stats[0..31]  : unsorted-group starts entering round r
 #define K1_STAT_LARGE 32    // stats[32..63] : large groups registered in round r
 #define K1_STAT_ACTPOS 64   // stats[64..95] : positions still in unsorted groups entering round r
-#define K1_STAT_LIST 96     // stats[96..]   : sparse-phase list counters: [parity][3 classes], [6] = too-large count
+#define K1_STAT_LIST 96     // stats[96..103]: sparse-phase list counters [parity][4 size classes]
 #define K1_STATS 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS
 
@@ -41,7 +41,8 @@ struct K1Buf {
     u64* listT[2];    // sparse phase: descriptors of groups of <= 8 rotations (cur/next)
     u64* listS[2];    //               9..64 rotations
     u64* listM[2];    //               65..K1_MED_MAX rotations
-    u32 listTCap, listSCap, listMCap;
+    u64* listL[2];    //               more than K1_MED_MAX rotations
+    u32 listTCap, listSCap, listMCap, listLCap;
     u8* U;            // [nb][stride]   BWT output
     u32* pidx;        // [nb]           origPtr
 };

@@ -327,7 +327,7 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
 // (a persistent 8-per-CU grid walking the tiles was measured 2x SLOWER than one workgroup per
 // tile for k1_refine and 12 % slower here: per-tile cost varies too much for static striding)
 __global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int slot_out) {
-    update_ranks_tile(B, g, slot_out, blockIdx.y, blockIdx.x);
+    update_ranks_tile(B, g, slot_out, blockIdx.y, blockIdx.x);   // XCD-aware mapping measured neutral here
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -411,10 +411,15 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     }
     __syncthreads();
     const u64 lt = lanemask_lt();
+    // positions at or after the first head of the spill half belong to groups that start there,
+    // i.e. to the next tile: chunks beyond it need no look (wave-uniform bound)
+    const u32 spill_end = (hw[K1_HT / 32] & 1u) ? (u32)K1_HT
+                        : (nexth[K1_HT / 32 - 1] < K1_INF ? (u32)nexth[K1_HT / 32 - 1] : (u32)K1_WIN);
     // pass 1: count owned positions per wave, register large groups
     u32 cnt = 0;
     for (int it = 0; it < 16; it++) {
         const u32 q0 = w * 1024u + it * 64u;
+        if (q0 >= spill_end) break;                                   // wave-uniform
         if (chunk_all_sorted(hw, q0)) continue;                       // wave-uniform
         const u32 q = q0 + lane;
         const PosClass c = classify(hw, prevh, nexth, q);
@@ -437,6 +442,7 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     u32 run = wavebase;
     for (int it = 0; it < 16; it++) {
         const u32 q0 = w * 1024u + it * 64u;
+        if (q0 >= spill_end) break;
         if (chunk_all_sorted(hw, q0)) continue;
         const u32 q = q0 + lane;
         const PosClass c = classify(hw, prevh, nexth, q);
@@ -530,7 +536,9 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
 }
 
 __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, int mode, int round) {
-    refine_tile(B, g, h, mode, round, blockIdx.y, blockIdx.x);
+    u32 b, t;
+    if (!xcd_block_tile(g.nb, b, t)) return;
+    refine_tile(B, g, h, mode, round, b, t);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -669,12 +677,11 @@ __device__ __forceinline__ void sp_append_class(u64* list, u32* counter, u32 cap
 }
 __device__ __forceinline__ void sp_append(const K1Buf& B, int parity, bool pred, u32 b, u32 start, u32 len) {
     const u64 d = sp_desc(b, start, len);
-    u32* c = B.stats + K1_STAT_LIST + parity * 3;
+    u32* c = B.stats + K1_STAT_LIST + parity * 4;
     sp_append_class(B.listT[parity], c + 0, B.listTCap, pred && len <= SP_TINY, d);
     sp_append_class(B.listS[parity], c + 1, B.listSCap, pred && len > SP_TINY && len <= 64u, d);
     sp_append_class(B.listM[parity], c + 2, B.listMCap, pred && len > 64u && len <= K1_MED_MAX, d);
-    const u64 big = __ballot(pred && len > K1_MED_MAX);
-    if (big && (threadIdx.x & 63u) == 0) atomicAdd(&B.stats[K1_STAT_LIST + 6], (u32)__popcll(big));
+    sp_append_class(B.listL[parity], c + 3, B.listLCap, pred && len > K1_MED_MAX, d);
 }
 
 // one descriptor per unsorted group of the current head bitmap (run once, at the switch).
@@ -687,8 +694,8 @@ __global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
     if (!(B.FC[(size_t)b * g.htiles + t] & 1)) return;
     __shared__ u32 hw[132];
     __shared__ int nexth[132];
-    __shared__ u64 stT[K1_HT / 2], stS[K1_HT / 8], stM[K1_HT / 64];
-    __shared__ u32 cntc[4], basec[3];
+    __shared__ u64 stT[K1_HT / 2], stS[K1_HT / 8], stM[K1_HT / 64], stL[4];
+    __shared__ u32 cntc[4], basec[4];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* HC = B.HC + (size_t)b * g.hstride;
     if (tid < 130) hw[tid] = HC[(base >> 5) + tid];
@@ -726,12 +733,12 @@ __global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
         if (len <= SP_TINY) stT[atomicAdd(&cntc[0], 1u)] = d;
         else if (len <= 64u) stS[atomicAdd(&cntc[1], 1u)] = d;
         else if (len <= K1_MED_MAX) stM[atomicAdd(&cntc[2], 1u)] = d;
-        else atomicAdd(&cntc[3], 1u);
+        else { const u32 li = atomicAdd(&cntc[3], 1u); if (li < 4u) stL[li] = d; }   // <= 1 can start per tile
     }
     __syncthreads();
-    if (tid < 3 && cntc[tid]) basec[tid] = atomicAdd(&B.stats[K1_STAT_LIST + tid], cntc[tid]);
-    if (tid == 3 && cntc[3]) atomicAdd(&B.stats[K1_STAT_LIST + 6], cntc[3]);
+    if (tid < 4 && cntc[tid]) basec[tid] = atomicAdd(&B.stats[K1_STAT_LIST + tid], cntc[tid]);
     __syncthreads();
+    for (u32 i = tid; i < cntc[3] && i < 4u; i += 256) if (basec[3] + i < B.listLCap) B.listL[0][basec[3] + i] = stL[i];
     for (u32 i = tid; i < cntc[0]; i += 256) if (basec[0] + i < B.listTCap) B.listT[0][basec[0] + i] = stT[i];
     for (u32 i = tid; i < cntc[1]; i += 256) if (basec[1] + i < B.listSCap) B.listS[0][basec[1] + i] = stS[i];
     for (u32 i = tid; i < cntc[2]; i += 256) if (basec[2] + i < B.listMCap) B.listM[0][basec[2] + i] = stM[i];
@@ -749,7 +756,7 @@ __device__ __forceinline__ u32 sp_key(const K1Buf& B, const BatchGeom& g, u32 b,
 #define SP_CX(i, j) { const bool sw = k##i > k##j; const u32 tk = sw ? k##j : k##i, tv = sw ? v##j : v##i; \
                       k##j = sw ? k##i : k##j; v##j = sw ? v##i : v##j; k##i = tk; v##i = tv; }
 __global__ __launch_bounds__(256) void k1_sp_tiny(K1Buf B, BatchGeom g, u32 h, int mode, int parity) {
-    u32 cnt = B.stats[K1_STAT_LIST + parity * 3 + 0];
+    u32 cnt = B.stats[K1_STAT_LIST + parity * 4 + 0];
     if (cnt > B.listTCap) cnt = B.listTCap;
     const u32 nthreads = gridDim.x * 256u;
     const u32 rounds = (cnt + nthreads - 1u) / nthreads;        // uniform trip count: appends are wave-wide
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(256) void k1_sp_tiny(K1Buf B, BatchGeom g, u32 h, i
         const u32 tot = __shfl(incl, 63);
         if (tot) {
             u32 basev = 0;
-            if ((threadIdx.x & 63u) == 63u) basev = atomicAdd(&B.stats[K1_STAT_LIST + (parity ^ 1) * 3 + 0], tot);
+            if ((threadIdx.x & 63u) == 63u) basev = atomicAdd(&B.stats[K1_STAT_LIST + (parity ^ 1) * 4 + 0], tot);
             basev = __shfl(basev, 63);
             u32 o = basev + incl - nsub;
             u64* L = B.listT[parity ^ 1];
@@ -810,7 +817,7 @@ __global__ __launch_bounds__(256) void k1_sp_tiny(K1Buf B, BatchGeom g, u32 h, i
 __global__ __launch_bounds__(256) void k1_sp_small(K1Buf B, BatchGeom g, u32 h, int mode, int parity) {
     __shared__ u32 sk[4][64];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    u32 cnt = B.stats[K1_STAT_LIST + parity * 3 + 1];
+    u32 cnt = B.stats[K1_STAT_LIST + parity * 4 + 1];
     if (cnt > B.listSCap) cnt = B.listSCap;
     const u32 nwaves = gridDim.x * 4u;
     const u64 lt = lanemask_lt();
@@ -855,7 +862,7 @@ __global__ __launch_bounds__(256) void k1_sp_medium(K1Buf B, BatchGeom g, u32 h,
     __shared__ u32 ck[K1_MED_MAX], cv[K1_MED_MAX];
     __shared__ u32 hb[K1_MED_MAX / 32 + 2];
     const u32 tid = threadIdx.x;
-    u32 cnt = B.stats[K1_STAT_LIST + parity * 3 + 2];
+    u32 cnt = B.stats[K1_STAT_LIST + parity * 4 + 2];
     if (cnt > B.listMCap) cnt = B.listMCap;
     for (u32 gi = blockIdx.x; gi < cnt; gi += gridDim.x) {
         const u64 d = B.listM[parity][gi];
@@ -919,13 +926,79 @@ __global__ __launch_bounds__(256) void k1_sp_medium(K1Buf B, BatchGeom g, u32 h,
     }
 }
 
+// groups of more than K1_MED_MAX rotations: one 1024-thread workgroup each; 3 stable 7-bit LSD
+// passes through global memory (SB doubles as value scratch and, afterwards, as the rank array R)
+__global__ __launch_bounds__(1024) void k1_sp_large(K1Buf B, BatchGeom g, u32 h, int mode, int parity) {
+    __shared__ u32 wh[16][128];
+    __shared__ u32 dtot[128];
+    __shared__ u32 scan_sh[20];
+    __shared__ u32 s_carry;
+    const u32 tid = threadIdx.x;
+    u32 cnt = B.stats[K1_STAT_LIST + parity * 4 + 3];
+    if (cnt > B.listLCap) cnt = B.listLCap;
+    for (u32 gi = blockIdx.x; gi < cnt; gi += gridDim.x) {
+        const u64 d = B.listL[parity][gi];
+        const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
+        const u32 n = B.nlen[b];
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32* SB = B.SB + (size_t)b * g.stride + start;
+        u32* KA = B.KA + (size_t)b * g.stride + start;
+        u32* KB = B.KB + (size_t)b * g.stride + start;
+        const u32 hmod = h % n;
+        for (u32 i = tid; i < len; i += 1024) {
+            const u32 s = SA[i];
+            SB[i] = s;
+            KB[i] = sp_key(B, g, b, n, s, hmod, mode);
+        }
+        if (tid == 0) s_carry = 0;                           // (last head position + 1) so far
+        __syncthreads();
+        seg_radix_pass(KB, SB, KA, SA, len, 0, wh, dtot);
+        seg_radix_pass(KA, SA, KB, SB, len, 7, wh, dtot);
+        seg_radix_pass(KB, SB, KA, SA, len, 14, wh, dtot);
+        // ranks (into SB) and the still-tied sub-groups, 1024 positions at a time
+        for (u32 i0 = 0; i0 < len; i0 += 1024) {
+            const u32 i = i0 + tid;
+            const bool in = i < len;
+            const bool head = in && (i == 0 || KA[i] != KA[i - 1]);
+            const u32 v = head ? i + 1u : 0u;
+            // inclusive max-scan over the block (values are monotone where non-zero)
+            u32 m = v;
+            for (u32 off = 1; off < 64; off <<= 1) {
+                const u32 u = __shfl_up(m, off);
+                if ((tid & 63u) >= off && u > m) m = u;
+            }
+            if ((tid & 63u) == 63u) scan_sh[tid >> 6] = m;
+            __syncthreads();
+            u32 wprev = s_carry;
+            for (u32 ww = 0; ww < (tid >> 6); ww++) wprev = scan_sh[ww] > wprev ? scan_sh[ww] : wprev;
+            const u32 incl = m > wprev ? m : wprev;          // last head (+1) at or before i
+            u32 excl = __shfl_up(m, 1u);
+            if ((tid & 63u) == 0) excl = 0;
+            excl = excl > wprev ? excl : wprev;              // last head (+1) strictly before i
+            if (in) SB[i] = start + incl - 1u;
+            const u32 sublen = (head && i > 0) ? i - (excl - 1u) : 0u;
+            sp_append(B, parity ^ 1, sublen >= 2u, b, start + (excl ? excl - 1u : 0u), sublen);
+            __syncthreads();
+            if (tid == 1023) s_carry = incl;
+            __syncthreads();
+        }
+        {
+            const u32 lasthead = s_carry - 1u;               // the final sub-group [lasthead, len)
+            const u32 sublen = len - lasthead;
+            sp_append(B, parity ^ 1, tid == 0 && sublen >= 2u, b, start + lasthead, sublen);
+        }
+        __syncthreads();
+    }
+}
+
 // ISA[SA[p]] = R[p] for every position of the groups of this round
 __global__ __launch_bounds__(256) void k1_sp_update(K1Buf B, BatchGeom g, int parity) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    const u32* c = B.stats + K1_STAT_LIST + parity * 3;
+    const u32* c = B.stats + K1_STAT_LIST + parity * 4;
     const u32 ct = c[0] < B.listTCap ? c[0] : B.listTCap;
     const u32 cs = c[1] < B.listSCap ? c[1] : B.listSCap;
     const u32 cm = c[2] < B.listMCap ? c[2] : B.listMCap;
+    const u32 cl = c[3] < B.listLCap ? c[3] : B.listLCap;
     for (u32 gi = blockIdx.x * 256u + tid; gi < ct; gi += gridDim.x * 256u) {
         const u64 d = B.listT[parity][gi];
         const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
@@ -941,8 +1014,8 @@ __global__ __launch_bounds__(256) void k1_sp_update(K1Buf B, BatchGeom g, int pa
             B.ISA[(size_t)b * g.stride + B.SA[o]] = B.SB[o];
         }
     }
-    for (u32 gi = blockIdx.x; gi < cm; gi += gridDim.x) {
-        const u64 d = B.listM[parity][gi];
+    for (u32 gi = blockIdx.x; gi < cm + cl; gi += gridDim.x) {
+        const u64 d = gi < cm ? B.listM[parity][gi] : B.listL[parity][gi - cm];
         const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
         for (u32 i = tid; i < len; i += 256) {
             const size_t o = (size_t)b * g.stride + start + i;
@@ -952,21 +1025,17 @@ __global__ __launch_bounds__(256) void k1_sp_update(K1Buf B, BatchGeom g, int pa
 }
 
 __global__ void k1_sp_reset(K1Buf B, int parity) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        B.stats[K1_STAT_LIST + parity * 3 + 0] = 0;
-        B.stats[K1_STAT_LIST + parity * 3 + 1] = 0;
-        B.stats[K1_STAT_LIST + parity * 3 + 2] = 0;
-        B.stats[K1_STAT_LIST + 6] = 0;
-    }
+    if (threadIdx.x < 4 && blockIdx.x == 0) B.stats[K1_STAT_LIST + parity * 4 + threadIdx.x] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // BWT gather (lib/BWT.js:407-414)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g) {
-    const u32 b = blockIdx.y;
+    u32 b, tt;
+    if (!xcd_block_tile(g.nb, b, tt)) return;
     const u32 n = B.nlen[b];
-    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    const u32 p = tt * 256u + threadIdx.x;
     if (p >= n) return;
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32 s = B.SA[(size_t)b * g.stride + p];
@@ -991,6 +1060,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += 2 * al256((size_t)g.nb * (g.stride / 2) * 8);       // listT cur/next
     tot += 2 * al256((size_t)g.nb * (g.stride / 8) * 8);       // listS cur/next
     tot += 2 * al256((size_t)g.nb * (g.stride / 64) * 8);      // listM cur/next
+    tot += 2 * al256((size_t)g.nb * (g.stride / K1_MED_MAX + 1) * 8);   // listL cur/next
     return tot;
 }
 
@@ -1018,7 +1088,10 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.listS[0] = (u64*)p; p += al256((size_t)B.listSCap * 8);
     B.listS[1] = (u64*)p; p += al256((size_t)B.listSCap * 8);
     B.listM[0] = (u64*)p; p += al256((size_t)B.listMCap * 8);
-    B.listM[1] = (u64*)p;
+    B.listM[1] = (u64*)p; p += al256((size_t)B.listMCap * 8);
+    B.listLCap = g.nb * (g.stride / K1_MED_MAX + 1);
+    B.listL[0] = (u64*)p; p += al256((size_t)B.listLCap * 8);
+    B.listL[1] = (u64*)p;
 }
 
 static int g_k1_last_sparse_rounds = 0, g_k1_last_rounds = 0;
@@ -1028,6 +1101,7 @@ extern "C" int cjs_dbg_k1_rounds() { return g_k1_last_rounds; }
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     int sparse_rounds = 0;
     const dim3 gridR(g.rtiles, g.nb), gridH(g.htiles, g.nb);
+    const dim3 gridHX(g.htiles, (g.nb + 7u) & ~7u);           // XCD-aware kernels (see xcd_block_tile)
     const u32 initx = (g.hstride + 255) / 256;
     hipLaunchKernelGGL(k1_init, dim3(initx, g.nb), dim3(256), 0, stream, B, g);
     // 8 LSD passes over (key, index) pairs; buffers alternate (KB,SB), (KA,SA), ... and end in (KA,SA)
@@ -1059,7 +1133,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     int round = 0;
     const u32 large_grid = g.nb * 4 < 1024 ? (g.nb * 4 < 64 ? 64 : g.nb * 4) : 1024;
     bool sparse = false;
-    int parity = 0, retry_at = 0;
+    int parity = 0;
     const u64 total_n = (u64)g.nb * max_n;
     static const u64 sparse_min = []() -> u64 {              // tests lower this to reach the sparse phase
         const char* e = getenv("CJS_SPARSE_MIN");
@@ -1069,13 +1143,15 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const int mode = h >= max_n ? 1 : 0;      // last round: identical rotations by descending index
         if (!sparse) {
             HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
-            hipLaunchKernelGGL(k1_refine, gridH, dim3(256), 0, stream, B, g, (u32)h, mode, round);
+            hipLaunchKernelGGL(k1_refine, gridHX, dim3(256), 0, stream, B, g, (u32)h, mode, round);
             hipLaunchKernelGGL(k1_sort_large, dim3(large_grid), dim3(1024), 0, stream, B, g, (u32)h, mode, round);
             hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, round + 1);
             { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
-            if (mode == 0 && round >= retry_at && total_n >= sparse_min) {
-                // how much is still unsorted?  (one small read-back; worth it: a sparse round costs
-                // microseconds, a tile round a fixed ~0.7 ms per 10^8 positions)
+            if (mode == 0 && total_n >= sparse_min) {
+                // How much is still unsorted?  One small read-back per tile round: a list-driven
+                // round costs what the unsorted groups cost, a tile round a fixed ~0.7 ms per 10^8
+                // positions -- but while most positions are still unsorted the tile round is the
+                // faster one (measured on tiled/periodic inputs), so switch below 1/8.
                 u32 hs[K1_STATS];
                 HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats, sizeof hs, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK_RET(hipStreamSynchronize(stream));
@@ -1083,16 +1159,15 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
                 if (actpos == 0) { round++; break; }           // everything sorted: no tie round needed
                 if (actpos * 8 < total_n) {
                     hipLaunchKernelGGL(k1_build_list, gridH, dim3(256), 0, stream, B, g);
-                    HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats, sizeof hs, hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK_RET(hipStreamSynchronize(stream));
-                    if (hs[K1_STAT_LIST + 6] == 0) { sparse = true; parity = 0; }
-                    else { hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0); retry_at = round + 3; }
+                    sparse = true;
+                    parity = 0;
                 }
             }
         } else {
             hipLaunchKernelGGL(k1_sp_tiny, dim3(1024), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
             hipLaunchKernelGGL(k1_sp_small, dim3(2048), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
             hipLaunchKernelGGL(k1_sp_medium, dim3(512), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
+            hipLaunchKernelGGL(k1_sp_large, dim3(256), dim3(1024), 0, stream, B, g, (u32)h, mode, parity);
             hipLaunchKernelGGL(k1_sp_update, dim3(1024), dim3(256), 0, stream, B, g, parity);
             hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, parity);
             parity ^= 1;
@@ -1103,7 +1178,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     }
     g_k1_last_sparse_rounds = sparse_rounds;
     g_k1_last_rounds = round;
-    hipLaunchKernelGGL(k1_finish, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1_finish, dim3((max_n + 255) / 256, (g.nb + 7u) & ~7u), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
