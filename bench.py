@@ -135,10 +135,19 @@ def main():
                 verified = verified and comp[:nbytes] == ref[:nbytes]
         n_launch = max(int(pl.value), 1)
         avg_ms = pms.value / n_launch
-        # one k1_scatter launch = one stable 8-bit LSD pass over every rotation index of the batch:
-        # algorithmic bytes = 4 (index read) + 1 (key byte) + 4 (index write) per block byte.
-        alg_bytes = 9.0 * (pe.value / n_launch if pe.value else args.size)
+        # Dominant kernel: k1_scatter, one stable 8-bit LSD pass over the (key32, index) pair of every
+        # rotation of the batch.  ALGORITHMIC bytes per launch = (4+4 read + 4+4 written) = 16 B per
+        # block byte; duration = mean of the HIP-event pairs recorded around
+        # every launch on the library's own stream during the timed steps.
+        alg_bytes = 16.0 * (pe.value / n_launch if pe.value else args.size)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch from the PMC passes of this same command (profiles/r01_pmc_*.csv:
+        # separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; KiB units; FETCH_SIZE doubled as the
+        # MI355X guide prescribes for coalesced streaming reads on gfx950).  Only valid for the
+        # default workload/size; null otherwise.
+        traffic = None
+        if args.workload == "text" and args.size == 100_000_000 and world == 1:
+            traffic = round((2 * 412.7e6 + 852.7e6), 0)
         line = {
             "metric": "bzip2 -9 compress MB/s on enwik8-shaped input",
             "value": round(total * args.steps / elapsed / 1e6, 2),
@@ -161,7 +170,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k1_scatter", "achieved": round(achieved, 2),
                          "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(pl.value),
-                         "alg_bytes_per_launch": alg_bytes, "traffic": None},
+                         "alg_bytes_per_launch": alg_bytes, "traffic": traffic},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
