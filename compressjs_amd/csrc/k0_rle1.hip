@@ -20,7 +20,7 @@
 //   k0_chain                  -> (start, end, length, correction) of every block of the input
 //   k0_materialize            -> T (RLE1 output) of the blocks of one batch
 //   k0_pad                    -> T_ext wrap-around padding
-//   k0_crc                    -> CRC of the input bytes each block consumed: 1024 independent
+//   k0_crc                    -> CRC of the input bytes each block consumed: 256 independent
 //                                table-driven streams per block, combined with x^(8m) mod P.
 #include "pipeline.h"
 
@@ -469,7 +469,7 @@ __device__ __forceinline__ u32 gf_shift(u32 v, u64 m, const u32* pw) {
     return v;
 }
 
-__global__ __launch_bounds__(1024) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
+__global__ __launch_bounds__(256) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
     const u32 b = blockIdx.x, kb = first_block + b, tid = threadIdx.x;
     if (kb >= *K.nBlocks) return;
     __shared__ u32 tab[256];
@@ -487,11 +487,25 @@ __global__ __launch_bounds__(1024) void k0_crc(K0Buf K, Pipe P, u32 first_block)
     }
     __syncthreads();
     const u64 s = K.blkStart[kb], e = K.blkEnd[kb], len = e - s;
-    const u64 per = (len + 1023) / 1024;
+    const u64 per = (((len + 255) / 256) + 15) & ~(u64)15;    // multiple of 16: aligned 16-byte loads inside
     const u64 lo = s + (u64)tid * per < e ? s + (u64)tid * per : e;
     const u64 hi = lo + per < e ? lo + per : e;
     u32 crc = 0;                                          // raw remainder (init 0)
-    for (u64 j = lo; j < hi; j++) crc = (crc << 8) ^ tab[((crc >> 24) ^ K.in[j]) & 0xffu];
+    u64 j = lo;
+    for (; j < hi && (((uintptr_t)(K.in + j)) & 15u); j++) crc = (crc << 8) ^ tab[((crc >> 24) ^ K.in[j]) & 0xffu];
+    for (; j + 16 <= hi; j += 16) {
+        const uint4 v = *(const uint4*)(K.in + j);
+        const u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 wd = wds[q];                        // little-endian: lowest address in the low byte
+            crc = (crc << 8) ^ tab[((crc >> 24) ^ wd) & 0xffu];
+            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 8)) & 0xffu];
+            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 16)) & 0xffu];
+            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 24)) & 0xffu];
+        }
+    }
+    for (; j < hi; j++) crc = (crc << 8) ^ tab[((crc >> 24) ^ K.in[j]) & 0xffu];
     if (hi > lo) {
         crc = gf_shift(crc, e - hi, pw);
         atomicXor(&acc, crc);
@@ -559,7 +573,7 @@ int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream) {
     const u32 gx = cap / K0_TILE + 2;
     hipLaunchKernelGGL(k0_materialize, dim3(gx, P.g.nb), dim3(256), 0, stream, K, P, first_block, cap);
     hipLaunchKernelGGL(k0_pad, dim3(P.g.nb), dim3(64), 0, stream, P);
-    hipLaunchKernelGGL(k0_crc, dim3(P.g.nb), dim3(1024), 0, stream, K, P, first_block);
+    hipLaunchKernelGGL(k0_crc, dim3(P.g.nb), dim3(256), 0, stream, K, P, first_block);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u3
 // group heads after the 8-byte sort
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g) {
-    const u32 b = blockIdx.y, t = blockIdx.x;
+    u32 b, t;
+    if (!xcd_block_tile(g.nb, b, t)) return;
     const u32 n = B.nlen[b];
     const u32 base = t * K1_HT;
     if (base >= n) return;
@@ -498,9 +499,10 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
         __syncthreads();
     }
     // bigger groups: in-place bitonic network for arbitrary length (flip + half-cleaners, all
-    // ascending; pairs whose upper index falls beyond the group are skipped)
+    // ascending; pairs whose upper index falls beyond the group are skipped).  One WAVE per group:
+    // the waves of the workgroup sort different groups concurrently and need no block barrier.
     const u32 nb = nbig;
-    for (u32 gi = 0; gi < nb; gi++) {
+    for (u32 gi = w; gi < nb; gi += 4) {
         const u32 e0 = biglist[gi] & 0xFFFFu, sz = biglist[gi] >> 16;
         u32* gk = ck + e0;
         u32* gv = cv + e0;
@@ -508,22 +510,23 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
         while (M < sz) M <<= 1;
         for (u32 k = 2; k <= M; k <<= 1) {
             const u32 hk = k >> 1;
-            for (u32 i = tid; i < (M >> 1); i += 256) {
+            for (u32 i = lane; i < (M >> 1); i += 64) {
                 const u32 blk = i / hk, off = i - blk * hk;
                 const u32 lo = blk * k + off, hi = blk * k + (k - 1u - off);
                 if (hi < sz) cmpx(gk, gv, lo, hi);
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             for (u32 j = k >> 2; j > 0; j >>= 1) {
-                for (u32 i = tid; i < (M >> 1); i += 256) {
+                for (u32 i = lane; i < (M >> 1); i += 64) {
                     const u32 lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
                     const u32 hi = lo | j;
                     if (hi < sz) cmpx(gk, gv, lo, hi);
                 }
-                __syncthreads();
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
+    __syncthreads();
     // write back + new heads
     for (u32 e = tid; e < m; e += 256) {
         const u32 q = cp[e];
@@ -1126,7 +1129,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             pr->elements += (u64)g.nb * max_n;
         }
     }
-    hipLaunchKernelGGL(k1_init_heads, gridH, dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g);
     hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, 0);
     { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
     const size_t hbytes = (size_t)g.nb * g.hstride * 4;

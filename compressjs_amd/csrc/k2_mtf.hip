@@ -247,6 +247,9 @@ __global__ __launch_bounds__(256) void k2_symcount(Pipe P) {
     if (threadIdx.x == 0) P.symCnt[(size_t)b * g.rtiles + t] = tot;
 }
 
+// A tile of 4096 runs emits at most 4096 * 21 symbols; the common case fits the LDS stage and is
+// written out with consecutive lanes on consecutive addresses, the rest goes straight to memory.
+#define K2_STAGE 12288
 __global__ __launch_bounds__(256) void k2_emit(Pipe P) {
     const BatchGeom g = P.g;
     const u32 b = blockIdx.y, t = blockIdx.x;
@@ -255,6 +258,8 @@ __global__ __launch_bounds__(256) void k2_emit(Pipe P) {
     if (t0 >= nr) return;
     __shared__ u32 sh[256];
     __shared__ u32 hist[260];
+    __shared__ u16 stage[K2_STAGE];
+    __shared__ u32 s_total;
     const u32 tid = threadIdx.x;
     for (u32 i = tid; i < 260; i += 256) hist[i] = 0;
     const u8* J = P.J + (size_t)b * g.stride;
@@ -267,26 +272,35 @@ __global__ __launch_bounds__(256) void k2_emit(Pipe P) {
         const u32 r = r0 + k;
         if (r < nr) { u32 z; mine += run_symbols(J[r], RHpos[r + 1] - RHpos[r], z); }
     }
-    u32 off = P.symCnt[(size_t)b * g.rtiles + t] + block_excl_scan_256(mine, sh);
+    if (r0 <= nr - 1 && nr - 1 < r0 + 16u) mine += 1u;                 // EOB
+    const u32 ex = block_excl_scan_256(mine, sh);
+    if (tid == 255) s_total = ex + mine;
+    __syncthreads();
+    const u32 total = s_total;
+    const bool staged = total <= K2_STAGE;
+    const u32 tile_off = P.symCnt[(size_t)b * g.rtiles + t];
+    u32 off = ex;                                                      // tile-relative
     for (int k = 0; k < 16; k++) {
         const u32 r = r0 + k;
         if (r >= nr) break;
         const u32 j = J[r];
         u32 z;
         run_symbols(j, RHpos[r + 1] - RHpos[r], z);
-        if (j) { A[off++] = (u16)(j + 1u); atomicAdd(&hist[j + 1u], 1u); }
+#define K2_PUT(sym) do { if (staged) stage[off] = (u16)(sym); else A[tile_off + off] = (u16)(sym); off++; atomicAdd(&hist[(sym)], 1u); } while (0)
+        if (j) K2_PUT(j + 1u);
         while (z) {                                   // lib/Bzip2.js:783-794
-            if (z & 1u) { A[off++] = 0; atomicAdd(&hist[0], 1u); z -= 1u; }
-            else { A[off++] = 1; atomicAdd(&hist[1], 1u); z -= 2u; }
+            if (z & 1u) { K2_PUT(0u); z -= 1u; }
+            else { K2_PUT(1u); z -= 2u; }
             z >>= 1;
         }
         if (r == nr - 1) {                            // end of block symbol, lib/Bzip2.js:814
             const u32 eob = P.alpha[b] + 1u;
-            A[off++] = (u16)eob;
-            atomicAdd(&hist[eob], 1u);
+            K2_PUT(eob);
         }
+#undef K2_PUT
     }
     __syncthreads();
+    if (staged) for (u32 i = tid; i < total; i += 256) A[tile_off + i] = stage[i];
     u32* freq = P.freq + (size_t)b * K2_FREQ_PITCH;
     for (u32 i = tid; i < 260; i += 256) if (hist[i]) atomicAdd(&freq[i], hist[i]);
 }
