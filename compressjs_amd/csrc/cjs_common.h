@@ -22,8 +22,11 @@ typedef unsigned long long u64;
 // Block b of a batch owns element range [b*stride, b*stride + n_b) in every per-element array.
 // stride = level*100000-19 rounded up to a multiple of 4096, plus one guard tile.
 #define K1_RT 4096          // radix-sort tile (elements per workgroup per pass)
-#define K1_HT 2048          // refinement tile (suffix-array positions owned by one workgroup)
+#ifndef K1_HT
+#define K1_HT 1024          // refinement tile (suffix-array positions owned by one workgroup)
+#endif
 #define K1_WIN (2 * K1_HT)  // refinement window: own tile + spill-over of the last owned group
+#define K1_WW (K1_WIN / 32 + 2)  // head-bitmap words a refinement window looks at
 #define K1_TPAD 64          // T_ext holds n + K1_TPAD bytes: T_ext[i] = T[i mod n]
 
 struct BatchGeom {

@@ -216,8 +216,8 @@ __global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g) {
     const u32* SA = B.SA + (size_t)b * g.stride;
     const u32* KH = B.KA + (size_t)b * g.stride;     // bytes 0..3 of every rotation, in SA order
     u32* HN = B.HN + (size_t)b * g.hstride;
-    for (int it = 0; it < 8; it++) {
-        const u32 p = base + w * 512u + it * 64u + lane;
+    for (int it = 0; it < K1_HT / 256; it++) {
+        const u32 p = base + w * (K1_HT / 4u) + it * 64u + lane;
         u32 hi = 0, lo = 0;
         if (p < n) { hi = KH[p]; lo = load_be32(T + SA[p] + 4); }
         u32 phi = __shfl_up(hi, 1u), plo = __shfl_up(lo, 1u);
@@ -245,14 +245,14 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
         if (threadIdx.x == 0) B.FN[fidx] = 0;
         return;
     }
-    __shared__ u32 hc[68], hn[68];
+    __shared__ u32 hc[K1_HT / 32 + 4], hn[K1_HT / 32 + 4];
     __shared__ int prevh[64];
     __shared__ int inHead;
     __shared__ u32 red[2];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* HC = B.HC + (size_t)b * g.hstride;
     const u32* HN = B.HN + (size_t)b * g.hstride;
-    if (tid < 68) {
+    if (tid < K1_HT / 32 + 4) {
         hc[tid] = HC[(base >> 5) + tid];
         hn[tid] = HN[(base >> 5) + tid];
     }
@@ -288,8 +288,8 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
     const u32* SA = B.SA + (size_t)b * g.stride;
     u32* ISA = B.ISA + (size_t)b * g.stride;
     u32 nstart = 0, nact = 0;
-    for (int it = 0; it < 8; it++) {
-        const u32 q0 = w * 512u + it * 64u;
+    for (int it = 0; it < K1_HT / 256; it++) {
+        const u32 q0 = w * (K1_HT / 4u) + it * 64u;
         // 64 positions at once (wave-uniform): heads of this chunk and of the positions after them
         const u32 wi = q0 >> 5;
         const u64 c64 = (u64)hc[wi] | ((u64)hc[wi + 1] << 32);
@@ -327,8 +327,15 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
 
 // (a persistent 8-per-CU grid walking the tiles was measured 2x SLOWER than one workgroup per
 // tile for k1_refine and 12 % slower here: per-tile cost varies too much for static striding)
+// K1_UPT tiles per workgroup: the refinement tile is small for occupancy in k1_refine, but this
+// kernel is dispatch-bound in the later (sparse) rounds, so it walks several tiles per workgroup.
+#define K1_UPT 1   /* measured: 1 tile per workgroup is fastest (latency-bound, wants parallelism) */
 __global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int slot_out) {
-    update_ranks_tile(B, g, slot_out, blockIdx.y, blockIdx.x);   // XCD-aware mapping measured neutral here
+    for (u32 k = 0; k < K1_UPT; k++) {
+        const u32 t = blockIdx.x * K1_UPT + k;
+        if (t < g.htiles) update_ranks_tile(B, g, slot_out, blockIdx.y, t);
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -380,8 +387,8 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     const u32 base = t * K1_HT;
     if (base >= n) return;
     if (!(B.FC[(size_t)b * g.htiles + t] & 1)) return;
-    __shared__ u32 hw[132];
-    __shared__ int prevh[132], nexth[132];
+    __shared__ u32 hw[K1_WW + 2];
+    __shared__ int prevh[K1_WW + 2], nexth[K1_WW + 2];
     __shared__ u32 ck[K1_WIN], cv[K1_WIN];
     __shared__ u16 cp[K1_WIN], csz[K1_WIN];
     __shared__ u32 wtot[4];
@@ -393,10 +400,10 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     u32* SA = B.SA + (size_t)b * g.stride;
     const u32* ISA = B.ISA + (size_t)b * g.stride;
     const u32 wbase = base >> 5;
-    if (tid < 130) hw[tid] = HC[wbase + tid];
+    if (tid < K1_WW) hw[tid] = HC[wbase + tid];
     if (tid == 0) nbig = 0;
     __syncthreads();
-    if (tid < 130) {
+    if (tid < K1_WW) {
         int pv = -1;
         for (int i = (int)tid - 1; i >= 0; i--) {
             const u32 wd = hw[i];
@@ -404,7 +411,7 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
         }
         prevh[tid] = pv;
         int nx = K1_INF;
-        for (int i = (int)tid + 1; i < 130; i++) {
+        for (int i = (int)tid + 1; i < K1_WW; i++) {
             const u32 wd = hw[i];
             if (wd) { nx = i * 32 + __ffs((int)wd) - 1; break; }
         }
@@ -418,8 +425,8 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
                         : (nexth[K1_HT / 32 - 1] < K1_INF ? (u32)nexth[K1_HT / 32 - 1] : (u32)K1_WIN);
     // pass 1: count owned positions per wave, register large groups
     u32 cnt = 0;
-    for (int it = 0; it < 16; it++) {
-        const u32 q0 = w * 1024u + it * 64u;
+    for (int it = 0; it < K1_WIN / 256; it++) {
+        const u32 q0 = w * (K1_WIN / 4u) + it * 64u;
         if (q0 >= spill_end) break;                                   // wave-uniform
         if (chunk_all_sorted(hw, q0)) continue;                       // wave-uniform
         const u32 q = q0 + lane;
@@ -441,8 +448,8 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     // pass 2: gather keys of owned positions into the compact arrays
     const u32 hm = h % n;
     u32 run = wavebase;
-    for (int it = 0; it < 16; it++) {
-        const u32 q0 = w * 1024u + it * 64u;
+    for (int it = 0; it < K1_WIN / 256; it++) {
+        const u32 q0 = w * (K1_WIN / 4u) + it * 64u;
         if (q0 >= spill_end) break;
         if (chunk_all_sorted(hw, q0)) continue;
         const u32 q = q0 + lane;
@@ -475,9 +482,9 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     __syncthreads();
     {
         // enumeration sort inside every small group (<= K1_SMALL elements)
-        u32 nk[16], nv[16], ns[16];
+        u32 nk[K1_WIN / 256], nv[K1_WIN / 256], ns[K1_WIN / 256];
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
+        for (int it = 0; it < K1_WIN / 256; it++) {
             const u32 e = tid + (u32)it * 256u;
             ns[it] = 0xFFFFFFFFu;
             if (e < m && csz[e] <= K1_SMALL) {
@@ -494,7 +501,7 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 16; it++)
+        for (int it = 0; it < K1_WIN / 256; it++)
             if (ns[it] != 0xFFFFFFFFu) { ck[ns[it]] = nk[it]; cv[ns[it]] = nv[it]; }
         __syncthreads();
     }
@@ -689,32 +696,31 @@ __device__ __forceinline__ void sp_append(const K1Buf& B, int parity, bool pred,
 
 // one descriptor per unsorted group of the current head bitmap (run once, at the switch).
 // Descriptors are staged in LDS per size class; one global atomic per class and workgroup.
-__global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
-    const u32 b = blockIdx.y, t = blockIdx.x;
+__device__ __forceinline__ void build_list_tile(const K1Buf& B, const BatchGeom& g, u32 b, u32 t) {
     const u32 n = B.nlen[b];
     const u32 base = t * K1_HT;
     if (base >= n) return;
     if (!(B.FC[(size_t)b * g.htiles + t] & 1)) return;
-    __shared__ u32 hw[132];
-    __shared__ int nexth[132];
+    __shared__ u32 hw[K1_WW + 2];
+    __shared__ int nexth[K1_WW + 2];
     __shared__ u64 stT[K1_HT / 2], stS[K1_HT / 8], stM[K1_HT / 64], stL[4];
     __shared__ u32 cntc[4], basec[4];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* HC = B.HC + (size_t)b * g.hstride;
-    if (tid < 130) hw[tid] = HC[(base >> 5) + tid];
+    if (tid < K1_WW) hw[tid] = HC[(base >> 5) + tid];
     if (tid < 4) cntc[tid] = 0;
     __syncthreads();
-    if (tid < 130) {
+    if (tid < K1_WW) {
         int nx = K1_INF;
-        for (int i = (int)tid + 1; i < 130; i++) {
+        for (int i = (int)tid + 1; i < K1_WW; i++) {
             const u32 wd = hw[i];
             if (wd) { nx = i * 32 + __ffs((int)wd) - 1; break; }
         }
         nexth[tid] = nx;
     }
     __syncthreads();
-    for (int it = 0; it < 8; it++) {
-        const u32 q0 = w * 512u + it * 64u;
+    for (int it = 0; it < K1_HT / 256; it++) {
+        const u32 q0 = w * (K1_HT / 4u) + it * 64u;
         if (chunk_all_sorted(hw, q0)) continue;                  // wave-uniform
         const u32 q = q0 + lane;
         const u32 wq = q >> 5, bq = q & 31u;
@@ -726,7 +732,7 @@ __global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
         if (!starts) continue;
         if (endp >= K1_INF) {
             // longer than the window: find the next head in the global bitmap
-            u32 wi = (base >> 5) + 130u;
+            u32 wi = (base >> 5) + (u32)K1_WW;
             u32 wd = 0;
             while (wi < g.hstride && (wd = HC[wi]) == 0u) wi++;
             endp = (int)(wi * 32u + (u32)__ffs((int)wd) - 1u) - (int)base;
@@ -745,6 +751,13 @@ __global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
     for (u32 i = tid; i < cntc[0]; i += 256) if (basec[0] + i < B.listTCap) B.listT[0][basec[0] + i] = stT[i];
     for (u32 i = tid; i < cntc[1]; i += 256) if (basec[1] + i < B.listSCap) B.listS[0][basec[1] + i] = stS[i];
     for (u32 i = tid; i < cntc[2]; i += 256) if (basec[2] + i < B.listMCap) B.listM[0][basec[2] + i] = stM[i];
+}
+__global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
+    for (u32 k = 0; k < K1_UPT; k++) {
+        const u32 t = blockIdx.x * K1_UPT + k;
+        if (t < g.htiles) build_list_tile(B, g, blockIdx.y, t);
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ u32 sp_key(const K1Buf& B, const BatchGeom& g, u32 b, u32 n, u32 s, u32 hm, int mode) {
@@ -1104,6 +1117,7 @@ extern "C" int cjs_dbg_k1_rounds() { return g_k1_last_rounds; }
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     int sparse_rounds = 0;
     const dim3 gridR(g.rtiles, g.nb), gridH(g.htiles, g.nb);
+    const dim3 gridU((g.htiles + K1_UPT - 1) / K1_UPT, g.nb);
     const dim3 gridHX(g.htiles, (g.nb + 7u) & ~7u);           // XCD-aware kernels (see xcd_block_tile)
     const u32 initx = (g.hstride + 255) / 256;
     hipLaunchKernelGGL(k1_init, dim3(initx, g.nb), dim3(256), 0, stream, B, g);
@@ -1130,7 +1144,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         }
     }
     hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g);
-    hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, 0);
+    hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, 0);
     { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
     const size_t hbytes = (size_t)g.nb * g.hstride * 4;
     int round = 0;
@@ -1148,7 +1162,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
             hipLaunchKernelGGL(k1_refine, gridHX, dim3(256), 0, stream, B, g, (u32)h, mode, round);
             hipLaunchKernelGGL(k1_sort_large, dim3(large_grid), dim3(1024), 0, stream, B, g, (u32)h, mode, round);
-            hipLaunchKernelGGL(k1_update_ranks, gridH, dim3(256), 0, stream, B, g, round + 1);
+            hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, round + 1);
             { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
             if (mode == 0 && total_n >= sparse_min) {
                 // How much is still unsorted?  One small read-back per tile round: a list-driven
@@ -1161,7 +1175,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
                 const u64 actpos = hs[K1_STAT_ACTPOS + round + 1];
                 if (actpos == 0) { round++; break; }           // everything sorted: no tie round needed
                 if (actpos * 8 < total_n) {
-                    hipLaunchKernelGGL(k1_build_list, gridH, dim3(256), 0, stream, B, g);
+                    hipLaunchKernelGGL(k1_build_list, gridU, dim3(256), 0, stream, B, g);
                     sparse = true;
                     parity = 0;
                 }
