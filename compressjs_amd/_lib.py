@@ -13,9 +13,11 @@ _lib = None
 
 # every symbol include/compressjs_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_bz2_compress_bound", "cjs_bz2_compress",
-           "cjs_bz2_compress_device", "cjs_bz2_plan", "cjs_bz2_encode_blocks",
+           "cjs_bz2_compress_device", "cjs_bz2_plan", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
+           "cjs_bwtc_compress_bound",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
-           "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch",
+           "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
+           "cjs_suffixsort",
            "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages", "cjs_dbg_k1_sparse_rounds",
            "cjs_dbg_k1_rounds"]
 
@@ -53,6 +55,10 @@ def load(path: str | None = None):
     L.cjs_bz2_compress.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64]
     L.cjs_bz2_compress_device.restype = C.c_int64
     L.cjs_bz2_compress_device.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64]
+    L.cjs_bwtc_compress_bound.restype = C.c_int64
+    L.cjs_bwtc_compress_bound.argtypes = [C.c_uint64]
+    L.cjs_bwtc_compress.restype = C.c_int64
+    L.cjs_bwtc_compress.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, C.c_int64]
     L.cjs_bz2_plan.restype = C.c_int64
     L.cjs_bz2_plan.argtypes = [vp, vp, C.c_uint64, C.c_int]
     L.cjs_bz2_encode_blocks.restype = C.c_int64
@@ -71,6 +77,10 @@ def load(path: str | None = None):
                                    C.POINTER(C.c_uint64)]
     L.cjs_bwt_cyclic.restype = C.c_int32
     L.cjs_bwt_cyclic.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.cjs_bwt_linear.restype = C.c_int32
+    L.cjs_bwt_linear.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.cjs_suffixsort.restype = C.c_int32
+    L.cjs_suffixsort.argtypes = [vp, vp, C.c_uint32]
     L.cjs_bwt_cyclic_batch.restype = C.c_int32
     L.cjs_bwt_cyclic_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     L.cjs_dbg_bwt_batch_time.restype = C.c_int32
@@ -89,6 +99,8 @@ def check(rc: int, what: str = "call") -> int:
         raise ValueError("Invalid block size multiplier")          # lib/Bzip2.js:888-890
     if rc == -21:
         raise CompressjsAmdError("%s: output buffer too small" % what)
+    if rc == -24:
+        raise CompressjsAmdError("%s: this codec variant is not accelerated (BWTC levels 1-5)" % what)
     if rc == -23:
         raise CompressjsAmdError("%s: no HIP device visible (the product has no CPU path)" % what)
     if rc <= -100:

@@ -50,6 +50,15 @@ class Context:
         _lib.check(n, "cjs_bz2_compress")
         return out[:n].tobytes()
 
+    def bwtc_compress(self, data: np.ndarray, level: int = 9, declared_size=None) -> bytes:
+        d = np.ascontiguousarray(data, dtype=np.uint8)
+        cap = int(self.L.cjs_bwtc_compress_bound(d.size))
+        out = np.empty(cap, dtype=np.uint8)
+        n = self.L.cjs_bwtc_compress(self.h, d.ctypes.data, d.size, int(level), out.ctypes.data, cap,
+                                     d.size if declared_size is None else declared_size)
+        _lib.check(n, "cjs_bwtc_compress")
+        return out[:n].tobytes()
+
     # device-resident (torch tensors on this context's GPU) ----------------------------------
     def compress_device(self, d_in, d_out, level: int = 9) -> int:
         """d_in / d_out: torch uint8 CUDA tensors.  Returns the number of bytes written."""
@@ -163,8 +172,42 @@ class Bzip2:
         return _deliver(out, outStream)
 
 
+class BWTC:
+    """compressjs.BWTC (lib/BWTC.js), compress side, levels 6-9: BWT + MTF/RLE2 on MI355X, the
+    adaptive range coder on the host."""
+
+    @staticmethod
+    def compressFile(inStream, outStream=None, props=None):
+        level = 9
+        if isinstance(props, (int, float)) and not isinstance(props, bool) and 1 <= props <= 9:
+            level = int(props)                                                   # lib/BWTC.js:16-19
+        known = not hasattr(inStream, "readByte") or hasattr(inStream, "size")
+        data = _coerce_input(inStream)
+        size = data.size if known else -1                                        # lib/Util.js:119-124
+        return _deliver(default_context().bwtc_compress(data, level, size), outStream)
+
+
 class BWT:
     """compressjs.BWT (lib/BWT.js:302-419): the cyclic transform used by bzip2."""
+
+    @staticmethod
+    def bwtransform(T, U, A, n, alphabetSize=256):
+        """BWT.bwtransform (lib/BWT.js:328-350); A is the reference's scratch array, unused here."""
+        t = np.ascontiguousarray(np.asarray(T)[:n], dtype=np.uint8)
+        u = np.zeros(max(n, 1), dtype=np.uint8)
+        p = C.c_uint32(0)
+        _lib.check(_lib.load().cjs_bwt_linear(t.ctypes.data, u.ctypes.data, n, C.byref(p)), "cjs_bwt_linear")
+        U[:n] = u[:n] if isinstance(U, np.ndarray) else bytes(u[:n])
+        return int(p.value)
+
+    @staticmethod
+    def suffixsort(T, SA, n, alphabetSize=256):
+        """BWT.suffixsort (lib/BWT.js:305-321)."""
+        t = np.ascontiguousarray(np.asarray(T)[:n], dtype=np.uint8)
+        sa = np.zeros(max(n, 1), dtype=np.int32)
+        _lib.check(_lib.load().cjs_suffixsort(t.ctypes.data, sa.ctypes.data, n), "cjs_suffixsort")
+        SA[:n] = sa[:n]
+        return 0
 
     @staticmethod
     def bwtransform2(T, U, n, alphabetSize=256):

@@ -3,6 +3,7 @@
 #include "cjs_common.h"
 #include "k1_bwt.h"
 #include "pipeline.h"
+#include "bwtc_host.h"
 #include <vector>
 #include <string.h>
 #include <stdlib.h>
@@ -15,7 +16,8 @@ static int ensure_device() {
 
 // Cyclic BWT of several independent blocks (block i = T + i*cap, length nlen[i] <= cap).
 static int32_t bwt_batch_impl(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
-                              uint8_t* U, uint32_t* pidx, int reps, float* ms_out) {
+                              uint8_t* U, uint32_t* pidx, int reps, float* ms_out, int linear = 0,
+                              int32_t* SAout = nullptr) {
     if (!T || !U || !nlen || !pidx || nb == 0 || cap == 0 || cap > (1u << 20) - 1) return CJS_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
@@ -32,13 +34,14 @@ static int32_t bwt_batch_impl(const uint8_t* T, const uint32_t* nlen, uint32_t n
         const u8* src = T + (size_t)b * cap;
         if (n) {
             memcpy(dst, src, n);
-            for (u32 i = 0; i < K1_TPAD; i++) dst[n + i] = dst[i % n] ;
+            for (u32 i = 0; i < K1_TPAD; i++) dst[n + i] = linear ? 0 : dst[i % n];
         }
     }
     // blocks of length 0/1 never reach the kernels (lib/BWT.js:376-379)
     K1Buf B;
     memset(&B, 0, sizeof B);
     u8 *dT = nullptr, *dU = nullptr; u32 *dN = nullptr, *dP = nullptr; void* ws = nullptr;
+    int* dSA = nullptr;
     const size_t wsb = k1_workspace_bytes(g);
     hipStream_t st = nullptr;
     hipError_t e;
@@ -54,6 +57,8 @@ static int32_t bwt_batch_impl(const uint8_t* T, const uint32_t* nlen, uint32_t n
     TRY(hipMemsetAsync(dP, 0, nb * 4, st));
     k1_carve(B, g, ws);
     B.T = dT; B.nlen = dN; B.U = dU; B.pidx = dP;
+    B.linear = linear ? 1u : 0u;
+    if (SAout) { TRY(hipMalloc((void**)&dSA, (size_t)nb * g.stride * 4)); B.SAout = dSA; }
     if (max_n >= 2) {
         hipEvent_t e0, e1;
         TRY(hipEventCreate(&e0)); TRY(hipEventCreate(&e1));
@@ -75,12 +80,16 @@ static int32_t bwt_batch_impl(const uint8_t* T, const uint32_t* nlen, uint32_t n
         TRY(hipMemcpy(pidx, dP, nb * 4, hipMemcpyDeviceToHost));
         for (u32 b = 0; b < nb; b++) {
             if (lens[b] >= 2) memcpy(U + (size_t)b * cap, hu.data() + (size_t)b * g.stride, lens[b]);
-            else { if (lens[b] == 1) U[(size_t)b * cap] = T[(size_t)b * cap]; pidx[b] = 0; }
+            else { if (lens[b] == 1) U[(size_t)b * cap] = T[(size_t)b * cap]; pidx[b] = linear ? lens[b] : 0; }   // lib/BWT.js:332-335,376-379
+        }
+        if (SAout) for (u32 b = 0; b < nb; b++) {
+            if (lens[b] >= 2) { TRY(hipMemcpy(SAout + (size_t)b * cap, dSA + (size_t)b * g.stride, (size_t)lens[b] * 4, hipMemcpyDeviceToHost)); }
+            else if (lens[b] == 1) SAout[(size_t)b * cap] = 0;
         }
     }
 done:
     if (st) (void)hipStreamDestroy(st);
-    (void)hipFree(dT); (void)hipFree(dU); (void)hipFree(dN); (void)hipFree(dP); (void)hipFree(ws);
+    (void)hipFree(dT); (void)hipFree(dU); (void)hipFree(dN); (void)hipFree(dP); (void)hipFree(ws); (void)hipFree(dSA);
     return rc;
 #undef TRY
 }
@@ -93,6 +102,20 @@ extern "C" int32_t cjs_bwt_cyclic_batch(const uint8_t* T, const uint32_t* nlen, 
 extern "C" int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                                           uint8_t* U, uint32_t* pidx, int reps, float* ms) {
     return bwt_batch_impl(T, nlen, nb, cap, U, pidx, reps, ms);
+}
+
+// = BWT.bwtransform(T, U, A, n, 256) -> pidx   (lib/BWT.js:328-350): BWT of T$ with implicit sentinel
+extern "C" int32_t cjs_bwt_linear(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx) {
+    if (n == 0) { if (pidx) *pidx = 0; return CJS_OK; }
+    return bwt_batch_impl(T, &n, 1, n, U, pidx, 0, nullptr, 1, nullptr);
+}
+// = BWT.suffixsort(T, SA, n, 256)               (lib/BWT.js:305-321)
+extern "C" int32_t cjs_suffixsort(const uint8_t* T, int32_t* SA, uint32_t n) {
+    if (n == 0) return CJS_OK;
+    if (!SA) return CJS_E_ARG;
+    std::vector<u8> u(n);
+    u32 p = 0;
+    return bwt_batch_impl(T, &n, 1, n, u.data(), &p, 0, nullptr, 1, SA);
 }
 
 extern "C" int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx) {
@@ -444,6 +467,81 @@ extern "C" int64_t cjs_bz2_encode_blocks(cjs_ctx* c, uint32_t first, uint32_t co
     if (crc_fold) *crc_fold = hs.crc;                // k5 folded from 0: exactly P
     if (n_done) *n_done = count;
     return (int64_t)hs.bits;
+#undef TRYR
+}
+
+// ---------------------------------------------------------------------------------------------
+// BWTC.compressFile(input, null, level), level 6..9 (lib/BWTC.js:12-139): BWT + MTF/RLE2 on the
+// GPU per 100000*level-byte block, adaptive range coder on the host (serial by construction).
+// Levels 1-5 use DefSumModel (lib/BWTC.js:107), which is out of scope -> CJS_E_UNSUPPORTED.
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t cjs_bwtc_compress_bound(uint64_t in_len) { return (int64_t)bwtc_bound(in_len); }
+
+extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
+                                     uint64_t out_cap, int64_t declared_size) {
+    if (!c || (!in && in_len) || !out) return CJS_E_ARG;
+    if (level < 1 || level > 9) level = 9;                         // lib/BWTC.js:16-19: bad props -> 9
+    if (level < 6) return CJS_E_UNSUPPORTED;
+    hipError_t e;
+    int rc;
+#define TRYR(x) if ((e = (x)) != hipSuccess) { if (coder) (void)bwtc_end(coder); return CJS_E_HIP - (int)e; }
+    bwtc_coder* coder = nullptr;
+    TRYR(hipSetDevice(c->device));
+    const u32 bs = (u32)level * 100000u;
+    rc = grow(&c->din, &c->din_bytes, in_len + 64);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    if (in_len) TRYR(hipMemcpyAsync(c->din, in, in_len, hipMemcpyHostToDevice, st));
+    const u64 nblocks = (in_len + bs - 1) / bs;
+    BatchGeom g = make_geom(c->sub_blocks, bs);
+    coder = bwtc_begin(out, out_cap, declared_size, level);
+    std::vector<u32> nl(c->sub_blocks), hpos(c->sub_blocks), hpidx(c->sub_blocks), hused((size_t)c->sub_blocks * 8);
+    std::vector<u16> hA;
+    TRYR(hipEventRecord(c->ev0, st));
+    float gpu_ms = 0.f;
+    for (u64 first = 0; first < nblocks; first += c->sub_blocks) {
+        const u32 nb = (u32)(nblocks - first < c->sub_blocks ? nblocks - first : c->sub_blocks);
+        Pipe P;
+        pipe_carve(P, g, c->ws[0]);
+        P.g.nb = nb;
+        P.k1.largeCap = nb * (g.htiles + 1);
+        P.k1.linear = 1;
+        u32 max_n = 0;
+        for (u32 b = 0; b < nb; b++) {
+            const u64 off = (first + b) * bs;
+            nl[b] = (u32)(in_len - off < bs ? in_len - off : bs);
+            if (nl[b] > max_n) max_n = nl[b];
+        }
+        // T_ext rows: block bytes followed by zeros (linear mode pads with the smallest symbol)
+        TRYR(hipMemsetAsync(P.T, 0, (size_t)nb * g.tstride, st));
+        const u32 full = (nl[nb - 1] == bs) ? nb : nb - 1;
+        if (full) TRYR(hipMemcpy2DAsync(P.T, g.tstride, (const u8*)c->din + first * bs, bs, bs, full, hipMemcpyDeviceToDevice, st));
+        if (full < nb) TRYR(hipMemcpyAsync(P.T + (size_t)full * g.tstride, (const u8*)c->din + (first + full) * bs, nl[nb - 1], hipMemcpyDeviceToDevice, st));
+        TRYR(hipMemcpyAsync(P.nlen, nl.data(), nb * 4, hipMemcpyHostToDevice, st));
+        rc = k1_run(P.k1, P.g, max_n, st);
+        if (!rc) rc = k2_run(P, max_n, st);
+        if (rc) { (void)bwtc_end(coder); return rc; }
+        TRYR(hipMemcpyAsync(hpos.data(), P.pos, nb * 4, hipMemcpyDeviceToHost, st));
+        TRYR(hipMemcpyAsync(hpidx.data(), P.pidx, nb * 4, hipMemcpyDeviceToHost, st));
+        TRYR(hipMemcpyAsync(hused.data(), P.used, (size_t)nb * 32, hipMemcpyDeviceToHost, st));
+        TRYR(hipStreamSynchronize(st));
+        for (u32 b = 0; b < nb; b++) {
+            const u32 nsym = hpos[b] - 1;                          // K2 appends bzip2's EOB; BWTC has none
+            hA.resize((size_t)nsym + 1);
+            if (nsym) TRYR(hipMemcpy(hA.data(), P.A + (size_t)b * g.stride, (size_t)nsym * 2, hipMemcpyDeviceToHost));
+            bwtc_block(coder, nl[b], hpidx[b], hused.data() + (size_t)b * 8, hA.data(), nsym);
+        }
+    }
+    TRYR(hipEventRecord(c->ev1, st));
+    TRYR(hipStreamSynchronize(st));
+    TRYR(hipEventElapsedTime(&gpu_ms, c->ev0, c->ev1));
+    c->last_ms = gpu_ms;
+    c->last_blocks = (u32)nblocks;
+    {
+        bwtc_coder* cc = coder;
+        coder = nullptr;
+        return bwtc_end(cc);
+    }
 #undef TRYR
 }
 

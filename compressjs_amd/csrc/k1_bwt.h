@@ -23,6 +23,8 @@ void k1_prof_destroy(K1Prof& p);
 
 struct K1Buf {
     K1Prof* prof;     // optional
+    u32 linear;       // 0: cyclic rotations (bzip2); 1: suffixes with implicit smallest sentinel
+    int* SAout;       // linear mode: optional copy of the suffix array [nb][stride]
     const u8* T;      // [nb][tstride]  T_ext[i] = T[i mod n]
     u32* SA;          // [nb][stride]   suffix array (result)
     u32* SB;          // [nb][stride]   ping-pong

@@ -362,6 +362,24 @@ __device__ __forceinline__ PosClass classify(const u32* hw, const int* prevh, co
     return c;
 }
 
+// Sort key of rotation/suffix s in a doubling round.
+//   cyclic (bzip2, BWT.bwtransform2): rank of the rotation h positions ahead, indices wrap;
+//   linear (BWT.suffixsort / bwtransform, implicit smallest sentinel): past the end sorts first,
+//     real ranks are shifted by one;
+//   mode 1 (last round, both): descending start index -- identical rotations, and in linear mode
+//     suffixes that ran into the zero padding with equal bytes, where the shorter one (larger start)
+//     is a proper prefix of the longer and therefore smaller.
+__device__ __forceinline__ u32 rot_key(const u32* ISA, u32 n, u32 s, u32 h, u32 hm, int mode, u32 linear) {
+    if (mode) return n - 1u - s;
+    if (linear) {
+        const u64 x = (u64)s + h;
+        return x >= n ? 0u : ISA[x] + 1u;
+    }
+    u32 x = s + hm;                     // hm = h mod n, hoisted by the caller
+    if (x >= n) x -= n;
+    return ISA[x];
+}
+
 // true when none of the 64 positions starting at window position q0 (a multiple of 64) belongs to
 // an unsorted group: every position is a head and so is its successor.  Wave-uniform.
 __device__ __forceinline__ bool chunk_all_sorted(const u32* hw, u32 q0) {
@@ -460,14 +478,7 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
         if (owned) {
             const u32 e = run + (u32)__popcll(bal & lt);
             const u32 s = SA[base + q];
-            u32 k;
-            if (mode == 0) {
-                u32 x = s + hm;
-                if (x >= n) x -= n;
-                k = ISA[x];
-            } else {
-                k = n - 1u - s;
-            }
+            const u32 k = rot_key(ISA, n, s, h, hm, mode, B.linear);
             ck[e] = ((u32)c.head << 20) | k;
             cv[e] = s;
             cp[e] = (u16)q;
@@ -634,14 +645,7 @@ __global__ __launch_bounds__(1024) void k1_sort_large(K1Buf B, BatchGeom g, u32 
         const u32 hm = h % n;
         for (u32 i = tid; i < L; i += 1024) {
             const u32 s = SA[i];
-            u32 k;
-            if (mode == 0) {
-                u32 x = s + hm;
-                if (x >= n) x -= n;
-                k = ISA[x];
-            } else {
-                k = n - 1u - s;
-            }
+            const u32 k = rot_key(ISA, n, s, h, hm, mode, B.linear);
             SB[i] = s;
             KB[i] = k;
         }
@@ -760,11 +764,8 @@ __global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
     }
 }
 
-__device__ __forceinline__ u32 sp_key(const K1Buf& B, const BatchGeom& g, u32 b, u32 n, u32 s, u32 hm, int mode) {
-    if (mode) return n - 1u - s;
-    u32 x = s + hm;
-    if (x >= n) x -= n;
-    return B.ISA[(size_t)b * g.stride + x];
+__device__ __forceinline__ u32 sp_key(const K1Buf& B, const BatchGeom& g, u32 b, u32 n, u32 s, u32 h, u32 hm, int mode) {
+    return rot_key(B.ISA + (size_t)b * g.stride, n, s, h, hm, mode, B.linear);
 }
 
 // groups of <= 8 rotations: one LANE each.  Keys and values live in registers; an 8-input
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(256) void k1_sp_tiny(K1Buf B, BatchGeom g, u32 h, i
         const u32 hm = h % n;
         u32 k0 = ~0u, k1 = ~0u, k2 = ~0u, k3 = ~0u, k4 = ~0u, k5 = ~0u, k6 = ~0u, k7 = ~0u;
         u32 v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0;
-#define SP_LD(i) if (len > i) { v##i = SA[i]; k##i = sp_key(B, g, b, n, v##i, hm, mode); }
+#define SP_LD(i) if (len > i) { v##i = SA[i]; k##i = sp_key(B, g, b, n, v##i, h, hm, mode); }
         SP_LD(0) SP_LD(1) SP_LD(2) SP_LD(3) SP_LD(4) SP_LD(5) SP_LD(6) SP_LD(7)
 #undef SP_LD
         SP_CX(0, 1) SP_CX(2, 3) SP_CX(4, 5) SP_CX(6, 7)
@@ -845,7 +846,7 @@ __global__ __launch_bounds__(256) void k1_sp_small(K1Buf B, BatchGeom g, u32 h, 
         u32* R = B.SB + (size_t)b * g.stride + start;
         const bool act = lane < len;
         const u32 s = act ? SA[lane] : 0u;
-        const u32 k = act ? sp_key(B, g, b, n, s, h % n, mode) : 0xFFFFFFFFu;
+        const u32 k = act ? sp_key(B, g, b, n, s, h, h % n, mode) : 0xFFFFFFFFu;
         u32 rank = 0;
         for (u32 j = 0; j < len; j++) {                        // wave-uniform trip count
             const u32 kj = __builtin_amdgcn_readlane(k, (int)j);
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(256) void k1_sp_medium(K1Buf B, BatchGeom g, u32 h,
         for (u32 i = tid; i < len; i += 256) {
             const u32 s = SA[i];
             cv[i] = s;
-            ck[i] = sp_key(B, g, b, n, s, hmod, mode);
+            ck[i] = sp_key(B, g, b, n, s, h, hmod, mode);
         }
         for (u32 i = tid; i < K1_MED_MAX / 32 + 2; i += 256) hb[i] = 0;
         __syncthreads();
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(1024) void k1_sp_large(K1Buf B, BatchGeom g, u32 h,
         for (u32 i = tid; i < len; i += 1024) {
             const u32 s = SA[i];
             SB[i] = s;
-            KB[i] = sp_key(B, g, b, n, s, hmod, mode);
+            KB[i] = sp_key(B, g, b, n, s, h, hmod, mode);
         }
         if (tid == 0) s_carry = 0;                           // (last head position + 1) so far
         __syncthreads();
@@ -1057,6 +1058,24 @@ __global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g) {
     const u32 s = B.SA[(size_t)b * g.stride + p];
     B.U[(size_t)b * g.stride + p] = T[s == 0 ? n - 1 : s - 1];
     if (s == 0) B.pidx[b] = p;
+}
+
+// linear mode: BWT.bwtransform (lib/BWT.js:328-350 + computeBWT :153-192) and BWT.suffixsort:
+//   U[0] = T[n-1]; ranks r of suffixes != 0 give T[SA[r]-1], shifted by one below the rank of
+//   suffix 0; pidx = that rank + 1.  SAout (optional) receives the suffix array itself.
+__global__ __launch_bounds__(256) void k1_finish_linear(K1Buf B, BatchGeom g, int* SAout) {
+    const u32 b = blockIdx.y;
+    const u32 n = B.nlen[b];
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const u8* T = B.T + (size_t)b * g.tstride;
+    const u32 s = B.SA[(size_t)b * g.stride + p];
+    const u32 p0 = B.ISA[(size_t)b * g.stride];          // rank of suffix 0 (all ranks are final)
+    if (SAout) SAout[(size_t)b * g.stride + p] = (int)s;
+    u8* U = B.U + (size_t)b * g.stride;
+    if (p == 0) U[0] = T[n - 1];
+    if (s == 0) B.pidx[b] = p + 1u;
+    else U[p < p0 ? p + 1u : p] = T[s - 1];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1195,7 +1214,8 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     }
     g_k1_last_sparse_rounds = sparse_rounds;
     g_k1_last_rounds = round;
-    hipLaunchKernelGGL(k1_finish, dim3((max_n + 255) / 256, (g.nb + 7u) & ~7u), dim3(256), 0, stream, B, g);
+    if (B.linear) hipLaunchKernelGGL(k1_finish_linear, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g, B.SAout);
+    else hipLaunchKernelGGL(k1_finish, dim3((max_n + 255) / 256, (g.nb + 7u) & ~7u), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -27,6 +27,16 @@ int64_t cjs_bz2_compress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int l
 /* The same with input and output resident in HBM (device pointers, d_out 4-byte aligned). */
 int64_t cjs_bz2_compress_device(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level, void* d_out,
                                 uint64_t out_cap);
+/* = BWTC.compressFile(input, null, level) for level 6..9   (reference: lib/BWTC.js:12-139,
+ * lib/Util.js:105-142).  GPU: BWT.bwtransform + MTF + RLE2 per 100000*level-byte block; host: the
+ * adaptive Fenwick model + range coder (serial by construction: lib/RangeCoder.js, lib/FenwickModel.js).
+ * declared_size = the size written into the header (input length, or -1 for streams of unknown
+ * size, lib/Util.js:119-124).  Levels 1-5 (DefSumModel) return CJS_E_UNSUPPORTED (-24). */
+int64_t cjs_bwtc_compress_bound(uint64_t in_len);
+int64_t cjs_bwtc_compress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
+                          uint64_t out_cap, int64_t declared_size);
+#define CJS_E_UNSUPPORTED (-24)
+
 /* Sharded encoding for multi-GPU runs (blocks are independent once the RLE1 split is known):
  * cjs_bz2_plan   = the readBlock chain of lib/Bzip2.js:913-922 over the whole (device) input;
  *                  returns the number of blocks and keeps the split in the context.
@@ -51,7 +61,11 @@ int32_t cjs_profile_read(cjs_ctx* ctx, float* total_ms, uint32_t* launches, uint
 
 /* = BWT.bwtransform2(T, U, n, 256) -> pidx            (reference: lib/BWT.js:372-417) */
 int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx);
-/* the same for nb independent blocks laid out at a fixed pitch `cap` (host pointers) */
+/* = BWT.bwtransform(T, U, A, n, 256) -> pidx           (reference: lib/BWT.js:328-350, :153-192) */
+int32_t cjs_bwt_linear(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx);
+/* = BWT.suffixsort(T, SA, n, 256)                      (reference: lib/BWT.js:305-321) */
+int32_t cjs_suffixsort(const uint8_t* T, int32_t* SA, uint32_t n);
+/* cjs_bwt_cyclic for nb independent blocks laid out at a fixed pitch `cap` (host pointers) */
 int32_t cjs_bwt_cyclic_batch(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                              uint8_t* U, uint32_t* pidx);
 

@@ -20,6 +20,10 @@ static void (*p_destroy)(cjs_ctx*);
 static int64_t (*p_bound)(uint64_t);
 static int64_t (*p_compress)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t);
 static int32_t (*p_bwt)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
+static int32_t (*p_bwtlin)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
+static int32_t (*p_sufsort)(const uint8_t*, int32_t*, uint32_t);
+static int64_t (*p_bwtc_bound)(uint64_t);
+static int64_t (*p_bwtc)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t);
 static void* g_lib;
 static cjs_ctx* g_ctx;
 static std::string g_err;
@@ -33,13 +37,18 @@ static bool load_lib(const char* path) {
     p_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bz2_compress_bound");
     p_compress = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bz2_compress");
     p_bwt = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t*))dlsym(g_lib, "cjs_bwt_cyclic");
-    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt) { g_err = "missing symbols"; return false; }
+    p_bwtlin = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t*))dlsym(g_lib, "cjs_bwt_linear");
+    p_sufsort = (int32_t(*)(const uint8_t*, int32_t*, uint32_t))dlsym(g_lib, "cjs_suffixsort");
+    p_bwtc_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bwtc_compress_bound");
+    p_bwtc = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t))dlsym(g_lib, "cjs_bwtc_compress");
+    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
     return true;
 }
 
 static napi_value throw_code(napi_env env, int64_t rc, const char* what) {
     char msg[160];
     if (rc == -20) snprintf(msg, sizeof msg, "Invalid block size multiplier");      // lib/Bzip2.js:889
+    else if (rc == -24) snprintf(msg, sizeof msg, "%s: BWTC levels 1-5 (DefSumModel) are not accelerated", what);
     else if (rc == -23) snprintf(msg, sizeof msg, "%s: no HIP device visible (compressjs_amd has no CPU path)", what);
     else snprintf(msg, sizeof msg, "%s failed with code %lld", what, (long long)rc);
     napi_throw_error(env, nullptr, msg);
@@ -117,12 +126,71 @@ static napi_value Bwt2(napi_env env, napi_callback_info info) {
     return r;
 }
 
+// bwtcCompress(bytes, level, declaredSize) -> Buffer            = BWTC.compressFile hot path
+static napi_value BwtcCompress(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t* in; size_t len;
+    if (argc < 3 || !get_bytes(env, argv[0], &in, &len)) { napi_throw_type_error(env, nullptr, "bwtcCompress(bytes, level, size)"); return nullptr; }
+    int32_t level = 9; int64_t declared = -1;
+    napi_get_value_int32(env, argv[1], &level);
+    napi_get_value_int64(env, argv[2], &declared);
+    if (!ensure_ctx(env)) return nullptr;
+    const uint64_t cap = (uint64_t)p_bwtc_bound(len);
+    uint8_t* tmp = (uint8_t*)malloc(cap);
+    if (!tmp) { napi_throw_error(env, nullptr, "out of memory"); return nullptr; }
+    const int64_t n = p_bwtc(g_ctx, in, len, level, tmp, cap, declared);
+    if (n < 0) { free(tmp); return throw_code(env, n, "cjs_bwtc_compress"); }
+    napi_value out; void* dst;
+    napi_create_buffer_copy(env, (size_t)n, tmp, &dst, &out);
+    free(tmp);
+    return out;
+}
+
+// bwtransform(T, U, n) -> pidx                                    = BWT.bwtransform
+static napi_value BwtLinear(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t *T, *U; size_t tl, ul; uint32_t n = 0;
+    if (argc < 3 || !get_bytes(env, argv[0], &T, &tl) || !get_bytes(env, argv[1], &U, &ul)) { napi_throw_type_error(env, nullptr, "bwtransform(T, U, n)"); return nullptr; }
+    napi_get_value_uint32(env, argv[2], &n);
+    if (n > tl || n > ul) { napi_throw_range_error(env, nullptr, "n exceeds the arrays"); return nullptr; }
+    if (!g_lib) { napi_throw_error(env, nullptr, "libcompressjs_amd.so not loaded"); return nullptr; }
+    uint32_t pidx = 0;
+    const int32_t rc = p_bwtlin(T, U, n, &pidx);
+    if (rc < 0) return throw_code(env, rc, "cjs_bwt_linear");
+    napi_value r;
+    napi_create_uint32(env, pidx, &r);
+    return r;
+}
+
+// suffixsort(T, SA: Int32Array, n)                                = BWT.suffixsort
+static napi_value SuffixSort(napi_env env, napi_callback_info info) {
+    size_t argc = 3; napi_value argv[3];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t* T; size_t tl; uint32_t n = 0;
+    if (argc < 3 || !get_bytes(env, argv[0], &T, &tl)) { napi_throw_type_error(env, nullptr, "suffixsort(T, SA, n)"); return nullptr; }
+    napi_typedarray_type tt; size_t sl; void* sa; napi_value ab; size_t off;
+    if (napi_get_typedarray_info(env, argv[1], &tt, &sl, &sa, &ab, &off) != napi_ok || tt != napi_int32_array) { napi_throw_type_error(env, nullptr, "SA must be an Int32Array"); return nullptr; }
+    napi_get_value_uint32(env, argv[2], &n);
+    if (n > tl || n > sl) { napi_throw_range_error(env, nullptr, "n exceeds the arrays"); return nullptr; }
+    if (!g_lib) { napi_throw_error(env, nullptr, "libcompressjs_amd.so not loaded"); return nullptr; }
+    const int32_t rc = p_sufsort(T, (int32_t*)sa, n);
+    if (rc < 0) return throw_code(env, rc, "cjs_suffixsort");
+    napi_value r;
+    napi_create_int32(env, 0, &r);
+    return r;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     napi_property_descriptor d[] = {
         {"load", nullptr, Load, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"lastError", nullptr, LastError, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"compress", nullptr, Compress, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtransform2", nullptr, Bwt2, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"bwtransform", nullptr, BwtLinear, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"suffixsort", nullptr, SuffixSort, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"bwtcCompress", nullptr, BwtcCompress, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;

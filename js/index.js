@@ -77,14 +77,54 @@ BWT.bwtransform2 = function(T, U, n, alphabetSize) {                  // lib/BWT
   for (var i = 0; i < n; i++) U[i] = u[i];
   return pidx;
 };
-['suffixsort', 'bwtransform', 'unbwtransform'].forEach(function(k) {
+BWT.bwtransform = function(T, U, A, n, alphabetSize) {               // lib/BWT.js:328
+  if (alphabetSize && alphabetSize > 256) {
+    if (reference) return reference.BWT.bwtransform(T, U, A, n, alphabetSize);
+    throw new Error('only byte alphabets are accelerated');
+  }
+  need();
+  var t = inputBytes(T), u = Buffer.alloc(Math.max(n, 1));
+  var pidx = addon.bwtransform(t, u, n);
+  for (var i = 0; i < n; i++) U[i] = u[i];
+  return pidx;
+};
+BWT.suffixsort = function(T, SA, n, alphabetSize) {                  // lib/BWT.js:305
+  if (alphabetSize && alphabetSize > 256) {
+    if (reference) return reference.BWT.suffixsort(T, SA, n, alphabetSize);
+    throw new Error('only byte alphabets are accelerated');
+  }
+  need();
+  var sa = (SA instanceof Int32Array) ? SA : new Int32Array(Math.max(n, 1));
+  addon.suffixsort(inputBytes(T), sa, n);
+  if (sa !== SA) for (var i = 0; i < n; i++) SA[i] = sa[i];
+  return 0;
+};
+['unbwtransform'].forEach(function(k) {
   BWT[k] = function() {
     if (!reference) throw new Error('BWT.' + k + ' is not on the accelerated path yet');
     return reference.BWT[k].apply(reference.BWT, arguments);
   };
 });
 
-var out = { version: '0.1.0-mi355x', Bzip2: Object.freeze(Bzip2), BWT: Object.freeze(BWT) };
+var BWTC = Object.create(null);
+BWTC.MAGIC = 'bwtc';
+BWTC.compressFile = function(inStream, outStream, props) {           // lib/BWTC.js:12
+  var level = (typeof props === 'number' && props >= 1 && props <= 9) ? props : 9;   // :16-19
+  if (level < 6) {   // DefSumModel levels are not accelerated
+    if (reference) return reference.BWTC.compressFile(inStream, outStream, props);
+    throw new Error('BWTC levels 1-5 are not on the accelerated path');
+  }
+  need();
+  var known = !(inStream && typeof inStream.readByte === 'function') || ('size' in inStream && inStream.size >= 0);
+  var bytes = inputBytes(inStream);
+  return deliver(addon.bwtcCompress(bytes, level, known ? bytes.length : -1), outStream);   // lib/Util.js:119-124
+};
+BWTC.decompressFile = function() {
+  if (!reference) throw new Error('BWTC.decompressFile is not on the accelerated path yet');
+  return reference.BWTC.decompressFile.apply(reference.BWTC, arguments);
+};
+
+var out = { version: '0.1.0-mi355x', Bzip2: Object.freeze(Bzip2), BWT: Object.freeze(BWT), BWTC: Object.freeze(BWTC) };
 if (reference) {
   Object.keys(reference).forEach(function(k) { if (!(k in out)) out[k] = reference[k]; });
 }

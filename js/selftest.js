@@ -18,5 +18,9 @@ res.bwt = [cjs.BWT.bwtransform2(Buffer.from('bcababa'), U, 7, 256), U.toString('
 var sink = { bytes: [], writeByte: function(b) { this.bytes.push(b); } };
 cjs.Bzip2.compressFile({ data: Buffer.from('hello hello hello'), i: 0, readByte: function() { return this.i < this.data.length ? this.data[this.i++] : -1; } }, sink, 9);
 res.stream_len = sink.bytes.length;
+res.bwtc_a1000 = sha(cjs.BWTC.compressFile(Buffer.alloc(1000, 'a'), null, 9));
+res.bwtc_bytes40 = sha(cjs.BWTC.compressFile(all, null, 6));
+var U2 = Buffer.alloc(6); res.bwt_linear = [cjs.BWT.bwtransform(Buffer.from('banana'), U2, null, 6, 256), U2.toString('ascii')];
+var SA = new Int32Array(6); cjs.BWT.suffixsort(Buffer.from('banana'), SA, 6, 256); res.sa = Array.from(SA);
 try { cjs.Bzip2.compressFile(Buffer.from('x'), null, 0); res.badlevel = 'no throw'; } catch (e) { res.badlevel = e.message; }
 console.log(JSON.stringify(res));

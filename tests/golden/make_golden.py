@@ -66,6 +66,10 @@ def main():
             jobs.append(dict(id="%s:sa" % cid, kind="sa", input=p))
         if cid in ("sample0", "sample1", "sample3", "empty", "a1000", "text100k"):
             jobs.append(dict(id="%s:bwtc:9" % cid, kind="bwtc", input=p, level=9))
+        for bc, lv in (("text950k", 9), ("text100k", 7), ("bytes40", 6), ("runs300k", 8), ("lcg250000", 9),
+                       ("a1", 9), ("text1k", 9), ("sample2", 6), ("text2500k", 8), ("zeros300k", 9)):
+            if cid == bc:
+                jobs.append(dict(id="%s:bwtc:%d" % (cid, lv), kind="bwtc", input=p, level=lv))
     jobs.append(dict(id="huff", kind="huff", cases=huff_cases()))
     jp, rp = os.path.join(tmp, "jobs.json"), os.path.join(tmp, "res.json")
     json.dump(jobs, open(jp, "w"))

@@ -135,3 +135,54 @@ print("ok", L.cjs_dbg_k1_rounds(), L.cjs_dbg_k1_sparse_rounds())
     env = dict(os.environ, CJS_SPARSE_MIN="100")
     out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600)
     assert out.decode().startswith("ok")
+
+
+def test_linear_bwt_and_suffix_array(golden):
+    """BWT.bwtransform / BWT.suffixsort (implicit smallest sentinel) on the linear mode of K1,
+    against the reference-made vectors and the oracle."""
+    L = _lib.load(stagelib.EMU_SO)
+    for cid in ["sample0", "banana", "a1", "a4", "ab500", "abc_tie", "mary9", "bytes40", "text1k"]:
+        d = cases.case_input(cid)
+        if d is None:
+            continue
+        d = np.ascontiguousarray(d)
+        u = np.zeros(max(d.size, 1), np.uint8)
+        p = C.c_uint32(0)
+        assert L.cjs_bwt_linear(d.ctypes.data, u.ctypes.data, d.size, C.byref(p)) == 0
+        sa = np.zeros(max(d.size, 1), np.int32)
+        assert L.cjs_suffixsort(d.ctypes.data, sa.ctypes.data, d.size) == 0
+        v = golden[cid + ":bwt"]
+        assert p.value == v["pidx"] and hashlib.sha256(u[:d.size].tobytes()).hexdigest() == v["u_sha256"], cid
+        assert hashlib.sha256(sa[:d.size].astype("<i4").tobytes()).hexdigest() == golden[cid + ":sa"]["sa_sha256"], cid
+    for raw in (b"ab\0\0\0\0\0\0\0\0\0ab\0\0\0", b"\0" * 50, b"mississippi"):
+        d = np.frombuffer(raw, dtype=np.uint8).copy()
+        u = np.zeros(d.size, np.uint8)
+        p = C.c_uint32(0)
+        assert L.cjs_bwt_linear(d.ctypes.data, u.ctypes.data, d.size, C.byref(p)) == 0
+        uo, po = oracle.bwt_linear(d)
+        assert p.value == po and np.array_equal(u, uo)
+
+
+def test_bwtc_streams_vs_reference_digest(emu_ctx, golden):
+    """BWTC -6..-9 (lib/BWTC.js): linear BWT + MTF/RLE2 through the kernels (CPU debug build here),
+    Fenwick model + range coder on the host; bit-identical to the reference."""
+    L, h = emu_ctx
+    n = 0
+    for k in sorted(k for k in golden if ":bwtc:" in k):
+        cid, _, lv = k.split(":")
+        if cid not in ("empty", "a1", "a1000", "sample0", "text1k", "bytes40", "text100k") or k == "text100k:bwtc:7":
+            continue
+        d = cases.case_input(cid)
+        if d is None:
+            continue
+        d = np.ascontiguousarray(d)
+        cap = int(L.cjs_bwtc_compress_bound(d.size))
+        out = np.zeros(cap, np.uint8)
+        m = L.cjs_bwtc_compress(h, d.ctypes.data, d.size, int(lv), out.ctypes.data, cap, d.size)
+        assert m == golden[k]["out_len"], k
+        assert hashlib.sha256(out[:m].tobytes()).hexdigest() == golden[k]["out_sha256"], k
+        n += 1
+    assert n >= 6
+    d = np.zeros(10, np.uint8)
+    out = np.zeros(256, np.uint8)
+    assert L.cjs_bwtc_compress(h, d.ctypes.data, 10, 3, out.ctypes.data, 256, 10) == -24   # DefSumModel levels

@@ -20,5 +20,9 @@ def test_node_dropin_digests(golden):
     assert r["bytes40"] == golden["bytes40:bz2:9"]["out_sha256"]
     assert r["lcg250000"] == golden["lcg250000:bz2:1"]["out_sha256"]
     assert r["bwt"] == [5, "cbbaaab"]                       # test/bwtest.js:39-44
+    assert r["bwtc_a1000"] == golden["a1000:bwtc:9"]["out_sha256"]
+    assert r["bwtc_bytes40"] == golden["bytes40:bwtc:6"]["out_sha256"]
+    assert r["bwt_linear"] == [4, "annbaa"]
+    assert r["sa"] == [5, 3, 1, 0, 4, 2]
     assert r["stream_len"] > 30
     assert r["badlevel"] == "Invalid block size multiplier"

@@ -142,3 +142,34 @@ def test_stream_input_and_output_coercions():
     with pytest.raises(TypeError):
         Bzip2.compressFile(data, len(ref) + 1)
     assert Bzip2.decompressFile(ref) == data
+
+
+def test_bwtc_and_linear_bwt_goldens(golden, ctx):
+    """BASELINE.json configs[4] path: BWTC -6..-9 streams and BWT.bwtransform / suffixsort vectors."""
+    n = 0
+    for k in sorted(k for k in golden if ":bwtc:" in k):
+        cid, _, lv = k.split(":")
+        d = cases.case_input(cid)
+        if d is None:
+            continue
+        o = ctx.bwtc_compress(d, int(lv))
+        assert len(o) == golden[k]["out_len"] and _sha(o) == golden[k]["out_sha256"], k
+        n += 1
+    assert n >= 12
+    for k in sorted(k for k in golden if k.endswith(":bwt")):
+        cid = k.split(":")[0]
+        d = cases.case_input(cid)
+        if d is None:
+            continue
+        U = np.zeros(max(d.size, 1), np.uint8)
+        p = BWT.bwtransform(d, U, None, d.size)
+        assert p == golden[k]["pidx"] and _sha(U[:d.size]) == golden[k]["u_sha256"], k
+        SA = np.zeros(max(d.size, 1), np.int32)
+        BWT.suffixsort(d, SA, d.size)
+        assert _sha(SA[:d.size].astype("<i4").tobytes()) == golden[cid + ":sa"]["sa_sha256"], k
+    big = synth.text_like(899_000, 41)
+    U = np.zeros(big.size, np.uint8)
+    p = BWT.bwtransform(big, U, None, big.size)
+    uo, po = oracle.bwt_linear(big)
+    assert p == po and np.array_equal(U, uo)
+    assert np.array_equal(oracle.unbwt_linear(U, p), big)         # BWT.unbwtransform inverts it
