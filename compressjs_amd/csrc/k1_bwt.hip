@@ -140,18 +140,30 @@ __global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u3
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32* kb = kin + (size_t)b * g.stride;
     const u32* vb = vin + (size_t)b * g.stride;
-    u32 kv[16], vv[16];
+    // One ranking pass: every lane learns its rank among the elements of its wave with the same
+    // digit (elements of earlier iterations first), and the wave's per-digit counts fall out of the
+    // same ballots -- no LDS atomics (text digits collide 10-way and more).
+    u32 kv[16], vv[16], rk[16];
+    const u64 lt = lanemask_lt();
 #pragma unroll
     for (int it = 0; it < 16; it++) {
         const u32 j = t0 + w * 1024u + it * 64u + lane;
+        const bool valid = j < n;
         u32 key = 0, val = 0;
-        if (j < n) {
+        if (valid) {
             key = FIRST ? load_be32(T + j + 4) : kb[j];
             val = FIRST ? j : vb[j];
-            atomicAdd(&wh[w][(key >> shift) & 255u], 1u);
         }
+        const u32 d = (key >> shift) & 255u;
+        const u64 m = match_any(d, 8, valid);
+        const u32 rank = (u32)__popcll(m & lt), cnt = (u32)__popcll(m);
+        const u32 prior = valid ? wh[w][d] : 0u;              // same digit, earlier iterations of this wave
+        __builtin_amdgcn_wave_barrier();
+        if (valid && rank == 0) wh[w][d] = prior + cnt;
+        __builtin_amdgcn_wave_barrier();
         kv[it] = key;
         vv[it] = val;
+        rk[it] = prior + rank;
     }
     __syncthreads();
     u32 total;
@@ -169,20 +181,12 @@ __global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u3
     const u32 ds = block_excl_scan_256(total, sh);
     dstart[tid] = ds;
     __syncthreads();
-    const u64 lt = lanemask_lt();
 #pragma unroll
     for (int it = 0; it < 16; it++) {
         const u32 j = t0 + w * 1024u + it * 64u + lane;
-        const bool valid = j < n;
-        const u32 d = (kv[it] >> shift) & 255u;
-        const u64 m = match_any(d, 8, valid);
-        const u32 rank = (u32)__popcll(m & lt), cnt = (u32)__popcll(m);
-        const u32 base = valid ? wh[w][d] : 0u;
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) wh[w][d] = base + cnt;
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            const u32 lp = dstart[d] + base + rank;
+        if (j < n) {
+            const u32 d = (kv[it] >> shift) & 255u;
+            const u32 lp = dstart[d] + wh[w][d] + rk[it];
             lk[lp] = kv[it];
             lv[lp] = vv[it];
         }
