@@ -173,3 +173,26 @@ def test_bwtc_and_linear_bwt_goldens(golden, ctx):
     uo, po = oracle.bwt_linear(big)
     assert p == po and np.array_equal(U, uo)
     assert np.array_equal(oracle.unbwt_linear(U, p), big)         # BWT.unbwtransform inverts it
+
+
+def test_error_codes_through_the_abi(ctx):
+    d = synth.text_like(200_000, 1)
+    out = np.zeros(1000, np.uint8)
+    rc = ctx.L.cjs_bz2_compress(ctx.h, d.ctypes.data, d.size, 9, out.ctypes.data, out.size)
+    assert rc == -21                                   # CJS_E_NOSPACE
+    assert ctx.L.cjs_bz2_compress(ctx.h, d.ctypes.data, d.size, 0, out.ctypes.data, out.size) == -20
+    with pytest.raises(ValueError, match="Invalid block size multiplier"):
+        Bzip2.compressFile(d, None, 11)
+    # the context is still usable afterwards
+    assert ctx.compress(d, 9) == oracle.bz2_compress(d, 9)
+
+
+def test_level1_many_batches():
+    """level 1: 99 981-byte blocks, more blocks than one batch holds (batches of 16)."""
+    c = Context(0, 16)
+    try:
+        d = np.concatenate([synth.text_like(3_000_000, 9), synth.runs_mixed(1_500_000, 2), synth.lcg_ascii(700_000, 5)])
+        a = c.compress(d, 1)
+        assert a == oracle.bz2_compress(d, 1)
+    finally:
+        c.close()
