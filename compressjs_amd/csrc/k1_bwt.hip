@@ -236,11 +236,86 @@ __global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g) {
     }
 }
 
+__device__ __forceinline__ u64 sp_desc(u32 b, u32 start, u32 len) {
+    return ((u64)b << 52) | ((u64)start << 26) | (u64)len;
+}
+#define SP_B(d) ((u32)((d) >> 52))
+#define SP_START(d) ((u32)(((d) >> 26) & 0x3FFFFFFu))
+#define SP_LEN(d) ((u32)((d) & 0x3FFFFFFu))
+#define SP_TINY 8u
+
+
+// Descriptors of the unsorted groups that START in tile [base, base+K1_HT) of block b, read from
+// a head bitmap whose words for the tile (+ `nwords` in total) are in LDS and whose full copy is
+// `Hglob`.  Staged per size class in LDS, then appended to the parity-0 lists with one global
+// atomic per class and workgroup.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void emit_group_descriptors(const K1Buf& B, const BatchGeom& g, u32 b, u32 base, u32 n,
+                                                       const u32* hwords, u32 nwords, const u32* Hglob) {
+    __shared__ u64 stT[K1_HT / 2], stS[K1_HT / 8], stM[K1_HT / 64 + 1], stL[4];
+    __shared__ u32 cntc[4], basec[4];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    if (tid < 4) cntc[tid] = 0;
+    __syncthreads();
+    for (int it = 0; it < K1_HT / 256; it++) {
+        const u32 q0 = w * (K1_HT / 4u) + it * 64u;
+        const u32 wi = q0 >> 5;
+        const u64 m64 = (u64)hwords[wi] | ((u64)hwords[wi + 1] << 32);
+        const u64 nx64 = (m64 >> 1) | ((u64)(hwords[wi + 2] & 1u) << 63);
+        const u64 starts64 = m64 & ~nx64;                            // head whose successor is not a head
+        if (starts64 == 0) continue;                                  // wave-uniform
+        const u32 q = q0 + lane;
+        const bool starts = ((starts64 >> lane) & 1u) && base + q < n;
+        // end of the group = next head after q: first in the LDS words, else in the global bitmap
+        u32 endq = 0;
+        bool found = false;
+        if (starts) {
+            u32 wq = q >> 5;
+            u32 mm = (q & 31u) == 31u ? 0u : (hwords[wq] & (0xFFFFFFFEu << (q & 31u)));
+            while (!mm && ++wq < nwords) mm = hwords[wq];
+            if (mm) { endq = wq * 32u + (u32)__ffs((int)mm) - 1u; found = true; }
+        }
+        u64 far = __ballot(starts && !found);
+        while (far) {                                                 // rare: a group longer than the LDS window
+            const int src = __ffsll((long long)far) - 1;
+            far &= far - 1;
+            const u32 w0 = (base >> 5) + nwords;
+            u32 endg = 0;
+            bool got = false;
+            for (u32 it2 = 0; !got; it2++) {
+                const u32 gw = w0 + lane + 64u * it2;
+                const u32 wd = gw < g.hstride ? Hglob[gw] : 0xFFFFFFFFu;
+                const u64 bal = __ballot(wd != 0u);
+                if (bal) {
+                    const int fl = __ffsll((long long)bal) - 1;
+                    endg = __shfl(gw * 32u + (u32)__ffs((int)wd) - 1u, fl);
+                    got = true;
+                }
+            }
+            if ((int)lane == src) { endq = endg - base; found = true; }
+        }
+        if (starts) {
+            const u32 len = endq - q;
+            const u64 d = sp_desc(b, base + q, len);
+            if (len <= 8u) stT[atomicAdd(&cntc[0], 1u)] = d;
+            else if (len <= 64u) stS[atomicAdd(&cntc[1], 1u)] = d;
+            else if (len <= K1_MED_MAX) stM[atomicAdd(&cntc[2], 1u)] = d;
+            else { const u32 li = atomicAdd(&cntc[3], 1u); if (li < 4u) stL[li] = d; }
+        }
+    }
+    __syncthreads();
+    if (tid < 4 && cntc[tid]) basec[tid] = atomicAdd(&B.stats[K1_STAT_LIST + tid], cntc[tid]);
+    __syncthreads();
+    for (u32 i = tid; i < cntc[0]; i += 256) if (basec[0] + i < B.listTCap) B.listT[0][basec[0] + i] = stT[i];
+    for (u32 i = tid; i < cntc[1]; i += 256) if (basec[1] + i < B.listSCap) B.listS[0][basec[1] + i] = stS[i];
+    for (u32 i = tid; i < cntc[2]; i += 256) if (basec[2] + i < B.listMCap) B.listM[0][basec[2] + i] = stM[i];
+    for (u32 i = tid; i < cntc[3] && i < 4u; i += 256) if (basec[3] + i < B.listLCap) B.listL[0][basec[3] + i] = stL[i];
+}
+
 // ---------------------------------------------------------------------------------------------
 // rank update: ISA[SA[p]] = position of p's group head under HN, for every p that was in an
 // unsorted group under HC.  Also produces next round's tile flags and active-group count.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeom& g, int slot_out, u32 b, u32 t) {
+__device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeom& g, int slot_out, u32 b, u32 t, int emit) {
     const u32 n = B.nlen[b];
     const u32 base = t * K1_HT;
     if (base >= n) return;
@@ -327,6 +402,9 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
         if (red[0]) atomicAdd(&B.stats[K1_STAT_ACTIVE + slot_out], red[0]);
         if (red[1]) atomicAdd(&B.stats[K1_STAT_ACTPOS + slot_out], red[1]);
     }
+    // descriptor lists for a possible switch to the sparse phase after this round (the tile's
+    // bitmap words are already in LDS; a separate pass over the bitmaps cost 0.9 ms)
+    if (emit && red[0]) emit_group_descriptors(B, g, b, base, n, hn, K1_HT / 32 + 4, HN);
 }
 
 // (a persistent 8-per-CU grid walking the tiles was measured 2x SLOWER than one workgroup per
@@ -334,10 +412,10 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
 // K1_UPT tiles per workgroup: the refinement tile is small for occupancy in k1_refine, but this
 // kernel is dispatch-bound in the later (sparse) rounds, so it walks several tiles per workgroup.
 #define K1_UPT 1   /* measured: 1 tile per workgroup is fastest (latency-bound, wants parallelism) */
-__global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int slot_out) {
+__global__ __launch_bounds__(256) void k1_update_ranks(K1Buf B, BatchGeom g, int slot_out, int emit) {
     for (u32 k = 0; k < K1_UPT; k++) {
         const u32 t = blockIdx.x * K1_UPT + k;
-        if (t < g.htiles) update_ranks_tile(B, g, slot_out, blockIdx.y, t);
+        if (t < g.htiles) update_ranks_tile(B, g, slot_out, blockIdx.y, t, emit);
         __syncthreads();
     }
 }
@@ -670,14 +748,6 @@ __global__ __launch_bounds__(1024) void k1_sort_large(K1Buf B, BatchGeom g, u32 
 // R (= SB) and are copied into ISA by k1_sp_update after every group of the round has read its
 // keys.  The head bitmaps are not maintained any more.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 sp_desc(u32 b, u32 start, u32 len) {
-    return ((u64)b << 52) | ((u64)start << 26) | (u64)len;
-}
-#define SP_B(d) ((u32)((d) >> 52))
-#define SP_START(d) ((u32)(((d) >> 26) & 0x3FFFFFFu))
-#define SP_LEN(d) ((u32)((d) & 0x3FFFFFFu))
-#define SP_TINY 8u
-
 // Append one descriptor per lane with pred set: ONE atomic per wave and class (the lists' counters
 // are single words; per-lane atomics on them saturate at ~90 per microsecond).  Must be called by
 // all lanes of the wave (wave-uniform control flow).
@@ -700,72 +770,6 @@ __device__ __forceinline__ void sp_append(const K1Buf& B, int parity, bool pred,
     sp_append_class(B.listS[parity], c + 1, B.listSCap, pred && len > SP_TINY && len <= 64u, d);
     sp_append_class(B.listM[parity], c + 2, B.listMCap, pred && len > 64u && len <= K1_MED_MAX, d);
     sp_append_class(B.listL[parity], c + 3, B.listLCap, pred && len > K1_MED_MAX, d);
-}
-
-// one descriptor per unsorted group of the current head bitmap (run once, at the switch).
-// Descriptors are staged in LDS per size class; one global atomic per class and workgroup.
-__device__ __forceinline__ void build_list_tile(const K1Buf& B, const BatchGeom& g, u32 b, u32 t) {
-    const u32 n = B.nlen[b];
-    const u32 base = t * K1_HT;
-    if (base >= n) return;
-    if (!(B.FC[(size_t)b * g.htiles + t] & 1)) return;
-    __shared__ u32 hw[K1_WW + 2];
-    __shared__ int nexth[K1_WW + 2];
-    __shared__ u64 stT[K1_HT / 2], stS[K1_HT / 8], stM[K1_HT / 64], stL[4];
-    __shared__ u32 cntc[4], basec[4];
-    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    const u32* HC = B.HC + (size_t)b * g.hstride;
-    if (tid < K1_WW) hw[tid] = HC[(base >> 5) + tid];
-    if (tid < 4) cntc[tid] = 0;
-    __syncthreads();
-    if (tid < K1_WW) {
-        int nx = K1_INF;
-        for (int i = (int)tid + 1; i < K1_WW; i++) {
-            const u32 wd = hw[i];
-            if (wd) { nx = i * 32 + __ffs((int)wd) - 1; break; }
-        }
-        nexth[tid] = nx;
-    }
-    __syncthreads();
-    for (int it = 0; it < K1_HT / 256; it++) {
-        const u32 q0 = w * (K1_HT / 4u) + it * 64u;
-        if (chunk_all_sorted(hw, q0)) continue;                  // wave-uniform
-        const u32 q = q0 + lane;
-        const u32 wq = q >> 5, bq = q & 31u;
-        const u32 word = hw[wq];
-        const bool is_head = (word >> bq) & 1u;
-        const u32 high = bq == 31u ? 0u : (word & (0xFFFFFFFEu << bq));
-        int endp = high ? (int)(wq * 32u + (u32)__ffs((int)high) - 1u) : nexth[wq];
-        const bool starts = is_head && base + q < n && endp != (int)q + 1;
-        if (!starts) continue;
-        if (endp >= K1_INF) {
-            // longer than the window: find the next head in the global bitmap
-            u32 wi = (base >> 5) + (u32)K1_WW;
-            u32 wd = 0;
-            while (wi < g.hstride && (wd = HC[wi]) == 0u) wi++;
-            endp = (int)(wi * 32u + (u32)__ffs((int)wd) - 1u) - (int)base;
-        }
-        const u32 len = (u32)endp - q;
-        const u64 d = sp_desc(b, base + q, len);
-        if (len <= SP_TINY) stT[atomicAdd(&cntc[0], 1u)] = d;
-        else if (len <= 64u) stS[atomicAdd(&cntc[1], 1u)] = d;
-        else if (len <= K1_MED_MAX) stM[atomicAdd(&cntc[2], 1u)] = d;
-        else { const u32 li = atomicAdd(&cntc[3], 1u); if (li < 4u) stL[li] = d; }   // <= 1 can start per tile
-    }
-    __syncthreads();
-    if (tid < 4 && cntc[tid]) basec[tid] = atomicAdd(&B.stats[K1_STAT_LIST + tid], cntc[tid]);
-    __syncthreads();
-    for (u32 i = tid; i < cntc[3] && i < 4u; i += 256) if (basec[3] + i < B.listLCap) B.listL[0][basec[3] + i] = stL[i];
-    for (u32 i = tid; i < cntc[0]; i += 256) if (basec[0] + i < B.listTCap) B.listT[0][basec[0] + i] = stT[i];
-    for (u32 i = tid; i < cntc[1]; i += 256) if (basec[1] + i < B.listSCap) B.listS[0][basec[1] + i] = stS[i];
-    for (u32 i = tid; i < cntc[2]; i += 256) if (basec[2] + i < B.listMCap) B.listM[0][basec[2] + i] = stM[i];
-}
-__global__ __launch_bounds__(256) void k1_build_list(K1Buf B, BatchGeom g) {
-    for (u32 k = 0; k < K1_UPT; k++) {
-        const u32 t = blockIdx.x * K1_UPT + k;
-        if (t < g.htiles) build_list_tile(B, g, blockIdx.y, t);
-        __syncthreads();
-    }
 }
 
 __device__ __forceinline__ u32 sp_key(const K1Buf& B, const BatchGeom& g, u32 b, u32 n, u32 s, u32 h, u32 hm, int mode) {
@@ -1167,7 +1171,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         }
     }
     hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g);
-    hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, 0);
+    hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, 0, 0);
     { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
     const size_t hbytes = (size_t)g.nb * g.hstride * 4;
     int round = 0;
@@ -1182,26 +1186,25 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     for (u64 h = 8;; h <<= 1) {
         const int mode = h >= max_n ? 1 : 0;      // last round: identical rotations by descending index
         if (!sparse) {
+            const bool try_sparse = mode == 0 && total_n >= sparse_min;
             HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
             hipLaunchKernelGGL(k1_refine, gridHX, dim3(256), 0, stream, B, g, (u32)h, mode, round);
             hipLaunchKernelGGL(k1_sort_large, dim3(large_grid), dim3(1024), 0, stream, B, g, (u32)h, mode, round);
-            hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, round + 1);
+            hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, round + 1, try_sparse ? 1 : 0);
             { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
-            if (mode == 0 && total_n >= sparse_min) {
+            if (try_sparse) {
                 // How much is still unsorted?  One small read-back per tile round: a list-driven
                 // round costs what the unsorted groups cost, a tile round a fixed ~0.7 ms per 10^8
                 // positions -- but while most positions are still unsorted the tile round is the
-                // faster one (measured on tiled/periodic inputs), so switch below 1/8.
+                // faster one (measured on tiled/periodic inputs), so switch below 1/8.  The lists
+                // were already filled by k1_update_ranks; they are dropped if we stay.
                 u32 hs[K1_STATS];
                 HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats, sizeof hs, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK_RET(hipStreamSynchronize(stream));
                 const u64 actpos = hs[K1_STAT_ACTPOS + round + 1];
                 if (actpos == 0) { round++; break; }           // everything sorted: no tie round needed
-                if (actpos * 8 < total_n) {
-                    hipLaunchKernelGGL(k1_build_list, gridU, dim3(256), 0, stream, B, g);
-                    sparse = true;
-                    parity = 0;
-                }
+                if (actpos * 8 < total_n) { sparse = true; parity = 0; }
+                else hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0);
             }
         } else {
             hipLaunchKernelGGL(k1_sp_tiny, dim3(1024), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
