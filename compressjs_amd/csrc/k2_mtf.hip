@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
     const u8* RHsym = P.RHsym + (size_t)b * g.stride;
     u8* J = P.J + (size_t)b * g.stride;
     const u64 lt = lanemask_lt();
+    __shared__ u8 occ[4][256];
+    for (u32 i = lane; i < 256; i += 64) occ[w][i] = 0;
+    __builtin_amdgcn_wave_barrier();
     for (int it = 0; it < 16; it++) {
         const int base = (int)(seg * K2_SEG + it * 64u);
         if ((u32)base >= nr) break;                       // wave-uniform
@@ -199,11 +202,30 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
             const int lsel = k == 0 ? l0 : k == 1 ? l1 : k == 2 ? l2 : l3;
             p = own ? base + 63 - __clzll((long long)own) : lsel;
         }
+        // which symbols occur in this 64-run step?  (LDS flags; each lane owns symbols k*64+lane)
+        if (valid) occ[w][c] = 1;
+        __builtin_amdgcn_wave_barrier();
+        u64 occm[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const u8 f = occ[w][k * 64 + lane];
+            occm[k] = __ballot(f != 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid) occ[w][c] = 0;
         u32 idx = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            u64 um = usedw[k];
-            while (um) {                                   // wave-uniform loop over used symbols
+            // symbols that do not occur in the step: their last occurrence is the table entry
+            u64 um = usedw[k] & ~occm[k];
+            while (um) {                                   // wave-uniform
+                const int sl = __ffsll((long long)um) - 1;
+                um &= um - 1;
+                idx += (__builtin_amdgcn_readlane(Lr[k], sl) > p) ? 1u : 0u;
+            }
+            // symbols that occur: last occurrence before my lane from the ballot, else the table
+            um = occm[k];
+            while (um) {
                 const int sl = __ffsll((long long)um) - 1;
                 um &= um - 1;
                 const u32 s = (u32)(k * 64 + sl);
@@ -212,7 +234,7 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
                 const u64 mlt = ms & lt;
                 const int Lsi = mlt ? base + 63 - __clzll((long long)mlt) : Ls;
                 idx += (Lsi > p) ? 1u : 0u;
-                if (ms && (int)lane == sl) Lr[k] = base + 63 - __clzll((long long)ms);
+                if ((int)lane == sl) Lr[k] = base + 63 - __clzll((long long)ms);
             }
         }
         if (valid) J[r] = (u8)idx;
