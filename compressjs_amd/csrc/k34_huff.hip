@@ -221,16 +221,13 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
         for (u32 gi = tid; gi < nSel; gi += 1024)
             if (sel[gi] == which) atomicAdd(&chist[cost[gi]], 1u);
         __syncthreads();
-        if (tid == 0) {
-            const u32 m = cnt[which], half = m >> 1;      // :712
-            u32 lower = 0, c = 0;
-            // smallest c with lower + chist[c] > half  (elements of stable rank >= half move)
-            for (c = 0; c < 1024; c++) {
-                if (lower + chist[c] > half) break;
-                lower += chist[c];
-            }
-            s_cstar = c;
-            s_keep = half - lower;
+        {
+            // smallest c with (#groups of cost < c) + chist[c] > half: elements of stable rank >= half move
+            const u32 half = cnt[which] >> 1;             // :712
+            u32 tot;
+            const u32 mine = chist[tid];
+            const u32 lower = block_excl_scan_1024(mine, scan_sh, &tot);
+            if (lower <= half && half < lower + mine) { s_cstar = tid; s_keep = half - lower; }
         }
         __syncthreads();
         {
