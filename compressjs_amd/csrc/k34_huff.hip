@@ -122,17 +122,28 @@ __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* Aw = (const u32*)A;
     const u32 nchunks = (nSel + K34_GROUPS_PER_CHUNK - 1) / K34_GROUPS_PER_CHUNK;
-    for (u32 c = w; c < nchunks; c += 16) {
-        const u32 g0 = c * K34_GROUPS_PER_CHUNK;
-        const u32 sym0 = g0 * CJS_GROUP;
+    // software pipeline: the words of chunk c+16 are in flight while chunk c is consumed from LDS
+    u32 pre[13];
+    auto fetch = [&](u32 c) {
+        const u32 sym0 = c * K34_GROUPS_PER_CHUNK * CJS_GROUP;
         const u32 nsym = pos - sym0 < 1600u ? pos - sym0 : 1600u;
         const u32 nwords = (nsym + 1u) >> 1;
 #pragma unroll
         for (int k = 0; k < 13; k++) {
             const u32 j = lane + 64u * (u32)k;
-            if (j < nwords) stage_w[j] = Aw[(sym0 >> 1) + j];
+            pre[k] = j < nwords ? Aw[(sym0 >> 1) + j] : 0u;
+        }
+    };
+    if (w < nchunks) fetch(w);
+    for (u32 c = w; c < nchunks; c += 16) {
+        const u32 g0 = c * K34_GROUPS_PER_CHUNK;
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            const u32 j = lane + 64u * (u32)k;
+            if (j < K34_STAGE_WORDS) stage_w[j] = pre[k];
         }
         __builtin_amdgcn_wave_barrier();
+        if (c + 16 < nchunks) fetch(c + 16);
         const u32 gi = g0 + lane;
         if (lane < K34_GROUPS_PER_CHUNK && gi < nSel) {
             const u32 cnt = pos - gi * CJS_GROUP < CJS_GROUP ? pos - gi * CJS_GROUP : CJS_GROUP;
