@@ -491,7 +491,7 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     __shared__ int prevh[K1_WW + 2], nexth[K1_WW + 2];
     __shared__ u32 ck[K1_WIN], cv[K1_WIN];
     __shared__ u16 cp[K1_WIN], csz[K1_WIN];
-    __shared__ u32 wtot[4];
+    __shared__ u32 chunkoff[K1_WIN / 64 + 1];
     __shared__ u32 biglist[64];
     __shared__ u32 nbig;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
@@ -502,6 +502,19 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     const u32 wbase = base >> 5;
     if (tid < K1_WW) hw[tid] = HC[wbase + tid];
     if (tid == 0) nbig = 0;
+    // The 64-position chunks of the window are dealt round-robin to the 4 waves (chunk ci = it*4+w)
+    // so that all waves share the own half.  For those chunks the suffix index and its round key
+    // are fetched NOW -- two dependent HBM/L2 round trips that overlap the bitmap work below
+    // (in the dense first round nearly every own position is in an unsorted group).
+    const u32 hm = h % n;
+    u32 pre_s[K1_HT / 256], pre_k[K1_HT / 256];
+#pragma unroll
+    for (int it = 0; it < K1_HT / 256; it++) {
+        const u32 q = ((u32)it * 4u + w) * 64u + lane;
+        pre_s[it] = base + q < n ? SA[base + q] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < K1_HT / 256; it++) pre_k[it] = rot_key(ISA, n, pre_s[it], h, hm, mode, B.linear);
     __syncthreads();
     if (tid < K1_WW) {
         int pv = -1;
@@ -523,44 +536,49 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
     // i.e. to the next tile: chunks beyond it need no look (wave-uniform bound)
     const u32 spill_end = (hw[K1_HT / 32] & 1u) ? (u32)K1_HT
                         : (nexth[K1_HT / 32 - 1] < K1_INF ? (u32)nexth[K1_HT / 32 - 1] : (u32)K1_WIN);
-    // pass 1: count owned positions per wave, register large groups
-    u32 cnt = 0;
+    // pass 1: owned positions per chunk, register large groups
     for (int it = 0; it < K1_WIN / 256; it++) {
-        const u32 q0 = w * (K1_WIN / 4u) + it * 64u;
-        if (q0 >= spill_end) break;                                   // wave-uniform
-        if (chunk_all_sorted(hw, q0)) continue;                       // wave-uniform
-        const u32 q = q0 + lane;
-        const PosClass c = classify(hw, prevh, nexth, q);
-        const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
-        const bool owned = c.head >= 0 && c.head < K1_HT && size >= 2 && size <= K1_HT && base + q < n;
-        if (c.is_head && q < K1_HT && base + q < n && size > K1_HT) {
-            const u32 idx = atomicAdd(&B.stats[K1_STAT_LARGE + round], 1u);
-            if (idx < B.largeCap) B.large[idx] = make_uint2(b, base + q);
+        const u32 ci = (u32)it * 4u + w;
+        const u32 q0 = ci * 64u;
+        u32 c64 = 0;
+        if (q0 < spill_end && !chunk_all_sorted(hw, q0)) {            // wave-uniform
+            const u32 q = q0 + lane;
+            const PosClass c = classify(hw, prevh, nexth, q);
+            const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
+            const bool owned = c.head >= 0 && c.head < K1_HT && size >= 2 && size <= K1_HT && base + q < n;
+            if (c.is_head && q < K1_HT && base + q < n && size > K1_HT) {
+                const u32 idx = atomicAdd(&B.stats[K1_STAT_LARGE + round], 1u);
+                if (idx < B.largeCap) B.large[idx] = make_uint2(b, base + q);
+            }
+            c64 = (u32)__popcll(__ballot(owned));
         }
-        cnt += (u32)__popcll(__ballot(owned));
+        if (lane == 0) chunkoff[ci] = c64;
     }
-    if (lane == 0) wtot[w] = cnt;
     __syncthreads();
-    u32 wavebase = 0;
-    for (u32 i = 0; i < w; i++) wavebase += wtot[i];
-    const u32 m = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (tid == 0) {                                                   // exclusive scan over the chunks
+        u32 run = 0;
+        for (u32 ci = 0; ci < K1_WIN / 64; ci++) { const u32 c = chunkoff[ci]; chunkoff[ci] = run; run += c; }
+        chunkoff[K1_WIN / 64] = run;
+    }
+    __syncthreads();
+    const u32 m = chunkoff[K1_WIN / 64];
     if (m == 0) return;
-    // pass 2: gather keys of owned positions into the compact arrays
-    const u32 hm = h % n;
-    u32 run = wavebase;
+    // pass 2: keys of owned positions into the compact arrays
+#pragma unroll
     for (int it = 0; it < K1_WIN / 256; it++) {
-        const u32 q0 = w * (K1_WIN / 4u) + it * 64u;
-        if (q0 >= spill_end) break;
-        if (chunk_all_sorted(hw, q0)) continue;
+        const u32 ci = (u32)it * 4u + w;
+        const u32 q0 = ci * 64u;
+        if (q0 >= spill_end || chunk_all_sorted(hw, q0)) continue;    // wave-uniform
         const u32 q = q0 + lane;
         const PosClass c = classify(hw, prevh, nexth, q);
         const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
         const bool owned = c.head >= 0 && c.head < K1_HT && size >= 2 && size <= K1_HT && base + q < n;
         const u64 bal = __ballot(owned);
         if (owned) {
-            const u32 e = run + (u32)__popcll(bal & lt);
-            const u32 s = SA[base + q];
-            const u32 k = rot_key(ISA, n, s, h, hm, mode, B.linear);
+            const u32 e = chunkoff[ci] + (u32)__popcll(bal & lt);
+            u32 s, k;
+            if (it < K1_HT / 256) { s = pre_s[it]; k = pre_k[it]; }   // own half: prefetched (static index)
+            else { s = SA[base + q]; k = rot_key(ISA, n, s, h, hm, mode, B.linear); }
             ck[e] = ((u32)c.head << 20) | k;
             cv[e] = s;
             cp[e] = (u16)q;
@@ -570,7 +588,6 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
                 biglist[bi] = e | ((u32)size << 16);
             }
         }
-        run += (u32)__popcll(bal);
     }
     __syncthreads();
     {
