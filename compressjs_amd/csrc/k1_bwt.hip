@@ -336,6 +336,14 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
         hn[tid] = HN[(base >> 5) + tid];
     }
     if (tid == 0) { red[0] = 0; red[1] = 0; }
+    // suffix indices of the tile, fetched while the bitmap words are on their way
+    const u32* SA = B.SA + (size_t)b * g.stride;
+    u32 pre_s[K1_HT / 256];
+#pragma unroll
+    for (int it = 0; it < K1_HT / 256; it++) {
+        const u32 p = base + w * (K1_HT / 4u) + (u32)it * 64u + lane;
+        pre_s[it] = p < n ? SA[p] : 0u;
+    }
     __syncthreads();
     if (w == 0) {
         const u32 word = hn[lane];
@@ -364,9 +372,9 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
         if (lane == 0) inHead = found;
     }
     __syncthreads();
-    const u32* SA = B.SA + (size_t)b * g.stride;
     u32* ISA = B.ISA + (size_t)b * g.stride;
     u32 nstart = 0, nact = 0;
+#pragma unroll
     for (int it = 0; it < K1_HT / 256; it++) {
         const u32 q0 = w * (K1_HT / 4u) + it * 64u;
         // 64 positions at once (wave-uniform): heads of this chunk and of the positions after them
@@ -391,7 +399,7 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
             if (mask) r = base + wq * 32u + 31u - (u32)__clz((int)mask);
             else if (prevh[wq] >= 0) r = base + (u32)prevh[wq];
             else r = (u32)inHead;
-            ISA[SA[p]] = r;
+            ISA[pre_s[it]] = r;
         }
     }
     if (nact) atomicAdd(&red[1], nact);
