@@ -313,12 +313,64 @@ __device__ u64 k0_run_end(const K0Buf& K, u64 s, u64* sh) {
 }
 
 // ---- the serial chain over blocks -----------------------------------------------------------------
+// ---- speculative parallel chain --------------------------------------------------------------------
+// If no block boundary cuts a run of 4 or more equal bytes and no boundary byte emits two output
+// bytes across it, block j ends exactly where C reaches (j+1)*cap, and all boundaries can be searched
+// independently.  One workgroup per boundary computes e_j = min{ i : C(i) >= j*cap } and flags the
+// boundary if the assumption fails there; k0_chain then resumes serially from the first flagged
+// boundary (usually there is none: 112 searches in parallel instead of a 112-step chain).
+__global__ __launch_bounds__(256) void k0_chain_spec(K0Buf K, u32 cap) {
+    __shared__ u64 sh[256];
+    __shared__ u32 sh32[4];
+    const u64 total = K.tileC[K.ntiles];
+    const u64 nfull = total / cap;                        // boundaries 1..nfull
+    const u64 j = (u64)blockIdx.x + 1;
+    if (j > nfull) return;
+    u64 ce = 0;
+    const u64 e = k0_searchC(K, j * (u64)cap, 0, sh, sh32, &ce);
+    if (threadIdx.x == 0) {
+        bool bad = e > K.in_len || ce != j * (u64)cap;
+        if (!bad && e < K.in_len && e > 0 && K.in[e - 1] == K.in[e]) {
+            // the boundary lies inside a run: harmless only if the whole run is shorter than 4
+            const u8 c = K.in[e];
+            u32 len = 2;
+            for (u64 q = e + 1; q < K.in_len && len < 4 && K.in[q] == c; q++) len++;
+            for (u64 q = e - 1; q > 0 && len < 4 && K.in[q - 1] == c; q--) len++;
+            bad = len >= 4;
+        }
+        K.specEnd[j] = e;
+        K.specC[j] = ce;
+        if (bad) atomicMin((unsigned long long*)K.specBad, (unsigned long long)j);
+    }
+}
+
+// blocks 0 .. kb0-1 straight from the speculation; kb0 = first flagged boundary (or nfull)
+__global__ __launch_bounds__(256) void k0_chain_accept(K0Buf K, u32 cap) {
+    const u64 total = K.tileC[K.ntiles];
+    const u64 nfull = total / cap;
+    u64 kb0 = *K.specBad < nfull ? *K.specBad : nfull;    // block k ends at boundary k+1 <= kb0
+    if (kb0 > K.maxBlocks) kb0 = K.maxBlocks;
+    for (u64 k = (u64)blockIdx.x * 256u + threadIdx.x; k < kb0; k += (u64)gridDim.x * 256u) {
+        const u64 s = k ? K.specEnd[k] : 0;
+        K.blkStart[k] = s;
+        K.blkEnd[k] = K.specEnd[k + 1];
+        K.blkN[k] = cap;
+        K.blkAdj[k] = k * (u64)cap;                       // = C(s)
+        K.blkRe[k] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void k0_chain(K0Buf K, u32 cap) {
     __shared__ u64 sh[256];
     __shared__ u32 sh32[4];
-    u64 s = 0, cnext = 0;
-    bool have_cnext = true;                               // C(0) = 0
-    u32 kb = 0;
+    // resume after the speculated prefix
+    const u64 total = K.tileC[K.ntiles];
+    const u64 nfull = total / cap;
+    u64 kb0 = *K.specBad < nfull ? *K.specBad : nfull;
+    if (kb0 > K.maxBlocks) kb0 = K.maxBlocks;
+    u64 s = kb0 ? K.specEnd[kb0] : 0, cnext = kb0 ? K.specC[kb0] : 0;
+    bool have_cnext = true;                               // C(s) is known (C(0) = 0)
+    u32 kb = (u32)kb0;
     while (s < K.in_len && kb < K.maxBlocks) {
         const bool cut = s > 0 && K.in[s - 1] == K.in[s];
         u64 e = s, adj = 0, re = s;
@@ -522,7 +574,7 @@ size_t k0_bytes(u64 in_len, u32 cap) {
     size_t tot = 0;
     tot += 3 * (((ntiles + 2) * 8 + 255) & ~(size_t)255);
     tot += ((nchunks + 1) * 8 + 255) & ~(size_t)255;
-    tot += 4 * ((maxBlocks * 8 + 255) & ~(size_t)255) + ((maxBlocks * 4 + 255) & ~(size_t)255) + 256;
+    tot += 6 * (((maxBlocks + 2) * 8 + 255) & ~(size_t)255) + ((maxBlocks * 4 + 255) & ~(size_t)255) + 512;
     return tot;
 }
 
@@ -544,7 +596,11 @@ void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws) {
     K.blkAdj = (u64*)p; p += bb;
     K.blkRe = (u64*)p; p += bb;
     K.blkN = (u32*)p; p += ((size_t)K.maxBlocks * 4 + 255) & ~(size_t)255;
-    K.nBlocks = (u32*)p;
+    const size_t sb = (((size_t)K.maxBlocks + 2) * 8 + 255) & ~(size_t)255;
+    K.specEnd = (u64*)p; p += sb;
+    K.specC = (u64*)p; p += sb;
+    K.nBlocks = (u32*)p; p += 256;
+    K.specBad = (u64*)p;
 }
 
 // whole-input pre-pass: tile scans + block chain.  After it *K.nBlocks and blk* are valid.
@@ -563,6 +619,10 @@ int k0_prepass(K0Buf K, u32 cap, hipStream_t stream) {
     hipLaunchKernelGGL(k0_scan_local<false>, dim3(nc), dim3(256), 0, stream, K.tileC, K.chunk, K.ntiles);
     hipLaunchKernelGGL(k0_scan_chunks<false>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, K.tileC + K.ntiles);
     hipLaunchKernelGGL(k0_scan_apply<false>, dim3(nc), dim3(256), 0, stream, K.tileC, (const u64*)K.chunk, K.ntiles);
+    HIP_CHECK_RET(hipMemsetAsync(K.specBad, 0xFF, 8, stream));
+    const u32 nspec = (u32)(K.in_len * 5 / 4 / cap + 2 < K.maxBlocks ? K.in_len * 5 / 4 / cap + 2 : K.maxBlocks);
+    hipLaunchKernelGGL(k0_chain_spec, dim3(nspec), dim3(256), 0, stream, K, cap);
+    hipLaunchKernelGGL(k0_chain_accept, dim3((nspec + 255) / 256), dim3(256), 0, stream, K, cap);
     hipLaunchKernelGGL(k0_chain, dim3(1), dim3(256), 0, stream, K, cap);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;

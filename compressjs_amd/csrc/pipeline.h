@@ -81,6 +81,9 @@ struct K0Buf {
     u64* blkRe;        // [maxBlocks] end of the run the block start cuts (== blkStart if none)
     u32* blkN;         // [maxBlocks] block length after RLE1
     u32* nBlocks;      // [1]
+    u64* specEnd;      // [maxBlocks+2] speculative chain: boundary j = min{ i : C(i) >= j*cap }
+    u64* specC;        // [maxBlocks+2] C at that boundary
+    u64* specBad;      // [1] first boundary where the speculation does not hold (UINT64_MAX: none)
 };
 size_t k0_bytes(u64 in_len, u32 cap);
 void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws);
