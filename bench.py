@@ -59,11 +59,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path)"
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("CJS_DIST_BACKEND", "nccl")    # "gloo": ranks may share a GPU (test rigs only)
+    if backend == "nccl":
+        assert local < ndev, "one process per GPU: LOCAL_RANK %d but %d GPUs visible" % (local, ndev)
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from compressjs_amd import synth
     from compressjs_amd.bzip2 import Context
@@ -106,7 +114,7 @@ def main():
     ctx.L.cjs_profile_read(ctx.h, C.byref(pms), C.byref(pl), C.byref(pe))
     ctx.L.cjs_profile_enable(ctx.h, 0)
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())

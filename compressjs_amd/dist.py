@@ -72,9 +72,12 @@ def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch
         seg_cap = per * (level * 100000 * 2 + 32768) + 4096
         seg = torch.zeros(seg_cap, dtype=torch.uint8, device=dev)
     bits, fold, cnt = ctx.encode_blocks(first, count, seg)
-    mine = torch.tensor([bits, fold, cnt], dtype=torch.int64, device=dev)
+    # collectives run on the tensors' own device with RCCL ("nccl"); with the gloo backend (CPU tests,
+    # or several ranks sharing one GPU) they are staged through host memory
+    cdev = dev if (world == 1 or dist.get_backend(group) != "gloo") else torch.device("cpu")
+    mine = torch.tensor([bits, fold, cnt], dtype=torch.int64, device=cdev)
     if world > 1:
-        allv = [torch.zeros(3, dtype=torch.int64, device=dev) for _ in range(world)]
+        allv = [torch.zeros(3, dtype=torch.int64, device=cdev) for _ in range(world)]
         dist.all_gather(allv, mine, group=group)
         meta = torch.stack(allv).cpu().tolist()
     else:
@@ -91,8 +94,10 @@ def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch
     padded = torch.zeros(maxlen, dtype=torch.uint8, device=dev)
     padded[:shifted.numel()] = shifted
     if world > 1:
-        gl = [torch.zeros(maxlen, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        dist.gather(padded, gl, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        gl = [torch.zeros(maxlen, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
+        dist.gather(padded.to(cdev), gl, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if rank == 0:
+            gl = [t.to(dev) for t in gl]
     else:
         gl = [padded]
     if rank != 0:
