@@ -201,6 +201,14 @@ class BWT:
         return int(p.value)
 
     @staticmethod
+    def unbwtransform(T, U, LF, n, pidx):
+        """BWT.unbwtransform (lib/BWT.js:352-363); LF is the reference's scratch array, unused."""
+        t = np.ascontiguousarray(np.asarray(T)[:n], dtype=np.uint8)
+        u = np.zeros(max(n, 1), dtype=np.uint8)
+        _lib.check(_lib.load().cjs_unbwt_linear(t.ctypes.data, u.ctypes.data, n, int(pidx)), "cjs_unbwt_linear")
+        U[:n] = u[:n] if isinstance(U, np.ndarray) else bytes(u[:n])
+
+    @staticmethod
     def suffixsort(T, SA, n, alphabetSize=256):
         """BWT.suffixsort (lib/BWT.js:305-321)."""
         t = np.ascontiguousarray(np.asarray(T)[:n], dtype=np.uint8)

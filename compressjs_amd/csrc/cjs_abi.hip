@@ -118,6 +118,34 @@ extern "C" int32_t cjs_suffixsort(const uint8_t* T, int32_t* SA, uint32_t n) {
     return bwt_batch_impl(T, &n, 1, n, u.data(), &p, 0, nullptr, 1, SA);
 }
 
+// = BWT.unbwtransform(T, U, LF, n, pidx)          (lib/BWT.js:352-363): inverse of cjs_bwt_linear
+extern "C" int32_t cjs_unbwt_linear(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t pidx) {
+    if (n == 0) return CJS_OK;
+    if (!T || !U || pidx > n) return CJS_E_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    u8 *dT = nullptr, *dU = nullptr; void* ws = nullptr;
+    hipStream_t st = nullptr;
+    hipError_t e;
+    const size_t wsb = (size_t)n * 20 + ((size_t)(n + 4095) / 4096) * 1024 + 256;
+#define TRY(x) if ((e = (x)) != hipSuccess) { rc = CJS_E_HIP - (int)e; goto done; }
+    TRY(hipStreamCreate(&st));
+    TRY(hipMalloc((void**)&dT, n));
+    TRY(hipMalloc((void**)&dU, n));
+    TRY(hipMalloc(&ws, wsb));
+    TRY(hipMemcpyAsync(dT, T, n, hipMemcpyHostToDevice, st));
+    TRY(hipMemsetAsync(dU, 0, n, st));
+    rc = k6_unbwt_linear(dT, dU, n, pidx, ws, st);
+    if (rc) goto done;
+    TRY(hipStreamSynchronize(st));
+    TRY(hipMemcpy(U, dU, n, hipMemcpyDeviceToHost));
+done:
+    if (st) (void)hipStreamDestroy(st);
+    (void)hipFree(dT); (void)hipFree(dU); (void)hipFree(ws);
+    return rc;
+#undef TRY
+}
+
 extern "C" int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx) {
     if (n == 0) { if (pidx) *pidx = 0; return CJS_OK; }
     return cjs_bwt_cyclic_batch(T, &n, 1, n, U, pidx);

@@ -89,6 +89,7 @@ size_t k0_bytes(u64 in_len, u32 cap);
 void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws);
 int k0_prepass(K0Buf K, u32 cap, hipStream_t stream);
 
+int k6_unbwt_linear(const u8* dT, u8* dU, u32 n, u32 pidx, void* ws, hipStream_t stream);
 int k2_run(Pipe P, u32 max_n, hipStream_t stream);
 int k34_run(Pipe P, hipStream_t stream);
 int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after = nullptr, hipEvent_t done = nullptr);

@@ -65,6 +65,8 @@ int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx)
 int32_t cjs_bwt_linear(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx);
 /* = BWT.suffixsort(T, SA, n, 256)                      (reference: lib/BWT.js:305-321) */
 int32_t cjs_suffixsort(const uint8_t* T, int32_t* SA, uint32_t n);
+/* = BWT.unbwtransform(T, U, LF, n, pidx)                (reference: lib/BWT.js:352-363); list ranking */
+int32_t cjs_unbwt_linear(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t pidx);
 /* cjs_bwt_cyclic for nb independent blocks laid out at a fixed pitch `cap` (host pointers) */
 int32_t cjs_bwt_cyclic_batch(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                              uint8_t* U, uint32_t* pidx);

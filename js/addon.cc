@@ -22,6 +22,7 @@ static int64_t (*p_compress)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, 
 static int32_t (*p_bwt)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
 static int32_t (*p_bwtlin)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
 static int32_t (*p_sufsort)(const uint8_t*, int32_t*, uint32_t);
+static int32_t (*p_unbwt)(const uint8_t*, uint8_t*, uint32_t, uint32_t);
 static int64_t (*p_bwtc_bound)(uint64_t);
 static int64_t (*p_bwtc)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t);
 static void* g_lib;
@@ -39,9 +40,10 @@ static bool load_lib(const char* path) {
     p_bwt = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t*))dlsym(g_lib, "cjs_bwt_cyclic");
     p_bwtlin = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t*))dlsym(g_lib, "cjs_bwt_linear");
     p_sufsort = (int32_t(*)(const uint8_t*, int32_t*, uint32_t))dlsym(g_lib, "cjs_suffixsort");
+    p_unbwt = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t))dlsym(g_lib, "cjs_unbwt_linear");
     p_bwtc_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bwtc_compress_bound");
     p_bwtc = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t))dlsym(g_lib, "cjs_bwtc_compress");
-    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
+    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
     return true;
 }
 
@@ -164,6 +166,23 @@ static napi_value BwtLinear(napi_env env, napi_callback_info info) {
     return r;
 }
 
+// unbwtransform(T, U, n, pidx)                                   = BWT.unbwtransform
+static napi_value UnBwtLinear(napi_env env, napi_callback_info info) {
+    size_t argc = 4; napi_value argv[4];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t *T, *U; size_t tl, ul; uint32_t n = 0, pidx = 0;
+    if (argc < 4 || !get_bytes(env, argv[0], &T, &tl) || !get_bytes(env, argv[1], &U, &ul)) { napi_throw_type_error(env, nullptr, "unbwtransform(T, U, n, pidx)"); return nullptr; }
+    napi_get_value_uint32(env, argv[2], &n);
+    napi_get_value_uint32(env, argv[3], &pidx);
+    if (n > tl || n > ul) { napi_throw_range_error(env, nullptr, "n exceeds the arrays"); return nullptr; }
+    if (!g_lib) { napi_throw_error(env, nullptr, "libcompressjs_amd.so not loaded"); return nullptr; }
+    const int32_t rc = p_unbwt(T, U, n, pidx);
+    if (rc < 0) return throw_code(env, rc, "cjs_unbwt_linear");
+    napi_value r;
+    napi_get_undefined(env, &r);
+    return r;
+}
+
 // suffixsort(T, SA: Int32Array, n)                                = BWT.suffixsort
 static napi_value SuffixSort(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value argv[3];
@@ -189,6 +208,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"compress", nullptr, Compress, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtransform2", nullptr, Bwt2, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtransform", nullptr, BwtLinear, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"unbwtransform", nullptr, UnBwtLinear, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"suffixsort", nullptr, SuffixSort, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtcCompress", nullptr, BwtcCompress, nullptr, nullptr, nullptr, napi_default, nullptr},
     };

@@ -3,6 +3,7 @@
 //
 //   Bzip2.compressFile(input, [output], [level])   -> MI355X (N-API addon -> C ABI -> HIP kernels)
 //   BWT.bwtransform2(T, U, n, [alphabetSize])       -> MI355X
+//   BWT.bwtransform / suffixsort / unbwtransform, BWTC.compressFile (levels 6-9) -> MI355X
 //   everything else (decompressFile, decompressBlock, table, the other 12 codecs)
 //       -> delegated unchanged to an installed reference package (require('compressjs')), when
 //          there is one; otherwise those properties throw.  Decoding is format-determined and is
@@ -99,12 +100,12 @@ BWT.suffixsort = function(T, SA, n, alphabetSize) {                  // lib/BWT.
   if (sa !== SA) for (var i = 0; i < n; i++) SA[i] = sa[i];
   return 0;
 };
-['unbwtransform'].forEach(function(k) {
-  BWT[k] = function() {
-    if (!reference) throw new Error('BWT.' + k + ' is not on the accelerated path yet');
-    return reference.BWT[k].apply(reference.BWT, arguments);
-  };
-});
+BWT.unbwtransform = function(T, U, LF, n, pidx) {                   // lib/BWT.js:352 (LF: scratch, unused here)
+  need();
+  var t = inputBytes(T), u = Buffer.alloc(Math.max(n, 1));
+  addon.unbwtransform(t, u, n, pidx);
+  for (var i = 0; i < n; i++) U[i] = u[i];
+};
 
 var BWTC = Object.create(null);
 BWTC.MAGIC = 'bwtc';

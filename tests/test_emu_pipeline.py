@@ -163,6 +163,25 @@ def test_linear_bwt_and_suffix_array(golden):
         assert p.value == po and np.array_equal(u, uo)
 
 
+def test_inverse_linear_bwt_by_list_ranking():
+    """BWT.unbwtransform (lib/BWT.js:352-363) as counting-sort LF links + list ranking (K6): inverts
+    the oracle's bwtransform, and agrees with the oracle's serial LF walk."""
+    L = _lib.load(stagelib.EMU_SO)
+    raws = [b"banana", b"a", b"ab", b"aaaa", b"mississippi", b"\0" * 50, b"ab" * 40, bytes(range(256)) * 3]
+    datas = [np.frombuffer(r, dtype=np.uint8).copy() for r in raws]
+    datas += [cases.case_input(c) for c in ("mary9", "text1k", "bytes40", "text100k")]
+    for d in datas:
+        d = np.ascontiguousarray(d)
+        u, p = oracle.bwt_linear(d)
+        out = np.zeros(d.size, np.uint8)
+        assert L.cjs_unbwt_linear(np.ascontiguousarray(u).ctypes.data, out.ctypes.data, d.size, p) == 0
+        assert np.array_equal(out, d) and np.array_equal(out, oracle.unbwt_linear(u, p))
+    assert L.cjs_unbwt_linear(datas[0].ctypes.data, datas[0].ctypes.data, 0, 0) == 0          # n = 0
+    out = np.zeros(6, np.uint8)
+    assert L.cjs_unbwt_linear(datas[0].ctypes.data, out.ctypes.data, 6, 7) == -22              # pidx > n
+    assert L.cjs_unbwt_linear(datas[0].ctypes.data, out.ctypes.data, 6, 2) == 0                # inconsistent pair: no fault
+
+
 def test_bwtc_streams_vs_reference_digest(emu_ctx, golden):
     """BWTC -6..-9 (lib/BWTC.js): linear BWT + MTF/RLE2 through the kernels (CPU debug build here),
     Fenwick model + range coder on the host; bit-identical to the reference."""

@@ -173,6 +173,15 @@ def test_bwtc_and_linear_bwt_goldens(golden, ctx):
     uo, po = oracle.bwt_linear(big)
     assert p == po and np.array_equal(U, uo)
     assert np.array_equal(oracle.unbwt_linear(U, p), big)         # BWT.unbwtransform inverts it
+    back = np.zeros(big.size, np.uint8)
+    BWT.unbwtransform(U, back, None, big.size, p)                 # K6: list ranking on the GPU
+    assert np.array_equal(back, big)
+    for raw in (b"banana", b"a", b"\0" * 70000, bytes(range(256)) * 20):
+        d = np.frombuffer(raw, dtype=np.uint8).copy()
+        u, pp = oracle.bwt_linear(d)
+        back = np.zeros(d.size, np.uint8)
+        BWT.unbwtransform(u, back, None, d.size, pp)
+        assert np.array_equal(back, d)
 
 
 def test_error_codes_through_the_abi(ctx):
