@@ -17,7 +17,7 @@ SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_bz2_compress_bound", "cjs_bz2_compr
            "cjs_bwtc_compress_bound",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
            "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
-           "cjs_suffixsort", "cjs_unbwt_linear",
+           "cjs_suffixsort", "cjs_unbwt_linear", "cjs_huff_lengths", "cjs_huff_lengths_batch",
            "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages", "cjs_dbg_k1_sparse_rounds",
            "cjs_dbg_k1_rounds"]
 
@@ -83,6 +83,10 @@ def load(path: str | None = None):
     L.cjs_suffixsort.argtypes = [vp, vp, C.c_uint32]
     L.cjs_unbwt_linear.restype = C.c_int32
     L.cjs_unbwt_linear.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    L.cjs_huff_lengths.restype = C.c_int32
+    L.cjs_huff_lengths.argtypes = [vp, C.c_uint32, C.c_uint32]
+    L.cjs_huff_lengths_batch.restype = C.c_int32
+    L.cjs_huff_lengths_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
     L.cjs_bwt_cyclic_batch.restype = C.c_int32
     L.cjs_bwt_cyclic_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     L.cjs_dbg_bwt_batch_time.restype = C.c_int32

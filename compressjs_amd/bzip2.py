@@ -172,6 +172,28 @@ class Bzip2:
         return _deliver(out, outStream)
 
 
+class HuffmanAllocator:
+    """require('compressjs/lib/HuffmanAllocator') (lib/HuffmanAllocator.js:199-226)."""
+
+    @staticmethod
+    def allocateHuffmanCodeLengths(array, maximumLength):
+        """In place, like the reference: ascending weights in, code lengths out."""
+        a = np.ascontiguousarray(np.asarray(array, dtype=np.int64))
+        _lib.check(_lib.load().cjs_huff_lengths(a.ctypes.data, a.size, int(maximumLength)), "cjs_huff_lengths")
+        for i in range(a.size):
+            array[i] = int(a[i])
+
+    @staticmethod
+    def allocate_many(arrays, maximumLength):
+        """`count` independent arrays in one launch; returns a list of lists."""
+        off = np.zeros(len(arrays) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(a) for a in arrays])
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.int64) for a in arrays]) if arrays else np.zeros(0, np.int64))
+        _lib.check(_lib.load().cjs_huff_lengths_batch(flat.ctypes.data, off.ctypes.data, len(arrays), int(maximumLength)),
+                   "cjs_huff_lengths_batch")
+        return [flat[off[k]:off[k + 1]].tolist() for k in range(len(arrays))]
+
+
 class BWTC:
     """compressjs.BWTC (lib/BWTC.js), compress side, levels 6-9: BWT + MTF/RLE2 on MI355X, the
     adaptive range coder on the host."""

@@ -146,6 +146,41 @@ done:
 #undef TRY
 }
 
+// = allocateHuffmanCodeLengths(array, maxLength)   (lib/HuffmanAllocator.js:199-222), `count`
+// independent arrays at once: array k is arr[off[k] .. off[k+1]), ascending weights in, lengths out.
+extern "C" int32_t cjs_huff_lengths_batch(int64_t* arr, const uint32_t* off, uint32_t count, uint32_t max_len) {
+    if (count == 0) return CJS_OK;
+    if (!arr || !off || max_len < 1 || max_len > 62) return CJS_E_ARG;
+    for (u32 k = 0; k < count; k++) {
+        if (off[k + 1] < off[k]) return CJS_E_ARG;
+        const u64 len = off[k + 1] - off[k];
+        if (len > (1ull << max_len)) return CJS_E_ARG;          // no prefix code that short exists
+    }
+    const u32 total = off[count];
+    if (total == 0) return CJS_OK;
+    int rc = ensure_device();
+    if (rc) return rc;
+    long long* d_arr = nullptr; u32* d_off = nullptr;
+    hipError_t e;
+#define TRY(x) if ((e = (x)) != hipSuccess) { rc = CJS_E_HIP - (int)e; goto done; }
+    TRY(hipMalloc((void**)&d_arr, (size_t)total * 8));
+    TRY(hipMalloc((void**)&d_off, (size_t)(count + 1) * 4));
+    TRY(hipMemcpy(d_arr, arr, (size_t)total * 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(d_off, off, (size_t)(count + 1) * 4, hipMemcpyHostToDevice));
+    rc = k3_alloc_lengths_run(d_arr, d_off, count, (int)max_len, nullptr);
+    if (rc) goto done;
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(arr, d_arr, (size_t)total * 8, hipMemcpyDeviceToHost));
+done:
+    (void)hipFree(d_arr); (void)hipFree(d_off);
+    return rc;
+#undef TRY
+}
+extern "C" int32_t cjs_huff_lengths(int64_t* arr, uint32_t n, uint32_t max_len) {
+    const uint32_t off[2] = {0, n};
+    return cjs_huff_lengths_batch(arr, off, 1, max_len);
+}
+
 extern "C" int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx) {
     if (n == 0) { if (pidx) *pidx = 0; return CJS_OK; }
     return cjs_bwt_cyclic_batch(T, &n, 1, n, U, pidx);

@@ -21,25 +21,27 @@
 #define HB_PITCH 264
 
 // ---- allocator (serial, one lane) ------------------------------------------------------------
-__device__ int ha_first(const int* a, int len, int i, int nodes_to_move) {           // :52-73
+template <typename I>
+__device__ int ha_first(const I* a, int len, int i, int nodes_to_move) {             // :52-73
     const int limit = i;
     int k = len - 2;
-    while (i >= nodes_to_move && (a[i] % len) > limit) { k = i; i -= (limit - i + 1); }
+    while (i >= nodes_to_move && (int)(a[i] % len) > limit) { k = i; i -= (limit - i + 1); }
     if (i < nodes_to_move - 1) i = nodes_to_move - 1;
     while (k > i + 1) {
         const int t = (i + k) >> 1;
-        if ((a[t] % len) > limit) k = t; else i = t;
+        if ((int)(a[t] % len) > limit) k = t; else i = t;
     }
     return k;
 }
 
-__device__ void ha_allocate(int* a, int len, int maxlen) {
+template <typename I>
+__device__ void ha_allocate(I* a, int len, int maxlen) {
     // setExtendedParentPointers :79-105
     a[0] += a[1];
     {
         int head = 0, top = 2;
         for (int tail = 1; tail < len - 1; tail++) {
-            int t;
+            I t;
             if (top >= len || a[head] < a[top]) { t = a[head]; a[head++] = tail; }
             else t = a[top++];
             if (top >= len || (head < tail && a[head] < a[top])) { t += a[head]; a[head++] = tail + len; }
@@ -50,7 +52,7 @@ __device__ void ha_allocate(int* a, int len, int maxlen) {
     // findNodesToRelocate :114-124
     int reloc = len - 2;
     for (int d = 1; d < maxlen - 1 && reloc > 1; d++) reloc = ha_first(a, len, reloc - 1, 0);
-    if ((a[0] % len) >= reloc) {
+    if ((int)(a[0] % len) >= reloc) {
         // allocateNodeLengths :131-148
         int first = len - 2, next = len - 1;
         for (int depth = 1, avail = 2; avail > 0; depth++) {
@@ -288,6 +290,24 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
 
 int k34_run(Pipe P, hipStream_t stream) {
     hipLaunchKernelGGL(k34_tables, dim3(P.g.nb), dim3(1024), 0, stream, P);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
+// ---- standalone allocator entry (HuffmanAllocator.allocateHuffmanCodeLengths, :199-222) ------
+// One lane per array; 64-bit cells because callers of the JS function may pass weights whose sum
+// exceeds 2^31 (the block pipeline above never does).
+__global__ __launch_bounds__(64) void k3_alloc_lengths(long long* arr, const u32* off, u32 count, int maxlen) {
+    const u32 t = blockIdx.x * 64u + threadIdx.x;
+    if (t >= count) return;
+    long long* a = arr + off[t];
+    const int len = (int)(off[t + 1] - off[t]);
+    if (len == 2) { a[0] = 1; a[1] = 1; }                                   // :201-205
+    else if (len == 1) a[0] = 1;
+    else if (len > 2) ha_allocate<long long>(a, len, maxlen);
+}
+int k3_alloc_lengths_run(long long* d_arr, const u32* d_off, u32 count, int maxlen, hipStream_t stream) {
+    hipLaunchKernelGGL(k3_alloc_lengths, dim3((count + 63) / 64), dim3(64), 0, stream, d_arr, d_off, count, maxlen);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -67,6 +67,13 @@ int32_t cjs_bwt_linear(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx)
 int32_t cjs_suffixsort(const uint8_t* T, int32_t* SA, uint32_t n);
 /* = BWT.unbwtransform(T, U, LF, n, pidx)                (reference: lib/BWT.js:352-363); list ranking */
 int32_t cjs_unbwt_linear(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t pidx);
+
+/* = require('compressjs/lib/HuffmanAllocator').allocateHuffmanCodeLengths(array, maxLength)
+ *   (reference: lib/HuffmanAllocator.js:199-222, exercised by test/huffman.js): in place, ascending
+ *   weights in, code lengths out.  64-bit cells carry any integer weight a JS caller can pass.
+ *   The batch form runs `count` independent arrays, array k = arr[off[k] .. off[k+1]). */
+int32_t cjs_huff_lengths(int64_t* arr, uint32_t n, uint32_t max_len);
+int32_t cjs_huff_lengths_batch(int64_t* arr, const uint32_t* off, uint32_t count, uint32_t max_len);
 /* cjs_bwt_cyclic for nb independent blocks laid out at a fixed pitch `cap` (host pointers) */
 int32_t cjs_bwt_cyclic_batch(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                              uint8_t* U, uint32_t* pidx);

@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 typedef struct cjs_ctx cjs_ctx;
 static cjs_ctx* (*p_create)(int, uint32_t);
@@ -23,6 +24,7 @@ static int32_t (*p_bwt)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
 static int32_t (*p_bwtlin)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
 static int32_t (*p_sufsort)(const uint8_t*, int32_t*, uint32_t);
 static int32_t (*p_unbwt)(const uint8_t*, uint8_t*, uint32_t, uint32_t);
+static int32_t (*p_hufflen)(int64_t*, uint32_t, uint32_t);
 static int64_t (*p_bwtc_bound)(uint64_t);
 static int64_t (*p_bwtc)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t);
 static void* g_lib;
@@ -41,9 +43,10 @@ static bool load_lib(const char* path) {
     p_bwtlin = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t*))dlsym(g_lib, "cjs_bwt_linear");
     p_sufsort = (int32_t(*)(const uint8_t*, int32_t*, uint32_t))dlsym(g_lib, "cjs_suffixsort");
     p_unbwt = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t))dlsym(g_lib, "cjs_unbwt_linear");
+    p_hufflen = (int32_t(*)(int64_t*, uint32_t, uint32_t))dlsym(g_lib, "cjs_huff_lengths");
     p_bwtc_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bwtc_compress_bound");
     p_bwtc = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t))dlsym(g_lib, "cjs_bwtc_compress");
-    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
+    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_hufflen || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
     return true;
 }
 
@@ -183,6 +186,27 @@ static napi_value UnBwtLinear(napi_env env, napi_callback_info info) {
     return r;
 }
 
+// huffLengths(a: Float64Array, maxLen)  in place                 = allocateHuffmanCodeLengths
+static napi_value HuffLengths(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    napi_typedarray_type tt; size_t n; void* data; napi_value ab; size_t off; uint32_t maxlen = 0;
+    if (argc < 2 || napi_get_typedarray_info(env, argv[0], &tt, &n, &data, &ab, &off) != napi_ok || tt != napi_float64_array) {
+        napi_throw_type_error(env, nullptr, "huffLengths(Float64Array, maxLen)"); return nullptr;
+    }
+    napi_get_value_uint32(env, argv[1], &maxlen);
+    if (!g_lib) { napi_throw_error(env, nullptr, "libcompressjs_amd.so not loaded"); return nullptr; }
+    std::vector<int64_t> a(n);
+    double* d = (double*)data;
+    for (size_t i = 0; i < n; i++) a[i] = (int64_t)d[i];
+    const int32_t rc = p_hufflen(a.data(), (uint32_t)n, maxlen);
+    if (rc < 0) return throw_code(env, rc, "cjs_huff_lengths");
+    for (size_t i = 0; i < n; i++) d[i] = (double)a[i];
+    napi_value r;
+    napi_get_undefined(env, &r);
+    return r;
+}
+
 // suffixsort(T, SA: Int32Array, n)                                = BWT.suffixsort
 static napi_value SuffixSort(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value argv[3];
@@ -209,6 +233,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"bwtransform2", nullptr, Bwt2, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtransform", nullptr, BwtLinear, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"unbwtransform", nullptr, UnBwtLinear, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"huffLengths", nullptr, HuffLengths, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"suffixsort", nullptr, SuffixSort, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtcCompress", nullptr, BwtcCompress, nullptr, nullptr, nullptr, napi_default, nullptr},
     };

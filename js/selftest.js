@@ -23,5 +23,6 @@ res.bwtc_bytes40 = sha(cjs.BWTC.compressFile(all, null, 6));
 var U2 = Buffer.alloc(6); res.bwt_linear = [cjs.BWT.bwtransform(Buffer.from('banana'), U2, null, 6, 256), U2.toString('ascii')];
 var SA = new Int32Array(6); cjs.BWT.suffixsort(Buffer.from('banana'), SA, 6, 256); res.sa = Array.from(SA);
 var U3 = Buffer.alloc(6); cjs.BWT.unbwtransform(Buffer.from('annbaa'), U3, null, 6, 4); res.unbwt = U3.toString('ascii');
+var hl = [1, 1, 1, 1, 1]; cjs.HuffmanAllocator.allocateHuffmanCodeLengths(hl, 32); res.huff = hl;
 try { cjs.Bzip2.compressFile(Buffer.from('x'), null, 0); res.badlevel = 'no throw'; } catch (e) { res.badlevel = e.message; }
 console.log(JSON.stringify(res));

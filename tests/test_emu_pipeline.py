@@ -182,6 +182,27 @@ def test_inverse_linear_bwt_by_list_ranking():
     assert L.cjs_unbwt_linear(datas[0].ctypes.data, out.ctypes.data, 6, 2) == 0                # inconsistent pair: no fault
 
 
+def test_allocator_entry_vs_reference_vectors(golden):
+    """cjs_huff_lengths(_batch) = allocateHuffmanCodeLengths: the 8 KATs of test/huffman.js:15-77 and
+    the 408 reference-made fuzz vectors (both branches of the length limiter)."""
+    from test_oracle import HUFF_KATS
+    L = _lib.load(stagelib.EMU_SO)
+    for freq, maxlen, expect in HUFF_KATS:
+        a = np.array(freq, dtype=np.int64)
+        assert L.cjs_huff_lengths(a.ctypes.data, a.size, maxlen) == 0
+        assert a.tolist() == expect
+    for ml in (3, 6, 20, 32):
+        cs = [c for c in golden["huff"]["cases"] if c["max_len"] == ml]
+        off = np.zeros(len(cs) + 1, dtype=np.uint32)
+        off[1:] = np.cumsum([len(c["freq"]) for c in cs])
+        flat = np.concatenate([np.array(c["freq"], dtype=np.int64) for c in cs])
+        assert L.cjs_huff_lengths_batch(flat.ctypes.data, off.ctypes.data, len(cs), ml) == 0
+        for k, c in enumerate(cs):
+            assert flat[off[k]:off[k + 1]].tolist() == c["lengths"], (ml, k)
+    a = np.ones(9, dtype=np.int64)
+    assert L.cjs_huff_lengths(a.ctypes.data, 9, 3) == -22            # 9 symbols cannot fit 3-bit codes
+
+
 def test_bwtc_streams_vs_reference_digest(emu_ctx, golden):
     """BWTC -6..-9 (lib/BWTC.js): linear BWT + MTF/RLE2 through the kernels (CPU debug build here),
     Fenwick model + range coder on the host; bit-identical to the reference."""

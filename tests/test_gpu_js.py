@@ -24,6 +24,7 @@ def test_node_dropin_digests(golden):
     assert r["bwtc_bytes40"] == golden["bytes40:bwtc:6"]["out_sha256"]
     assert r["bwt_linear"] == [4, "annbaa"]
     assert r["sa"] == [5, 3, 1, 0, 4, 2]
+    assert r["huff"] == [3, 3, 2, 2, 2]                     # test/huffman.js:24-28
     assert r["unbwt"] == "banana"                          # BWT.unbwtransform, lib/BWT.js:352-363
     assert r["stream_len"] > 30
     assert r["badlevel"] == "Invalid block size multiplier"

@@ -184,6 +184,20 @@ def test_bwtc_and_linear_bwt_goldens(golden, ctx):
         assert np.array_equal(back, d)
 
 
+def test_allocator_entry_kats_and_fuzz(golden):
+    """allocateHuffmanCodeLengths through the C ABI on the GPU: test/huffman.js KATs + reference-made fuzz."""
+    from compressjs_amd import HuffmanAllocator
+    from test_oracle import HUFF_KATS
+    for freq, maxlen, expect in HUFF_KATS:
+        a = list(freq)
+        HuffmanAllocator.allocateHuffmanCodeLengths(a, maxlen)
+        assert a == expect
+    for ml in (3, 6, 20, 32):
+        cs = [c for c in golden["huff"]["cases"] if c["max_len"] == ml]
+        got = HuffmanAllocator.allocate_many([c["freq"] for c in cs], ml)
+        assert got == [c["lengths"] for c in cs]
+
+
 def test_error_codes_through_the_abi(ctx):
     d = synth.text_like(200_000, 1)
     out = np.zeros(1000, np.uint8)
