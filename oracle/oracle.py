@@ -14,8 +14,8 @@ MAX_GROUPS = 6
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "bz2_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("bz2_oracle.c", "bz2_decode_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return _SO
 
@@ -65,8 +65,48 @@ def lib():
         L.orc_bz2_block_stages.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_int,
                                            C.POINTER(BlockInfo), C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]
+        L.orc_bz2_decompress.restype = C.c_int64
+        L.orc_bz2_decompress.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int,
+                                         C.POINTER(C.c_int), C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_bz2_decompress_block.restype = C.c_int64
+        L.orc_bz2_decompress_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                                               C.POINTER(C.c_int)]
         _lib = L
     return _lib
+
+
+class DBlock(C.Structure):
+    _fields_ = [("start_bit", C.c_uint64), ("end_bit", C.c_uint64), ("n", C.c_uint32),
+                ("orig_ptr", C.c_uint32), ("crc", C.c_uint32), ("pad", C.c_uint32), ("out_bytes", C.c_uint64)]
+
+
+DECODE_DETAIL = {0: None, 1: "bad magic", 2: "level out of range", 3: "initial position out of bounds",
+                 4: "Bad block CRC", 5: "Bad stream CRC"}
+
+
+def bz2_decompress(stream, multistream: bool = False, max_blocks: int = 1 << 16):
+    """Bunzip.decode (lib/Bzip2.js:454-481) -> (ret, detail, output bytes or None, [(start_bit, out_bytes)])."""
+    d = _u8(stream)
+    det, nb = C.c_int(0), C.c_uint32(0)
+    blocks = (DBlock * max_blocks)()
+    probe = np.zeros(1, dtype=np.uint8)
+    n = lib().orc_bz2_decompress(_ptr(d), d.size, _ptr(probe), 0, int(multistream), C.byref(det), blocks, max_blocks, C.byref(nb))
+    if n < 0:
+        return int(n), det.value, None, []
+    out = np.zeros(max(int(n), 1), dtype=np.uint8)
+    n2 = lib().orc_bz2_decompress(_ptr(d), d.size, _ptr(out), int(n), int(multistream), C.byref(det), blocks, max_blocks, C.byref(nb))
+    assert n2 == n
+    tab = [(int(blocks[i].start_bit), int(blocks[i].out_bytes)) for i in range(min(nb.value, max_blocks))]
+    return int(n), det.value, out[:n].tobytes(), tab
+
+
+def bz2_decompress_block(stream, bitpos: int, cap: int = 1 << 26):
+    """Bunzip.decodeBlock (lib/Bzip2.js:482-503) -> (ret, detail, bytes or None)."""
+    d = _u8(stream)
+    det = C.c_int(0)
+    out = np.zeros(cap, dtype=np.uint8)
+    n = lib().orc_bz2_decompress_block(_ptr(d), d.size, int(bitpos), _ptr(out), cap, C.byref(det))
+    return (int(n), det.value, out[:n].tobytes()) if n >= 0 else (int(n), det.value, None)
 
 
 def _u8(a) -> np.ndarray:

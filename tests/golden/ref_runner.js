@@ -54,6 +54,24 @@ jobs.forEach(function(j) {
       HA.allocateHuffmanCodeLengths(a, c.max_len);
       return { freq: c.freq, max_len: c.max_len, lengths: a };
     });
+  } else if (j.kind === 'unbz2' || j.kind === 'unbz2block') {
+    // Bzip2.decompressFile / decompressBlock / table of the reference on a (possibly malformed) stream
+    var st = fs.readFileSync(j.input);
+    r.stream_len = st.length; r.stream_sha256 = sha(st);
+    try {
+      var dec = j.kind === 'unbz2' ? cjs.Bzip2.decompressFile(st, undefined, !!j.multistream)
+                                   : cjs.Bzip2.decompressBlock(st, j.bitpos);
+      dec = Buffer.from(dec);
+      r.ok = true; r.out_len = dec.length; r.out_sha256 = sha(dec);
+      if (j.kind === 'unbz2') {
+        var tb = [];
+        try { cjs.Bzip2.table(st, function(pos, size) { tb.push([pos, size]); }, !!j.multistream); r.table = tb; }
+        catch (e2) { r.table_error = String(e2.message); }
+      }
+    } catch (e) {
+      r.ok = false; r.error_code = (typeof e.errorCode === 'number') ? e.errorCode : null;
+      r.message = String(e.message); r.error_type = e.constructor && e.constructor.name;
+    }
   } else if (j.kind === 'crc') {
     var CRC32 = require(path.join(REF, 'lib', 'CRC32.js'));
     var d = fs.readFileSync(j.input), c = new CRC32();
