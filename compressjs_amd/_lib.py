@@ -18,6 +18,8 @@ SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_bz2_compress_bound", "cjs_bz2_compr
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
            "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
            "cjs_suffixsort", "cjs_unbwt_linear", "cjs_huff_lengths", "cjs_huff_lengths_batch",
+           "cjs_bz2_decompress", "cjs_bz2_decompress_device", "cjs_bz2_decompress_block", "cjs_bz2_table",
+           "cjs_bz2_last_size", "cjs_bz2_fetch", "cjs_bz2_last_detail", "cjs_bz2_last_decode_ms",
            "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages", "cjs_dbg_k1_sparse_rounds",
            "cjs_dbg_k1_rounds"]
 
@@ -92,9 +94,44 @@ def load(path: str | None = None):
     L.cjs_dbg_bwt_batch_time.restype = C.c_int32
     L.cjs_dbg_bwt_batch_time.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_int,
                                          C.POINTER(C.c_float)]
+    L.cjs_bz2_decompress.restype = C.c_int64
+    L.cjs_bz2_decompress.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int]
+    L.cjs_bz2_decompress_device.restype = C.c_int64
+    L.cjs_bz2_decompress_device.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_int]
+    L.cjs_bz2_decompress_block.restype = C.c_int64
+    L.cjs_bz2_decompress_block.argtypes = [vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64]
+    L.cjs_bz2_table.restype = C.c_int64
+    L.cjs_bz2_table.argtypes = [vp, vp, C.c_uint64, C.c_int, vp, vp, C.c_uint32]
+    L.cjs_bz2_last_size.restype = C.c_int64
+    L.cjs_bz2_last_size.argtypes = [vp]
+    L.cjs_bz2_fetch.restype = C.c_int64
+    L.cjs_bz2_fetch.argtypes = [vp, vp, C.c_uint64]
+    L.cjs_bz2_last_detail.restype = C.c_int32
+    L.cjs_bz2_last_detail.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.cjs_bz2_last_decode_ms.restype = C.c_float
+    L.cjs_bz2_last_decode_ms.argtypes = [vp]
     if path is None:
         _lib = L
     return L
+
+
+# Bunzip's errors (lib/Bzip2.js:62-88): TypeError with .errorCode, message + optional detail
+DECODE_MESSAGES = {-1: "Bad file checksum", -2: "Not bzip data", -3: "Unexpected input EOF", -4: "Unexpected output EOF",
+                   -5: "Data error", -6: "Out of memory", -7: "Obsolete (pre 0.9.5) bzip format not supported."}
+
+
+def raise_decode_error(L, h, rc: int):
+    """Raise what the reference's _throw(status, optDetail) raises for a negative decoder code."""
+    if rc not in DECODE_MESSAGES:
+        check(rc, "cjs_bz2_decompress")
+    got, want = C.c_uint32(0), C.c_uint32(0)
+    d = L.cjs_bz2_last_detail(h, C.byref(got), C.byref(want))
+    detail = {1: "bad magic", 2: "level out of range", 3: "initial position out of bounds",
+              4: "Bad block CRC (got %x expected %x)" % (got.value, want.value),
+              5: "Bad stream CRC (got %x expected %x)" % (got.value, want.value)}.get(d)
+    err = TypeError(DECODE_MESSAGES[rc] + (": " + detail if detail else ""))
+    err.errorCode = rc
+    raise err
 
 
 def check(rc: int, what: str = "call") -> int:

@@ -59,6 +59,55 @@ class Context:
         _lib.check(n, "cjs_bwtc_compress")
         return out[:n].tobytes()
 
+    def decompress(self, stream, multistream: bool = False) -> bytes:
+        """Bzip2.decompressFile on host buffers; raises the reference's TypeError(.errorCode) on bad input."""
+        d = np.ascontiguousarray(stream, dtype=np.uint8)
+        n = self.L.cjs_bz2_decompress(self.h, d.ctypes.data, d.size, None, 0, int(bool(multistream)))
+        if n == -21:                                   # size now known: fetch the retained result
+            n = int(self.L.cjs_bz2_last_size(self.h))
+            out = np.empty(max(n, 1), dtype=np.uint8)
+            _lib.check(self.L.cjs_bz2_fetch(self.h, out.ctypes.data, n), "cjs_bz2_fetch")
+            return out[:n].tobytes()
+        if n < 0:
+            _lib.raise_decode_error(self.L, self.h, int(n))
+        return b""
+
+    def decompress_block(self, stream, bitpos: int) -> bytes:
+        """Bzip2.decompressBlock (lib/Bzip2.js:482-503)."""
+        d = np.ascontiguousarray(stream, dtype=np.uint8)
+        n = self.L.cjs_bz2_decompress_block(self.h, d.ctypes.data, d.size, int(bitpos), None, 0)
+        if n == -21:
+            n = int(self.L.cjs_bz2_last_size(self.h))
+            out = np.empty(max(n, 1), dtype=np.uint8)
+            _lib.check(self.L.cjs_bz2_fetch(self.h, out.ctypes.data, n), "cjs_bz2_fetch")
+            return out[:n].tobytes()
+        if n < 0:
+            _lib.raise_decode_error(self.L, self.h, int(n))
+        return b""
+
+    def table(self, stream, multistream: bool = False):
+        """Bzip2.table (lib/Bzip2.js:508-548) -> [(bit position, decoded bytes)]."""
+        d = np.ascontiguousarray(stream, dtype=np.uint8)
+        cap = d.size // 8 + 16
+        pos = np.zeros(cap, dtype=np.uint64)
+        size = np.zeros(cap, dtype=np.uint64)
+        n = self.L.cjs_bz2_table(self.h, d.ctypes.data, d.size, int(bool(multistream)), pos.ctypes.data, size.ctypes.data, cap)
+        if n < 0:
+            _lib.raise_decode_error(self.L, self.h, int(n))
+        return [(int(pos[i]), int(size[i])) for i in range(int(n))]
+
+    def decompress_device(self, d_in, d_out, multistream: bool = False) -> int:
+        """Stream and output are torch uint8 CUDA tensors; returns the decoded size."""
+        n = self.L.cjs_bz2_decompress_device(self.h, d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(),
+                                             int(bool(multistream)))
+        if n < 0 and n != -21:
+            _lib.raise_decode_error(self.L, self.h, int(n))
+        return _lib.check(n, "cjs_bz2_decompress_device")
+
+    @property
+    def last_decode_ms(self) -> float:
+        return float(self.L.cjs_bz2_last_decode_ms(self.h))
+
     # device-resident (torch tensors on this context's GPU) ----------------------------------
     def compress_device(self, d_in, d_out, level: int = 9) -> int:
         """d_in / d_out: torch uint8 CUDA tensors.  Returns the number of bytes written."""
@@ -155,21 +204,21 @@ class Bzip2:
 
     @staticmethod
     def decompressFile(inStream, outStream=None, multistream=False):
-        """Decoding is fully determined by the format; it is not on the accelerated path yet
-        (SURVEY.md 8f-1).  Delegates to the interpreter's libbz2 binding."""
-        import bz2
-        data = _coerce_input(inStream).tobytes()
-        try:
-            if multistream:
-                out = bz2.decompress(data)
-            else:
-                d = bz2.BZ2Decompressor()
-                out = d.decompress(data)
-        except (OSError, ValueError) as ex:
-            err = TypeError("Data integrity error")
-            err.errorCode = -5
-            raise err from ex
-        return _deliver(out, outStream)
+        """Bzip2.decompressFile = Bunzip.decode (lib/Bzip2.js:454-481) on the GPU decoder (K7-K9)."""
+        data = _coerce_input(inStream)
+        return _deliver(default_context().decompress(data, multistream), outStream)
+
+    @staticmethod
+    def decompressBlock(inStream, bitPos, outStream=None):
+        """Bzip2.decompressBlock = Bunzip.decodeBlock (lib/Bzip2.js:482-503)."""
+        data = _coerce_input(inStream)
+        return _deliver(default_context().decompress_block(data, bitPos), outStream)
+
+    @staticmethod
+    def table(inStream, callback, multistream=False):
+        """Bzip2.table (lib/Bzip2.js:508-548): callback(position in bits, decoded bytes) per block."""
+        for pos, size in default_context().table(_coerce_input(inStream), multistream):
+            callback(pos, size)
 
 
 class HuffmanAllocator:

@@ -4,6 +4,7 @@
 #include "k1_bwt.h"
 #include "pipeline.h"
 #include "bwtc_host.h"
+#include "decode_host.h"
 #include <vector>
 #include <string.h>
 #include <stdlib.h>
@@ -305,6 +306,9 @@ struct cjs_ctx {
     K0Buf plan;
     int plan_level;
     u32 plan_blocks;
+    // decoder state (allocated by the first decompress call)
+    DecState* dec;
+    float dec_ms;
 };
 
 extern "C" void cjs_destroy(cjs_ctx* c);
@@ -353,6 +357,7 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     k1_prof_destroy(c->prof);
+    dec_free(c->dec);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -625,3 +630,79 @@ extern "C" int32_t cjs_profile_read(cjs_ctx* c, float* total_ms, uint32_t* launc
     if (elements) *elements = el;
     return rc;
 }
+
+// ---------------------------------------------------------------------------------------------
+// decoder: Bzip2.decompressFile / decompressBlock / table (lib/Bzip2.js:454-548)
+// ---------------------------------------------------------------------------------------------
+static u32 dec_slots(const cjs_ctx* c) { return c->batch_blocks < 16 ? 16u : c->batch_blocks; }
+
+static int64_t dec_deliver(cjs_ctx* c, int64_t n, uint8_t* out, uint64_t out_cap, bool out_dev) {
+    if (n < 0) return n;
+    if ((uint64_t)n > out_cap) return CJS_E_NOSPACE;             // result stays fetchable (cjs_bz2_fetch)
+    if (n == 0) return 0;
+    if (!out) return CJS_E_ARG;
+    u64 sz = 0;
+    const u8* d = dec_output(c->dec, &sz);
+    hipError_t e = hipMemcpyAsync(out, d, (size_t)n, out_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? n : (int64_t)(CJS_E_HIP - (int)e);
+}
+
+static int64_t dec_timed(cjs_ctx* c, const uint8_t* in, uint64_t in_len, bool in_dev, int multistream, bool check_crc) {
+    if (!c || (!in && in_len)) return CJS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return CJS_E_NOGPU;
+    (void)hipEventRecord(c->ev0, c->stream);
+    const int64_t n = dec_stream(&c->dec, dec_slots(c), c->stream, in, in_len, in_dev, multistream, check_crc);
+    (void)hipEventRecord(c->ev1, c->stream);
+    (void)hipStreamSynchronize(c->stream);
+    c->dec_ms = 0.f;
+    (void)hipEventElapsedTime(&c->dec_ms, c->ev0, c->ev1);
+    return n;
+}
+
+extern "C" int64_t cjs_bz2_decompress(cjs_ctx* c, const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_cap,
+                                      int multistream) {
+    return dec_deliver(c, dec_timed(c, in, in_len, false, multistream, true), out, out_cap, false);
+}
+extern "C" int64_t cjs_bz2_decompress_device(cjs_ctx* c, const uint8_t* d_in, uint64_t in_len, uint8_t* d_out,
+                                             uint64_t out_cap, int multistream) {
+    return dec_deliver(c, dec_timed(c, d_in, in_len, true, multistream, true), d_out, out_cap, true);
+}
+extern "C" int64_t cjs_bz2_decompress_block(cjs_ctx* c, const uint8_t* in, uint64_t in_len, uint64_t bitpos,
+                                            uint8_t* out, uint64_t out_cap) {
+    if (!c || (!in && in_len)) return CJS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return CJS_E_NOGPU;
+    return dec_deliver(c, dec_block(&c->dec, dec_slots(c), c->stream, in, in_len, bitpos), out, out_cap, false);
+}
+// Bzip2.table: callback(position in bits, decoded bytes) per block -> two arrays; returns the block count
+extern "C" int64_t cjs_bz2_table(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int multistream, uint64_t* positions,
+                                 uint64_t* sizes, uint32_t cap) {
+    const int64_t n = dec_timed(c, in, in_len, false, multistream, false);     // the stream CRC is ignored (:536)
+    if (n < 0) return n;
+    const u64 *p = nullptr, *z = nullptr;
+    const u32 nb = dec_table(c->dec, &p, &z);
+    for (u32 i = 0; i < nb && i < cap; i++) { if (positions) positions[i] = p[i]; if (sizes) sizes[i] = z[i]; }
+    return (int64_t)nb;
+}
+// size / bytes of the last successful decode (for callers that learn the size from the first call)
+extern "C" int64_t cjs_bz2_last_size(cjs_ctx* c) {
+    u64 sz = 0;
+    if (!c || !c->dec) return 0;
+    (void)dec_output(c->dec, &sz);
+    return (int64_t)sz;
+}
+extern "C" int64_t cjs_bz2_fetch(cjs_ctx* c, uint8_t* out, uint64_t out_cap) {
+    if (!c || !c->dec) return CJS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return CJS_E_NOGPU;
+    return dec_deliver(c, cjs_bz2_last_size(c), out, out_cap, false);
+}
+// detail of the last decoder error: 1 'bad magic', 2 'level out of range', 3 'initial position out of
+// bounds', 4 'Bad block CRC (got .. expected ..)', 5 'Bad stream CRC (got .. expected ..)'
+extern "C" int32_t cjs_bz2_last_detail(cjs_ctx* c, uint32_t* crc_got, uint32_t* crc_expected) {
+    int d = 0; u32 g = 0, w = 0;
+    if (c && c->dec) dec_error_info(c->dec, &d, &g, &w);
+    if (crc_got) *crc_got = g;
+    if (crc_expected) *crc_expected = w;
+    return d;
+}
+extern "C" float cjs_bz2_last_decode_ms(cjs_ctx* c) { return c ? c->dec_ms : 0.f; }

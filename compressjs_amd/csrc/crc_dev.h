@@ -1,0 +1,63 @@
+// CRC-32 (poly 0x04c11db7, MSB first; lib/CRC32.js:37-103) of a byte range by one 256-thread workgroup:
+// 256 independent table-driven slices, combined with x^(8m) mod P.  Shared by K0 (encoder: CRC of
+// the input bytes a block consumed) and K9 (decoder: CRC of the bytes a block decodes to).
+#pragma once
+#include "cjs_common.h"
+
+#define CRC_POLY 0x04c11db7u
+__device__ __forceinline__ u32 gf_mul(u32 a, u32 b) {    // a*b mod P over GF(2), P = x^32 + CRC_POLY
+    u32 r = 0;
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r & 0x80000000u) ? CRC_POLY : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+// v * x^(8*m) mod P using pw[k] = x^(8*2^k) mod P
+__device__ __forceinline__ u32 gf_shift(u32 v, u64 m, const u32* pw) {
+    for (int k = 0; m; k++, m >>= 1) if (m & 1u) v = gf_mul(v, pw[k]);
+    return v;
+}
+
+// All 256 threads of the block call this; tab[256], pw[40] and *acc are LDS scratch.  The CRC of
+// in[s, e) (init 0xffffffff, final complement) is returned to every thread.
+__device__ __forceinline__ u32 crc_range_block(const u8* in, u64 s, u64 e, u32* tab, u32* pw, u32* acc) {
+    const u32 tid = threadIdx.x;
+    if (tid < 256) {   // lib/CRC32.js:37-70
+        u32 c = tid << 24;
+        for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : (c << 1);
+        tab[tid] = c;
+    }
+    if (tid == 0) {
+        *acc = 0;
+        u32 p = 0x100u;                                   // x^8
+        for (int k = 0; k < 40; k++) { pw[k] = p; p = gf_mul(p, p); }
+    }
+    __syncthreads();
+    const u64 len = e - s;
+    const u64 per = (((len + 255) / 256) + 15) & ~(u64)15;    // multiple of 16: aligned 16-byte loads inside
+    const u64 lo = s + (u64)tid * per < e ? s + (u64)tid * per : e;
+    const u64 hi = lo + per < e ? lo + per : e;
+    u32 crc = 0;                                          // raw remainder (init 0)
+    u64 j = lo;
+    for (; j < hi && (((uintptr_t)(in + j)) & 15u); j++) crc = (crc << 8) ^ tab[((crc >> 24) ^ in[j]) & 0xffu];
+    for (; j + 16 <= hi; j += 16) {
+        const uint4 v = *(const uint4*)(in + j);
+        const u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 wd = wds[q];                        // little-endian: lowest address in the low byte
+            crc = (crc << 8) ^ tab[((crc >> 24) ^ wd) & 0xffu];
+            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 8)) & 0xffu];
+            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 16)) & 0xffu];
+            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 24)) & 0xffu];
+        }
+    }
+    for (; j < hi; j++) crc = (crc << 8) ^ tab[((crc >> 24) ^ in[j]) & 0xffu];
+    if (hi > lo) {
+        crc = gf_shift(crc, e - hi, pw);
+        atomicXor(acc, crc);
+    }
+    __syncthreads();
+    return ~(*acc ^ gf_shift(0xffffffffu, len, pw));
+}

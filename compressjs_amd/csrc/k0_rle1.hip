@@ -23,6 +23,7 @@
 //   k0_crc                    -> CRC of the input bytes each block consumed: 256 independent
 //                                table-driven streams per block, combined with x^(8m) mod P.
 #include "pipeline.h"
+#include "crc_dev.h"
 
 #define K0_TILE 4096
 #define K0_NONE 0ull          // boundary positions are stored +1 so that 0 means "none"
@@ -506,64 +507,14 @@ __global__ __launch_bounds__(64) void k0_pad(Pipe P) {
 }
 
 // ---- CRC -----------------------------------------------------------------------------------------------
-#define CRC_POLY 0x04c11db7u
-__device__ __forceinline__ u32 gf_mul(u32 a, u32 b) {    // a*b mod P over GF(2), P = x^32 + CRC_POLY
-    u32 r = 0;
-    for (int i = 31; i >= 0; i--) {
-        r = (r << 1) ^ ((r & 0x80000000u) ? CRC_POLY : 0u);
-        if ((b >> i) & 1u) r ^= a;
-    }
-    return r;
-}
-// v * x^(8*m) mod P using pw[k] = x^(8*2^k) mod P
-__device__ __forceinline__ u32 gf_shift(u32 v, u64 m, const u32* pw) {
-    for (int k = 0; m; k++, m >>= 1) if (m & 1u) v = gf_mul(v, pw[k]);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
-    const u32 b = blockIdx.x, kb = first_block + b, tid = threadIdx.x;
+    const u32 b = blockIdx.x, kb = first_block + b;
     if (kb >= *K.nBlocks) return;
     __shared__ u32 tab[256];
     __shared__ u32 pw[40];
     __shared__ u32 acc;
-    if (tid < 256) {   // lib/CRC32.js:37-70
-        u32 c = tid << 24;
-        for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : (c << 1);
-        tab[tid] = c;
-    }
-    if (tid == 0) {
-        acc = 0;
-        u32 p = 0x100u;                                   // x^8
-        for (int k = 0; k < 40; k++) { pw[k] = p; p = gf_mul(p, p); }
-    }
-    __syncthreads();
-    const u64 s = K.blkStart[kb], e = K.blkEnd[kb], len = e - s;
-    const u64 per = (((len + 255) / 256) + 15) & ~(u64)15;    // multiple of 16: aligned 16-byte loads inside
-    const u64 lo = s + (u64)tid * per < e ? s + (u64)tid * per : e;
-    const u64 hi = lo + per < e ? lo + per : e;
-    u32 crc = 0;                                          // raw remainder (init 0)
-    u64 j = lo;
-    for (; j < hi && (((uintptr_t)(K.in + j)) & 15u); j++) crc = (crc << 8) ^ tab[((crc >> 24) ^ K.in[j]) & 0xffu];
-    for (; j + 16 <= hi; j += 16) {
-        const uint4 v = *(const uint4*)(K.in + j);
-        const u32 wds[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const u32 wd = wds[q];                        // little-endian: lowest address in the low byte
-            crc = (crc << 8) ^ tab[((crc >> 24) ^ wd) & 0xffu];
-            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 8)) & 0xffu];
-            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 16)) & 0xffu];
-            crc = (crc << 8) ^ tab[((crc >> 24) ^ (wd >> 24)) & 0xffu];
-        }
-    }
-    for (; j < hi; j++) crc = (crc << 8) ^ tab[((crc >> 24) ^ K.in[j]) & 0xffu];
-    if (hi > lo) {
-        crc = gf_shift(crc, e - hi, pw);
-        atomicXor(&acc, crc);
-    }
-    __syncthreads();
-    if (tid == 0) P.crc[b] = ~(acc ^ gf_shift(0xffffffffu, len, pw));
+    const u32 c = crc_range_block(K.in, K.blkStart[kb], K.blkEnd[kb], tab, pw, &acc);
+    if (threadIdx.x == 0) P.crc[b] = c;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------

@@ -1,0 +1,310 @@
+// K7: bzip2 block discovery and entropy decode for gfx950 (Bunzip._get_next_block, lib/Bzip2.js:153-366).
+//
+//   k7_scan_magic   every bit offset of the stream is tested for the 48-bit block magic
+//                   (0x314159265359) and the end-of-stream magic (0x177245385090); hits are appended
+//                   to a candidate list.  The reference never searches - it reads the next header
+//                   where the previous block ended - so the host walks the real chain through the
+//                   candidates afterwards (decode.hip) and ignores hits that are not on it.
+//   k7_decode       one WAVE per candidate block.  The 64 lanes execute one uniform instruction
+//                   stream (the Huffman/MTF recurrences are serial) and use the vector registers as
+//                   tables indexed with v_readlane instead of going to LDS for every symbol:
+//                     - 2 x 64 stream words prefetched per lane (coalesced 256-byte loads),
+//                     - limit[] / base[] of the current coding table: lane L holds length L; the
+//                       code length is one ballot of "prefix(L) <= limit[L]" (:290-297),
+//                     - permute[] of the current table: 3 registers x 64 lanes (two u16 each),
+//                     - the 256-entry MTF list, kept in the byte domain (entries are symToByte values):
+//                       4 bytes per lane, shifted with one DPP wave_shr,
+//                     - 256 output bytes staged 4 per lane and stored as one coalesced 256-byte row.
+//                   Output: the BWT last column (dbuf low bytes) of the block, its length, origPtr,
+//                   the stored CRC, the bit position where the block ends, or an Err code.
+#include "decode.h"
+
+#define WHOLEPI 0x314159265359ull
+#define SQRTPI 0x177245385090ull
+
+__global__ __launch_bounds__(256) void k7_scan_magic(const u8* in, u64 len, u64 first_bit, u64* cand, u32* ncand, u32 cap) {
+    __shared__ u8 s[256 + 8];
+    const u64 b0 = (u64)blockIdx.x * 256u;
+    const u32 tid = threadIdx.x;
+    s[tid] = b0 + tid < len ? in[b0 + tid] : 0;
+    if (tid < 8) s[256 + tid] = b0 + 256 + tid < len ? in[b0 + 256 + tid] : 0;
+    __syncthreads();
+    if (b0 + tid >= len) return;
+    u64 w = 0;
+    for (int k = 0; k < 8; k++) w = (w << 8) | s[tid + k];
+    for (int sft = 0; sft < 8; sft++) {
+        const u64 v = (w >> (16 - sft)) & 0xFFFFFFFFFFFFull;
+        const u64 bit = (b0 + tid) * 8u + sft;
+        if ((v == WHOLEPI || v == SQRTPI) && bit >= first_bit) {     // bits past the end read as 0 (lib/BitStream.js:84)
+            const u32 k = atomicAdd(ncand, 1u);
+            if (k < cap) cand[k] = (bit << 1) | (v == SQRTPI ? 1u : 0u);
+        }
+    }
+}
+
+// ---- uniform bit reader over the padded stream (words beyond the stream read as 0: lib/BitStream.js:84)
+// Words are appended to the window strictly in order, so chunk c+1 (64 words, one per lane) is always
+// requested a whole chunk - 2048 bits - before its first word is needed; it is byte swapped when it
+// becomes the current chunk, long after the load was issued.
+struct BitRd {
+    const u32* w;      // 4-byte aligned stream
+    u64 zeroChunk;     // a chunk that lies entirely in the zero padding behind the stream
+    u32 ca, cb;        // this lane's word of the current chunk (MSB first) and of the next one (raw)
+    u64 win;           // next unread bits, MSB aligned
+    int avail;         // valid bits in win
+    u64 next;          // index of the next word to append to win
+};
+__device__ __forceinline__ u32 br_load(const BitRd& r, u64 chunk) {
+    const u64 c = chunk < r.zeroChunk ? chunk : r.zeroChunk;      // unconditional load: nothing waits on it here
+    return r.w[c * 64u + lane_id()];
+}
+__device__ __forceinline__ u32 br_word(BitRd& r) {
+    const u32 k = (u32)r.next & 63u;
+    if (k == 0) { r.ca = __builtin_bswap32(r.cb); r.cb = br_load(r, (r.next >> 6) + 1u); }
+    r.next++;
+    return (u32)__builtin_amdgcn_readlane((int)r.ca, (int)k);
+}
+__device__ __forceinline__ void br_init(BitRd& r, const u32* w, u64 zeroChunk, u64 bitpos) {
+    r.w = w; r.zeroChunk = zeroChunk;
+    r.next = bitpos >> 5;
+    const u64 chunk = r.next >> 6;
+    r.cb = br_load(r, chunk);
+    r.ca = 0;
+    if (r.next & 63u) { r.ca = __builtin_bswap32(r.cb); r.cb = br_load(r, chunk + 1u); }
+    const u64 hi = br_word(r);
+    const u64 lo = br_word(r);
+    const int sk = (int)(bitpos & 31u);
+    r.win = ((hi << 32) | lo) << sk;
+    r.avail = 64 - sk;
+}
+__device__ __forceinline__ void br_consume(BitRd& r, int n) {
+    r.win <<= n;
+    r.avail -= n;
+    if (r.avail <= 32) {
+        r.win |= (u64)br_word(r) << (32 - r.avail);
+        r.avail += 32;
+    }
+}
+__device__ __forceinline__ u32 br_get(BitRd& r, int n) {          // 1 <= n <= 32
+    const u32 v = (u32)(r.win >> (64 - n));
+    br_consume(r, n);
+    return v;
+}
+__device__ __forceinline__ u64 br_tell(const BitRd& r) { return r.next * 32u - (u64)r.avail; }
+
+// set byte `idx` (0..255) of a table spread 4 bytes per lane
+__device__ __forceinline__ void tab_set(u32& reg, u32 idx, u32 val) {
+    if (lane_id() == (idx >> 2)) reg = (reg & ~(0xffu << (8u * (idx & 3u)))) | (val << (8u * (idx & 3u)));
+}
+
+#define K7_FAIL(code) do { st = (code); goto finish; } while (0)
+// append one byte of the block: 4 bytes are gathered in a scalar, every 4th byte moves the word into
+// its lane, every 256th byte stores the row (coalesced 256 bytes)
+#define K7_PUT(uc) do {                                                                        \
+        acc |= (u32)(uc) << (8u * (cnt & 3u));                                                 \
+        cnt++;                                                                                 \
+        if (!(cnt & 3u)) {                                                                     \
+            ow = lane == (((cnt - 1u) >> 2) & 63u) ? acc : ow;                                 \
+            acc = 0;                                                                           \
+            if (!(cnt & 255u)) out32[(size_t)((cnt >> 8) - 1u) * 64u + lane] = ow;             \
+        }                                                                                      \
+    } while (0)
+
+__global__ __launch_bounds__(64) void k7_decode(DecBuf D, u32 first, u32 count) {
+    const u32 slot = blockIdx.x;
+    if (slot >= count) return;
+    const u32 lane = lane_id();
+    __shared__ int s_limLA[6][32];     // left-aligned (to 20 bits) limit of every code length; -1 = length not used
+    __shared__ u32 s_limit[6][32];
+    __shared__ u32 s_base[6][32];
+    __shared__ u16 s_perm[6][384];
+    __shared__ u8 s_len[264];
+    __shared__ u32 s_sel[4096];        // 32768 selectors, 4 bits each
+
+    const u64 start = D.cand[first + slot] >> 1;
+    u32* out32 = (u32*)(D.tt + (size_t)slot * D.ttStride);
+    BitRd r;
+    const u64 t_start = clock64();
+    u64 nsym = 0;
+    br_init(r, D.in32, D.zeroChunk, start + 48);
+    int st = 0;
+    u32 cnt = 0, origPtr = 0, acc = 0;
+    const u32 crc = br_get(r, 32);
+    u32 mw = 0, ow = 0;                // MTF list in the byte domain (4 entries per lane), output staging
+    int symTotal = 0, groupCount = 0, symCount = 0;
+    u32 nSel = 0;
+
+    if (br_get(r, 1)) K7_FAIL(DEC_OBSOLETE);                                  // :174-175
+    origPtr = br_get(r, 24);
+    {                                                                          // :185-195  symToByte
+        const u32 t = br_get(r, 16);
+        for (int i = 0; i < 16; i++)
+            if (t & (1u << (15 - i))) {
+                const u32 k = br_get(r, 16);
+                for (int j = 0; j < 16; j++)
+                    if (k & (1u << (15 - j))) { tab_set(mw, (u32)symTotal, (u32)(i * 16 + j)); symTotal++; }
+            }
+    }
+    groupCount = (int)br_get(r, 3);                                            // :198-200
+    if (groupCount < 2 || groupCount > 6) K7_FAIL(DEC_DATA_ERROR);
+    nSel = br_get(r, 15);                                                      // :205-207
+    if (nSel == 0) K7_FAIL(DEC_DATA_ERROR);
+    {                                                                          // :209-221
+        u64 list = 0;     // mtfSymbol[0..6]: entries >= groupCount are 0, as in the reference's zeroed buffer
+        for (int i = 0; i < groupCount; i++) list |= (u64)i << (8 * i);
+        u32 pack = 0;
+        for (u32 i = 0; i < nSel; i++) {
+            const u32 v = (u32)(r.win >> 56);                 // next 8 bits
+            const int ones = __builtin_clz(~(v << 24));       // leading 1s
+            if (ones > groupCount) K7_FAIL(DEC_DATA_ERROR);
+            br_consume(r, ones + 1);
+            const int j = ones;
+            const u64 src = (list >> (8 * j)) & 0xffu;
+            const u64 lowmask = (1ull << (8 * j)) - 1ull;
+            list = (list & ~((1ull << (8 * (j + 1))) - 1ull)) | ((list & lowmask) << 8) | src;
+            pack |= (u32)src << (4u * (i & 7u));
+            if ((i & 7u) == 7u || i + 1 == nSel) { if (lane == 0) s_sel[i >> 3] = pack; pack = 0; }
+        }
+    }
+    symCount = symTotal + 2;
+    for (int g = 0; g < groupCount; g++) {                                     // :226-296
+        int t = (int)br_get(r, 5);
+        for (int i = 0; i < symCount; i++) {
+            for (;;) {
+                if (t < 1 || t > 20) K7_FAIL(DEC_DATA_ERROR);
+                if (!br_get(r, 1)) break;
+                if (!br_get(r, 1)) t++; else t--;
+            }
+            if (lane == 0) s_len[i] = (u8)t;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            int minLen = s_len[0], maxLen = s_len[0];
+            for (int i = 1; i < symCount; i++) { const int l = s_len[i]; if (l > maxLen) maxLen = l; if (l < minLen) minLen = l; }
+            u32 temp[22];
+            for (int i = 0; i < 22; i++) temp[i] = 0;
+            for (int i = 0; i < symCount; i++) temp[s_len[i]]++;
+            u32 startp[22];
+            u32 a = 0;
+            for (int i = 0; i < 22; i++) { startp[i] = a; a += temp[i]; }
+            for (int i = 0; i < 384; i++) s_perm[g][i] = 0;
+            for (int i = 0; i < symCount; i++) s_perm[g][startp[s_len[i]]++] = (u16)i;     // ordered by (length, symbol)
+            for (int i = 0; i < 32; i++) { s_limit[g][i] = 0; s_base[g][i] = 0; s_limLA[g][i] = -1; }
+            u32 pp = 0, tsum = 0;
+            for (int i = minLen; i < maxLen; i++) {
+                pp += temp[i];
+                s_limit[g][i] = pp - 1u;
+                pp <<= 1;
+                tsum += temp[i];
+                s_base[g][i + 1] = pp - tsum;
+            }
+            s_limit[g][maxLen] = pp + temp[maxLen] - 1u;
+            s_base[g][minLen] = 0;
+            for (int i = minLen; i <= maxLen; i++) {           // (v20 >> (20-i)) <= limit[i]  <=>  v20 <= limLA[i]
+                const u32 lim = s_limit[g][i];
+                s_limLA[g][i] = lim >= (1u << i) - 1u ? 0x7fffffff : (int)(((lim + 1u) << (20 - i)) - 1u);
+            }
+        }
+        __syncthreads();
+    }
+    {
+        // :301-366  the symbol loop
+        int limLA = -1;
+        u32 base = 0, pp0 = 0, pp1 = 0, pp2 = 0;
+        const bool is0 = lane == 0;
+        int left = 0;                 // symbols left in the current group of 50
+        u32 selector = 0;
+        int runPos = 0;
+        long long runT = 0;
+        for (;;) {
+            if (left == 0) {
+                left = 50;
+                if (selector >= nSel) K7_FAIL(DEC_DATA_ERROR);
+                const u32 g = (u32)__builtin_amdgcn_readfirstlane((int)((s_sel[selector >> 3] >> (4u * (selector & 7u))) & 15u));
+                selector++;
+                limLA = lane < 32u ? s_limLA[g][lane] : -1;
+                base = s_base[g][lane & 31u];
+                const u32* pm = (const u32*)&s_perm[g][0];
+                pp0 = pm[lane]; pp1 = pm[64 + lane]; pp2 = pm[128 + lane];
+            }
+            left--;
+            nsym++;
+            const u32 v20 = (u32)(r.win >> 44);
+            const u64 m = __ballot((int)v20 <= limLA);
+            if (m == 0) K7_FAIL(DEC_DATA_ERROR);                               // i > maxLen (:292)
+            const int len = __builtin_ctzll(m);
+            br_consume(r, len);
+            const u32 j = (v20 >> (20 - len)) - (u32)__builtin_amdgcn_readlane((int)base, len);
+            if (j >= 258u) K7_FAIL(DEC_DATA_ERROR);                            // :299-300 (base <= 2^28: no wrap)
+            const u32 preg = j < 128u ? pp0 : (j < 256u ? pp1 : pp2);
+            const u32 sym = ((u32)__builtin_amdgcn_readlane((int)preg, (int)((j >> 1) & 63u)) >> (16u * (j & 1u))) & 0xffffu;
+            if (sym < 2u) {                                                    // :318-335
+                if (!runPos) { runPos = 1; runT = 0; }
+                runT += sym == 0 ? (long long)runPos : 2ll * (long long)runPos;
+                runPos = (int)((u32)runPos << 1);
+                continue;
+            }
+            if (runPos) {                                                      // :340-347
+                runPos = 0;
+                if (runT < 0) K7_FAIL(DEC_DATA_ERROR);                         // the reference never terminates here
+                if ((long long)cnt + runT > (long long)DEC_CAP) K7_FAIL(DEC_DATA_ERROR);
+                const u32 uc = (u32)__builtin_amdgcn_readlane((int)mw, 0) & 0xffu;
+                u32 t = (u32)runT;
+                while (t && (cnt & 3u)) { K7_PUT(uc); t--; }
+                while (t >= 4u) {                              // whole words: lanes [k4, k4+nw) of the row
+                    const u32 k4 = (cnt >> 2) & 63u;
+                    const u32 nw = (t >> 2) < 64u - k4 ? (t >> 2) : 64u - k4;
+                    ow = (lane >= k4 && lane < k4 + nw) ? uc * 0x01010101u : ow;
+                    cnt += 4u * nw; t -= 4u * nw;
+                    if (!(cnt & 255u)) out32[(size_t)((cnt >> 8) - 1u) * 64u + lane] = ow;
+                }
+                while (t) { K7_PUT(uc); t--; }
+            }
+            if (sym > (u32)symTotal) break;                                    // :349-350
+            if (cnt >= DEC_CAP) K7_FAIL(DEC_DATA_ERROR);
+            {                                                                  // mtf(mtfSymbol, sym - 1) :53-60
+                const u32 idx = sym - 1u, ql = idx >> 2, sh8 = 8u * (idx & 3u);
+                const u32 src = ((u32)__builtin_amdgcn_readlane((int)mw, (int)ql) >> sh8) & 0xffu;
+                const u32 lowmask = (1u << sh8) - 1u, keepmask = (~lowmask) << 8;
+                if (ql == 0) {
+                    const u32 nv = (mw & keepmask) | ((mw & lowmask) << 8) | src;
+                    mw = is0 ? nv : mw;
+                } else {
+                    const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)mw, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                    const u32 carry = is0 ? src : (up >> 24);
+                    const u32 full = (mw << 8) | carry;
+                    const u32 part = (mw & keepmask) | ((mw & lowmask) << 8) | carry;
+                    mw = lane < ql ? full : (lane == ql ? part : mw);
+                }
+                K7_PUT(src);
+            }
+        }
+    }
+    if (cnt & 3u) ow = lane == ((cnt >> 2) & 63u) ? acc : ow;
+    if (cnt & 255u) out32[(size_t)(cnt >> 8) * 64u + lane] = ow;
+    if (origPtr >= cnt) st = DEC_DATA_ERROR;                                   // :372
+finish:
+    if (lane == 0) {
+        DecResult res;
+        res.endbit = br_tell(r);
+        res.status = st;
+        res.n = cnt;
+        res.origPtr = origPtr;
+        res.crc = crc;
+        res.cycles = clock64() - t_start;
+        res.symbols = nsym;
+        D.res[slot] = res;
+    }
+}
+
+int k7_scan(const u8* d_in, u64 len, u64 first_bit, u64* d_cand, u32* d_ncand, u32 cap, hipStream_t stream) {
+    HIP_CHECK_RET(hipMemsetAsync(d_ncand, 0, 4, stream));
+    if (len) hipLaunchKernelGGL(k7_scan_magic, dim3((u32)((len + 255) / 256)), dim3(256), 0, stream, d_in, len, first_bit, d_cand, d_ncand, cap);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+int k7_run(DecBuf D, u32 first, u32 count, hipStream_t stream) {
+    hipLaunchKernelGGL(k7_decode, dim3(count), dim3(64), 0, stream, D, first, count);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}

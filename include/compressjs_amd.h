@@ -105,6 +105,30 @@ int cjs_dbg_k1_rounds(void);
 int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                              int upto, cjs_dbg_stage_out* out);
 
+/* ---- decoder --------------------------------------------------------
+ * = Bzip2.decompressFile(input, output, multistream) = Bunzip.decode   (reference: lib/Bzip2.js:454-481,
+ *   _start_bunzip :137-152, _get_next_block :153-398, _read_bunzip :405-448).
+ * Returns the decoded size or a negative code: the reference's own Err values -2 NOT_BZIP_DATA,
+ * -5 DATA_ERROR, -7 OBSOLETE_INPUT (lib/Bzip2.js:62-72; which one, and when, follows the reference's
+ * sequential order), or -21 when `out_cap` is too small (the result stays in HBM: cjs_bz2_last_size /
+ * cjs_bz2_fetch), -22/-23/-100-e as above.  cjs_bz2_last_detail gives the optDetail of the error. */
+int64_t cjs_bz2_decompress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_cap,
+                           int multistream);
+/* the same with the stream and the output resident in HBM */
+int64_t cjs_bz2_decompress_device(cjs_ctx* ctx, const uint8_t* d_in, uint64_t in_len, uint8_t* d_out,
+                                  uint64_t out_cap, int multistream);
+/* = Bzip2.decompressBlock(input, bitPos, output) = Bunzip.decodeBlock   (reference: lib/Bzip2.js:482-503) */
+int64_t cjs_bz2_decompress_block(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, uint64_t bitpos, uint8_t* out,
+                                 uint64_t out_cap);
+/* = Bzip2.table(input, callback, multistream)   (reference: lib/Bzip2.js:508-548): positions[i] (bits)
+ *   and sizes[i] (decoded bytes) of block i, at most `cap` of them; returns the number of blocks */
+int64_t cjs_bz2_table(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int multistream, uint64_t* positions,
+                      uint64_t* sizes, uint32_t cap);
+int64_t cjs_bz2_last_size(cjs_ctx* ctx);
+int64_t cjs_bz2_fetch(cjs_ctx* ctx, uint8_t* out, uint64_t out_cap);
+int32_t cjs_bz2_last_detail(cjs_ctx* ctx, uint32_t* crc_got, uint32_t* crc_expected);
+float cjs_bz2_last_decode_ms(cjs_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

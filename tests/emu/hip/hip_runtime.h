@@ -222,6 +222,14 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 #define hipHostMallocDefault 0
 static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
 template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return emu_shfl_(v, lane); }
+static inline long long clock64() { return 0; }
+// DPP: only wave_shr:1 (0x138) is used by the kernels: lane l reads lane l-1, lane 0 keeps `old`
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    if (ctrl != 0x138) abort();
+    const int l = emu::lane();
+    const int v = emu_shfl_(src, l > 0 ? l - 1 : 0);
+    return l > 0 ? v : old;
+}
 template <class T> static inline T __builtin_amdgcn_readfirstlane(T v) {
     unsigned long long act = __ballot(1);
     return emu_shfl_(v, __builtin_ctzll(act));

@@ -219,3 +219,52 @@ def test_level1_many_batches():
         assert a == oracle.bz2_compress(d, 1)
     finally:
         c.close()
+
+
+def test_decoder_every_reference_vector(ctx):
+    """The GPU decoder against all 138 reference-made decode outcomes (tests/golden/golden_decode.json):
+    valid streams of both encoders, truncations, concatenations with/without multistream, bit flips."""
+    import json
+    import os
+    import decode_cases
+    from decode_check import check_block, check_stream, check_table
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_decode.json")) as f:
+        g = json.load(f)["vectors"]
+    L, h = ctx.L, ctx.h
+    by, n = {}, 0
+    for sid, s, ms in decode_cases.streams():
+        by[sid] = s
+        if s is None:
+            continue
+        check_stream(L, h, sid, s, ms, g[sid])
+        if g[sid]["ok"] and "table" in g[sid] and len(s) > 4:
+            check_table(L, h, sid, s, ms, g[sid])
+        n += 1
+    assert n >= 120            # 133 when test/sample*.bz2 are staged
+    for sid, bitpos in decode_cases.BLOCK_CASES:
+        if by.get(sid) is not None:
+            check_block(L, h, sid, by[sid], bitpos, g["block:%s@%d" % (sid, bitpos)])
+
+
+def test_decoder_round_trip_full_size(ctx):
+    """compress -> decompress on the GPU at BASELINE sizes (10^7 B text, -9 and -1), plus libbzip2's
+    encoder output for the same bytes; API-level wrappers."""
+    d = synth.text_like(10_000_000, 77)
+    raw = d.tobytes()
+    for lv in (9, 1):
+        z = ctx.compress(d, lv)
+        assert ctx.decompress(np.frombuffer(z, dtype=np.uint8)) == raw
+    z = bz2.compress(raw, 5)
+    assert Bzip2.decompressFile(z) == raw
+    tab = ctx.table(np.frombuffer(z, dtype=np.uint8))
+    assert sum(sz for _, sz in tab) == len(raw) and tab[0][0] == 32
+    first = Bzip2.decompressBlock(z, tab[1][0])
+    assert first == raw[tab[0][1]:tab[0][1] + tab[1][1]]
+    with pytest.raises(TypeError) as ei:
+        Bzip2.decompressFile(z[:len(z) // 2])
+    assert ei.value.errorCode == -5
+    import torch
+    zi = torch.frombuffer(bytearray(z), dtype=torch.uint8).cuda()
+    out = torch.empty(len(raw) + 16, dtype=torch.uint8, device="cuda")
+    assert ctx.decompress_device(zi, out) == len(raw)
+    assert out[:len(raw)].cpu().numpy().tobytes() == raw
