@@ -25,6 +25,12 @@ static int32_t (*p_bwtlin)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
 static int32_t (*p_sufsort)(const uint8_t*, int32_t*, uint32_t);
 static int32_t (*p_unbwt)(const uint8_t*, uint8_t*, uint32_t, uint32_t);
 static int32_t (*p_hufflen)(int64_t*, uint32_t, uint32_t);
+static int64_t (*p_dec)(cjs_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t, int);
+static int64_t (*p_decblk)(cjs_ctx*, const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t);
+static int64_t (*p_table)(cjs_ctx*, const uint8_t*, uint64_t, int, uint64_t*, uint64_t*, uint32_t);
+static int64_t (*p_lastsize)(cjs_ctx*);
+static int64_t (*p_fetch)(cjs_ctx*, uint8_t*, uint64_t);
+static int32_t (*p_detail)(cjs_ctx*, uint32_t*, uint32_t*);
 static int64_t (*p_bwtc_bound)(uint64_t);
 static int64_t (*p_bwtc)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t);
 static void* g_lib;
@@ -44,9 +50,15 @@ static bool load_lib(const char* path) {
     p_sufsort = (int32_t(*)(const uint8_t*, int32_t*, uint32_t))dlsym(g_lib, "cjs_suffixsort");
     p_unbwt = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t))dlsym(g_lib, "cjs_unbwt_linear");
     p_hufflen = (int32_t(*)(int64_t*, uint32_t, uint32_t))dlsym(g_lib, "cjs_huff_lengths");
+    p_dec = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t, int))dlsym(g_lib, "cjs_bz2_decompress");
+    p_decblk = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, uint64_t, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bz2_decompress_block");
+    p_table = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint64_t*, uint64_t*, uint32_t))dlsym(g_lib, "cjs_bz2_table");
+    p_lastsize = (int64_t(*)(cjs_ctx*))dlsym(g_lib, "cjs_bz2_last_size");
+    p_fetch = (int64_t(*)(cjs_ctx*, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bz2_fetch");
+    p_detail = (int32_t(*)(cjs_ctx*, uint32_t*, uint32_t*))dlsym(g_lib, "cjs_bz2_last_detail");
     p_bwtc_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bwtc_compress_bound");
     p_bwtc = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t))dlsym(g_lib, "cjs_bwtc_compress");
-    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_hufflen || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
+    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_hufflen || !p_dec || !p_decblk || !p_table || !p_lastsize || !p_fetch || !p_detail || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
     return true;
 }
 
@@ -207,6 +219,78 @@ static napi_value HuffLengths(napi_env env, napi_callback_info info) {
     return r;
 }
 
+// Bunzip's _throw(status, optDetail) (lib/Bzip2.js:82-88): TypeError with .errorCode and the reference's text
+static napi_value throw_decode(napi_env env, int64_t rc) {
+    const char* base = rc == -2 ? "Not bzip data" : rc == -5 ? "Data error" : rc == -7 ? "Obsolete (pre 0.9.5) bzip format not supported." : nullptr;
+    if (!base) return throw_code(env, rc, "cjs_bz2_decompress");
+    uint32_t got = 0, want = 0;
+    const int d = p_detail(g_ctx, &got, &want);
+    char msg[200];
+    if (d == 1) snprintf(msg, sizeof msg, "%s: bad magic", base);
+    else if (d == 2) snprintf(msg, sizeof msg, "%s: level out of range", base);
+    else if (d == 3) snprintf(msg, sizeof msg, "%s: initial position out of bounds", base);
+    else if (d == 4) snprintf(msg, sizeof msg, "%s: Bad block CRC (got %x expected %x)", base, got, want);
+    else if (d == 5) snprintf(msg, sizeof msg, "%s: Bad stream CRC (got %x expected %x)", base, got, want);
+    else snprintf(msg, sizeof msg, "%s", base);
+    napi_value m, e, code;
+    napi_create_string_utf8(env, msg, NAPI_AUTO_LENGTH, &m);
+    napi_create_type_error(env, nullptr, m, &e);
+    napi_create_int32(env, (int32_t)rc, &code);
+    napi_set_named_property(env, e, "errorCode", code);
+    napi_throw(env, e);
+    return nullptr;
+}
+static napi_value fetch_result(napi_env env, int64_t n) {
+    if (n == -21) n = p_lastsize(g_ctx);                       // decoded; the size is known now
+    else if (n < 0) return throw_decode(env, n);
+    napi_value out; void* dst = nullptr;
+    napi_create_buffer(env, (size_t)n, &dst, &out);
+    if (n > 0) {
+        const int64_t m = p_fetch(g_ctx, (uint8_t*)dst, (uint64_t)n);
+        if (m < 0) return throw_code(env, m, "cjs_bz2_fetch");
+    }
+    return out;
+}
+// decompress(bytes, multistream) -> Buffer                        = Bzip2.decompressFile
+static napi_value Decompress(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t* in; size_t len; bool ms = false;
+    if (argc < 1 || !get_bytes(env, argv[0], &in, &len)) { napi_throw_type_error(env, nullptr, "decompress(bytes, multistream)"); return nullptr; }
+    if (argc > 1) napi_get_value_bool(env, argv[1], &ms);
+    if (!ensure_ctx(env)) return nullptr;
+    return fetch_result(env, p_dec(g_ctx, in, len, nullptr, 0, ms ? 1 : 0));
+}
+// decompressBlock(bytes, bitPos) -> Buffer                        = Bzip2.decompressBlock
+static napi_value DecompressBlock(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t* in; size_t len; double pos = 0;
+    if (argc < 2 || !get_bytes(env, argv[0], &in, &len)) { napi_throw_type_error(env, nullptr, "decompressBlock(bytes, bitPos)"); return nullptr; }
+    napi_get_value_double(env, argv[1], &pos);
+    if (!ensure_ctx(env)) return nullptr;
+    return fetch_result(env, p_decblk(g_ctx, in, len, (uint64_t)pos, nullptr, 0));
+}
+// table(bytes, multistream) -> Float64Array [pos0, size0, pos1, size1, ...]   = Bzip2.table
+static napi_value Table(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t* in; size_t len; bool ms = false;
+    if (argc < 1 || !get_bytes(env, argv[0], &in, &len)) { napi_throw_type_error(env, nullptr, "table(bytes, multistream)"); return nullptr; }
+    if (argc > 1) napi_get_value_bool(env, argv[1], &ms);
+    if (!ensure_ctx(env)) return nullptr;
+    const uint32_t cap = (uint32_t)(len / 8 + 16);
+    std::vector<uint64_t> pos(cap), size(cap);
+    const int64_t n = p_table(g_ctx, in, len, ms ? 1 : 0, pos.data(), size.data(), cap);
+    if (n < 0) return throw_decode(env, n);
+    napi_value ab, arr; void* data = nullptr;
+    napi_create_arraybuffer(env, (size_t)n * 16, &data, &ab);
+    double* d = (double*)data;
+    for (int64_t i = 0; i < n; i++) { d[2 * i] = (double)pos[i]; d[2 * i + 1] = (double)size[i]; }
+    napi_create_typedarray(env, napi_float64_array, (size_t)n * 2, ab, 0, &arr);
+    return arr;
+}
+
 // suffixsort(T, SA: Int32Array, n)                                = BWT.suffixsort
 static napi_value SuffixSort(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value argv[3];
@@ -233,6 +317,9 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"bwtransform2", nullptr, Bwt2, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtransform", nullptr, BwtLinear, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"unbwtransform", nullptr, UnBwtLinear, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"decompress", nullptr, Decompress, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"decompressBlock", nullptr, DecompressBlock, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"table", nullptr, Table, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"huffLengths", nullptr, HuffLengths, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"suffixsort", nullptr, SuffixSort, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtcCompress", nullptr, BwtcCompress, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -4,10 +4,10 @@
 //   Bzip2.compressFile(input, [output], [level])   -> MI355X (N-API addon -> C ABI -> HIP kernels)
 //   BWT.bwtransform2(T, U, n, [alphabetSize])       -> MI355X
 //   BWT.bwtransform / suffixsort / unbwtransform, BWTC.compressFile (levels 6-9) -> MI355X
-//   everything else (decompressFile, decompressBlock, table, the other 12 codecs)
+//   Bzip2.decompressFile / decompressBlock / table   -> MI355X (GPU decoder K7-K9)
+//   everything else (BWTC.decompressFile, BWTC levels 1-5, the other 12 codecs)
 //       -> delegated unchanged to an installed reference package (require('compressjs')), when
-//          there is one; otherwise those properties throw.  Decoding is format-determined and is
-//          listed as the next row to accelerate (SURVEY.md 8f-1).
+//          there is one; otherwise those properties throw.
 'use strict';
 var path = require('path');
 var addon = require(path.join(__dirname, '..', 'build', 'compressjs_amd.node'));
@@ -59,12 +59,19 @@ Bzip2.compressFile = function(inStream, outStream, props) {          // lib/Bzip
   need();
   return deliver(addon.compress(inputBytes(inStream), level), outStream);
 };
-['decompressFile', 'decompressBlock', 'table'].forEach(function(k) {
-  Bzip2[k] = function() {
-    if (!reference) throw new Error('Bzip2.' + k + ' is not on the accelerated path yet; install the reference package (compressjs) to delegate it');
-    return reference.Bzip2[k].apply(reference.Bzip2, arguments);
-  };
-});
+Bzip2.decompressFile = function(input, output, multistream) {       // lib/Bzip2.js:454,931 (Bunzip.decode)
+  need();
+  return deliver(addon.decompress(inputBytes(input), !!multistream), output);
+};
+Bzip2.decompressBlock = function(input, bitPos, output) {            // lib/Bzip2.js:482,932
+  need();
+  return deliver(addon.decompressBlock(inputBytes(input), bitPos), output);
+};
+Bzip2.table = function(input, callback, multistream) {               // lib/Bzip2.js:508,933
+  need();
+  var t = addon.table(inputBytes(input), !!multistream);
+  for (var i = 0; i < t.length; i += 2) callback(t[i], t[i + 1]);
+};
 
 var BWT = Object.create(null);
 BWT.bwtransform2 = function(T, U, n, alphabetSize) {                  // lib/BWT.js:372

@@ -24,5 +24,13 @@ var U2 = Buffer.alloc(6); res.bwt_linear = [cjs.BWT.bwtransform(Buffer.from('ban
 var SA = new Int32Array(6); cjs.BWT.suffixsort(Buffer.from('banana'), SA, 6, 256); res.sa = Array.from(SA);
 var U3 = Buffer.alloc(6); cjs.BWT.unbwtransform(Buffer.from('annbaa'), U3, null, 6, 4); res.unbwt = U3.toString('ascii');
 var hl = [1, 1, 1, 1, 1]; cjs.HuffmanAllocator.allocateHuffmanCodeLengths(hl, 32); res.huff = hl;
+var z = cjs.Bzip2.compressFile(lcg, null, 1);
+res.roundtrip = sha(cjs.Bzip2.decompressFile(z)) === sha(lcg);
+var tb = []; cjs.Bzip2.table(z, function(p, n) { tb.push([p, n]); }); res.table = tb;
+res.block1 = sha(cjs.Bzip2.decompressBlock(z, tb[1][0])) === sha(lcg.slice(tb[0][1], tb[0][1] + tb[1][1]));
+var zb = Buffer.from(z); zb[zb.length - 3] ^= 1;
+try { cjs.Bzip2.decompressFile(zb); res.badcrc = 'no throw'; } catch (e) { res.badcrc = [e.constructor.name, e.errorCode, e.message.replace(/\(.*\)/, '()')]; }
+try { cjs.Bzip2.decompressFile(Buffer.from('BZx9')); res.badmagic = 'no throw'; } catch (e) { res.badmagic = [e.errorCode, e.message]; }
+res.sized = cjs.Bzip2.decompressFile(cjs.Bzip2.compressFile(Buffer.from('hello hello')), 11).length;
 try { cjs.Bzip2.compressFile(Buffer.from('x'), null, 0); res.badlevel = 'no throw'; } catch (e) { res.badlevel = e.message; }
 console.log(JSON.stringify(res));

@@ -25,6 +25,10 @@ def test_node_dropin_digests(golden):
     assert r["bwt_linear"] == [4, "annbaa"]
     assert r["sa"] == [5, 3, 1, 0, 4, 2]
     assert r["huff"] == [3, 3, 2, 2, 2]                     # test/huffman.js:24-28
+    assert r["roundtrip"] is True and r["block1"] is True and r["sized"] == 11   # GPU decoder behind Bzip2.decompressFile/Block
+    assert r["table"] == golden["lcg250000:bz2:1"]["blocks"]                       # Bzip2.table == the reference's own table
+    assert r["badcrc"] == ["TypeError", -5, "Data error: Bad stream CRC ()"]
+    assert r["badmagic"] == [-2, "Not bzip data: bad magic"]
     assert r["unbwt"] == "banana"                          # BWT.unbwtransform, lib/BWT.js:352-363
     assert r["stream_len"] > 30
     assert r["badlevel"] == "Invalid block size multiplier"
