@@ -32,6 +32,7 @@ struct DecResult {
     u32 crc;         // targetBlockCRC
     u64 cycles;      // shader clocks k7_decode spent on the block (s_memtime)
     u64 symbols;     // Huffman symbols decoded
+    u64 pwait, cwait; // clocks the boundary wave / the symbol wave spent waiting for each other
 };
 
 struct DecBuf {

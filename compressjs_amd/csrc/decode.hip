@@ -235,10 +235,11 @@ static int decode_batch(DecState& S, hipStream_t st, const u64* pos, u32 count, 
     TRYH(hipMemcpyAsync(res.data(), S.D.res, (size_t)count * sizeof(DecResult), hipMemcpyDeviceToHost, st));
     TRYH(hipStreamSynchronize(st));
     if (getenv("CJS_DEC_TRACE")) {
-        u64 cy = 0, sy = 0, by = 0;
-        for (u32 i = 0; i < count; i++) { cy += res[i].cycles; sy += res[i].symbols; by += res[i].n; }
-        fprintf(stderr, "[k7] %u blocks: %.1f Mcycles/block, %.0f symbols/block, %.0f bytes/block, %.1f cycles/symbol\n", count,
-                cy / 1e6 / count, (double)sy / count, (double)by / count, sy ? (double)cy / sy : 0.0);
+        u64 cy = 0, sy = 0, by = 0, pw = 0, cw = 0;
+        for (u32 i = 0; i < count; i++) { cy += res[i].cycles; sy += res[i].symbols; by += res[i].n; pw += res[i].pwait; cw += res[i].cwait; }
+        fprintf(stderr, "[k7] %u blocks: %.1f Mcycles/block, %.0f symbols/block, %.0f bytes/block, %.1f cycles/symbol (boundary wave waits %.1f, symbol wave waits %.1f)\n",
+                count, cy / 1e6 / count, (double)sy / count, (double)by / count, sy ? (double)cy / sy : 0.0,
+                sy ? (double)pw / sy : 0.0, sy ? (double)cw / sy : 0.0);
     }
     return 0;
 }

@@ -5,7 +5,8 @@
 //                   to a candidate list.  The reference never searches - it reads the next header
 //                   where the previous block ended - so the host walks the real chain through the
 //                   candidates afterwards (decode.hip) and ignores hits that are not on it.
-//   k7_decode       one WAVE per candidate block.  The 64 lanes execute one uniform instruction
+//   k7_decode       two WAVES per candidate block (code boundaries | symbols, RLE2, MTF), pipelined
+//                   through an LDS ring.  The 64 lanes of a wave execute one uniform instruction
 //                   stream (the Huffman/MTF recurrences are serial) and use the vector registers as
 //                   tables indexed with v_readlane instead of going to LDS for every symbol:
 //                     - 2 x 64 stream words prefetched per lane (coalesced 256-byte loads),
@@ -97,7 +98,6 @@ __device__ __forceinline__ void tab_set(u32& reg, u32 idx, u32 val) {
     if (lane_id() == (idx >> 2)) reg = (reg & ~(0xffu << (8u * (idx & 3u)))) | (val << (8u * (idx & 3u)));
 }
 
-#define K7_FAIL(code) do { st = (code); goto finish; } while (0)
 // append one byte of the block: 4 bytes are gathered in a scalar, every 4th byte moves the word into
 // its lane, every 256th byte stores the row (coalesced 256 bytes)
 #define K7_PUT(uc) do {                                                                        \
@@ -110,189 +110,275 @@ __device__ __forceinline__ void tab_set(u32& reg, u32 idx, u32 val) {
         }                                                                                      \
     } while (0)
 
-__global__ __launch_bounds__(64) void k7_decode(DecBuf D, u32 first, u32 count) {
+#define K7_RING 4096u        // u16 records in flight between the two waves
+
+// workgroup-scope publish / observe of a flag in LDS
+__device__ __forceinline__ void lds_publish(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ u32 lds_observe(u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Two waves per block, a software pipeline through an LDS ring:
+//   wave 0  parses the block header, then only finds code boundaries: one (table, canonical index)
+//           record per Huffman symbol (lib/Bzip2.js:283-300);
+//   wave 1  turns records into symbols (permute[] gather, 64 at a time), undoes RLE2 and MTF and
+//           writes the block's last column (:305-366).
+// Both recurrences are serial; splitting them halves the dependent instruction chain per symbol.
+__global__ __launch_bounds__(128) void k7_decode(DecBuf D, u32 first, u32 count) {
     const u32 slot = blockIdx.x;
     if (slot >= count) return;
     const u32 lane = lane_id();
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably uniform: keeps the wave's state in SGPRs
     __shared__ int s_limLA[6][32];     // left-aligned (to 20 bits) limit of every code length; -1 = length not used
     __shared__ u32 s_limit[6][32];
     __shared__ u32 s_base[6][32];
     __shared__ u16 s_perm[6][384];
+    __shared__ u32 s_jeob[6];          // canonical index of the end-of-block symbol in every table
     __shared__ u8 s_len[264];
     __shared__ u32 s_sel[4096];        // 32768 selectors, 4 bits each
+    __shared__ u16 s_ring[K7_RING];
+    __shared__ u32 s_mtf[64];          // initial MTF list (= symToByte), 4 entries per lane
+    __shared__ u32 s_head, s_tail, s_done, s_abort, s_symTotal, s_hdr;
+    __shared__ int s_pstat, s_cstat;
+    __shared__ u32 s_cnt, s_origPtr, s_crc;
+    __shared__ u64 s_endbit, s_nsym, s_pwait, s_cwait;
 
-    const u64 start = D.cand[first + slot] >> 1;
-    u32* out32 = (u32*)(D.tt + (size_t)slot * D.ttStride);
-    BitRd r;
     const u64 t_start = clock64();
-    u64 nsym = 0;
-    br_init(r, D.in32, D.zeroChunk, start + 48);
-    int st = 0;
-    u32 cnt = 0, origPtr = 0, acc = 0;
-    const u32 crc = br_get(r, 32);
-    u32 mw = 0, ow = 0;                // MTF list in the byte domain (4 entries per lane), output staging
-    int symTotal = 0, groupCount = 0, symCount = 0;
+    if (threadIdx.x == 0) { s_head = 0; s_tail = 0; s_done = 0; s_abort = 0; s_pstat = 0; s_cstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; }
+    __syncthreads();
+    BitRd r;
     u32 nSel = 0;
-
-    if (br_get(r, 1)) K7_FAIL(DEC_OBSOLETE);                                  // :174-175
-    origPtr = br_get(r, 24);
-    {                                                                          // :185-195  symToByte
-        const u32 t = br_get(r, 16);
-        for (int i = 0; i < 16; i++)
-            if (t & (1u << (15 - i))) {
-                const u32 k = br_get(r, 16);
-                for (int j = 0; j < 16; j++)
-                    if (k & (1u << (15 - j))) { tab_set(mw, (u32)symTotal, (u32)(i * 16 + j)); symTotal++; }
+    if (wave == 0) {
+        const u64 start = D.cand[first + slot] >> 1;
+        br_init(r, D.in32, D.zeroChunk, start + 48);
+        int st = 0;
+        const u32 crc = br_get(r, 32);
+        u32 origPtr = 0, mw = 0;
+        int symTotal = 0, groupCount = 0, symCount = 0;
+        do {
+            if (br_get(r, 1)) { st = DEC_OBSOLETE; break; }                    // :174-175
+            origPtr = br_get(r, 24);
+            {                                                                  // :185-195  symToByte
+                const u32 t = br_get(r, 16);
+                for (int i = 0; i < 16; i++)
+                    if (t & (1u << (15 - i))) {
+                        const u32 k = br_get(r, 16);
+                        for (int j = 0; j < 16; j++)
+                            if (k & (1u << (15 - j))) { tab_set(mw, (u32)symTotal, (u32)(i * 16 + j)); symTotal++; }
+                    }
             }
+            groupCount = (int)br_get(r, 3);                                    // :198-200
+            if (groupCount < 2 || groupCount > 6) { st = DEC_DATA_ERROR; break; }
+            nSel = br_get(r, 15);                                              // :205-207
+            if (nSel == 0) { st = DEC_DATA_ERROR; break; }
+            {                                                                  // :209-221
+                u64 list = 0;     // mtfSymbol[0..6]: entries >= groupCount are 0, as in the reference's zeroed buffer
+                for (int i = 0; i < groupCount; i++) list |= (u64)i << (8 * i);
+                u32 pack = 0;
+                for (u32 i = 0; i < nSel; i++) {
+                    const u32 v = (u32)(r.win >> 56);                 // next 8 bits
+                    const int ones = __builtin_clz(~(v << 24));       // leading 1s
+                    if (ones > groupCount) { st = DEC_DATA_ERROR; break; }
+                    br_consume(r, ones + 1);
+                    const int j = ones;
+                    const u64 src = (list >> (8 * j)) & 0xffu;
+                    const u64 lowmask = (1ull << (8 * j)) - 1ull;
+                    list = (list & ~((1ull << (8 * (j + 1))) - 1ull)) | ((list & lowmask) << 8) | src;
+                    pack |= (u32)src << (4u * (i & 7u));
+                    if ((i & 7u) == 7u || i + 1 == nSel) { if (lane == 0) s_sel[i >> 3] = pack; pack = 0; }
+                }
+                if (st) break;
+            }
+            symCount = symTotal + 2;
+            for (int g = 0; g < groupCount && !st; g++) {                      // :226-296
+                int t = (int)br_get(r, 5);
+                for (int i = 0; i < symCount && !st; i++) {
+                    for (;;) {
+                        if (t < 1 || t > 20) { st = DEC_DATA_ERROR; break; }
+                        if (!br_get(r, 1)) break;
+                        if (!br_get(r, 1)) t++; else t--;
+                    }
+                    if (lane == 0) s_len[i] = (u8)t;
+                }
+                if (st) break;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    int minLen = s_len[0], maxLen = s_len[0];
+                    for (int i = 1; i < symCount; i++) { const int l = s_len[i]; if (l > maxLen) maxLen = l; if (l < minLen) minLen = l; }
+                    u32 temp[22];
+                    for (int i = 0; i < 22; i++) temp[i] = 0;
+                    for (int i = 0; i < symCount; i++) temp[s_len[i]]++;
+                    u32 startp[22];
+                    u32 a = 0;
+                    for (int i = 0; i < 22; i++) { startp[i] = a; a += temp[i]; }
+                    for (int i = 0; i < 384; i++) s_perm[g][i] = 0;
+                    for (int i = 0; i < symCount; i++) {                       // ordered by (length, symbol)
+                        const u32 at = startp[s_len[i]]++;
+                        s_perm[g][at] = (u16)i;
+                        if (i == symCount - 1) s_jeob[g] = at;
+                    }
+                    for (int i = 0; i < 32; i++) { s_limit[g][i] = 0; s_base[g][i] = 0; s_limLA[g][i] = -1; }
+                    u32 pp = 0, tsum = 0;
+                    for (int i = minLen; i < maxLen; i++) {
+                        pp += temp[i];
+                        s_limit[g][i] = pp - 1u;
+                        pp <<= 1;
+                        tsum += temp[i];
+                        s_base[g][i + 1] = pp - tsum;
+                    }
+                    s_limit[g][maxLen] = pp + temp[maxLen] - 1u;
+                    s_base[g][minLen] = 0;
+                    for (int i = minLen; i <= maxLen; i++) {           // (v20 >> (20-i)) <= limit[i]  <=>  v20 <= limLA[i]
+                        const u32 lim = s_limit[g][i];
+                        s_limLA[g][i] = lim >= (1u << i) - 1u ? 0x7fffffff : (int)(((lim + 1u) << (20 - i)) - 1u);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } while (0);
+        s_mtf[lane] = mw;
+        if (lane == 0) { s_pstat = st; s_origPtr = origPtr; s_crc = crc; s_symTotal = (u32)symTotal; s_hdr = st == 0 ? 1u : 0u; }
     }
-    groupCount = (int)br_get(r, 3);                                            // :198-200
-    if (groupCount < 2 || groupCount > 6) K7_FAIL(DEC_DATA_ERROR);
-    nSel = br_get(r, 15);                                                      // :205-207
-    if (nSel == 0) K7_FAIL(DEC_DATA_ERROR);
-    {                                                                          // :209-221
-        u64 list = 0;     // mtfSymbol[0..6]: entries >= groupCount are 0, as in the reference's zeroed buffer
-        for (int i = 0; i < groupCount; i++) list |= (u64)i << (8 * i);
-        u32 pack = 0;
-        for (u32 i = 0; i < nSel; i++) {
-            const u32 v = (u32)(r.win >> 56);                 // next 8 bits
-            const int ones = __builtin_clz(~(v << 24));       // leading 1s
-            if (ones > groupCount) K7_FAIL(DEC_DATA_ERROR);
-            br_consume(r, ones + 1);
-            const int j = ones;
-            const u64 src = (list >> (8 * j)) & 0xffu;
-            const u64 lowmask = (1ull << (8 * j)) - 1ull;
-            list = (list & ~((1ull << (8 * (j + 1))) - 1ull)) | ((list & lowmask) << 8) | src;
-            pack |= (u32)src << (4u * (i & 7u));
-            if ((i & 7u) == 7u || i + 1 == nSel) { if (lane == 0) s_sel[i >> 3] = pack; pack = 0; }
-        }
-    }
-    symCount = symTotal + 2;
-    for (int g = 0; g < groupCount; g++) {                                     // :226-296
-        int t = (int)br_get(r, 5);
-        for (int i = 0; i < symCount; i++) {
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane((int)s_hdr)) {
+        if (wave == 0) {
+            // ---- wave 0: code boundaries only --------------------------------------------------------
+            int limLA = -1, st = 0;
+            u32 base = 0, g = 0, jeob = 0, recv = 0;
+            int left = 0;                 // symbols left in the current group of 50
+            u32 selector = 0, np = 0;
+            u64 nsym = 0, pwait = 0;
+            bool eob = false;
             for (;;) {
-                if (t < 1 || t > 20) K7_FAIL(DEC_DATA_ERROR);
-                if (!br_get(r, 1)) break;
-                if (!br_get(r, 1)) t++; else t--;
-            }
-            if (lane == 0) s_len[i] = (u8)t;
-        }
-        __syncthreads();
-        if (lane == 0) {
-            int minLen = s_len[0], maxLen = s_len[0];
-            for (int i = 1; i < symCount; i++) { const int l = s_len[i]; if (l > maxLen) maxLen = l; if (l < minLen) minLen = l; }
-            u32 temp[22];
-            for (int i = 0; i < 22; i++) temp[i] = 0;
-            for (int i = 0; i < symCount; i++) temp[s_len[i]]++;
-            u32 startp[22];
-            u32 a = 0;
-            for (int i = 0; i < 22; i++) { startp[i] = a; a += temp[i]; }
-            for (int i = 0; i < 384; i++) s_perm[g][i] = 0;
-            for (int i = 0; i < symCount; i++) s_perm[g][startp[s_len[i]]++] = (u16)i;     // ordered by (length, symbol)
-            for (int i = 0; i < 32; i++) { s_limit[g][i] = 0; s_base[g][i] = 0; s_limLA[g][i] = -1; }
-            u32 pp = 0, tsum = 0;
-            for (int i = minLen; i < maxLen; i++) {
-                pp += temp[i];
-                s_limit[g][i] = pp - 1u;
-                pp <<= 1;
-                tsum += temp[i];
-                s_base[g][i + 1] = pp - tsum;
-            }
-            s_limit[g][maxLen] = pp + temp[maxLen] - 1u;
-            s_base[g][minLen] = 0;
-            for (int i = minLen; i <= maxLen; i++) {           // (v20 >> (20-i)) <= limit[i]  <=>  v20 <= limLA[i]
-                const u32 lim = s_limit[g][i];
-                s_limLA[g][i] = lim >= (1u << i) - 1u ? 0x7fffffff : (int)(((lim + 1u) << (20 - i)) - 1u);
-            }
-        }
-        __syncthreads();
-    }
-    {
-        // :301-366  the symbol loop
-        int limLA = -1;
-        u32 base = 0, pp0 = 0, pp1 = 0, pp2 = 0;
-        const bool is0 = lane == 0;
-        int left = 0;                 // symbols left in the current group of 50
-        u32 selector = 0;
-        int runPos = 0;
-        long long runT = 0;
-        for (;;) {
-            if (left == 0) {
-                left = 50;
-                if (selector >= nSel) K7_FAIL(DEC_DATA_ERROR);
-                const u32 g = (u32)__builtin_amdgcn_readfirstlane((int)((s_sel[selector >> 3] >> (4u * (selector & 7u))) & 15u));
-                selector++;
-                limLA = lane < 32u ? s_limLA[g][lane] : -1;
-                base = s_base[g][lane & 31u];
-                const u32* pm = (const u32*)&s_perm[g][0];
-                pp0 = pm[lane]; pp1 = pm[64 + lane]; pp2 = pm[128 + lane];
-            }
-            left--;
-            nsym++;
-            const u32 v20 = (u32)(r.win >> 44);
-            const u64 m = __ballot((int)v20 <= limLA);
-            if (m == 0) K7_FAIL(DEC_DATA_ERROR);                               // i > maxLen (:292)
-            const int len = __builtin_ctzll(m);
-            br_consume(r, len);
-            const u32 j = (v20 >> (20 - len)) - (u32)__builtin_amdgcn_readlane((int)base, len);
-            if (j >= 258u) K7_FAIL(DEC_DATA_ERROR);                            // :299-300 (base <= 2^28: no wrap)
-            const u32 preg = j < 128u ? pp0 : (j < 256u ? pp1 : pp2);
-            const u32 sym = ((u32)__builtin_amdgcn_readlane((int)preg, (int)((j >> 1) & 63u)) >> (16u * (j & 1u))) & 0xffffu;
-            if (sym < 2u) {                                                    // :318-335
-                if (!runPos) { runPos = 1; runT = 0; }
-                runT += sym == 0 ? (long long)runPos : 2ll * (long long)runPos;
-                runPos = (int)((u32)runPos << 1);
-                continue;
-            }
-            if (runPos) {                                                      // :340-347
-                runPos = 0;
-                if (runT < 0) K7_FAIL(DEC_DATA_ERROR);                         // the reference never terminates here
-                if ((long long)cnt + runT > (long long)DEC_CAP) K7_FAIL(DEC_DATA_ERROR);
-                const u32 uc = (u32)__builtin_amdgcn_readlane((int)mw, 0) & 0xffu;
-                u32 t = (u32)runT;
-                while (t && (cnt & 3u)) { K7_PUT(uc); t--; }
-                while (t >= 4u) {                              // whole words: lanes [k4, k4+nw) of the row
-                    const u32 k4 = (cnt >> 2) & 63u;
-                    const u32 nw = (t >> 2) < 64u - k4 ? (t >> 2) : 64u - k4;
-                    ow = (lane >= k4 && lane < k4 + nw) ? uc * 0x01010101u : ow;
-                    cnt += 4u * nw; t -= 4u * nw;
-                    if (!(cnt & 255u)) out32[(size_t)((cnt >> 8) - 1u) * 64u + lane] = ow;
+                if (left == 0) {
+                    left = 50;
+                    if (selector >= nSel) { st = DEC_DATA_ERROR; break; }
+                    g = (u32)__builtin_amdgcn_readfirstlane((int)((s_sel[selector >> 3] >> (4u * (selector & 7u))) & 15u));
+                    selector++;
+                    limLA = lane < 32u ? s_limLA[g][lane] : -1;
+                    base = s_base[g][lane & 31u];
+                    jeob = (u32)__builtin_amdgcn_readfirstlane((int)s_jeob[g]);
                 }
-                while (t) { K7_PUT(uc); t--; }
-            }
-            if (sym > (u32)symTotal) break;                                    // :349-350
-            if (cnt >= DEC_CAP) K7_FAIL(DEC_DATA_ERROR);
-            {                                                                  // mtf(mtfSymbol, sym - 1) :53-60
-                const u32 idx = sym - 1u, ql = idx >> 2, sh8 = 8u * (idx & 3u);
-                const u32 src = ((u32)__builtin_amdgcn_readlane((int)mw, (int)ql) >> sh8) & 0xffu;
-                const u32 lowmask = (1u << sh8) - 1u, keepmask = (~lowmask) << 8;
-                if (ql == 0) {
-                    const u32 nv = (mw & keepmask) | ((mw & lowmask) << 8) | src;
-                    mw = is0 ? nv : mw;
-                } else {
-                    const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)mw, 0x138, 0xf, 0xf, false);   // wave_shr:1
-                    const u32 carry = is0 ? src : (up >> 24);
-                    const u32 full = (mw << 8) | carry;
-                    const u32 part = (mw & keepmask) | ((mw & lowmask) << 8) | carry;
-                    mw = lane < ql ? full : (lane == ql ? part : mw);
+                left--;
+                nsym++;
+                const u32 v20 = (u32)(r.win >> 44);
+                const u64 m = __ballot((int)v20 <= limLA);
+                if (m == 0) { st = DEC_DATA_ERROR; break; }                    // i > maxLen (:292)
+                const int len = __builtin_ctzll(m);
+                br_consume(r, len);
+                const u32 j = (v20 >> (20 - len)) - (u32)__builtin_amdgcn_readlane((int)base, len);
+                if (j >= 258u) { st = DEC_DATA_ERROR; break; }                 // :299-300 (base <= 2^28: no wrap)
+                recv = lane == (np & 63u) ? (j | (g << 9)) : recv;
+                np++;
+                eob = j == jeob;
+                if (eob || !(np & 63u)) {
+                    const u32 b0 = (np - 1u) & ~63u;                           // first record of this batch
+                    if (b0 + 64u - lds_observe(&s_tail) > K7_RING) {
+                        const u64 w0 = clock64();
+                        while (b0 + 64u - lds_observe(&s_tail) > K7_RING && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(2);
+                        pwait += clock64() - w0;
+                    }
+                    if (b0 + lane < np) s_ring[(b0 + lane) & (K7_RING - 1u)] = (u16)recv;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) lds_publish(&s_head, np);
+                    if (eob || lds_observe(&s_abort)) break;
                 }
-                K7_PUT(src);
             }
+            if (lane == 0) { s_pstat = st; s_endbit = br_tell(r); s_nsym = nsym; s_pwait = pwait; lds_publish(&s_done, 1u); }
+        } else {
+            // ---- wave 1: records -> symbols -> RLE2 -> MTF -> last column ------------------------------
+            u32* out32 = (u32*)(D.tt + (size_t)slot * D.ttStride);
+            const u32 symTotal = (u32)__builtin_amdgcn_readfirstlane((int)s_symTotal);
+            u32 mw = s_mtf[lane], ow = 0, acc = 0, cnt = 0;
+            const bool is0 = lane == 0;
+            int runPos = 0, st = 0;
+            long long runT = 0;
+            u32 consumed = 0;
+            u64 cwait = 0;
+            bool finished = false;
+            while (!finished) {
+                u32 head = lds_observe(&s_head);
+                if (head == consumed) {
+                    if (lds_observe(&s_done)) {
+                        head = lds_observe(&s_head);
+                        if (head == consumed) break;                           // wave 0 stopped without end-of-block
+                    } else { const u64 w0 = clock64(); __builtin_amdgcn_s_sleep(2); cwait += clock64() - w0; continue; }
+                }
+                const u32 b0 = consumed & ~63u;
+                const u32 hi = head - b0 < 64u ? head - b0 : 64u;              // records [consumed, b0+hi) are ready
+                u32 symv = 0;
+                if (lane < hi) {
+                    const u32 rec = s_ring[(b0 + lane) & (K7_RING - 1u)];
+                    symv = s_perm[rec >> 9][rec & 511u];
+                }
+                for (u32 k = consumed - b0; k < hi; k++) {
+                    const u32 sym = (u32)__builtin_amdgcn_readlane((int)symv, (int)k);
+                    if (sym < 2u) {                                            // :318-335
+                        if (!runPos) { runPos = 1; runT = 0; }
+                        runT += sym == 0 ? (long long)runPos : 2ll * (long long)runPos;
+                        runPos = (int)((u32)runPos << 1);
+                        continue;
+                    }
+                    if (runPos) {                                              // :340-347
+                        runPos = 0;
+                        if (runT < 0) { st = DEC_DATA_ERROR; break; }          // the reference never terminates here
+                        if ((long long)cnt + runT > (long long)DEC_CAP) { st = DEC_DATA_ERROR; break; }
+                        const u32 uc = (u32)__builtin_amdgcn_readlane((int)mw, 0) & 0xffu;
+                        u32 t = (u32)runT;
+                        while (t && (cnt & 3u)) { K7_PUT(uc); t--; }
+                        while (t >= 4u) {                              // whole words: lanes [k4, k4+nw) of the row
+                            const u32 k4 = (cnt >> 2) & 63u;
+                            const u32 nw = (t >> 2) < 64u - k4 ? (t >> 2) : 64u - k4;
+                            ow = (lane >= k4 && lane < k4 + nw) ? uc * 0x01010101u : ow;
+                            cnt += 4u * nw; t -= 4u * nw;
+                            if (!(cnt & 255u)) out32[(size_t)((cnt >> 8) - 1u) * 64u + lane] = ow;
+                        }
+                        while (t) { K7_PUT(uc); t--; }
+                    }
+                    if (sym > symTotal) { finished = true; break; }            // :349-350
+                    if (cnt >= DEC_CAP) { st = DEC_DATA_ERROR; break; }
+                    {                                                          // mtf(mtfSymbol, sym - 1) :53-60
+                        const u32 idx = sym - 1u, ql = idx >> 2, sh8 = 8u * (idx & 3u);
+                        const u32 src = ((u32)__builtin_amdgcn_readlane((int)mw, (int)ql) >> sh8) & 0xffu;
+                        const u32 lowmask = (1u << sh8) - 1u, keepmask = (~lowmask) << 8;
+                        if (ql == 0) {
+                            const u32 nv = (mw & keepmask) | ((mw & lowmask) << 8) | src;
+                            mw = is0 ? nv : mw;
+                        } else {
+                            const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)mw, 0x138, 0xf, 0xf, false);   // wave_shr:1
+                            const u32 carry = is0 ? src : (up >> 24);
+                            const u32 full = (mw << 8) | carry;
+                            const u32 part = (mw & keepmask) | ((mw & lowmask) << 8) | carry;
+                            mw = lane < ql ? full : (lane == ql ? part : mw);
+                        }
+                        K7_PUT(src);
+                    }
+                }
+                if (st) { if (lane == 0) lds_publish(&s_abort, 1u); break; }
+                consumed = b0 + hi;
+                if (lane == 0) lds_publish(&s_tail, consumed);
+            }
+            if (!st && !finished) st = -1;                                     // wave 0 reports why it stopped
+            if (st == 0) {
+                if (cnt & 3u) ow = lane == ((cnt >> 2) & 63u) ? acc : ow;
+                if (cnt & 255u) out32[(size_t)(cnt >> 8) * 64u + lane] = ow;
+            }
+            if (lane == 0) { s_cstat = st; s_cnt = cnt; s_cwait = cwait; lds_publish(&s_abort, 1u); }
         }
     }
-    if (cnt & 3u) ow = lane == ((cnt >> 2) & 63u) ? acc : ow;
-    if (cnt & 255u) out32[(size_t)(cnt >> 8) * 64u + lane] = ow;
-    if (origPtr >= cnt) st = DEC_DATA_ERROR;                                   // :372
-finish:
-    if (lane == 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
         DecResult res;
-        res.endbit = br_tell(r);
+        int st = s_pstat;
+        if (st == 0 && s_hdr) st = s_cstat == -1 ? DEC_DATA_ERROR : s_cstat;
+        if (st == 0 && s_origPtr >= s_cnt) st = DEC_DATA_ERROR;               // :372
+        res.endbit = s_endbit;
         res.status = st;
-        res.n = cnt;
-        res.origPtr = origPtr;
-        res.crc = crc;
+        res.n = s_cnt;
+        res.origPtr = s_origPtr;
+        res.crc = s_crc;
         res.cycles = clock64() - t_start;
-        res.symbols = nsym;
+        res.symbols = s_nsym;
+        res.pwait = s_pwait;
+        res.cwait = s_cwait;
         D.res[slot] = res;
     }
 }
@@ -304,7 +390,7 @@ int k7_scan(const u8* d_in, u64 len, u64 first_bit, u64* d_cand, u32* d_ncand, u
     return CJS_OK;
 }
 int k7_run(DecBuf D, u32 first, u32 count, hipStream_t stream) {
-    hipLaunchKernelGGL(k7_decode, dim3(count), dim3(64), 0, stream, D, first, count);
+    hipLaunchKernelGGL(k7_decode, dim3(count), dim3(128), 0, stream, D, first, count);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -223,6 +223,10 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
 template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return emu_shfl_(v, lane); }
 static inline long long clock64() { return 0; }
+static inline void __builtin_amdgcn_s_sleep(int) { emu::yield_(); }
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+template <class T> static inline void __hip_atomic_store(T* p, T v, int, int) { *(volatile T*)p = v; }
+template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *(volatile T*)p; }
 // DPP: only wave_shr:1 (0x138) is used by the kernels: lane l reads lane l-1, lane 0 keeps `old`
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
     if (ctrl != 0x138) abort();

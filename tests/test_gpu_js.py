@@ -32,3 +32,24 @@ def test_node_dropin_digests(golden):
     assert r["unbwt"] == "banana"                          # BWT.unbwtransform, lib/BWT.js:352-363
     assert r["stream_len"] > 30
     assert r["badlevel"] == "Invalid block size multiplier"
+
+
+def test_cli_round_trip(tmp_path):
+    """bin/compressjs-amd (the reference's bin/compressjs flags): -z at the default level 7, -d, -b."""
+    import bz2
+    if shutil.which("node") is None or not os.path.exists(os.path.join(ROOT, "build", "compressjs_amd.node")):
+        pytest.skip("node or the addon is not available on this box")
+    cli = os.path.join(ROOT, "bin", "compressjs-amd")
+    src = tmp_path / "in.txt"
+    data = (b"The quick brown fox jumps over the lazy dog. " * 30000)[:1_200_000]
+    src.write_bytes(data)
+    z = tmp_path / "out.bz2"
+    subprocess.check_call(["node", cli, "-z", str(src), str(z)], cwd=ROOT, timeout=300)
+    zb = z.read_bytes()
+    assert zb[:4] == b"BZh7" and bz2.decompress(zb) == data          # default level 7 (bin/compressjs:58)
+    back = subprocess.check_output(["node", cli, "-d", str(z)], cwd=ROOT, timeout=300)
+    assert back == data
+    blk = subprocess.check_output(["node", cli, "-d", "-b", "32", str(z)], cwd=ROOT, timeout=300)
+    assert data.startswith(blk) and len(blk) > 600000
+    r = subprocess.run(["node", cli, "-d", "-9", str(z)], cwd=ROOT, capture_output=True, timeout=60)
+    assert r.returncode == 1 and b"Compression level has no effect when decompressing." in r.stderr
