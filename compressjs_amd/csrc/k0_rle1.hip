@@ -39,16 +39,35 @@ __device__ __forceinline__ u32 k0_c(u64 k) {
 }
 
 // ---- per-tile: last run boundary (position j with j == 0 or in[j] != in[j-1]), stored +1 -------
+// 16 consecutive input bytes of a thread: one 16-byte load when the address allows it
+__device__ __forceinline__ void load16(const K0Buf& K, u64 j0, u8* b) {
+    if (j0 + 16u <= K.in_len && ((((uintptr_t)K.in) + j0) & 15u) == 0) {
+        const uint4 v = *(const uint4*)(K.in + j0);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = (u8)(w[k >> 2] >> (8 * (k & 3)));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = j0 + k < K.in_len ? K.in[j0 + k] : 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k0_tile_last(K0Buf K) {
     const u64 t = blockIdx.x;
-    const u64 t0 = t * K0_TILE;
+    const u64 j0 = t * K0_TILE + threadIdx.x * 16u;
     __shared__ unsigned long long last;
     if (threadIdx.x == 0) last = K0_NONE;
     __syncthreads();
     u64 mine = K0_NONE;
-    for (int k = 0; k < 16; k++) {
-        const u64 j = t0 + (u64)k * 256u + threadIdx.x;
-        if (j < K.in_len && (j == 0 || K.in[j] != K.in[j - 1])) mine = j + 1;
+    if (j0 < K.in_len) {
+        u8 b[16];
+        load16(K, j0, b);
+        const u8 prev = j0 ? K.in[j0 - 1] : 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u64 j = j0 + k;
+            if (j < K.in_len && (j == 0 || b[k] != (k ? b[k - 1] : prev))) mine = j + 1;
+        }
     }
     if (mine != K0_NONE) atomicMax(&last, (unsigned long long)mine);
     __syncthreads();
@@ -136,9 +155,10 @@ __device__ __forceinline__ u64 tile_runstarts(const K0Buf& K, u64 t, u64 rs_in, 
     u64 lastb = K0_NONE;
     u8 prev = 0;
     if (j0 > 0 && j0 - 1 < K.in_len) prev = K.in[j0 - 1];
+    load16(K, j0, b);
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         const u64 j = j0 + k;
-        b[k] = j < K.in_len ? K.in[j] : 0;
         if (j < K.in_len && (j == 0 || b[k] != (k ? b[k - 1] : prev))) lastb = j + 1;
     }
     sh[tid] = lastb;
