@@ -19,7 +19,7 @@ SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_bz2_compress_bound", "cjs_bz2_compr
            "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
            "cjs_suffixsort", "cjs_unbwt_linear", "cjs_huff_lengths", "cjs_huff_lengths_batch",
            "cjs_bz2_decompress", "cjs_bz2_decompress_device", "cjs_bz2_decompress_block", "cjs_bz2_table",
-           "cjs_bz2_last_size", "cjs_bz2_fetch", "cjs_bz2_last_detail", "cjs_bz2_last_decode_ms",
+           "cjs_bz2_last_size", "cjs_bz2_fetch", "cjs_bwtc_decompress", "cjs_bwtc_last_size", "cjs_bwtc_fetch", "cjs_bz2_last_detail", "cjs_bz2_last_decode_ms",
            "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages", "cjs_dbg_k1_sparse_rounds",
            "cjs_dbg_k1_rounds"]
 
@@ -108,6 +108,12 @@ def load(path: str | None = None):
     L.cjs_bz2_fetch.argtypes = [vp, vp, C.c_uint64]
     L.cjs_bz2_last_detail.restype = C.c_int32
     L.cjs_bz2_last_detail.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.cjs_bwtc_decompress.restype = C.c_int64
+    L.cjs_bwtc_decompress.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_int64)]
+    L.cjs_bwtc_last_size.restype = C.c_int64
+    L.cjs_bwtc_last_size.argtypes = [vp]
+    L.cjs_bwtc_fetch.restype = C.c_int64
+    L.cjs_bwtc_fetch.argtypes = [vp, vp, C.c_uint64]
     L.cjs_bz2_last_decode_ms.restype = C.c_float
     L.cjs_bz2_last_decode_ms.argtypes = [vp]
     if path is None:
@@ -142,6 +148,10 @@ def check(rc: int, what: str = "call") -> int:
         raise ValueError("Invalid block size multiplier")          # lib/Bzip2.js:888-890
     if rc == -21:
         raise CompressjsAmdError("%s: output buffer too small" % what)
+    if rc == -30:
+        raise RuntimeError("Bad magic")                             # lib/Util.js:150-152
+    if rc == -31:
+        raise CompressjsAmdError("%s: corrupt or truncated stream" % what)
     if rc == -24:
         raise CompressjsAmdError("%s: this codec variant is not accelerated (BWTC levels 1-5)" % what)
     if rc == -23:

@@ -96,6 +96,19 @@ class Context:
             _lib.raise_decode_error(self.L, self.h, int(n))
         return [(int(pos[i]), int(size[i])) for i in range(int(n))]
 
+    def bwtc_decompress(self, stream) -> bytes:
+        """BWTC.decompressFile (lib/BWTC.js:141-233): host range decoder, inverse BWT on the GPU (K6)."""
+        d = np.ascontiguousarray(stream, dtype=np.uint8)
+        declared = C.c_int64(-1)
+        n = self.L.cjs_bwtc_decompress(self.h, d.ctypes.data, d.size, None, 0, C.byref(declared))
+        if n == -21:
+            n = int(self.L.cjs_bwtc_last_size(self.h))
+            out = np.empty(max(n, 1), dtype=np.uint8)
+            _lib.check(self.L.cjs_bwtc_fetch(self.h, out.ctypes.data, n), "cjs_bwtc_fetch")
+            return out[:n].tobytes()
+        _lib.check(n, "cjs_bwtc_decompress")
+        return b""
+
     def decompress_device(self, d_in, d_out, multistream: bool = False) -> int:
         """Stream and output are torch uint8 CUDA tensors; returns the decoded size."""
         n = self.L.cjs_bz2_decompress_device(self.h, d_in.data_ptr(), d_in.numel(), d_out.data_ptr(), d_out.numel(),
@@ -256,6 +269,12 @@ class BWTC:
         data = _coerce_input(inStream)
         size = data.size if known else -1                                        # lib/Util.js:119-124
         return _deliver(default_context().bwtc_compress(data, level, size), outStream)
+
+
+    @staticmethod
+    def decompressFile(inStream, outStream=None):
+        """BWTC.decompressFile (lib/BWTC.js:141-233), levels 6-9."""
+        return _deliver(default_context().bwtc_decompress(_coerce_input(inStream)), outStream)
 
 
 class BWT:

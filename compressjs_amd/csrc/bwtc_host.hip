@@ -10,8 +10,11 @@
 //   LogDistanceModel.encode      lib/LogDistanceModel.js:24-36
 //   FenwickModel                 lib/FenwickModel.js:13-32,47-87,137-172
 //   BWTC.compressFile body       lib/BWTC.js:12-139
+// and the decoder sides: RangeCoder :146-226, NoModel.decode :22-29, LogDistanceModel.decode :37-44,
+// FenwickModel._decode/decode :88-136, Util.decompressFileHelper lib/Util.js:143-166, BWTC.decompressFile :141-233.
 #include "bwtc_host.h"
 #include <string.h>
+#include <vector>
 
 namespace {
 
@@ -211,4 +214,174 @@ int64_t bwtc_end(bwtc_coder* c) {
     const int64_t n = c->out.overflow ? -21 : (int64_t)c->out.n;
     delete c;
     return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct RangeDec {                            // lib/RangeCoder.js:146-226 (EXTRA_BITS = 7)
+    const uint8_t* p; uint64_t n, pos;
+    uint32_t low, range, help; int32_t buffer;
+    bool eof;
+    int32_t readByte() { if (pos < n) return p[pos++]; eof = true; return -1; }
+    void start() { buffer = readByte(); low = (uint32_t)buffer >> 1; range = 1u << 7; help = 0; }   // decodeStart(true)
+    void normalize() {                       // :157-166
+        while (range <= BOTTOM) {
+            low = (low << 8) | (((uint32_t)buffer << 7) & 0xFFu);
+            buffer = readByte();
+            low |= (uint32_t)buffer >> 1;
+            range <<= 8;
+        }
+    }
+    uint32_t culFreq(uint32_t tot) {         // :173-178
+        normalize();
+        help = range / tot;
+        if (help == 0) { eof = true; return 0; }
+        const uint32_t tmp = low / help;
+        return tmp >= tot ? tot - 1 : tmp;
+    }
+    uint32_t culShift(int shift) {           // :179-185
+        normalize();
+        help = range >> shift;
+        if (help == 0) { eof = true; return 0; }
+        const uint32_t tmp = low / help;
+        return (tmp >> shift) ? (1u << shift) - 1u : tmp;
+    }
+    void update(uint32_t sy_f, uint32_t lt_f, uint32_t tot_f) {     // :192-200
+        const uint32_t tmp = help * lt_f;
+        low -= tmp;
+        if (lt_f + sy_f < tot_f) range = help * sy_f; else range -= tmp;
+    }
+    uint32_t bit() { const uint32_t t = culShift(1); update(1, t, 2); return t; }           // :203-207
+    uint32_t byte() { const uint32_t t = culShift(8); update(1, t, 256); return t; }        // :209-213
+};
+
+uint32_t nomodel_decode(RangeDec& rc, int bits) {                            // lib/NoModel.js:22-29
+    uint32_t r = 0;
+    for (int i = bits - 1; i >= 0; i--) r = (r << 1) | rc.bit();
+    return r;
+}
+
+uint32_t logdist_decode(RangeDec& rc, int lgbits) {                          // lib/LogDistanceModel.js:37-44
+    const uint32_t lg = nomodel_decode(rc, lgbits);
+    if (lg < 2) return lg;
+    if (lg > 32) { rc.eof = true; return 0; }
+    return (1u << (lg - 1)) + nomodel_decode(rc, (int)lg - 1);
+}
+
+uint32_t fenwick_decode1(Fenwick& m, RangeDec& rc, bool isEscape) {          // lib/FenwickModel.js:88-128
+    uint32_t mask = 0xFFFF0000u; int shift = 16;
+    uint32_t update = m.increment << 16;
+    if (isEscape) { mask = 0x0000FFFFu; update -= 1u; shift = 0; }
+    const uint32_t tot_f = (m.tree[1] & mask) >> shift;
+    if (tot_f == 0) { rc.eof = true; return 0; }
+    const uint32_t prob = rc.culFreq(tot_f);
+    uint32_t i = 1, lt_f = 0;
+    while (i < m.numSyms) {
+        m.tree[i] += update;
+        const uint32_t leftProb = (m.tree[2 * i] & mask) >> shift;
+        i *= 2;
+        if ((prob - lt_f) >= leftProb) { lt_f += leftProb; i++; }
+    }
+    const uint32_t symbol = i - m.numSyms;
+    const uint32_t sy_f = (m.tree[i] & mask) >> shift;
+    m.tree[i] += update;
+    rc.update(sy_f, lt_f, tot_f);
+    if (symbol == m.numSyms - 1 && (m.tree[1] & 0xFFFFu) == 1u) {            // the last escape: zero it out
+        update = 0u - m.tree[i];
+        while (i >= 1) { m.tree[i] += update; i >>= 1; }
+    }
+    if (((m.tree[1] & 0xFFFF0000u) >> 16) >= m.max_prob) m.rescale();
+    return symbol;
+}
+uint32_t fenwick_decode(Fenwick& m, RangeDec& rc) {                          // :129-136
+    uint32_t s = fenwick_decode1(m, rc, false);
+    if (s == m.numSyms - 1) s = fenwick_decode1(m, rc, true);
+    return s;
+}
+
+}  // namespace
+
+int bwtc_decode(const uint8_t* in, uint64_t len, int64_t* declared_size, void* user, bwtc_block_fn on_block) {
+    // Util.decompressFileHelper (lib/Util.js:143-166)
+    const char* magic = "bwtc";
+    for (int i = 0; i < 4; i++) if ((uint64_t)i >= len || in[i] != (uint8_t)magic[i]) return BWTC_E_MAGIC;
+    uint64_t pos = 4;
+    double n = 0;                                                            // readUnsignedNumber :211-220
+    for (;;) {
+        if (pos >= len) return BWTC_E_CORRUPT;
+        const uint32_t c = in[pos++];
+        if (c & 0x80u) { n += (double)(c & 0x7Fu); break; }
+        n = (n + (double)c) * 128.0;
+    }
+    if (declared_size) *declared_size = (int64_t)n - 1;
+    RangeDec rc;
+    rc.p = in; rc.n = len; rc.pos = pos; rc.eof = false;
+    rc.start();                                                              // lib/BWTC.js:142-143
+    uint32_t blockSize = rc.byte();                                          // :144
+    if (rc.eof || blockSize < 1 || blockSize > 9) return BWTC_E_CORRUPT;
+    if (blockSize <= 5) return BWTC_E_FAST;                                  // :146 DefSumModel levels
+    blockSize *= 100000u;
+    const int lgbits = fls((uint32_t)(1 + fls(blockSize - 1)) - 1);          // LogDistanceModel(blockSize, 0, NoModel, NoModel)
+    std::vector<uint8_t> b(blockSize);
+    uint8_t M[256];
+    for (;;) {
+        const uint32_t ind = rc.culFreq(3);                                  // :158-159
+        rc.update(1, ind, 3);
+        if (rc.eof) return BWTC_E_CORRUPT;
+        uint32_t length;
+        if (ind == 0) length = blockSize;
+        else if (ind == 1) length = logdist_decode(rc, lgbits);
+        else break;                                                          // :166-167
+        const uint32_t pidx = logdist_decode(rc, lgbits);                    // :170
+        if (rc.eof || length > blockSize || pidx > length) return BWTC_E_CORRUPT;
+        uint16_t useTree[512];                                               // :172-186
+        useTree[0] = 1;
+        for (int i = 1; i < 512; i++) {
+            const int parent = i >> 1;
+            const int full = 1 << (9 - fls((uint32_t)i));
+            if (useTree[parent] == 0 || useTree[parent] == full * 2) useTree[i] = useTree[parent] >> 1;
+            else if (i >= 256) useTree[i] = (uint16_t)rc.bit();
+            else {
+                const uint32_t v = rc.culFreq(3);
+                rc.update(1, v, 3);
+                useTree[i] = (uint16_t)(v == 2 ? full : v);
+            }
+        }
+        uint32_t alphabetSize = 0;                                           // :188-193
+        for (int i = 0; i < 256; i++) if (useTree[256 + i]) M[alphabetSize++] = (uint8_t)i;
+        if (rc.eof) return BWTC_E_CORRUPT;
+        Fenwick model;
+        model.init(alphabetSize + 1, 0xFF00, 0x0100);                        // :196-197
+        uint64_t val = 1;
+        for (uint64_t i = 0; i < length;) {                                  // :200-212
+            const uint32_t c = fenwick_decode(model, rc);
+            if (rc.eof) return BWTC_E_CORRUPT;
+            if (c <= 1) {
+                const uint64_t cnt = val * (c + 1);
+                if (i + cnt > length) return BWTC_E_CORRUPT;                 // the reference would write past the block
+                memset(b.data() + i, 0, cnt);
+                i += cnt;
+                val *= 2;
+            } else {
+                val = 1;
+                if (c - 1 >= alphabetSize) return BWTC_E_CORRUPT;
+                b[i++] = (uint8_t)(c - 1);
+            }
+        }
+        for (uint32_t i = 0; i < length; i++) {                              // MTF decode :214-222
+            uint32_t j = b[i];
+            if (j >= alphabetSize) return BWTC_E_CORRUPT;
+            const uint8_t c = M[j];
+            b[i] = c;
+            for (; j > 0; j--) M[j] = M[j - 1];
+            M[0] = c;
+        }
+        const int rc2 = on_block(user, b.data(), length, pidx);
+        if (rc2) return rc2;
+    }
+    rc.normalize();                                                          // decodeFinish :216-219
+    return 0;
 }

@@ -309,6 +309,7 @@ struct cjs_ctx {
     // decoder state (allocated by the first decompress call)
     DecState* dec;
     float dec_ms;
+    std::vector<u8>* bwtc_out;  // result of the last cjs_bwtc_decompress
 };
 
 extern "C" void cjs_destroy(cjs_ctx* c);
@@ -358,6 +359,7 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     k1_prof_destroy(c->prof);
     dec_free(c->dec);
+    delete c->bwtc_out;
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -706,3 +708,55 @@ extern "C" int32_t cjs_bz2_last_detail(cjs_ctx* c, uint32_t* crc_got, uint32_t* 
     return d;
 }
 extern "C" float cjs_bz2_last_decode_ms(cjs_ctx* c) { return c ? c->dec_ms : 0.f; }
+
+// ---------------------------------------------------------------------------------------------
+// BWTC.decompressFile (lib/BWTC.js:141-233): host range decoder (serial), inverse BWT of every block on
+// the GPU (K6).  The decoded bytes are retained for cjs_bwtc_fetch when `out_cap` is too small.
+// ---------------------------------------------------------------------------------------------
+struct BwtcSink {
+    cjs_ctx* c; u8 *dT, *dU; void* ws; std::vector<u8>* out; int err;
+};
+static int bwtc_on_block(void* user, const uint8_t* T, uint32_t length, uint32_t pidx) {
+    BwtcSink* k = (BwtcSink*)user;
+    if (length == 0) return 0;
+    hipStream_t st = k->c->stream;
+    hipError_t e = hipMemcpyAsync(k->dT, T, length, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return CJS_E_HIP - (int)e;
+    const int rc = k6_unbwt_linear(k->dT, k->dU, length, pidx, k->ws, st);     // BWT.unbwtransform :224
+    if (rc) return rc;
+    const size_t at = k->out->size();
+    k->out->resize(at + length);
+    e = hipMemcpyAsync(k->out->data() + at, k->dU, length, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    return e == hipSuccess ? 0 : CJS_E_HIP - (int)e;
+}
+extern "C" int64_t cjs_bwtc_decompress(cjs_ctx* c, const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_cap,
+                                       int64_t* declared_size) {
+    if (!c || (!in && in_len)) return CJS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return CJS_E_NOGPU;
+    if (!c->bwtc_out) c->bwtc_out = new std::vector<u8>();
+    c->bwtc_out->clear();
+    BwtcSink k = {c, nullptr, nullptr, nullptr, c->bwtc_out, 0};
+    const u32 bs = 900000u;
+    const size_t wsb = (size_t)bs * 20 + ((size_t)(bs + 4095) / 4096) * 1024 + 256;
+    int rc = CJS_OK;
+    hipError_t e;
+    if ((e = hipMalloc((void**)&k.dT, bs)) != hipSuccess || (e = hipMalloc((void**)&k.dU, bs)) != hipSuccess ||
+        (e = hipMalloc(&k.ws, wsb)) != hipSuccess) rc = CJS_E_HIP - (int)e;
+    if (!rc) rc = bwtc_decode(in, in_len, declared_size, &k, bwtc_on_block);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(k.dT); (void)hipFree(k.dU); (void)hipFree(k.ws);
+    if (rc) { c->bwtc_out->clear(); return rc; }
+    const u64 n = c->bwtc_out->size();
+    if (n > out_cap) return CJS_E_NOSPACE;
+    if (n) memcpy(out, c->bwtc_out->data(), n);
+    return (int64_t)n;
+}
+extern "C" int64_t cjs_bwtc_last_size(cjs_ctx* c) { return c && c->bwtc_out ? (int64_t)c->bwtc_out->size() : 0; }
+extern "C" int64_t cjs_bwtc_fetch(cjs_ctx* c, uint8_t* out, uint64_t out_cap) {
+    if (!c || !c->bwtc_out) return CJS_E_ARG;
+    const u64 n = c->bwtc_out->size();
+    if (n > out_cap) return CJS_E_NOSPACE;
+    if (n) memcpy(out, c->bwtc_out->data(), n);
+    return (int64_t)n;
+}

@@ -129,6 +129,18 @@ int64_t cjs_bz2_fetch(cjs_ctx* ctx, uint8_t* out, uint64_t out_cap);
 int32_t cjs_bz2_last_detail(cjs_ctx* ctx, uint32_t* crc_got, uint32_t* crc_expected);
 float cjs_bz2_last_decode_ms(cjs_ctx* ctx);
 
+/* = BWTC.decompressFile(input, output)   (reference: lib/BWTC.js:141-233 via Util.decompressFileHelper
+ *   lib/Util.js:143-166; decoder sides of lib/RangeCoder.js:146-226, lib/FenwickModel.js:88-136,
+ *   lib/LogDistanceModel.js:37-44, lib/NoModel.js:22-29).  Range decoder on the host (serial by
+ *   construction), BWT.unbwtransform of every block on the GPU.  Returns the decoded size, -30 'Bad
+ *   magic', -31 corrupt/truncated stream (undefined behaviour in the reference), -24 for levels 1-5,
+ *   -21 when out_cap is too small (then cjs_bwtc_last_size / cjs_bwtc_fetch).  *declared_size gets the
+ *   size recorded in the header (-1: unknown). */
+int64_t cjs_bwtc_decompress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_cap,
+                            int64_t* declared_size);
+int64_t cjs_bwtc_last_size(cjs_ctx* ctx);
+int64_t cjs_bwtc_fetch(cjs_ctx* ctx, uint8_t* out, uint64_t out_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,9 @@ static int64_t (*p_table)(cjs_ctx*, const uint8_t*, uint64_t, int, uint64_t*, ui
 static int64_t (*p_lastsize)(cjs_ctx*);
 static int64_t (*p_fetch)(cjs_ctx*, uint8_t*, uint64_t);
 static int32_t (*p_detail)(cjs_ctx*, uint32_t*, uint32_t*);
+static int64_t (*p_bwtc_dec)(cjs_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t, int64_t*);
+static int64_t (*p_bwtc_lastsize)(cjs_ctx*);
+static int64_t (*p_bwtc_fetch)(cjs_ctx*, uint8_t*, uint64_t);
 static int64_t (*p_bwtc_bound)(uint64_t);
 static int64_t (*p_bwtc)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t);
 static void* g_lib;
@@ -56,9 +59,12 @@ static bool load_lib(const char* path) {
     p_lastsize = (int64_t(*)(cjs_ctx*))dlsym(g_lib, "cjs_bz2_last_size");
     p_fetch = (int64_t(*)(cjs_ctx*, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bz2_fetch");
     p_detail = (int32_t(*)(cjs_ctx*, uint32_t*, uint32_t*))dlsym(g_lib, "cjs_bz2_last_detail");
+    p_bwtc_dec = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t, int64_t*))dlsym(g_lib, "cjs_bwtc_decompress");
+    p_bwtc_lastsize = (int64_t(*)(cjs_ctx*))dlsym(g_lib, "cjs_bwtc_last_size");
+    p_bwtc_fetch = (int64_t(*)(cjs_ctx*, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bwtc_fetch");
     p_bwtc_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bwtc_compress_bound");
     p_bwtc = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t))dlsym(g_lib, "cjs_bwtc_compress");
-    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_hufflen || !p_dec || !p_decblk || !p_table || !p_lastsize || !p_fetch || !p_detail || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
+    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_hufflen || !p_dec || !p_decblk || !p_table || !p_lastsize || !p_fetch || !p_detail || !p_bwtc_dec || !p_bwtc_lastsize || !p_bwtc_fetch || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
     return true;
 }
 
@@ -291,6 +297,24 @@ static napi_value Table(napi_env env, napi_callback_info info) {
     return arr;
 }
 
+// bwtcDecompress(bytes) -> Buffer                                = BWTC.decompressFile (levels 6-9)
+static napi_value BwtcDecompress(napi_env env, napi_callback_info info) {
+    size_t argc = 1; napi_value argv[1];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    uint8_t* in; size_t len;
+    if (argc < 1 || !get_bytes(env, argv[0], &in, &len)) { napi_throw_type_error(env, nullptr, "bwtcDecompress(bytes)"); return nullptr; }
+    if (!ensure_ctx(env)) return nullptr;
+    int64_t declared = -1;
+    int64_t n = p_bwtc_dec(g_ctx, in, len, nullptr, 0, &declared);
+    if (n == -21) n = p_bwtc_lastsize(g_ctx);
+    else if (n == -30) { napi_throw_error(env, nullptr, "Bad magic"); return nullptr; }      // lib/Util.js:150-152
+    else if (n < 0) return throw_code(env, n, "cjs_bwtc_decompress");
+    napi_value out; void* dst = nullptr;
+    napi_create_buffer(env, (size_t)n, &dst, &out);
+    if (n > 0 && p_bwtc_fetch(g_ctx, (uint8_t*)dst, (uint64_t)n) < 0) return throw_code(env, -22, "cjs_bwtc_fetch");
+    return out;
+}
+
 // suffixsort(T, SA: Int32Array, n)                                = BWT.suffixsort
 static napi_value SuffixSort(napi_env env, napi_callback_info info) {
     size_t argc = 3; napi_value argv[3];
@@ -320,6 +344,7 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"decompress", nullptr, Decompress, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"decompressBlock", nullptr, DecompressBlock, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"table", nullptr, Table, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"bwtcDecompress", nullptr, BwtcDecompress, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"huffLengths", nullptr, HuffLengths, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"suffixsort", nullptr, SuffixSort, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtcCompress", nullptr, BwtcCompress, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -5,7 +5,8 @@
 //   BWT.bwtransform2(T, U, n, [alphabetSize])       -> MI355X
 //   BWT.bwtransform / suffixsort / unbwtransform, BWTC.compressFile (levels 6-9) -> MI355X
 //   Bzip2.decompressFile / decompressBlock / table   -> MI355X (GPU decoder K7-K9)
-//   everything else (BWTC.decompressFile, BWTC levels 1-5, the other 12 codecs)
+//   BWTC.decompressFile (levels 6-9)                  -> host range decoder + MI355X inverse BWT
+//   everything else (BWTC levels 1-5, the other 12 codecs)
 //       -> delegated unchanged to an installed reference package (require('compressjs')), when
 //          there is one; otherwise those properties throw.
 'use strict';
@@ -136,9 +137,17 @@ BWTC.compressFile = function(inStream, outStream, props) {           // lib/BWTC
   var bytes = inputBytes(inStream);
   return deliver(addon.bwtcCompress(bytes, level, known ? bytes.length : -1), outStream);   // lib/Util.js:119-124
 };
-BWTC.decompressFile = function() {
-  if (!reference) throw new Error('BWTC.decompressFile is not on the accelerated path yet');
-  return reference.BWTC.decompressFile.apply(reference.BWTC, arguments);
+BWTC.decompressFile = function(inStream, outStream) {               // lib/BWTC.js:141
+  need();
+  var bytes = inputBytes(inStream);
+  // byte 4.. = varint(size+1), then the block-size byte goes through the range coder: levels 1-5 are
+  // recognised by the C ABI (-24) and handed to the reference when it is installed
+  try {
+    return deliver(addon.bwtcDecompress(bytes), outStream);
+  } catch (e) {
+    if (reference && /levels 1-5/.test(String(e.message))) return reference.BWTC.decompressFile(inStream, outStream);
+    throw e;
+  }
 };
 
 var out = { version: '0.1.0-mi355x', Bzip2: Object.freeze(Bzip2), BWT: Object.freeze(BWT), BWTC: Object.freeze(BWTC),

@@ -32,5 +32,6 @@ var zb = Buffer.from(z); zb[zb.length - 3] ^= 1;
 try { cjs.Bzip2.decompressFile(zb); res.badcrc = 'no throw'; } catch (e) { res.badcrc = [e.constructor.name, e.errorCode, e.message.replace(/\(.*\)/, '()')]; }
 try { cjs.Bzip2.decompressFile(Buffer.from('BZx9')); res.badmagic = 'no throw'; } catch (e) { res.badmagic = [e.errorCode, e.message]; }
 res.sized = cjs.Bzip2.decompressFile(cjs.Bzip2.compressFile(Buffer.from('hello hello')), 11).length;
+res.bwtc_roundtrip = sha(cjs.BWTC.decompressFile(cjs.BWTC.compressFile(lcg, null, 7))) === sha(lcg);
 try { cjs.Bzip2.compressFile(Buffer.from('x'), null, 0); res.badlevel = 'no throw'; } catch (e) { res.badlevel = e.message; }
 console.log(JSON.stringify(res));

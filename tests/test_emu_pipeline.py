@@ -270,3 +270,36 @@ def test_decoder_multi_block_and_long_runs(emu_ctx):
     for sid, s, ms in decode_cases.streams():
         if sid in want and s is not None:
             check_stream(L, h, sid, s, ms, g[sid])
+
+
+def test_bwtc_decode_inverts_reference_streams(emu_ctx, golden):
+    """BWTC.decompressFile: host range decoder + K6 on the streams the reference's BWTC.compressFile
+    produced (ours are bit-identical to them, checked above): decoding gives the input back."""
+    L, h = emu_ctx
+    n = 0
+    for k in sorted(k for k in golden if ":bwtc:" in k):
+        cid, _, lv = k.split(":")
+        if cid not in ("empty", "a1", "a1000", "sample0", "text1k", "bytes40", "text100k") or k == "text100k:bwtc:7":
+            continue
+        d = cases.case_input(cid)
+        if d is None:
+            continue
+        d = np.ascontiguousarray(d)
+        cap = int(L.cjs_bwtc_compress_bound(d.size))
+        z = np.zeros(cap, np.uint8)
+        m = L.cjs_bwtc_compress(h, d.ctypes.data, d.size, int(lv), z.ctypes.data, cap, d.size)
+        assert hashlib.sha256(z[:m].tobytes()).hexdigest() == golden[k]["out_sha256"], k
+        out = np.zeros(max(d.size, 1), np.uint8)
+        declared = C.c_int64(-7)
+        r = L.cjs_bwtc_decompress(h, z.ctypes.data, m, out.ctypes.data, d.size, C.byref(declared))
+        assert r == d.size and declared.value == d.size, (k, r, declared.value)
+        assert np.array_equal(out[:d.size], d), k
+        if d.size > 8:
+            assert L.cjs_bwtc_decompress(h, z.ctypes.data, m, out.ctypes.data, d.size - 1, C.byref(declared)) == -21
+            assert L.cjs_bwtc_last_size(h) == d.size
+            r2 = L.cjs_bwtc_decompress(h, z.ctypes.data, m // 2, out.ctypes.data, d.size, C.byref(declared))
+            assert r2 == -31 or 0 <= r2 <= d.size, (k, r2)          # truncated: an error code or a short result, never a fault
+        n += 1
+    assert n >= 6
+    bad = np.frombuffer(b"bwtx\x81\x09", dtype=np.uint8).copy()
+    assert L.cjs_bwtc_decompress(h, bad.ctypes.data, bad.size, None, 0, None) == -30            # 'Bad magic'

@@ -29,6 +29,7 @@ def test_node_dropin_digests(golden):
     assert r["table"] == golden["lcg250000:bz2:1"]["blocks"]                       # Bzip2.table == the reference's own table
     assert r["badcrc"] == ["TypeError", -5, "Data error: Bad stream CRC ()"]
     assert r["badmagic"] == [-2, "Not bzip data: bad magic"]
+    assert r["bwtc_roundtrip"] is True
     assert r["unbwt"] == "banana"                          # BWT.unbwtransform, lib/BWT.js:352-363
     assert r["stream_len"] > 30
     assert r["badlevel"] == "Invalid block size multiplier"

@@ -167,6 +167,14 @@ def test_bwtc_and_linear_bwt_goldens(golden, ctx):
         SA = np.zeros(max(d.size, 1), np.int32)
         BWT.suffixsort(d, SA, d.size)
         assert _sha(SA[:d.size].astype("<i4").tobytes()) == golden[cid + ":sa"]["sa_sha256"], k
+    from compressjs_amd import BWTC
+    for cid, lv in (("text100k", 9), ("bytes40", 6), ("runs300k", 8), ("text2500k", 8), ("empty", 9), ("a1", 9)):
+        d = cases.case_input(cid)
+        z = ctx.bwtc_compress(d, lv)
+        assert _sha(z) == golden["%s:bwtc:%d" % (cid, lv)]["out_sha256"]
+        assert BWTC.decompressFile(z) == d.tobytes(), cid            # BWTC.decompressFile: host range decoder + K6
+    with pytest.raises(RuntimeError, match="Bad magic"):
+        BWTC.decompressFile(b"bwtx\x81\x09")
     big = synth.text_like(899_000, 41)
     U = np.zeros(big.size, np.uint8)
     p = BWT.bwtransform(big, U, None, big.size)
