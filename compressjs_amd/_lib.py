@@ -19,7 +19,7 @@ SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_bz2_compress_bound", "cjs_bz2_compr
            "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
            "cjs_suffixsort", "cjs_unbwt_linear", "cjs_huff_lengths", "cjs_huff_lengths_batch",
            "cjs_bz2_decompress", "cjs_bz2_decompress_device", "cjs_bz2_decompress_block", "cjs_bz2_table",
-           "cjs_bz2_last_size", "cjs_bz2_fetch", "cjs_bwtc_decompress", "cjs_bwtc_last_size", "cjs_bwtc_fetch", "cjs_bz2_last_detail", "cjs_bz2_last_decode_ms",
+           "cjs_bz2_last_size", "cjs_bz2_fetch", "cjs_shift_bits", "cjs_bwtc_decompress", "cjs_bwtc_last_size", "cjs_bwtc_fetch", "cjs_bz2_last_detail", "cjs_bz2_last_decode_ms",
            "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages", "cjs_dbg_k1_sparse_rounds",
            "cjs_dbg_k1_rounds"]
 
@@ -108,6 +108,8 @@ def load(path: str | None = None):
     L.cjs_bz2_fetch.argtypes = [vp, vp, C.c_uint64]
     L.cjs_bz2_last_detail.restype = C.c_int32
     L.cjs_bz2_last_detail.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.cjs_shift_bits.restype = C.c_int32
+    L.cjs_shift_bits.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
     L.cjs_bwtc_decompress.restype = C.c_int64
     L.cjs_bwtc_decompress.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_int64)]
     L.cjs_bwtc_last_size.restype = C.c_int64

@@ -142,6 +142,10 @@ class Context:
         _lib.check(bits, "cjs_bz2_encode_blocks")
         return int(bits), int(fold.value), int(cnt.value)
 
+    def shift_bits(self, d_seg, nbytes: int, s: int, d_out):
+        """d_out[:nbytes+1] = d_seg[:nbytes] shifted right by s bits (torch uint8 tensors on this context's device)."""
+        return _lib.check(self.L.cjs_shift_bits(self.h, d_seg.data_ptr(), int(nbytes), int(s), d_out.data_ptr()), "cjs_shift_bits")
+
     @property
     def last_device_ms(self) -> float:
         return float(self.L.cjs_last_device_ms(self.h))

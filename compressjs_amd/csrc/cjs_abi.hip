@@ -760,3 +760,14 @@ extern "C" int64_t cjs_bwtc_fetch(cjs_ctx* c, uint8_t* out, uint64_t out_cap) {
     if (n) memcpy(out, c->bwtc_out->data(), n);
     return (int64_t)n;
 }
+
+// Seam helper of the multi-GPU assembly (compressjs_amd/dist.py): d_out[0 .. nbytes] = the nbytes of
+// d_in shifted right by `s` (0..7) bits.  Device pointers; d_out needs nbytes + 1 bytes.
+extern "C" int32_t cjs_shift_bits(cjs_ctx* c, const uint8_t* d_in, uint64_t nbytes, uint32_t s, uint8_t* d_out) {
+    if (!c || !d_in || !d_out || s > 7) return CJS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return CJS_E_NOGPU;
+    const int rc = k5_shift_bits_run(d_in, nbytes, s, d_out, c->stream);
+    if (rc) return rc;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? CJS_OK : CJS_E_HIP - (int)e;
+}

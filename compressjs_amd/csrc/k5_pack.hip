@@ -392,3 +392,18 @@ int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after, hipEvent_t d
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
+
+// ---- multi-GPU seam: a rank's segment starts at bit 0; in the assembled stream it starts at bit s ----
+// out[0 .. nbytes] = in[0 .. nbytes) shifted right by s (0..7) bits, MSB first (one extra byte of tail)
+__global__ __launch_bounds__(256) void k5_shift_bits(const u8* in, u64 nbytes, u32 s, u8* out) {
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i > nbytes) return;
+    const u32 cur = i < nbytes ? in[i] : 0u;
+    const u32 prev = i ? in[i - 1] : 0u;
+    out[i] = (u8)((cur >> s) | (prev << (8u - s)));
+}
+int k5_shift_bits_run(const u8* d_in, u64 nbytes, u32 s, u8* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k5_shift_bits, dim3((u32)((nbytes + 256) / 256)), dim3(256), 0, stream, d_in, nbytes, s & 7u, d_out);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}

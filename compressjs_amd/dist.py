@@ -17,6 +17,9 @@ chain without exchanging per-block CRCs.  Everything below is plain torch ops an
 tensors too (the gloo tests drive it with the CPU logic-debug build of the kernels)."""
 from __future__ import annotations
 
+import os
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -65,13 +68,24 @@ def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     dev = d_in.device
+    trace = [] if os.environ.get("CJS_DIST_TRACE") else None
+
+    def mark(name):
+        if trace is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            trace.append((name, time.perf_counter()))
+
+    mark("start")
     nblocks = ctx.plan(d_in, level)
+    mark("plan")
     first, count = block_range(nblocks, rank, world)
     if seg is None:
         per = (nblocks + world - 1) // world
         seg_cap = per * (level * 100000 * 2 + 32768) + 4096
         seg = torch.zeros(seg_cap, dtype=torch.uint8, device=dev)
     bits, fold, cnt = ctx.encode_blocks(first, count, seg)
+    mark("encode")
     # collectives run on the tensors' own device with RCCL ("nccl"); with the gloo backend (CPU tests,
     # or several ranks sharing one GPU) they are staged through host memory
     cdev = dev if (world == 1 or dist.get_backend(group) != "gloo") else torch.device("cpu")
@@ -87,12 +101,13 @@ def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch
         offs.append(pos)
         pos += b
         crc = _rotl32(crc, k) ^ (f & 0xFFFFFFFF)
+    mark("all_gather")
     my_off = offs[rank]
     nbytes = (bits + 7) // 8
-    shifted = shift_bits(seg, nbytes, my_off % 8)
     maxlen = max((b + 7) // 8 for b, _, _ in meta) + 1
     padded = torch.zeros(maxlen, dtype=torch.uint8, device=dev)
-    padded[:shifted.numel()] = shifted
+    ctx.shift_bits(seg, nbytes, my_off % 8, padded)               # one pass (k5_shift_bits); shift_bits() below is the spec
+    mark("shift")
     if world > 1:
         gl = [torch.zeros(maxlen, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
         dist.gather(padded.to(cdev), gl, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
@@ -100,6 +115,7 @@ def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch
             gl = [t.to(dev) for t in gl]
     else:
         gl = [padded]
+    mark("gather")
     if rank != 0:
         return None
     toff, tbytes, total = trailer_bytes(pos, crc)
@@ -112,4 +128,7 @@ def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch
         final[o:o + n] |= gl[r][:n]
     tb = torch.tensor(list(tbytes), dtype=torch.uint8, device=dev)
     final[toff:toff + tb.numel()] |= tb
+    mark("assemble")
+    if trace is not None:
+        print("[dist] " + ", ".join("%s %.2f ms" % (n, (t - trace[i][1]) * 1e3) for i, (n, t) in enumerate(trace[1:])), flush=True)
     return final[:total]

@@ -141,6 +141,10 @@ int64_t cjs_bwtc_decompress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, ui
 int64_t cjs_bwtc_last_size(cjs_ctx* ctx);
 int64_t cjs_bwtc_fetch(cjs_ctx* ctx, uint8_t* out, uint64_t out_cap);
 
+/* multi-GPU seam helper: d_out[0 .. nbytes] = d_in[0 .. nbytes) shifted right by s (0..7) bits (MSB first).
+ * Used when a rank's bit-0-aligned segment (cjs_bz2_encode_blocks) is placed at its offset in the stream. */
+int32_t cjs_shift_bits(cjs_ctx* ctx, const uint8_t* d_in, uint64_t nbytes, uint32_t s, uint8_t* d_out);
+
 #ifdef __cplusplus
 }
 #endif

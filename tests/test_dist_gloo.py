@@ -62,3 +62,27 @@ def test_shift_and_trailer_helpers():
     off, tb, total = trailer_bytes(32, 0)
     assert off == 4 and total == 14 and tb == bytes.fromhex("17724538509000000000")
     assert _rotl32(0x80000001, 1) == 0x00000003
+
+
+def test_shift_kernel_equals_spec():
+    """cjs_shift_bits (k5_shift_bits through the CPU debug build) against the torch restatement."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stagelib
+    from compressjs_amd import _lib
+    from compressjs_amd.bzip2 import Context
+    from compressjs_amd.dist import shift_bits
+    stagelib.build_emu()
+    saved = _lib._lib
+    _lib._lib = _lib.load(stagelib.EMU_SO)
+    try:
+        ctx = Context(0, 2)
+        g = torch.Generator().manual_seed(5)
+        seg = torch.randint(0, 256, (5000,), dtype=torch.uint8, generator=g)
+        for n in (0, 1, 2, 255, 256, 257, 4999):
+            for s in range(8):
+                out = torch.full((n + 1,), 0xAA, dtype=torch.uint8)
+                ctx.shift_bits(seg, n, s, out)
+                assert torch.equal(out, shift_bits(seg, n, s)), (n, s)
+        ctx.close()
+    finally:
+        _lib._lib = saved
