@@ -155,7 +155,7 @@ def check(rc: int, what: str = "call") -> int:
     if rc == -31:
         raise CompressjsAmdError("%s: corrupt or truncated stream" % what)
     if rc == -24:
-        raise CompressjsAmdError("%s: this codec variant is not accelerated (BWTC levels 1-5)" % what)
+        raise CompressjsAmdError("%s: not supported by this build (code -24)" % what)
     if rc == -23:
         raise CompressjsAmdError("%s: no HIP device visible (the product has no CPU path)" % what)
     if rc <= -100:

@@ -11,10 +11,8 @@ int64_t bwtc_end(bwtc_coder* c);
 // every block is handed to `on_block` as the BWT string (MTF and zero-run coding already undone)
 // with its primary index; the caller inverts the BWT on the GPU (K6).
 // Returns 0, BWTC_E_MAGIC ('Bad magic', lib/Util.js:150-152), BWTC_E_CORRUPT (input ends early or is
-// inconsistent: the reference has no defined behaviour there), BWTC_E_FAST (levels 1-5, DefSumModel),
-// or the non-zero value on_block returned.
+// inconsistent: the reference has no defined behaviour there), or the non-zero value on_block returned.
 #define BWTC_E_MAGIC (-30)
 #define BWTC_E_CORRUPT (-31)
-#define BWTC_E_FAST (-24)
 typedef int (*bwtc_block_fn)(void* user, const uint8_t* T, uint32_t length, uint32_t pidx);
 int bwtc_decode(const uint8_t* in, uint64_t len, int64_t* declared_size, void* user, bwtc_block_fn on_block);

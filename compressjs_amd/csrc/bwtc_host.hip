@@ -152,6 +152,76 @@ struct Fenwick {                                                             // 
     }
 };
 
+
+struct RangeDec;
+// DefSumModel (lib/DefSumModel.js:11-139): the model of BWTC levels 1-5.  prob[] / escape[] are cumulative.
+struct DefSum {
+    uint32_t numSyms, updateCount, updateThresh;
+    uint16_t prob[304], escape[304], update[304];
+    uint16_t probToSym[256], escProbToSym[304];
+    bool dec;
+    void init(uint32_t size, bool isDecoder) {                               // :11-37
+        numSyms = size; dec = isDecoder;
+        memset(prob, 0, sizeof prob); memset(escape, 0, sizeof escape); memset(update, 0, sizeof update);
+        prob[size + 1] = 256;
+        for (uint32_t i = 0; i <= size; i++) escape[i] = (uint16_t)i;
+        updateCount = 0;
+        updateThresh = 256 - 128;
+        if (!dec) return;
+        for (int i = 0; i < 256; i++) probToSym[i] = (uint16_t)size;
+        for (uint32_t i = 0; i < size; i++) escProbToSym[i] = (uint16_t)i;
+    }
+    void upd(uint32_t symbol) {                                              // _update :41-97
+        if (symbol == numSyms) {
+            if (update[symbol] >= 40) return;
+            if (updateCount >= updateThresh - 1) return;
+        }
+        update[symbol]++;
+        updateCount++;
+        if (updateCount < updateThresh) return;
+        uint32_t cumProb = 0, cumEscProb = 0, odd = 0, i;
+        escape[0] = 0; prob[0] = 0;
+        for (i = 0; i < numSyms + 1; i++) {
+            const uint32_t newProb = ((uint32_t)(prob[i + 1] - prob[i]) >> 1) + update[i];
+            if (newProb) {
+                prob[i] = (uint16_t)cumProb;
+                cumProb += newProb;
+                if (newProb & 1u) odd++;
+                escape[i] = (uint16_t)cumEscProb;
+            } else {
+                prob[i] = (uint16_t)cumProb;
+                escape[i] = (uint16_t)cumEscProb;
+                cumEscProb++;
+            }
+        }
+        prob[i] = (uint16_t)cumProb;
+        updateThresh = 256 - (cumProb - odd) / 2;
+        for (i = 0; i < numSyms + 1; i++) update[i] = 0;
+        update[numSyms] = 1;
+        updateCount = 1;
+        if (!dec) return;
+        uint32_t j = 0, k = 0;
+        for (i = 0; i < numSyms + 1; i++) {
+            const uint32_t probLimit = prob[i + 1];
+            for (; j < probLimit && j < 256; j++) probToSym[j] = (uint16_t)i;
+            if (i + 1 <= numSyms) {                                          // escape[numSyms+1] is past the reference's array
+                const uint32_t escProbLimit = escape[i + 1];
+                for (; k < escProbLimit && k < 304; k++) escProbToSym[k] = (uint16_t)i;
+            }
+        }
+    }
+    void encode(RangeEnc& rc, uint32_t symbol) {                             // :98-115
+        uint32_t lt_f = prob[symbol];
+        uint32_t sy_f = prob[symbol + 1] - lt_f;
+        if (sy_f) { rc.encodeShift(sy_f, lt_f, 8); upd(symbol); return; }
+        encode(rc, numSyms);
+        lt_f = escape[symbol];
+        sy_f = escape[symbol + 1] - lt_f;
+        rc.encodeFreq(sy_f, lt_f, escape[numSyms]);
+        upd(symbol);
+    }
+};
+
 }  // namespace
 
 struct bwtc_coder {
@@ -202,6 +272,12 @@ void bwtc_block(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* u
             const int v = useTree[i];
             rc.encodeFreq(1, v == 0 ? 0 : (v == full ? 2 : 1), 3);
         }
+    }
+    if (c->level <= 5) {                                                     // :107 `fast`
+        static thread_local DefSum dm;
+        dm.init(alphabetSize + 1, false);
+        for (uint32_t i = 0; i < nsym; i++) dm.encode(rc, sym[i]);
+        return;
     }
     Fenwick m;
     m.init(alphabetSize + 1, 0xFF00, 0x0100);                                // :105-106
@@ -296,6 +372,24 @@ uint32_t fenwick_decode1(Fenwick& m, RangeDec& rc, bool isEscape) {          // 
     if (((m.tree[1] & 0xFFFF0000u) >> 16) >= m.max_prob) m.rescale();
     return symbol;
 }
+uint32_t defsum_decode(DefSum& m, RangeDec& rc) {                            // lib/DefSumModel.js:116-137
+    uint32_t prob = rc.culShift(8);
+    uint32_t symbol = m.probToSym[prob & 255u];
+    uint32_t lt_f = m.prob[symbol];
+    uint32_t sy_f = m.prob[symbol + 1] - lt_f;
+    rc.update(sy_f, lt_f, 256);
+    m.upd(symbol);
+    if (symbol != m.numSyms) return symbol;
+    const uint32_t tot_f = m.escape[m.numSyms];
+    if (tot_f == 0) { rc.eof = true; return 0; }
+    prob = rc.culFreq(tot_f);
+    symbol = m.escProbToSym[prob < 304 ? prob : 303];
+    lt_f = m.escape[symbol];
+    sy_f = m.escape[symbol + 1] - lt_f;
+    rc.update(sy_f, lt_f, tot_f);
+    m.upd(symbol);
+    return symbol;
+}
 uint32_t fenwick_decode(Fenwick& m, RangeDec& rc) {                          // :129-136
     uint32_t s = fenwick_decode1(m, rc, false);
     if (s == m.numSyms - 1) s = fenwick_decode1(m, rc, true);
@@ -322,7 +416,7 @@ int bwtc_decode(const uint8_t* in, uint64_t len, int64_t* declared_size, void* u
     rc.start();                                                              // lib/BWTC.js:142-143
     uint32_t blockSize = rc.byte();                                          // :144
     if (rc.eof || blockSize < 1 || blockSize > 9) return BWTC_E_CORRUPT;
-    if (blockSize <= 5) return BWTC_E_FAST;                                  // :146 DefSumModel levels
+    const bool fast = blockSize <= 5;                                        // :146 DefSumModel levels
     blockSize *= 100000u;
     const int lgbits = fls((uint32_t)(1 + fls(blockSize - 1)) - 1);          // LogDistanceModel(blockSize, 0, NoModel, NoModel)
     std::vector<uint8_t> b(blockSize);
@@ -354,10 +448,12 @@ int bwtc_decode(const uint8_t* in, uint64_t len, int64_t* declared_size, void* u
         for (int i = 0; i < 256; i++) if (useTree[256 + i]) M[alphabetSize++] = (uint8_t)i;
         if (rc.eof) return BWTC_E_CORRUPT;
         Fenwick model;
-        model.init(alphabetSize + 1, 0xFF00, 0x0100);                        // :196-197
+        static thread_local DefSum dmodel;
+        if (fast) dmodel.init(alphabetSize + 1, true);                       // :198
+        else model.init(alphabetSize + 1, 0xFF00, 0x0100);                   // :196-197
         uint64_t val = 1;
         for (uint64_t i = 0; i < length;) {                                  // :200-212
-            const uint32_t c = fenwick_decode(model, rc);
+            const uint32_t c = fast ? defsum_decode(dmodel, rc) : fenwick_decode(model, rc);
             if (rc.eof) return BWTC_E_CORRUPT;
             if (c <= 1) {
                 const uint64_t cnt = val * (c + 1);

@@ -543,7 +543,7 @@ extern "C" int64_t cjs_bz2_encode_blocks(cjs_ctx* c, uint32_t first, uint32_t co
 // ---------------------------------------------------------------------------------------------
 // BWTC.compressFile(input, null, level), level 6..9 (lib/BWTC.js:12-139): BWT + MTF/RLE2 on the
 // GPU per 100000*level-byte block, adaptive range coder on the host (serial by construction).
-// Levels 1-5 use DefSumModel (lib/BWTC.js:107), which is out of scope -> CJS_E_UNSUPPORTED.
+// Levels 1-5 use DefSumModel (lib/BWTC.js:107), levels 6-9 FenwickModel; both coders run on the host.
 // ---------------------------------------------------------------------------------------------
 extern "C" int64_t cjs_bwtc_compress_bound(uint64_t in_len) { return (int64_t)bwtc_bound(in_len); }
 
@@ -551,7 +551,6 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
                                      uint64_t out_cap, int64_t declared_size) {
     if (!c || (!in && in_len) || !out) return CJS_E_ARG;
     if (level < 1 || level > 9) level = 9;                         // lib/BWTC.js:16-19: bad props -> 9
-    if (level < 6) return CJS_E_UNSUPPORTED;
     hipError_t e;
     int rc;
 #define TRYR(x) if ((e = (x)) != hipSuccess) { if (coder) (void)bwtc_end(coder); return CJS_E_HIP - (int)e; }

@@ -14,7 +14,7 @@ typedef unsigned long long u64;
 #define CJS_E_NOSPACE (-21)    // caller's output buffer too small
 #define CJS_E_ARG (-22)
 #define CJS_E_NOGPU (-23)      // no HIP device: the product has no CPU path
-#define CJS_E_UNSUPPORTED (-24)  // a variant of the codec that is out of scope (BWTC levels 1-5)
+#define CJS_E_UNSUPPORTED (-24)  // input outside what this build handles (e.g. a stream with more magic patterns than bytes / 4)
 #define CJS_E_HIP (-100)       // -100 - hipError_t
 
 #define CJS_WAVE 64

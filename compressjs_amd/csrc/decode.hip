@@ -119,7 +119,7 @@ static int stage_input(DecState& S, const u8* in, u64 len, bool in_dev, hipStrea
     }
     TRYH(hipMemsetAsync(S.d_in + (len & ~(u64)255), 0, need - (len & ~(u64)255), st));
     if (len) TRYH(hipMemcpyAsync(S.d_in, in, len, in_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    const u32 ccap = (u32)std::min<u64>(len / 8 + 16, 1u << 26);
+    const u32 ccap = (u32)std::min<u64>(len / 4 + 16, 1u << 27);      // a 48-bit pattern cannot occur more often than every 6 bytes
     if (ccap > S.cand_cap) {
         (void)hipFree(S.d_cand); S.d_cand = nullptr; S.cand_cap = 0;
         TRYH(hipMalloc((void**)&S.d_cand, (size_t)ccap * 8));
@@ -263,7 +263,7 @@ int64_t dec_stream(DecState** ps, u32 slots, hipStream_t st, const u8* in, u64 l
     u32 nc = 0;
     TRYH(hipMemcpyAsync(&nc, S.d_ncand, 4, hipMemcpyDeviceToHost, st));
     TRYH(hipStreamSynchronize(st));
-    if (nc > S.cand_cap) return CJS_E_UNSUPPORTED;                               // > len/8 magic hits: not a sane stream
+    if (nc > S.cand_cap) return CJS_E_UNSUPPORTED;                               // only when the 2^27 cap on candidates is hit
     std::vector<u64> cand(nc);
     if (nc) TRYH(hipMemcpy(cand.data(), S.d_cand, (size_t)nc * 8, hipMemcpyDeviceToHost));
     std::sort(cand.begin(), cand.end());

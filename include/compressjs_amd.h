@@ -31,7 +31,7 @@ int64_t cjs_bz2_compress_device(cjs_ctx* ctx, const void* d_in, uint64_t in_len,
  * lib/Util.js:105-142).  GPU: BWT.bwtransform + MTF + RLE2 per 100000*level-byte block; host: the
  * adaptive Fenwick model + range coder (serial by construction: lib/RangeCoder.js, lib/FenwickModel.js).
  * declared_size = the size written into the header (input length, or -1 for streams of unknown
- * size, lib/Util.js:119-124).  Levels 1-5 (DefSumModel) return CJS_E_UNSUPPORTED (-24). */
+ * size, lib/Util.js:119-124).  Levels 1-5 use DefSumModel (lib/DefSumModel.js), 6-9 FenwickModel. */
 int64_t cjs_bwtc_compress_bound(uint64_t in_len);
 int64_t cjs_bwtc_compress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
                           uint64_t out_cap, int64_t declared_size);
@@ -133,7 +133,7 @@ float cjs_bz2_last_decode_ms(cjs_ctx* ctx);
  *   lib/Util.js:143-166; decoder sides of lib/RangeCoder.js:146-226, lib/FenwickModel.js:88-136,
  *   lib/LogDistanceModel.js:37-44, lib/NoModel.js:22-29).  Range decoder on the host (serial by
  *   construction), BWT.unbwtransform of every block on the GPU.  Returns the decoded size, -30 'Bad
- *   magic', -31 corrupt/truncated stream (undefined behaviour in the reference), -24 for levels 1-5,
+ *   magic', -31 corrupt/truncated stream (undefined behaviour in the reference),
  *   -21 when out_cap is too small (then cjs_bwtc_last_size / cjs_bwtc_fetch).  *declared_size gets the
  *   size recorded in the header (-1: unknown). */
 int64_t cjs_bwtc_decompress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, uint8_t* out, uint64_t out_cap,

@@ -71,7 +71,7 @@ static bool load_lib(const char* path) {
 static napi_value throw_code(napi_env env, int64_t rc, const char* what) {
     char msg[160];
     if (rc == -20) snprintf(msg, sizeof msg, "Invalid block size multiplier");      // lib/Bzip2.js:889
-    else if (rc == -24) snprintf(msg, sizeof msg, "%s: BWTC levels 1-5 (DefSumModel) are not accelerated", what);
+    else if (rc == -24) snprintf(msg, sizeof msg, "%s: not supported by this build (code -24)", what);
     else if (rc == -23) snprintf(msg, sizeof msg, "%s: no HIP device visible (compressjs_amd has no CPU path)", what);
     else snprintf(msg, sizeof msg, "%s failed with code %lld", what, (long long)rc);
     napi_throw_error(env, nullptr, msg);

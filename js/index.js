@@ -5,8 +5,8 @@
 //   BWT.bwtransform2(T, U, n, [alphabetSize])       -> MI355X
 //   BWT.bwtransform / suffixsort / unbwtransform, BWTC.compressFile (levels 6-9) -> MI355X
 //   Bzip2.decompressFile / decompressBlock / table   -> MI355X (GPU decoder K7-K9)
-//   BWTC.decompressFile (levels 6-9)                  -> host range decoder + MI355X inverse BWT
-//   everything else (BWTC levels 1-5, the other 12 codecs)
+//   BWTC.decompressFile                               -> host range decoder + MI355X inverse BWT
+//   everything else (the other 12 codecs)
 //       -> delegated unchanged to an installed reference package (require('compressjs')), when
 //          there is one; otherwise those properties throw.
 'use strict';
@@ -128,10 +128,6 @@ var BWTC = Object.create(null);
 BWTC.MAGIC = 'bwtc';
 BWTC.compressFile = function(inStream, outStream, props) {           // lib/BWTC.js:12
   var level = (typeof props === 'number' && props >= 1 && props <= 9) ? props : 9;   // :16-19
-  if (level < 6) {   // DefSumModel levels are not accelerated
-    if (reference) return reference.BWTC.compressFile(inStream, outStream, props);
-    throw new Error('BWTC levels 1-5 are not on the accelerated path');
-  }
   need();
   var known = !(inStream && typeof inStream.readByte === 'function') || ('size' in inStream && inStream.size >= 0);
   var bytes = inputBytes(inStream);
@@ -140,14 +136,7 @@ BWTC.compressFile = function(inStream, outStream, props) {           // lib/BWTC
 BWTC.decompressFile = function(inStream, outStream) {               // lib/BWTC.js:141
   need();
   var bytes = inputBytes(inStream);
-  // byte 4.. = varint(size+1), then the block-size byte goes through the range coder: levels 1-5 are
-  // recognised by the C ABI (-24) and handed to the reference when it is installed
-  try {
-    return deliver(addon.bwtcDecompress(bytes), outStream);
-  } catch (e) {
-    if (reference && /levels 1-5/.test(String(e.message))) return reference.BWTC.decompressFile(inStream, outStream);
-    throw e;
-  }
+  return deliver(addon.bwtcDecompress(bytes), outStream);
 };
 
 var out = { version: '0.1.0-mi355x', Bzip2: Object.freeze(Bzip2), BWT: Object.freeze(BWT), BWTC: Object.freeze(BWTC),

@@ -67,7 +67,10 @@ def main():
         if cid in ("sample0", "sample1", "sample3", "empty", "a1000", "text100k"):
             jobs.append(dict(id="%s:bwtc:9" % cid, kind="bwtc", input=p, level=9))
         for bc, lv in (("text950k", 9), ("text100k", 7), ("bytes40", 6), ("runs300k", 8), ("lcg250000", 9),
-                       ("a1", 9), ("text1k", 9), ("sample2", 6), ("text2500k", 8), ("zeros300k", 9)):
+                       ("a1", 9), ("text1k", 9), ("sample2", 6), ("text2500k", 8), ("zeros300k", 9),
+                       # levels 1-5: DefSumModel instead of FenwickModel (lib/BWTC.js:107)
+                       ("text100k", 3), ("bytes40", 1), ("runs300k", 5), ("a1000", 2), ("lcg250000", 4), ("empty", 1),
+                       ("text950k", 5), ("sample1", 2), ("zeros300k", 1), ("text1k", 4)):
             if cid == bc:
                 jobs.append(dict(id="%s:bwtc:%d" % (cid, lv), kind="bwtc", input=p, level=lv))
     jobs.append(dict(id="huff", kind="huff", cases=huff_cases()))

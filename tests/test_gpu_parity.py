@@ -155,7 +155,7 @@ def test_bwtc_and_linear_bwt_goldens(golden, ctx):
         o = ctx.bwtc_compress(d, int(lv))
         assert len(o) == golden[k]["out_len"] and _sha(o) == golden[k]["out_sha256"], k
         n += 1
-    assert n >= 12
+    assert n >= 22
     for k in sorted(k for k in golden if k.endswith(":bwt")):
         cid = k.split(":")[0]
         d = cases.case_input(cid)
@@ -168,7 +168,8 @@ def test_bwtc_and_linear_bwt_goldens(golden, ctx):
         BWT.suffixsort(d, SA, d.size)
         assert _sha(SA[:d.size].astype("<i4").tobytes()) == golden[cid + ":sa"]["sa_sha256"], k
     from compressjs_amd import BWTC
-    for cid, lv in (("text100k", 9), ("bytes40", 6), ("runs300k", 8), ("text2500k", 8), ("empty", 9), ("a1", 9)):
+    for cid, lv in (("text100k", 9), ("bytes40", 6), ("runs300k", 8), ("text2500k", 8), ("empty", 9), ("a1", 9),
+                    ("text950k", 5), ("lcg250000", 4), ("zeros300k", 1)):           # 1-5: DefSumModel
         d = cases.case_input(cid)
         z = ctx.bwtc_compress(d, lv)
         assert _sha(z) == golden["%s:bwtc:%d" % (cid, lv)]["out_sha256"]
