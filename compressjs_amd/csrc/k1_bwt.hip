@@ -391,7 +391,6 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
         const u64 actc = ~(c64 & cnx);
         if (actc == 0) continue;                                      // wave-uniform
         const u32 q = q0 + lane;
-        const u32 p = base + q;
         if ((actc >> lane) & 1u) {
             const u32 wq = q >> 5;
             const u32 mask = hn[wq] & (0xFFFFFFFFu >> (31u - (q & 31u)));

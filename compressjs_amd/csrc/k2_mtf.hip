@@ -145,7 +145,6 @@ __global__ __launch_bounds__(256) void k2_lastocc(Pipe P) {
 }
 
 __global__ __launch_bounds__(256) void k2_lastscan(Pipe P) {
-    const BatchGeom g = P.g;
     const u32 b = blockIdx.x, s = threadIdx.x;
     const u32 nr = P.nruns[b];
     const u32 nseg = (nr + K2_SEG - 1) / K2_SEG;

@@ -44,7 +44,6 @@ __device__ __forceinline__ u32 mtf6_front(u32 list, u32 j, u32 s) {
 }
 
 __global__ __launch_bounds__(256) void k5_header(Pipe P) {
-    const BatchGeom g = P.g;
     const u32 b = blockIdx.x;
     const u32 n = P.nlen[b];
     const u32 tid = threadIdx.x;
