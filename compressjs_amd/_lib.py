@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcompressjs_amd.so")
+LIB_PATH = os.environ.get("COMPRESSJS_AMD_LIB") or os.path.join(_HERE, "libcompressjs_amd.so")   # same override as js/index.js
 _lib = None
 
 # every symbol include/compressjs_amd.h declares (tests check the .so exports all of them)

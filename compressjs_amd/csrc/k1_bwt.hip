@@ -69,42 +69,59 @@ __device__ __forceinline__ u32 load_be32(const u8* p) {
     return ((u32)p[0] << 24) | ((u32)p[1] << 16) | ((u32)p[2] << 8) | (u32)p[3];
 }
 
+// Sort tile: K1_SW waves x K1_SI elements per lane per workgroup (independent of the K2/K5 tile K1_RT).
+#ifndef K1_SW
+#define K1_SW 8
+#endif
+#ifndef K1_SI
+#define K1_SI 6       // measured (10^8 B text, ms/step): 4x16 16.72, 8x8 16.17, 8x6 16.13, 8x4 16.49, 16x4 16.71
+#endif
+#define K1_SWE (K1_SI * 64)          // elements per wave
+#define K1_ST (K1_SW * K1_SWE)
+#define K1_STH (K1_SW * 64)
+static inline u32 k1_stiles(const BatchGeom& g) { return (g.stride + K1_ST - 1) / K1_ST; }
+
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k1_hist(K1Buf B, BatchGeom g, const u32* keys, int shift) {
+__global__ __launch_bounds__(K1_STH) void k1_hist(K1Buf B, BatchGeom g, const u32* keys, int shift, u32 stiles) {
     const u32 b = blockIdx.y, t = blockIdx.x;
     const u32 n = B.nlen[b];
-    const u32 t0 = t * K1_RT;
+    const u32 t0 = t * K1_ST;
     if (t0 >= n) return;
-    __shared__ u32 wh[4][256];
+    __shared__ u32 wh[K1_SW][256];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    for (u32 i = tid; i < 1024; i += 256) (&wh[0][0])[i] = 0;
+    for (u32 i = tid; i < K1_SW * 256; i += K1_STH) (&wh[0][0])[i] = 0;
     __syncthreads();
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32* kb = keys + (size_t)b * g.stride;
 #pragma unroll 4
-    for (int it = 0; it < 16; it++) {
-        const u32 j = t0 + w * 1024u + it * 64u + lane;
+    for (int it = 0; it < K1_SI; it++) {
+        const u32 j = t0 + w * K1_SWE + it * 64u + lane;
         if (j < n) {
             const u32 key = FIRST ? load_be32(T + j + 4) : kb[j];
             atomicAdd(&wh[w][(key >> shift) & 255u], 1u);
         }
     }
     __syncthreads();
-    B.tileHist[((size_t)b * g.rtiles + t) * 256 + tid] = wh[0][tid] + wh[1][tid] + wh[2][tid] + wh[3][tid];
+    if (tid < 256) {
+        u32 sum = 0;
+#pragma unroll
+        for (int ww = 0; ww < K1_SW; ww++) sum += wh[ww][tid];
+        B.tileHist[((size_t)b * stiles + t) * 256 + tid] = sum;
+    }
 }
 
 // per block: turn per-tile digit counts into global start offsets (digit-major, tile-minor)
-__global__ __launch_bounds__(1024) void k1_scan(K1Buf B, BatchGeom g) {
+__global__ __launch_bounds__(1024) void k1_scan(K1Buf B, BatchGeom g, u32 stiles) {
     const u32 b = blockIdx.x;
     const u32 n = B.nlen[b];
-    const u32 nt = (n + K1_RT - 1) / K1_RT;
+    const u32 nt = (n + K1_ST - 1) / K1_ST;
     __shared__ u32 part[4][256];
     __shared__ u32 sh[256];
     const u32 tid = threadIdx.x, q = tid >> 8, d = tid & 255u;
     const u32 per = (nt + 3) / 4;
     const u32 tlo = q * per < nt ? q * per : nt;
     const u32 thi = tlo + per < nt ? tlo + per : nt;
-    u32* hist = B.tileHist + (size_t)b * g.rtiles * 256;
+    u32* hist = B.tileHist + (size_t)b * stiles * 256;
     u32 sum = 0;
 #pragma unroll 8
     for (u32 t = tlo; t < thi; t++) sum += hist[(size_t)t * 256 + d];
@@ -124,18 +141,21 @@ __global__ __launch_bounds__(1024) void k1_scan(K1Buf B, BatchGeom g) {
     }
 }
 
+// dynamic LDS: lk[K1_ST], lv[K1_ST]
 template <bool FIRST, bool REKEY>
-__global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u32* kin, const u32* vin, u32* kout,
-                                                  u32* vout, int shift) {
+__global__ __launch_bounds__(K1_STH) void k1_scatter(K1Buf B, BatchGeom g, const u32* kin, const u32* vin, u32* kout,
+                                                     u32* vout, int shift, u32 stiles) {
     const u32 b = blockIdx.y, t = blockIdx.x;
     const u32 n = B.nlen[b];
-    const u32 t0 = t * K1_RT;
+    const u32 t0 = t * K1_ST;
     if (t0 >= n) return;
-    __shared__ u32 wh[4][256];
+    __shared__ u32 wh[K1_SW][256];
     __shared__ u32 dstart[256], gbase[256], sh[256];
-    __shared__ u32 lk[K1_RT], lv[K1_RT];
+    HIP_DYNAMIC_SHARED(u32, k1_dyn)
+    u32* lk = k1_dyn;
+    u32* lv = k1_dyn + K1_ST;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    for (u32 i = tid; i < 1024; i += 256) (&wh[0][0])[i] = 0;
+    for (u32 i = tid; i < K1_SW * 256; i += K1_STH) (&wh[0][0])[i] = 0;
     __syncthreads();
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32* kb = kin + (size_t)b * g.stride;
@@ -143,11 +163,11 @@ __global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u3
     // One ranking pass: every lane learns its rank among the elements of its wave with the same
     // digit (elements of earlier iterations first), and the wave's per-digit counts fall out of the
     // same ballots -- no LDS atomics (text digits collide 10-way and more).
-    u32 kv[16], vv[16], rk[16];
+    u32 kv[K1_SI], vv[K1_SI], rk[K1_SI];
     const u64 lt = lanemask_lt();
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-        const u32 j = t0 + w * 1024u + it * 64u + lane;
+    for (int it = 0; it < K1_SI; it++) {
+        const u32 j = t0 + w * K1_SWE + it * 64u + lane;
         const bool valid = j < n;
         u32 key = 0, val = 0;
         if (valid) {
@@ -166,24 +186,24 @@ __global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u3
         rk[it] = prior + rank;
     }
     __syncthreads();
-    u32 total;
-    {
+    u32 total = 0;
+    if (tid < 256) {
         u32 o = 0;
 #pragma unroll
-        for (int ww = 0; ww < 4; ww++) {
+        for (int ww = 0; ww < K1_SW; ww++) {
             const u32 c = wh[ww][tid];
             wh[ww][tid] = o;                      // offset of wave ww inside digit `tid` of this tile
             o += c;
         }
         total = o;
-        gbase[tid] = B.tileHist[((size_t)b * g.rtiles + t) * 256 + tid];
+        gbase[tid] = B.tileHist[((size_t)b * stiles + t) * 256 + tid];
     }
     const u32 ds = block_excl_scan_256(total, sh);
-    dstart[tid] = ds;
+    if (tid < 256) dstart[tid] = ds;
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-        const u32 j = t0 + w * 1024u + it * 64u + lane;
+    for (int it = 0; it < K1_SI; it++) {
+        const u32 j = t0 + w * K1_SWE + it * 64u + lane;
         if (j < n) {
             const u32 d = (kv[it] >> shift) & 255u;
             const u32 lp = dstart[d] + wh[w][d] + rk[it];
@@ -192,10 +212,10 @@ __global__ __launch_bounds__(256) void k1_scatter(K1Buf B, BatchGeom g, const u3
         }
     }
     __syncthreads();
-    const u32 cntv = n - t0 < K1_RT ? n - t0 : K1_RT;
+    const u32 cntv = n - t0 < K1_ST ? n - t0 : K1_ST;
     u32* ko = kout + (size_t)b * g.stride;
     u32* vo = vout + (size_t)b * g.stride;
-    for (u32 i = tid; i < cntv; i += 256) {
+    for (u32 i = tid; i < cntv; i += K1_STH) {
         u32 key = lk[i];
         const u32 val = lv[i];
         const u32 d = (key >> shift) & 255u;
@@ -1121,7 +1141,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += 5 * al256(e * 4);                                   // SA SB ISA KA KB
     tot += 2 * al256((size_t)g.nb * g.hstride * 4);            // HC HN
     tot += 2 * al256((size_t)g.nb * g.htiles);                 // FC FN
-    tot += al256((size_t)g.nb * g.rtiles * 256 * 4);           // tileHist
+    tot += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);       // tileHist
     tot += al256(K1_STATS * 4);
     tot += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     tot += 2 * al256((size_t)g.nb * (g.stride / 2) * 8);       // listT cur/next
@@ -1143,7 +1163,7 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.HN = (u32*)p; p += al256((size_t)g.nb * g.hstride * 4);
     B.FC = (u8*)p; p += al256((size_t)g.nb * g.htiles);
     B.FN = (u8*)p; p += al256((size_t)g.nb * g.htiles);
-    B.tileHist = (u32*)p; p += al256((size_t)g.nb * g.rtiles * 256 * 4);
+    B.tileHist = (u32*)p; p += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);
     B.stats = (u32*)p; p += al256(K1_STATS * 4);
     B.large = (uint2*)p; p += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     B.largeCap = g.nb * (g.htiles + 1);
@@ -1167,7 +1187,18 @@ extern "C" int cjs_dbg_k1_rounds() { return g_k1_last_rounds; }
 
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     int sparse_rounds = 0;
-    const dim3 gridR(g.rtiles, g.nb), gridH(g.htiles, g.nb);
+    const dim3 gridH(g.htiles, g.nb);
+    const u32 stiles = k1_stiles(g);
+    const dim3 gridS(stiles, g.nb);
+    const size_t sdyn = (size_t)K1_ST * 8;                    // lk + lv of k1_scatter
+    static const bool lds_ok = []() {
+        bool ok = true;
+        ok = ok && hipFuncSetAttribute((const void*)k1_scatter<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K1_ST * 8) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)k1_scatter<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, K1_ST * 8) == hipSuccess;
+        ok = ok && hipFuncSetAttribute((const void*)k1_scatter<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, K1_ST * 8) == hipSuccess;
+        return ok;
+    }();
+    if (!lds_ok) return CJS_E_HIP;
     const dim3 gridU((g.htiles + K1_UPT - 1) / K1_UPT, g.nb);
     const dim3 gridHX(g.htiles, (g.nb + 7u) & ~7u);           // XCD-aware kernels (see xcd_block_tile)
     const u32 initx = (g.hstride + 255) / 256;
@@ -1179,15 +1210,15 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         u32* kout = (p & 1) ? B.KA : B.KB;
         u32* vout = (p & 1) ? B.SA : B.SB;
         const int shift = 8 * (p & 3);
-        if (p == 0) hipLaunchKernelGGL(k1_hist<true>, gridR, dim3(256), 0, stream, B, g, kin, shift);
-        else hipLaunchKernelGGL(k1_hist<false>, gridR, dim3(256), 0, stream, B, g, kin, shift);
-        hipLaunchKernelGGL(k1_scan, dim3(g.nb), dim3(1024), 0, stream, B, g);
+        if (p == 0) hipLaunchKernelGGL(k1_hist<true>, gridS, dim3(K1_STH), 0, stream, B, g, kin, shift, stiles);
+        else hipLaunchKernelGGL(k1_hist<false>, gridS, dim3(K1_STH), 0, stream, B, g, kin, shift, stiles);
+        hipLaunchKernelGGL(k1_scan, dim3(g.nb), dim3(1024), 0, stream, B, g, stiles);
         K1Prof* pr = B.prof;
         const bool timed = pr && pr->enabled && pr->used < K1_PROF_MAX;
         if (timed) (void)hipEventRecord(pr->ev[2 * pr->used], stream);
-        if (p == 0) hipLaunchKernelGGL((k1_scatter<true, false>), gridR, dim3(256), 0, stream, B, g, kin, vin, kout, vout, shift);
-        else if (p == 3) hipLaunchKernelGGL((k1_scatter<false, true>), gridR, dim3(256), 0, stream, B, g, kin, vin, kout, vout, shift);
-        else hipLaunchKernelGGL((k1_scatter<false, false>), gridR, dim3(256), 0, stream, B, g, kin, vin, kout, vout, shift);
+        if (p == 0) hipLaunchKernelGGL((k1_scatter<true, false>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
+        else if (p == 3) hipLaunchKernelGGL((k1_scatter<false, true>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
+        else hipLaunchKernelGGL((k1_scatter<false, false>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
         if (timed) {
             (void)hipEventRecord(pr->ev[2 * pr->used + 1], stream);
             pr->used++;

@@ -223,6 +223,8 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
 template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return emu_shfl_(v, lane); }
 static inline long long clock64() { return 0; }
+#define hipFuncAttributeMaxDynamicSharedMemorySize 8
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline void __builtin_amdgcn_s_sleep(int) { emu::yield_(); }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 template <class T> static inline void __hip_atomic_store(T* p, T v, int, int) { *(volatile T*)p = v; }
