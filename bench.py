@@ -130,6 +130,11 @@ def main():
             dec = bz2.BZ2Decompressor()
             got = dec.decompress(comp, limit)
             verified = bool(got == host[:limit].tobytes())
+            # the whole stream through the GPU decoder (K7-K9), compared on the device
+            back = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+            nback = ctx.decompress_device(out, back)
+            verified = verified and nback == total and bool(torch.equal(back[:total], d_in[:total]))
+            del back
             cpu, ref = cpu_baseline(host, args.level, min(args.cpu_sample, total))
             # parity of the leading blocks against the oracle (bit-exact): blocks are encoded
             # independently of what follows, so the oracle's stream of the sample is a prefix of
