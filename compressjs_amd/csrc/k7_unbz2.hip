@@ -15,7 +15,7 @@
 //                     - permute[] of the current table: 3 registers x 64 lanes (two u16 each),
 //                     - the 256-entry MTF list, kept in the byte domain (entries are symToByte values):
 //                       4 bytes per lane, shifted with one DPP wave_shr,
-//                     - 256 output bytes staged 4 per lane and stored as one coalesced 256-byte row.
+//                     - output: one (byte, count) token per literal/run, expanded 64 tokens at a time.
 //                   Output: the BWT last column (dbuf low bytes) of the block, its length, origPtr,
 //                   the stored CRC, the bit position where the block ends, or an Err code.
 #include "decode.h"
@@ -98,31 +98,22 @@ __device__ __forceinline__ void tab_set(u32& reg, u32 idx, u32 val) {
     if (lane_id() == (idx >> 2)) reg = (reg & ~(0xffu << (8u * (idx & 3u)))) | (val << (8u * (idx & 3u)));
 }
 
-// append one byte of the block: 4 bytes are gathered in a scalar, every 4th byte moves the word into
-// its lane, every 256th byte stores the row (coalesced 256 bytes)
-#define K7_PUT(uc) do {                                                                        \
-        acc |= (u32)(uc) << (8u * (cnt & 3u));                                                 \
-        cnt++;                                                                                 \
-        if (!(cnt & 3u)) {                                                                     \
-            ow = lane == (((cnt - 1u) >> 2) & 63u) ? acc : ow;                                 \
-            acc = 0;                                                                           \
-            if (!(cnt & 255u)) out32[(size_t)((cnt >> 8) - 1u) * 64u + lane] = ow;             \
-        }                                                                                      \
-    } while (0)
-
-#define K7_RING 4096u        // u16 records in flight between the two waves
+#define K7_RING 4096u        // u16 records in flight between waves 0 and 1
+#define K7_TRING 1024u       // u32 tokens in flight between waves 1 and 2
 
 // workgroup-scope publish / observe of a flag in LDS
 __device__ __forceinline__ void lds_publish(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ u32 lds_observe(u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// Two waves per block, a software pipeline through an LDS ring:
+// Three waves per block, a software pipeline through two LDS rings:
 //   wave 0  parses the block header, then only finds code boundaries: one (table, canonical index)
 //           record per Huffman symbol (lib/Bzip2.js:283-300);
-//   wave 1  turns records into symbols (permute[] gather, 64 at a time), undoes RLE2 and MTF and
-//           writes the block's last column (:305-366).
-// Both recurrences are serial; splitting them halves the dependent instruction chain per symbol.
-__global__ __launch_bounds__(128) void k7_decode(DecBuf D, u32 first, u32 count) {
+//   wave 1  turns records into symbols (permute[] gather, 64 at a time), undoes RLE2 and MTF and emits
+//           one (byte, count) token per literal or run (:305-366);
+//   wave 2  expands 64 tokens per step into the block's last column (prefix sum of the counts, one
+//           coalesced byte store per row in the common all-literal case).
+// The two recurrences are serial; splitting them shortens the dependent instruction chain per symbol.
+__global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count) {
     const u32 slot = blockIdx.x;
     if (slot >= count) return;
     const u32 lane = lane_id();
@@ -137,12 +128,14 @@ __global__ __launch_bounds__(128) void k7_decode(DecBuf D, u32 first, u32 count)
     __shared__ u16 s_ring[K7_RING];
     __shared__ u32 s_mtf[64];          // initial MTF list (= symToByte), 4 entries per lane
     __shared__ u32 s_head, s_tail, s_done, s_abort, s_symTotal, s_hdr;
+    __shared__ u32 s_tring[K7_TRING];  // (byte | count << 8) tokens between waves 1 and 2
+    __shared__ u32 s_thead, s_ttail, s_tdone;
     __shared__ int s_pstat, s_cstat;
     __shared__ u32 s_cnt, s_origPtr, s_crc;
     __shared__ u64 s_endbit, s_nsym, s_pwait, s_cwait;
 
     const u64 t_start = clock64();
-    if (threadIdx.x == 0) { s_head = 0; s_tail = 0; s_done = 0; s_abort = 0; s_pstat = 0; s_cstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; }
+    if (threadIdx.x == 0) { s_thead = 0; s_ttail = 0; s_tdone = 0; s_head = 0; s_tail = 0; s_done = 0; s_abort = 0; s_pstat = 0; s_cstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; }
     __syncthreads();
     BitRd r;
     u32 nSel = 0;
@@ -283,17 +276,27 @@ __global__ __launch_bounds__(128) void k7_decode(DecBuf D, u32 first, u32 count)
                 }
             }
             if (lane == 0) { s_pstat = st; s_endbit = br_tell(r); s_nsym = nsym; s_pwait = pwait; lds_publish(&s_done, 1u); }
-        } else {
-            // ---- wave 1: records -> symbols -> RLE2 -> MTF -> last column ------------------------------
-            u32* out32 = (u32*)(D.tt + (size_t)slot * D.ttStride);
+        } else if (wave == 1) {
+            // ---- wave 1: records -> symbols -> RLE2 -> MTF -> (byte, count) tokens ---------------------
             const u32 symTotal = (u32)__builtin_amdgcn_readfirstlane((int)s_symTotal);
-            u32 mw = s_mtf[lane], ow = 0, acc = 0, cnt = 0;
+            u32 mw = s_mtf[lane], cnt = 0, tokv = 0, nt = 0;
             const bool is0 = lane == 0;
             int runPos = 0, st = 0;
             long long runT = 0;
             u32 consumed = 0;
             u64 cwait = 0;
             bool finished = false;
+            // one token per literal or run; 64 tokens are gathered in a register row and handed over at once
+#define K7_TOKEN(byte_, count_) do {                                                              \
+                tokv = lane == (nt & 63u) ? ((u32)(byte_) | ((u32)(count_) << 8)) : tokv;                 \
+                nt++;                                                                                     \
+                if (!(nt & 63u)) {                                                                        \
+                    while (nt - lds_observe(&s_ttail) > K7_TRING && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1); \
+                    s_tring[(nt - 64u + lane) & (K7_TRING - 1u)] = tokv;                                  \
+                    __builtin_amdgcn_wave_barrier();                                                      \
+                    if (lane == 0) lds_publish(&s_thead, nt);                                             \
+                }                                                                                         \
+            } while (0)
             while (!finished) {
                 u32 head = lds_observe(&s_head);
                 if (head == consumed) {
@@ -321,17 +324,11 @@ __global__ __launch_bounds__(128) void k7_decode(DecBuf D, u32 first, u32 count)
                         runPos = 0;
                         if (runT < 0) { st = DEC_DATA_ERROR; break; }          // the reference never terminates here
                         if ((long long)cnt + runT > (long long)DEC_CAP) { st = DEC_DATA_ERROR; break; }
-                        const u32 uc = (u32)__builtin_amdgcn_readlane((int)mw, 0) & 0xffu;
-                        u32 t = (u32)runT;
-                        while (t && (cnt & 3u)) { K7_PUT(uc); t--; }
-                        while (t >= 4u) {                              // whole words: lanes [k4, k4+nw) of the row
-                            const u32 k4 = (cnt >> 2) & 63u;
-                            const u32 nw = (t >> 2) < 64u - k4 ? (t >> 2) : 64u - k4;
-                            ow = (lane >= k4 && lane < k4 + nw) ? uc * 0x01010101u : ow;
-                            cnt += 4u * nw; t -= 4u * nw;
-                            if (!(cnt & 255u)) out32[(size_t)((cnt >> 8) - 1u) * 64u + lane] = ow;
+                        if (runT) {
+                            const u32 uc = (u32)__builtin_amdgcn_readlane((int)mw, 0) & 0xffu;
+                            K7_TOKEN(uc, (u32)runT);
+                            cnt += (u32)runT;
                         }
-                        while (t) { K7_PUT(uc); t--; }
                     }
                     if (sym > symTotal) { finished = true; break; }            // :349-350
                     if (cnt >= DEC_CAP) { st = DEC_DATA_ERROR; break; }
@@ -349,7 +346,8 @@ __global__ __launch_bounds__(128) void k7_decode(DecBuf D, u32 first, u32 count)
                             const u32 part = (mw & keepmask) | ((mw & lowmask) << 8) | carry;
                             mw = lane < ql ? full : (lane == ql ? part : mw);
                         }
-                        K7_PUT(src);
+                        K7_TOKEN(src, 1u);
+                        cnt++;
                     }
                 }
                 if (st) { if (lane == 0) lds_publish(&s_abort, 1u); break; }
@@ -357,11 +355,45 @@ __global__ __launch_bounds__(128) void k7_decode(DecBuf D, u32 first, u32 count)
                 if (lane == 0) lds_publish(&s_tail, consumed);
             }
             if (!st && !finished) st = -1;                                     // wave 0 reports why it stopped
-            if (st == 0) {
-                if (cnt & 3u) ow = lane == ((cnt >> 2) & 63u) ? acc : ow;
-                if (cnt & 255u) out32[(size_t)(cnt >> 8) * 64u + lane] = ow;
+            if (st == 0 && (nt & 63u)) {                                       // the last, partial row of tokens
+                const u32 t0 = nt & ~63u;
+                while (t0 + 64u - lds_observe(&s_ttail) > K7_TRING && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1);
+                if (t0 + lane < nt) s_tring[(t0 + lane) & (K7_TRING - 1u)] = tokv;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) lds_publish(&s_thead, nt);
             }
-            if (lane == 0) { s_cstat = st; s_cnt = cnt; s_cwait = cwait; lds_publish(&s_abort, 1u); }
+            if (lane == 0) { s_cstat = st; s_cnt = cnt; s_cwait = cwait; if (st) lds_publish(&s_abort, 1u); lds_publish(&s_tdone, 1u); }
+        } else {
+            // ---- wave 2: tokens -> bytes of the last column, 64 tokens per step -------------------------
+            u8* out = D.tt + (size_t)slot * D.ttStride;
+            u32 taken = 0, opos = 0;
+            for (;;) {
+                u32 head = lds_observe(&s_thead);
+                if (head == taken) {
+                    if (lds_observe(&s_tdone)) {
+                        head = lds_observe(&s_thead);
+                        if (head == taken) break;
+                    } else { __builtin_amdgcn_s_sleep(2); continue; }
+                }
+                const u32 hi = head - taken < 64u ? head - taken : 64u;        // rows are 64-aligned: taken % 64 == 0
+                const u32 tok = lane < hi ? s_tring[(taken + lane) & (K7_TRING - 1u)] : 0u;
+                const u32 c = tok >> 8, byte = tok & 0xffu;
+                const u32 incl = wave_incl_scan_u32(c);
+                const u32 at = opos + incl - c;
+                if (c == 1u) out[at] = (u8)byte;                               // the common case: one coalesced store per row
+                else if (c && c < 64u) for (u32 i = 0; i < c; i++) out[at + i] = (u8)byte;
+                u64 big = __ballot(c >= 64u);                                  // long runs: the whole wave fills each of them
+                while (big) {
+                    const int l = __builtin_ctzll(big);
+                    big &= big - 1;
+                    const u32 bc = (u32)__builtin_amdgcn_readlane((int)c, l), bat = (u32)__builtin_amdgcn_readlane((int)at, l);
+                    const u32 bb = (u32)__builtin_amdgcn_readlane((int)byte, l);
+                    for (u32 i = lane; i < bc; i += 64u) out[bat + i] = (u8)bb;
+                }
+                opos += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+                taken += hi;
+                if (lane == 0) lds_publish(&s_ttail, taken);
+            }
         }
     }
     __syncthreads();
@@ -390,7 +422,7 @@ int k7_scan(const u8* d_in, u64 len, u64 first_bit, u64* d_cand, u32* d_ncand, u
     return CJS_OK;
 }
 int k7_run(DecBuf D, u32 first, u32 count, hipStream_t stream) {
-    hipLaunchKernelGGL(k7_decode, dim3(count), dim3(128), 0, stream, D, first, count);
+    hipLaunchKernelGGL(k7_decode, dim3(count), dim3(192), 0, stream, D, first, count);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
