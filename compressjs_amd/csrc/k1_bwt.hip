@@ -19,6 +19,7 @@
 //
 // All integer; no floating point anywhere.
 #include "k1_bwt.h"
+#include <stdio.h>
 #include "devutil.h"
 #include <stdlib.h>
 
@@ -1234,6 +1235,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     bool sparse = false;
     int parity = 0;
     const u64 total_n = (u64)g.nb * max_n;
+    static const bool k1_trace = getenv("CJS_K1_TRACE") != nullptr;
     static const u64 sparse_min = []() -> u64 {              // tests lower this to reach the sparse phase
         const char* e = getenv("CJS_SPARSE_MIN");
         return e ? (u64)strtoull(e, nullptr, 10) : (u64)(1u << 20);
@@ -1270,6 +1272,16 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, parity);
             parity ^= 1;
             sparse_rounds++;
+            // The lists for the next round were filled by this one; once they are all empty every group is
+            // sorted and the remaining doubling rounds (always ceil(log2(n/8)) of them) would be no-ops.
+            // One 16-byte read-back every other round: it costs a stream sync, a skipped round six launches.
+            if (mode == 0 && (sparse_rounds & 1) == 0) {
+                u32 nx[4];
+                HIP_CHECK_RET(hipMemcpyAsync(nx, B.stats + K1_STAT_LIST + parity * 4, sizeof nx, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK_RET(hipStreamSynchronize(stream));
+                if (k1_trace) fprintf(stderr, "[k1] sparse round %d (h=%llu): next lists %u %u %u %u\n", sparse_rounds, (unsigned long long)h, nx[0], nx[1], nx[2], nx[3]);
+                if ((nx[0] | nx[1] | nx[2] | nx[3]) == 0) { round++; break; }
+            }
         }
         round++;
         if (mode == 1) break;
