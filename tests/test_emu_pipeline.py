@@ -300,3 +300,11 @@ def test_bwtc_decode_inverts_reference_streams(emu_ctx, golden):
     assert n >= 6
     bad = np.frombuffer(b"bwtx\x81\x09", dtype=np.uint8).copy()
     assert L.cjs_bwtc_decompress(h, bad.ctypes.data, bad.size, None, 0, None) == -30            # 'Bad magic'
+
+
+def test_decoder_differential_fuzz_vs_oracle(emu_ctx):
+    """Random small inputs -> valid streams -> flips / truncations / insertions / concatenations: the GPU
+    decoder (CPU debug build) and the oracle's decoder must agree on bytes, Err code and detail."""
+    import decode_fuzz
+    L, h = emu_ctx
+    assert decode_fuzz.fuzz(L, h, seed=20260925, cases=150) == 150

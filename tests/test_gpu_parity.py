@@ -277,3 +277,10 @@ def test_decoder_round_trip_full_size(ctx):
     out = torch.empty(len(raw) + 16, dtype=torch.uint8, device="cuda")
     assert ctx.decompress_device(zi, out) == len(raw)
     assert out[:len(raw)].cpu().numpy().tobytes() == raw
+
+
+def test_decoder_differential_fuzz_vs_oracle(ctx):
+    """1 500 mutated streams: GPU decoder vs the oracle's decoder (bytes, Err code, detail)."""
+    import decode_fuzz
+    for seed in (1, 2, 3):
+        assert decode_fuzz.fuzz(ctx.L, ctx.h, seed=seed, cases=500) == 500
