@@ -284,3 +284,38 @@ def test_decoder_differential_fuzz_vs_oracle(ctx):
     import decode_fuzz
     for seed in (1, 2, 3):
         assert decode_fuzz.fuzz(ctx.L, ctx.h, seed=seed, cases=500) == 500
+
+
+def test_compress_differential_fuzz_vs_oracle(ctx):
+    """Random inputs around the block-capacity boundaries (level*100000-19), mixtures of runs / text /
+    noise / periodic data, random levels: the GPU stream must equal the oracle's stream bit for bit."""
+    rng = np.random.RandomState(424242)
+
+    def piece(n):
+        k = rng.randint(0, 6)
+        if k == 0:
+            return rng.randint(0, 256, size=n).astype(np.uint8)
+        if k == 1:
+            return synth.text_like(max(n, 1), int(rng.randint(1, 1 << 20)))[:n]
+        if k == 2:
+            return synth.runs_mixed(max(n, 1), int(rng.randint(1, 1 << 20)))[:n]
+        if k == 3:
+            return np.full(n, rng.randint(0, 256), dtype=np.uint8)
+        if k == 4:
+            p = rng.randint(0, 256, size=rng.randint(1, 40)).astype(np.uint8)
+            return np.tile(p, n // p.size + 1)[:n]
+        return synth.lcg_ascii(max(n, 1), int(rng.randint(1, 1 << 20)))[:n]
+
+    for case in range(160):
+        level = int(rng.randint(1, 10))
+        cap = level * 100000 - 19
+        total = int(rng.choice([cap - 3, cap, cap + 1, cap + 255, 2 * cap + 17, 3 * cap - 1, 30011, 777, 1, 0, 1234567]))
+        total = min(total, 1_400_000)
+        parts, left = [], total
+        while left > 0:
+            n = int(min(left, rng.choice([1, 3, 4, 5, 255, 256, 1000, 50000, 99981, 300000])))
+            parts.append(piece(n))
+            left -= n
+        d = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+        got = ctx.compress(d, level)
+        assert got == oracle.bz2_compress(d, level), (case, level, total)
