@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--workload", default="text", choices=["text", "lcg"])
     ap.add_argument("--cpu-sample", type=int, default=12_000_000)
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--batch", type=int, default=128, help="bzip2 blocks in flight (over all streams)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,7 +82,7 @@ def main():
     total = args.size * world
     host = synth.text_like(total, 2025) if args.workload == "text" else synth.lcg_ascii(total, 7)
     d_in = torch.from_numpy(host).to(dev)
-    ctx = Context(local, 128)
+    ctx = Context(local, args.batch)
     bound = int(ctx.L.cjs_bz2_compress_bound(total))
     d_out = torch.zeros((bound + 3) & ~3, dtype=torch.uint8, device=dev)
     seg = None
@@ -177,7 +178,7 @@ def main():
                        "LCG(n, seed 7) random printable ASCII, %d bytes per GPU, bzip2 -%d; BASELINE.json configs[3]"
                        % (args.size, args.level),
                        "input_bytes": total, "compressed_bytes": len(comp),
-                       "blocks_in_flight": 128, "sharding": "blocks/%d" % world,
+                       "blocks_in_flight": args.batch, "sharding": "blocks/%d" % world,
                        "device_ms_per_step": round(dev_ms / args.steps, 3),
                        "bit_exact_vs_oracle_prefix_and_roundtrip": verified,
                        "sha256": hashlib.sha256(comp).hexdigest()},

@@ -6,6 +6,8 @@
 #include "bwtc_host.h"
 #include "decode_host.h"
 #include <vector>
+#include <atomic>
+#include <thread>
 #include <string.h>
 #include <stdlib.h>
 
@@ -321,7 +323,12 @@ extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
     memset(c, 0, sizeof *c);
     c->device = device;
     c->batch_blocks = batch_blocks ? batch_blocks : 128;
-    c->nstreams = 1;            // measured: 1 stream 25.8 ms, 2 streams 27.9 ms per 10^8 B (host read-backs in K1 serialise)
+    // CJS_STREAMS=2: two streams, each driven by its own host thread (issue_blocks): latency-bound kernels of
+    // one half of the batch (k34_tables: one workgroup per block, the sparse rounds, the small scans) overlap
+    // with the bandwidth-bound ones of the other.  Measured, 10^8 B text: 1 stream 15.99 ms, 2 streams 15.36-
+    // 15.61 ms, 3 streams 18.8 ms.  The default stays 1: with overlapping kernels neither HIP events nor
+    // rocprof give a per-launch duration that means anything for the roofline of the dominant kernel.
+    c->nstreams = 1;
     if (const char* ev = getenv("CJS_STREAMS")) {
         const int v = atoi(ev);
         if (v >= 1 && v <= CJS_NSTREAMS) c->nstreams = (u32)v;
@@ -382,31 +389,59 @@ static int grow(void** p, size_t* have, size_t need) {
 
 // Issue blocks [first, first+count) of the planned input K as sub-batches round-robin over the
 // context's streams.  Stream 0 must already hold the pre-pass + output zeroing (evReady).
+// One sub-batch = up to sub_blocks blocks through K0 (materialise) .. K5 on one stream.  The only
+// cross-stream dependency is the stream cursor: k5_blockscan of sub-batch j needs the cursor left by
+// sub-batch j-1 (an event); everything before it overlaps freely.
+static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap, u32 f, u32 nb, u32 si, void* d_out,
+                         uint64_t out_cap, Pipe& P) {
+    hipStream_t st = c->sub[si];
+    pipe_carve(P, g, c->ws[si]);
+    P.ss = c->d_ss;
+    P.out = (u32*)d_out;
+    P.outCapBytes = out_cap & ~(uint64_t)3;
+    P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
+    P.g.nb = nb;
+    P.k1.largeCap = nb * (g.htiles + 1);
+    int rc = k0_batch(K, P, f, cap, st);
+    if (rc) return rc;
+    return pipe_run_block_stages(P, cap, st, 4);
+}
+
 static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 count, void* d_out, uint64_t out_cap) {
     BatchGeom g = make_geom(c->sub_blocks, cap);
-    hipEvent_t prevScan = nullptr;
-    bool used[CJS_NSTREAMS] = {false, false, false, false};
-    u32 j = 0;
-    for (u32 f = first; f < first + count; f += c->sub_blocks, j++) {
-        const u32 si = j % c->nstreams;
-        hipStream_t st = c->sub[si];
-        const u32 nb = first + count - f < c->sub_blocks ? first + count - f : c->sub_blocks;
-        Pipe P;
-        pipe_carve(P, g, c->ws[si]);
-        P.ss = c->d_ss;
-        P.out = (u32*)d_out;
-        P.outCapBytes = out_cap & ~(uint64_t)3;
-        P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
-        P.g.nb = nb;
-        P.k1.largeCap = nb * (g.htiles + 1);
-        if (!used[si]) { HIP_CHECK_RET(hipStreamWaitEvent(st, c->evReady, 0)); used[si] = true; }
-        int rc = k0_batch(K, P, f, cap, st);
-        if (rc) return rc;
-        rc = pipe_run_block_stages(P, cap, st, 5, prevScan, c->evScan[si]);
-        if (rc) return rc;
-        prevScan = c->evScan[si];
+    // sub-batches of equal size, at least one per stream when there are enough blocks to share
+    u32 nsub = (count + c->sub_blocks - 1) / c->sub_blocks;
+    if (nsub < c->nstreams && count >= 16 * c->nstreams) nsub = c->nstreams;
+    const u32 per = nsub ? (count + nsub - 1) / nsub : 0;
+    const u32 ns = c->nstreams < nsub ? c->nstreams : nsub;
+    for (u32 i = 0; i < ns; i++) HIP_CHECK_RET(hipStreamWaitEvent(c->sub[i], c->evReady, 0));
+    // K1 steers itself with small read-backs (stream syncs), so every stream gets its own host thread:
+    // while one sub-batch waits for its counters the other keeps the GPU fed.  The cursor events are
+    // recorded and waited for in sub-batch order (`recorded` hands the order from thread to thread).
+    std::atomic<u32> recorded(0);
+    std::atomic<int> err(0);
+    auto worker = [&](u32 si) {
+        if (hipSetDevice(c->device) != hipSuccess) { err = CJS_E_NOGPU; return; }
+        for (u32 j = si; j < nsub; j += ns) {
+            const u32 f = first + j * per;
+            const u32 nb = first + count - f < per ? first + count - f : per;
+            Pipe P;
+            int rc = err.load() ? err.load() : run_sub_batch(c, K, g, cap, f, nb, si, d_out, out_cap, P);
+            while (recorded.load(std::memory_order_acquire) != j) std::this_thread::yield();
+            if (!rc && !err.load()) rc = k5_run(P, cap, c->sub[si], j ? c->evScan[(j - 1) % ns] : nullptr, c->evScan[si]);
+            if (rc) { int z = 0; err.compare_exchange_strong(z, rc); }
+            recorded.store(j + 1, std::memory_order_release);
+        }
+    };
+    if (ns <= 1) worker(0);
+    else {
+        std::vector<std::thread> th;
+        for (u32 i = 1; i < ns; i++) th.emplace_back(worker, i);
+        worker(0);
+        for (auto& t : th) t.join();
     }
-    for (int i = 0; i < CJS_NSTREAMS; i++) if (used[i]) {
+    if (err.load()) return err.load();
+    for (u32 i = 0; i < ns; i++) {
         HIP_CHECK_RET(hipEventRecord(c->evDone[i], c->sub[i]));
         HIP_CHECK_RET(hipStreamWaitEvent(c->stream, c->evDone[i], 0));
     }

@@ -1215,15 +1215,16 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         else hipLaunchKernelGGL(k1_hist<false>, gridS, dim3(K1_STH), 0, stream, B, g, kin, shift, stiles);
         hipLaunchKernelGGL(k1_scan, dim3(g.nb), dim3(1024), 0, stream, B, g, stiles);
         K1Prof* pr = B.prof;
-        const bool timed = pr && pr->enabled && pr->used < K1_PROF_MAX;
-        if (timed) (void)hipEventRecord(pr->ev[2 * pr->used], stream);
+        // slots are reserved atomically: sub-batches on different streams are driven by different host threads
+        const u32 slot = pr && pr->enabled ? __atomic_fetch_add(&pr->used, 1u, __ATOMIC_RELAXED) : K1_PROF_MAX;
+        const bool timed = slot < K1_PROF_MAX;
+        if (timed) (void)hipEventRecord(pr->ev[2 * slot], stream);
         if (p == 0) hipLaunchKernelGGL((k1_scatter<true, false>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
         else if (p == 3) hipLaunchKernelGGL((k1_scatter<false, true>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
         else hipLaunchKernelGGL((k1_scatter<false, false>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
         if (timed) {
-            (void)hipEventRecord(pr->ev[2 * pr->used + 1], stream);
-            pr->used++;
-            pr->elements += (u64)g.nb * max_n;
+            (void)hipEventRecord(pr->ev[2 * slot + 1], stream);
+            __atomic_fetch_add(&pr->elements, (u64)g.nb * max_n, __ATOMIC_RELAXED);
         }
     }
     hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g);
@@ -1306,6 +1307,7 @@ int k1_prof_enable(K1Prof& p, int on) {
 }
 int k1_prof_read(K1Prof& p, float* total_ms, u32* launches, u64* elements) {
     float tot = 0.f;
+    if (p.used > K1_PROF_MAX) p.used = K1_PROF_MAX;
     for (u32 i = 0; i < p.used; i++) {
         float ms = 0.f;
         HIP_CHECK_RET(hipEventSynchronize(p.ev[2 * i + 1]));

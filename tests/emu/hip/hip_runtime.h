@@ -19,6 +19,7 @@
 #include <tuple>
 #include <vector>
 
+#define CJS_CPU_DEBUG_BUILD 1     // the fiber scheduler is single-threaded: the library keeps to one stream
 #define __global__
 #define __device__
 #define __host__
