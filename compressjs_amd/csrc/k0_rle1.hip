@@ -24,6 +24,7 @@
 //                                table-driven streams per block, combined with x^(8m) mod P.
 #include "pipeline.h"
 #include "crc_dev.h"
+#include "devutil.h"
 
 #define K0_TILE 4096
 #define K0_NONE 0ull          // boundary positions are stored +1 so that 0 means "none"
@@ -161,16 +162,18 @@ __device__ __forceinline__ u64 tile_runstarts(const K0Buf& K, u64 t, u64 rs_in, 
         const u64 j = j0 + k;
         if (j < K.in_len && (j == 0 || b[k] != (k ? b[k - 1] : prev))) lastb = j + 1;
     }
-    sh[tid] = lastb;
-    __syncthreads();
-    for (u32 off = 1; off < 256; off <<= 1) {
-        u64 tv = 0;
-        if (tid >= off) tv = sh[tid - off];
-        __syncthreads();
-        if (tid >= off && tv > sh[tid]) sh[tid] = tv;
-        __syncthreads();
+    // exclusive max-scan over the 256 threads: shuffles inside a wave, one LDS hop across the 4 waves
+    u64 v = lastb;
+    const u32 lane = tid & 63u, w = tid >> 6;
+    for (u32 off = 1; off < 64; off <<= 1) {
+        const u64 u = __shfl_up(v, off);
+        if (lane >= off && u > v) v = u;
     }
-    const u64 before = tid ? sh[tid - 1] : K0_NONE;       // last boundary (+1) in earlier threads' bytes
+    if (lane == 63u) sh[w] = v;
+    __syncthreads();
+    u64 before = __shfl_up(v, 1u);                        // inclusive of the previous lane = exclusive here
+    if (lane == 0) before = K0_NONE;
+    for (u32 ww = 0; ww < w; ww++) if (sh[ww] > before) before = sh[ww];
     __syncthreads();
     return before != K0_NONE ? before - 1 : rs_in;
 }
@@ -186,12 +189,16 @@ __global__ __launch_bounds__(256) void k0_tile_cost(K0Buf K) {
     const u64 rs_in = rsin_raw != K0_NONE ? rsin_raw - 1 : 0;
     u64 rs = tile_runstarts(K, t, rs_in, b, sh);
     const u64 j0 = t * K0_TILE + threadIdx.x * 16u;
-    u32 c = 0;
+    u32 c = 0, sub = 0;                                   // sub = (j - rs) mod 255, kept incrementally: one division per thread
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         const u64 j = j0 + k;
         if (j >= K.in_len) break;
-        if (k == 0 ? (j == 0 || K.in[j - 1] != b[0]) : (b[k] != b[k - 1])) rs = j;
-        c += k0_c(j - rs);
+        const bool head = k == 0 ? (j == 0 || K.in[j - 1] != b[0]) : (b[k] != b[k - 1]);
+        if (head) { rs = j; sub = 0; }
+        else if (k == 0) sub = (u32)((j - rs) % 255u);
+        else sub = sub == 254u ? 0u : sub + 1u;
+        c += sub < 3u ? 1u : (sub == 3u ? 2u : 0u);
     }
     atomicAdd(&tot, c);
     __syncthreads();
@@ -475,27 +482,28 @@ __global__ __launch_bounds__(256) void k0_materialize(K0Buf K, Pipe P, u32 first
         u64 rs = tile_runstarts(K, t, rs_in, by, sh);
         const u64 j0 = t * K0_TILE + tid * 16u;
         // output position of the thread's first byte
-        u32 cs[16], mine = 0;
+        u32 cs[16], mine = 0, sub = 0;
+        bool have = false;                                // sub = (j - rss) mod 255 is valid
+#pragma unroll
         for (int k = 0; k < 16; k++) {
             const u64 j = j0 + k;
             cs[k] = 0;
             if (j >= K.in_len) continue;
-            if (k == 0 ? (j == 0 || K.in[j - 1] != by[0]) : (by[k] != by[k - 1])) rs = j;
-            const u64 rss = rs > s ? rs : s;              // the block start cuts the run
-            if (j >= s && j < e) { cs[k] = k0_c(j - rss); mine += cs[k]; }
+            const bool head = k == 0 ? (j == 0 || K.in[j - 1] != by[0]) : (by[k] != by[k - 1]);
+            if (head) rs = j;
+            if (j >= s && j < e) {
+                const u64 rss = rs > s ? rs : s;          // the block start cuts the run
+                if (j == rss) sub = 0;
+                else if (!have) sub = (u32)((j - rss) % 255u);      // one division per thread
+                else sub = sub == 254u ? 0u : sub + 1u;
+                have = true;
+                cs[k] = sub < 3u ? 1u : (sub == 3u ? 2u : 0u);
+                mine += cs[k];
+            }
         }
-        u32* s32 = (u32*)sh;
-        s32[tid] = mine;
-        __syncthreads();
-        for (u32 off = 1; off < 256; off <<= 1) {
-            u32 tv = 0;
-            if (tid >= off) tv = s32[tid - off];
-            __syncthreads();
-            if (tid >= off) s32[tid] += tv;
-            __syncthreads();
-        }
-        const u32 excl = tid ? s32[tid - 1] : 0;
-        __syncthreads();
+        u32 tile_total;
+        const u32 excl = block_excl_scan_1024(mine, (u32*)sh, &tile_total);   // wave shuffles + one LDS hop
+        (void)tile_total;
         // output bytes before the first in-block byte of this tile
         const u64 tb = t * K0_TILE > s ? t * K0_TILE : s;
         const u64 ob0 = tb <= re ? (u64)k0_g(tb - s) : K.tileC[t] - adj;   // tb > re implies tile-aligned tb
