@@ -42,6 +42,7 @@ struct DecBuf {
     u8* tt;              // [slots][ttStride]   BWT last column (dbuf low bytes)
     u32 ttStride;
     DecResult* res;      // [slots]
+    u32* sel;            // [slots][4160]  selectors of the block being decoded, 4 bits each (k7 scratch)
     // K8 / K9, indexed by slot
     u32* word;           // [slots][DEC_STRIDE]  (T[p] << 8) | F[p]
     u32* tileHist;       // [slots][DEC_TILES][256]

@@ -35,11 +35,13 @@ struct DecState {
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static int dec_alloc(DecState& S, u32 slots) {
+    if (S.slab) { (void)hipFree(S.slab); S.slab = nullptr; }
     S.slots = slots;
     const size_t n = slots;
     size_t tot = 0;
     const size_t o_tt = tot;        tot += al(n * DEC_STRIDE);
     const size_t o_res = tot;       tot += al(n * sizeof(DecResult));
+    const size_t o_sel = tot;       tot += al(n * 4160 * 4);
     const size_t o_word = tot;      tot += al(n * DEC_STRIDE * 4);
     const size_t o_hist = tot;      tot += al(n * DEC_TILES * 256 * 4);
     const size_t o_succ = tot;      tot += al(n * DEC_MAXSPL * 4);
@@ -58,9 +60,10 @@ static int dec_alloc(DecState& S, u32 slots) {
     const size_t o_crc = tot;       tot += al(n * 4);
     TRYH(hipMalloc(&S.slab, tot));
     u8* b = (u8*)S.slab;
-    memset(&S.D, 0, sizeof S.D);
+    { const u32* keep_in = S.D.in32; const u64 keep_zc = S.D.zeroChunk; memset(&S.D, 0, sizeof S.D); S.D.in32 = keep_in; S.D.zeroChunk = keep_zc; }
     S.D.tt = b + o_tt; S.D.ttStride = DEC_STRIDE;
     S.D.res = (DecResult*)(b + o_res);
+    S.D.sel = (u32*)(b + o_sel);
     S.D.word = (u32*)(b + o_word);
     S.D.tileHist = (u32*)(b + o_hist);
     S.D.splSucc = (u32*)(b + o_succ); S.D.splLen = (u32*)(b + o_len); S.D.splOff = (u32*)(b + o_off);
@@ -71,8 +74,20 @@ static int dec_alloc(DecState& S, u32 slots) {
     S.d_bcand = (u64*)(b + o_bcand); S.d_slotOf = (u32*)(b + o_slotof);
     S.d_outOff = (u64*)(b + o_outoff); S.d_crcOut = (u32*)(b + o_crc);
     S.D.cand = S.d_bcand; S.D.slotOf = S.d_slotOf; S.D.outOff = S.d_outOff; S.D.crcOut = S.d_crcOut;
-    TRYH(hipMalloc((void**)&S.d_ncand, 256));
+    if (!S.d_ncand) TRYH(hipMalloc((void**)&S.d_ncand, 256));
     return CJS_OK;
+}
+
+// slots for the blocks of this stream: as many as it has candidates, within [min_slots, DEC_MAX_SLOTS].
+// One k7_decode wave set per block is latency-bound, so throughput comes from the number of blocks in flight
+// (4 per CU fit); 5.7 MB of HBM per slot.
+#define DEC_MAX_SLOTS 4096u
+static int dec_fit_slots(DecState& S, u32 min_slots, size_t ncand) {
+    u32 want = (u32)std::min<size_t>(DEC_MAX_SLOTS, ncand);
+    if (want < min_slots) want = min_slots;
+    if (want <= S.slots) return CJS_OK;
+    want = (want + 63u) & ~63u;
+    return dec_alloc(S, want);
 }
 
 void dec_free(DecState* S) {
@@ -269,6 +284,8 @@ int64_t dec_stream(DecState** ps, u32 slots, hipStream_t st, const u8* in, u64 l
     std::sort(cand.begin(), cand.end());
     std::vector<u64> bpos;                                                       // block-magic positions only
     for (u64 c : cand) if (!(c & 1u)) bpos.push_back(c >> 1);
+    rc = dec_fit_slots(S, slots, bpos.size());
+    if (rc) return rc;
 
     std::vector<DecResult> res;
     std::vector<ValidBlk> valid;

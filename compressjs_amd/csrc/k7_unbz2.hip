@@ -124,7 +124,6 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
     __shared__ u16 s_perm[6][384];
     __shared__ u32 s_jeob[6];          // canonical index of the end-of-block symbol in every table
     __shared__ u8 s_len[264];
-    __shared__ u32 s_sel[4096];        // 32768 selectors, 4 bits each
     __shared__ u16 s_ring[K7_RING];
     __shared__ u32 s_mtf[64];          // initial MTF list (= symToByte), 4 entries per lane
     __shared__ u32 s_head, s_tail, s_done, s_abort, s_symTotal, s_hdr;
@@ -134,6 +133,7 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
     __shared__ u32 s_cnt, s_origPtr, s_crc;
     __shared__ u64 s_endbit, s_nsym, s_pwait, s_cwait;
 
+    u32* gsel = D.sel + (size_t)slot * 4160u;             // [4096 + 64] words: 32768 selectors, 4 bits each, + one row of slack
     const u64 t_start = clock64();
     if (threadIdx.x == 0) { s_thead = 0; s_ttail = 0; s_tdone = 0; s_head = 0; s_tail = 0; s_done = 0; s_abort = 0; s_pstat = 0; s_cstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; }
     __syncthreads();
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                     const u64 lowmask = (1ull << (8 * j)) - 1ull;
                     list = (list & ~((1ull << (8 * (j + 1))) - 1ull)) | ((list & lowmask) << 8) | src;
                     pack |= (u32)src << (4u * (i & 7u));
-                    if ((i & 7u) == 7u || i + 1 == nSel) { if (lane == 0) s_sel[i >> 3] = pack; pack = 0; }
+                    if ((i & 7u) == 7u || i + 1 == nSel) { if (lane == 0) gsel[i >> 3] = pack; pack = 0; }
                 }
                 if (st) break;
             }
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
             // ---- wave 0: code boundaries only --------------------------------------------------------
             int limLA = -1, st = 0;
             u32 base = 0, g = 0, jeob = 0, recv = 0;
+            u32 selrow = 0, selnext = gsel[lane];
             int left = 0;                 // symbols left in the current group of 50
             u32 selector = 0, np = 0;
             u64 nsym = 0, pwait = 0;
@@ -244,7 +245,10 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                 if (left == 0) {
                     left = 50;
                     if (selector >= nSel) { st = DEC_DATA_ERROR; break; }
-                    g = (u32)__builtin_amdgcn_readfirstlane((int)((s_sel[selector >> 3] >> (4u * (selector & 7u))) & 15u));
+                    // selectors live in HBM (16 KB per block would cost LDS residency): a register row of 64 words =
+                    // 512 selectors, the next row requested one row ahead like the stream words
+                    if ((selector & 511u) == 0) { selrow = selnext; selnext = gsel[(((selector >> 9) + 1u) << 6) + lane]; }
+                    g = ((u32)__builtin_amdgcn_readlane((int)selrow, (int)((selector >> 3) & 63u)) >> (4u * (selector & 7u))) & 15u;
                     selector++;
                     limLA = lane < 32u ? s_limLA[g][lane] : -1;
                     base = s_base[g][lane & 31u];

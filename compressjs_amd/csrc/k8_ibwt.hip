@@ -96,11 +96,14 @@ __device__ __forceinline__ bool is_spl(u32 x, u32 p0) { return (x % DEC_SPLIT) =
 __device__ __forceinline__ u32 spl_id(u32 x, u32 p0, u32 m) { return x == p0 ? m - 1u : x / DEC_SPLIT; }
 
 template <int WRITE>
-__global__ __launch_bounds__(256) void k8_walk(DecBuf D) {
-    const u32 slot = D.slotOf[blockIdx.y];
+__global__ __launch_bounds__(256) void k8_walk(DecBuf D, u32 nvalid) {
+    // all splitters of one block run on the same XCD: its 3.6 MB `word` array stays in that XCD's L2
+    u32 kb, bx;
+    if (!xcd_block_tile(nvalid, kb, bx)) return;
+    const u32 slot = D.slotOf[kb];
     const u32 n = D.res[slot].n, p0 = D.res[slot].origPtr;
     const u32 m = spl_count(n);
-    const u32 id = blockIdx.x * 256u + threadIdx.x;
+    const u32 id = bx * 256u + threadIdx.x;
     if (id >= m) return;
     if (WRITE && (D.flags[slot] & 1u)) return;
     const u32* word = D.word + (size_t)slot * DEC_STRIDE;
@@ -186,9 +189,9 @@ int k8_run(DecBuf D, u32 nvalid, hipStream_t stream) {
     hipLaunchKernelGGL(k8_hist, dim3(DEC_TILES, nvalid), dim3(256), 0, stream, D);
     hipLaunchKernelGGL(k8_scan, dim3(nvalid), dim3(256), 0, stream, D);
     hipLaunchKernelGGL(k8_links, dim3(DEC_TILES, nvalid), dim3(256), 0, stream, D);
-    hipLaunchKernelGGL(k8_walk<0>, dim3(sg, nvalid), dim3(256), 0, stream, D);
+    hipLaunchKernelGGL(k8_walk<0>, dim3(sg, (nvalid + 7u) & ~7u), dim3(256), 0, stream, D, nvalid);
     hipLaunchKernelGGL(k8_rank, dim3(nvalid), dim3(1024), 0, stream, D);
-    hipLaunchKernelGGL(k8_walk<1>, dim3(sg, nvalid), dim3(256), 0, stream, D);
+    hipLaunchKernelGGL(k8_walk<1>, dim3(sg, (nvalid + 7u) & ~7u), dim3(256), 0, stream, D, nvalid);
     hipLaunchKernelGGL(k8_serial, dim3(nvalid), dim3(64), 0, stream, D);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;

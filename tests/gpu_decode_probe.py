@@ -16,3 +16,5 @@ for it in range(3):
     print("decompress_device: %d -> %d bytes, wall %.1f ms (events %.1f ms) -> %.0f MB/s of output" % (z.size, m, dt * 1e3, ctx.last_decode_ms, m / dt / 1e6), flush=True)
 assert m == n and bool((out[:n].cpu().numpy() == d).all())
 print("round trip ok")
+if n >= 100_000_000:
+    print("blocks in flight: min(%d candidates, 4096); 3 waves per block" % ((n + 899980) // 899981))
