@@ -285,7 +285,8 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
             const u32 symTotal = (u32)__builtin_amdgcn_readfirstlane((int)s_symTotal);
             u32 mw = s_mtf[lane], cnt = 0, tokv = 0, nt = 0;
             const bool is0 = lane == 0;
-            int runPos = 0, st = 0;
+            int st = 0;
+            u32 runN = 0;                  // RUNA/RUNB symbols of the run in progress
             long long runT = 0;
             u32 consumed = 0;
             u64 cwait = 0;
@@ -316,16 +317,33 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                     const u32 rec = s_ring[(b0 + lane) & (K7_RING - 1u)];
                     symv = s_perm[rec >> 9][rec & 511u];
                 }
-                for (u32 k = consumed - b0; k < hi; k++) {
-                    const u32 sym = (u32)__builtin_amdgcn_readlane((int)symv, (int)k);
-                    if (sym < 2u) {                                            // :318-335
-                        if (!runPos) { runPos = 1; runT = 0; }
-                        runT += sym == 0 ? (long long)runPos : 2ll * (long long)runPos;
-                        runPos = (int)((u32)runPos << 1);
-                        continue;
+                // RUNA/RUNB symbols never enter the serial loop: a maximal stretch of them is a bijective
+                // base-2 number (:318-335) whose value falls out of two ballots; the loop below only visits
+                // literals and the end-of-block symbol
+                const u32 lo = consumed - b0;
+                const u64 inb = (hi == 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
+                const u64 mA = __ballot(symv == 0u) & inb, mB = __ballot(symv == 1u) & inb;
+                u64 lit = inb & ~(mA | mB);
+                u32 cur = lo;
+                for (;;) {
+                    const u32 k = lit ? (u32)__builtin_ctzll(lit) : hi;       // next literal, or the end of the row
+                    if (k > cur) {                                             // run symbols [cur, k): indices runN.. of the run
+                        const u32 len = k - cur;
+                        const u64 seg = len == 64u ? ~0ull : ((1ull << len) - 1ull);
+                        if (runN < 32u) {
+                            const u64 sa = ((mA >> cur) & seg) << runN, sb = ((mB >> cur) & seg) << runN;
+                            // int32 runPos of the reference: index 31 weighs -2^31, indices >= 32 weigh 0
+                            runT += (long long)(sa & 0x7fffffffull) + 2ll * (long long)(sb & 0x7fffffffull)
+                                    - (long long)(((sa >> 31) & 1ull) << 31) - 2ll * (long long)(((sb >> 31) & 1ull) << 31);
+                        }
+                        runN += len;
                     }
-                    if (runPos) {                                              // :340-347
-                        runPos = 0;
+                    if (!lit) break;
+                    lit &= lit - 1;
+                    cur = k + 1u;
+                    const u32 sym = (u32)__builtin_amdgcn_readlane((int)symv, (int)k);
+                    if (runN) {                                                // :340-347
+                        runN = 0;
                         if (runT < 0) { st = DEC_DATA_ERROR; break; }          // the reference never terminates here
                         if ((long long)cnt + runT > (long long)DEC_CAP) { st = DEC_DATA_ERROR; break; }
                         if (runT) {
@@ -333,6 +351,7 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                             K7_TOKEN(uc, (u32)runT);
                             cnt += (u32)runT;
                         }
+                        runT = 0;
                     }
                     if (sym > symTotal) { finished = true; break; }            // :349-350
                     if (cnt >= DEC_CAP) { st = DEC_DATA_ERROR; break; }
