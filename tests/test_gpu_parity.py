@@ -3,6 +3,7 @@ golden digests, and size-independent properties at BASELINE.json's full size.  R
 import bz2
 import ctypes as C
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -333,3 +334,22 @@ def test_bwtc_round_trip_fuzz(ctx):
              else synth.runs_mixed(max(n, 1), case + 1)[:n] if k == 2 else np.zeros(n, np.uint8))
         z = ctx.bwtc_compress(d, level)
         assert ctx.bwtc_decompress(np.frombuffer(z, dtype=np.uint8)) == d.tobytes(), (case, level, n, k)
+
+
+def test_two_streams_with_host_threads_same_bytes():
+    """CJS_STREAMS=2 (one host thread per stream, balanced sub-batches) must give the single-stream bytes."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "from compressjs_amd import synth\n"
+        "from compressjs_amd.bzip2 import Context\n"
+        "d = synth.text_like(30_000_000, 11)\n"
+        "c = Context(0, 32)\n"
+        "print(hashlib.sha256(c.compress(d, 9)).hexdigest(), hashlib.sha256(c.compress(d[:7_000_000], 3)).hexdigest())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for ns in ("1", "2", "3"):
+        env = dict(os.environ, CJS_STREAMS=ns)
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
+    assert outs[0] == outs[1] == outs[2], outs
