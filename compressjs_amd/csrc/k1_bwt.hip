@@ -815,6 +815,11 @@ __device__ __forceinline__ void sp_append(const K1Buf& B, int parity, bool pred,
     sp_append_class(B.listS[parity], c + 1, B.listSCap, pred && len > SP_TINY && len <= 64u, d);
     sp_append_class(B.listM[parity], c + 2, B.listMCap, pred && len > 64u && len <= K1_MED_MAX, d);
     sp_append_class(B.listL[parity], c + 3, B.listLCap, pred && len > K1_MED_MAX, d);
+    // rotations covered by the lists of the next round: (groups, rotations) unchanged from one round to
+    // the next <=> no group was split <=> none ever will be (k1_run jumps to the tie-break round)
+    u32 cov = pred ? len : 0u;
+    for (u32 off = 32; off; off >>= 1) cov += __shfl_xor(cov, off);
+    if ((threadIdx.x & 63u) == 0 && cov) atomicAdd(B.stats + K1_STAT_LISTPOS + parity, cov);
 }
 
 __device__ __forceinline__ u32 sp_key(const K1Buf& B, const BatchGeom& g, u32 b, u32 n, u32 s, u32 h, u32 hm, int mode) {
@@ -1096,6 +1101,7 @@ __global__ __launch_bounds__(256) void k1_sp_update(K1Buf B, BatchGeom g, int pa
 
 __global__ void k1_sp_reset(K1Buf B, int parity) {
     if (threadIdx.x < 4 && blockIdx.x == 0) B.stats[K1_STAT_LIST + parity * 4 + threadIdx.x] = 0;
+    if (threadIdx.x == 4 && blockIdx.x == 0) B.stats[K1_STAT_LISTPOS + parity] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1241,8 +1247,14 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const char* e = getenv("CJS_SPARSE_MIN");
         return e ? (u64)strtoull(e, nullptr, 10) : (u64)(1u << 20);
     }();
+    // If a doubling round splits no group, the classes "equal h-prefix" and "equal 2h-prefix" coincide, and
+    // then so do all later ones (s ~2h s' gives s+h ~h s'+h = s+h ~2h s'+h, i.e. s+2h ~h s'+2h): what is left are
+    // identical rotations, and only the tie-break round (descending index) remains to be run.  Periodic and
+    // tiled inputs reach that state after a few rounds instead of ceil(log2(n/8)).
+    bool force_final = false;
+    u64 prev_groups = ~0ull, prev_cov = ~0ull;
     for (u64 h = 8;; h <<= 1) {
-        const int mode = h >= max_n ? 1 : 0;      // last round: identical rotations by descending index
+        const int mode = (h >= max_n || force_final) ? 1 : 0;      // last round: identical rotations by descending index
         if (!sparse) {
             const bool try_sparse = mode == 0 && total_n >= sparse_min;
             HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
@@ -1261,6 +1273,10 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
                 HIP_CHECK_RET(hipStreamSynchronize(stream));
                 const u64 actpos = hs[K1_STAT_ACTPOS + round + 1];
                 if (actpos == 0) { round++; break; }           // everything sorted: no tie round needed
+                if (k1_trace) fprintf(stderr, "[k1] tile round %d (h=%llu): groups %u -> %u, rotations in groups %u -> %u\n", round, (unsigned long long)h,
+                                      hs[K1_STAT_ACTIVE + round], hs[K1_STAT_ACTIVE + round + 1], hs[K1_STAT_ACTPOS + round], hs[K1_STAT_ACTPOS + round + 1]);
+                if (hs[K1_STAT_ACTIVE + round + 1] == hs[K1_STAT_ACTIVE + round] && actpos == hs[K1_STAT_ACTPOS + round])
+                    force_final = true;                        // this round split nothing
                 if (actpos * 8 < total_n) { sparse = true; parity = 0; }
                 else hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0);
             }
@@ -1277,11 +1293,15 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             // sorted and the remaining doubling rounds (always ceil(log2(n/8)) of them) would be no-ops.
             // One 16-byte read-back every other round: it costs a stream sync, a skipped round six launches.
             if (mode == 0 && (sparse_rounds & 1) == 0) {
-                u32 nx[4];
-                HIP_CHECK_RET(hipMemcpyAsync(nx, B.stats + K1_STAT_LIST + parity * 4, sizeof nx, hipMemcpyDeviceToHost, stream));
+                u32 hs[K1_STATS - K1_STAT_LIST];
+                HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats + K1_STAT_LIST, sizeof hs, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK_RET(hipStreamSynchronize(stream));
-                if (k1_trace) fprintf(stderr, "[k1] sparse round %d (h=%llu): next lists %u %u %u %u\n", sparse_rounds, (unsigned long long)h, nx[0], nx[1], nx[2], nx[3]);
-                if ((nx[0] | nx[1] | nx[2] | nx[3]) == 0) { round++; break; }
+                const u32* nx = hs + parity * 4;
+                const u64 groups = (u64)nx[0] + nx[1] + nx[2] + nx[3], cov = hs[K1_STAT_LISTPOS - K1_STAT_LIST + parity];
+                if (k1_trace) fprintf(stderr, "[k1] sparse round %d (h=%llu): next lists %u %u %u %u covering %llu\n", sparse_rounds, (unsigned long long)h, nx[0], nx[1], nx[2], nx[3], (unsigned long long)cov);
+                if (groups == 0) { round++; break; }
+                if (groups == prev_groups && cov == prev_cov) force_final = true;     // two rounds without a split
+                prev_groups = groups; prev_cov = cov;
             }
         }
         round++;
