@@ -82,31 +82,40 @@ __device__ __forceinline__ u32 load_be32(const u8* p) {
 #define K1_STH (K1_SW * 64)
 static inline u32 k1_stiles(const BatchGeom& g) { return (g.stride + K1_ST - 1) / K1_ST; }
 
+// PMC (profiles/r01_pmc_lds_v6.csv): with one table per wave the LDS atomics of this kernel spend 4.3x
+// their active cycles on bank conflicts (text digits are skewed: a few byte values carry most of the
+// mass).  K1_HREP interleaved copies per wave (copy = lane % K1_HREP, word = bin * K1_HREP + copy) put
+// equal digits of neighbouring lanes on different banks.
+#ifndef K1_HREP
+#define K1_HREP 2       // measured ms per step: 1 copy 15.98, 2 copies 15.82, 4 copies 15.91, 8 copies 17.13 (LDS, zeroing)
+#endif
 template <bool FIRST>
 __global__ __launch_bounds__(K1_STH) void k1_hist(K1Buf B, BatchGeom g, const u32* keys, int shift, u32 stiles) {
     const u32 b = blockIdx.y, t = blockIdx.x;
     const u32 n = B.nlen[b];
     const u32 t0 = t * K1_ST;
     if (t0 >= n) return;
-    __shared__ u32 wh[K1_SW][256];
-    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    for (u32 i = tid; i < K1_SW * 256; i += K1_STH) (&wh[0][0])[i] = 0;
+    __shared__ u32 wh[K1_SW][256 * K1_HREP];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u, cp = lane % K1_HREP;
+    for (u32 i = tid; i < K1_SW * 256 * K1_HREP; i += K1_STH) (&wh[0][0])[i] = 0;
     __syncthreads();
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32* kb = keys + (size_t)b * g.stride;
-#pragma unroll 4
+#pragma unroll
     for (int it = 0; it < K1_SI; it++) {
         const u32 j = t0 + w * K1_SWE + it * 64u + lane;
         if (j < n) {
             const u32 key = FIRST ? load_be32(T + j + 4) : kb[j];
-            atomicAdd(&wh[w][(key >> shift) & 255u], 1u);
+            atomicAdd(&wh[w][((key >> shift) & 255u) * K1_HREP + cp], 1u);
         }
     }
     __syncthreads();
     if (tid < 256) {
         u32 sum = 0;
 #pragma unroll
-        for (int ww = 0; ww < K1_SW; ww++) sum += wh[ww][tid];
+        for (int ww = 0; ww < K1_SW; ww++)
+#pragma unroll
+            for (int c = 0; c < K1_HREP; c++) sum += wh[ww][tid * K1_HREP + c];
         B.tileHist[((size_t)b * stiles + t) * 256 + tid] = sum;
     }
 }
