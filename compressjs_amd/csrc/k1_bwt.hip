@@ -742,10 +742,12 @@ __device__ void seg_radix_pass(const u32* srcK, const u32* srcV, u32* dstK, u32*
     __syncthreads();
 }
 
+#define K1_MAJ_SIDE 2048u
 __global__ __launch_bounds__(1024) void k1_sort_large(K1Buf B, BatchGeom g, u32 h, int mode, int round) {
     __shared__ u32 wh[16][128];
     __shared__ u32 dtot[128];
-    __shared__ u32 s_end;
+    __shared__ u32 s_end, s_pivot, s_side[2];
+    __shared__ u32 sideK[2][K1_MAJ_SIDE], sideV[2][K1_MAJ_SIDE];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     u32 nl = B.stats[K1_STAT_LARGE + round];
     if (nl > B.largeCap) nl = B.largeCap;
@@ -779,16 +781,76 @@ __global__ __launch_bounds__(1024) void k1_sort_large(K1Buf B, BatchGeom g, u32 
         u32* KB = B.KB + (size_t)b * g.stride + start;
         const u32* ISA = B.ISA + (size_t)b * g.stride;
         const u32 hm = h % n;
+        // Repetitive inputs keep huge groups alive for log2(n) rounds in which all but ~2h keys of a group are
+        // equal.  A pivot taken from the middle of the group is then the majority key: count the two sides while
+        // gathering the keys, and if both are small do ONE stable 3-way partition pass (the sides are sorted in
+        // LDS) instead of three radix passes.
+        if (tid == 0) { s_pivot = rot_key(ISA, n, SA[L >> 1], h, hm, mode, B.linear); s_side[0] = 0; s_side[1] = 0; }
+        __syncthreads();
+        const u32 pivot = s_pivot;
+        u32 myl = 0, myg = 0;
         for (u32 i = tid; i < L; i += 1024) {
             const u32 s = SA[i];
             const u32 k = rot_key(ISA, n, s, h, hm, mode, B.linear);
             SB[i] = s;
             KB[i] = k;
+            myl += k < pivot ? 1u : 0u;
+            myg += k > pivot ? 1u : 0u;
+        }
+        for (u32 off = 32; off; off >>= 1) { myl += __shfl_xor(myl, off); myg += __shfl_xor(myg, off); }
+        if (lane == 0) { if (myl) atomicAdd(&s_side[0], myl); if (myg) atomicAdd(&s_side[1], myg); }
+        __syncthreads();
+        const u32 nlt = s_side[0], ngt = s_side[1];
+        if (nlt <= K1_MAJ_SIDE && ngt <= K1_MAJ_SIDE && (nlt + ngt) * 4u < L) {
+            const u32 neq = L - nlt - ngt;
+            u32 runE = 0, runL = 0, runG = 0;
+            for (u32 c0 = 0; c0 < L; c0 += 1024) {
+                const u32 i = c0 + tid;
+                const bool valid = i < L;
+                const u32 k = valid ? KB[i] : pivot, v = valid ? SB[i] : 0u;
+                const bool isE = valid && k == pivot, isL = valid && k < pivot, isG = valid && k > pivot;
+                u32 tot;
+                const u32 ex = block_excl_scan_1024((isE ? 1u : 0u) | (isL ? 1u << 16 : 0u), dtot, &tot);
+                const u32 posE = ex & 0xffffu, posL = ex >> 16, posG = tid - posE - posL;     // every earlier lane of a chunk is valid
+                if (isE) { KA[nlt + runE + posE] = k; SA[nlt + runE + posE] = v; }
+                if (isL) { sideK[0][runL + posL] = k; sideV[0][runL + posL] = v; }
+                if (isG) { sideK[1][runG + posG] = k; sideV[1][runG + posG] = v; }
+                const u32 cE = tot & 0xffffu, cL = tot >> 16, cV = L - c0 < 1024u ? L - c0 : 1024u;
+                runE += cE; runL += cL; runG += cV - cE - cL;
+            }
+            __syncthreads();
+            for (int side = 0; side < 2; side++) {
+                const u32 m = side ? ngt : nlt, dst0 = side ? nlt + neq : 0u;
+                if (m == 0) continue;                                   // uniform
+                u32 P = 2; while (P < m) P <<= 1;
+                u32* comp = sideK[side];                                // (key << 11 | arrival index): keys < 2^20
+                for (u32 i = tid; i < P; i += 1024) comp[i] = i < m ? (comp[i] << 11) | i : 0xFFFFFFFFu;
+                __syncthreads();
+                for (u32 kk = 2; kk <= P; kk <<= 1)
+                    for (u32 j = kk >> 1; j > 0; j >>= 1) {
+                        for (u32 i = tid; i < P; i += 1024) {
+                            const u32 x = i ^ j;
+                            if (x > i) {
+                                const u32 a = comp[i], bb = comp[x];
+                                const bool up = (i & kk) == 0;
+                                if ((a > bb) == up) { comp[i] = bb; comp[x] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                for (u32 i = tid; i < m; i += 1024) {
+                    const u32 c = comp[i];
+                    KA[dst0 + i] = c >> 11;
+                    SA[dst0 + i] = sideV[side][c & 2047u];
+                }
+                __syncthreads();
+            }
+        } else {
+            seg_radix_pass(KB, SB, KA, SA, L, 0, wh, dtot);
+            seg_radix_pass(KA, SA, KB, SB, L, 7, wh, dtot);
+            seg_radix_pass(KB, SB, KA, SA, L, 14, wh, dtot);
         }
         __syncthreads();
-        seg_radix_pass(KB, SB, KA, SA, L, 0, wh, dtot);
-        seg_radix_pass(KA, SA, KB, SB, L, 7, wh, dtot);
-        seg_radix_pass(KB, SB, KA, SA, L, 14, wh, dtot);
         for (u32 i = tid + 1; i < L; i += 1024)
             if (KA[i] != KA[i - 1]) atomicOr(&HN[(start + i) >> 5], 1u << ((start + i) & 31u));
         __syncthreads();
