@@ -42,12 +42,21 @@ class Context:
             pass
 
     # host buffers -------------------------------------------------------------------------
+    def _staging(self, cap: int) -> np.ndarray:
+        """A host buffer kept across calls: a fresh np.empty() would fault in every page the D2H copy touches."""
+        buf = getattr(self, "_obuf", None)
+        if buf is None or buf.size < cap:
+            buf = np.zeros(cap, dtype=np.uint8)
+            self._obuf = buf
+        return buf
+
     def compress(self, data: np.ndarray, level: int = 9) -> bytes:
         d = np.ascontiguousarray(data, dtype=np.uint8)
         cap = int(self.L.cjs_bz2_compress_bound(d.size))
-        out = np.empty(cap, dtype=np.uint8)
+        out = self._staging(cap)
         n = self.L.cjs_bz2_compress(self.h, d.ctypes.data, d.size, int(level), out.ctypes.data, cap)
         _lib.check(n, "cjs_bz2_compress")
+        self.last_call_ms = None
         return out[:n].tobytes()
 
     def bwtc_compress(self, data: np.ndarray, level: int = 9, declared_size=None) -> bytes:

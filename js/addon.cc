@@ -123,13 +123,13 @@ static napi_value Compress(napi_env env, napi_callback_info info) {
     if (level < 1 || level > 9) return throw_code(env, -20, "compress");
     if (!ensure_ctx(env)) return nullptr;
     const uint64_t cap = (uint64_t)p_bound(len);
-    uint8_t* tmp = (uint8_t*)malloc(cap);
-    if (!tmp) { napi_throw_error(env, nullptr, "out of memory"); return nullptr; }
-    const int64_t n = p_compress(g_ctx, in, len, level, tmp, cap);
-    if (n < 0) { free(tmp); return throw_code(env, n, "cjs_bz2_compress"); }
+    // staging kept across calls: a fresh malloc would fault in every page the D2H copy touches
+    static std::vector<uint8_t> stage;
+    if (stage.size() < cap) stage.resize(cap);
+    const int64_t n = p_compress(g_ctx, in, len, level, stage.data(), cap);
+    if (n < 0) return throw_code(env, n, "cjs_bz2_compress");
     napi_value out; void* dst;
-    napi_create_buffer_copy(env, (size_t)n, tmp, &dst, &out);
-    free(tmp);
+    napi_create_buffer_copy(env, (size_t)n, stage.data(), &dst, &out);
     return out;
 }
 
