@@ -56,7 +56,6 @@ class Context:
         out = self._staging(cap)
         n = self.L.cjs_bz2_compress(self.h, d.ctypes.data, d.size, int(level), out.ctypes.data, cap)
         _lib.check(n, "cjs_bz2_compress")
-        self.last_call_ms = None
         return out[:n].tobytes()
 
     def bwtc_compress(self, data: np.ndarray, level: int = 9, declared_size=None) -> bytes:
@@ -74,7 +73,7 @@ class Context:
         n = self.L.cjs_bz2_decompress(self.h, d.ctypes.data, d.size, None, 0, int(bool(multistream)))
         if n == -21:                                   # size now known: fetch the retained result
             n = int(self.L.cjs_bz2_last_size(self.h))
-            out = np.empty(max(n, 1), dtype=np.uint8)
+            out = self._staging(max(n, 1))
             _lib.check(self.L.cjs_bz2_fetch(self.h, out.ctypes.data, n), "cjs_bz2_fetch")
             return out[:n].tobytes()
         if n < 0:
@@ -87,7 +86,7 @@ class Context:
         n = self.L.cjs_bz2_decompress_block(self.h, d.ctypes.data, d.size, int(bitpos), None, 0)
         if n == -21:
             n = int(self.L.cjs_bz2_last_size(self.h))
-            out = np.empty(max(n, 1), dtype=np.uint8)
+            out = self._staging(max(n, 1))
             _lib.check(self.L.cjs_bz2_fetch(self.h, out.ctypes.data, n), "cjs_bz2_fetch")
             return out[:n].tobytes()
         if n < 0:
@@ -112,7 +111,7 @@ class Context:
         n = self.L.cjs_bwtc_decompress(self.h, d.ctypes.data, d.size, None, 0, C.byref(declared))
         if n == -21:
             n = int(self.L.cjs_bwtc_last_size(self.h))
-            out = np.empty(max(n, 1), dtype=np.uint8)
+            out = self._staging(max(n, 1))
             _lib.check(self.L.cjs_bwtc_fetch(self.h, out.ctypes.data, n), "cjs_bwtc_fetch")
             return out[:n].tobytes()
         _lib.check(n, "cjs_bwtc_decompress")
