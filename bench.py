@@ -50,7 +50,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=100_000_000, help="input bytes per GPU")
     ap.add_argument("--level", type=int, default=9)
-    ap.add_argument("--workload", default="text", choices=["text", "lcg"])
+    ap.add_argument("--workload", default="text", choices=["text", "lcg", "e8sa"],
+                    help="text: synthetic enwik8-shaped (default); lcg: random printable ASCII (configs[3]); "
+                         "e8sa: test/sample5.ref || test/sample4.ref tiled (SURVEY.md 8d E8S-A; needs the staged fixtures)")
     ap.add_argument("--cpu-sample", type=int, default=12_000_000)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--batch", type=int, default=128, help="bzip2 blocks in flight (over all streams)")
@@ -80,7 +82,15 @@ def main():
     from compressjs_amd.dist import sharded_compress
 
     total = args.size * world
-    host = synth.text_like(total, 2025) if args.workload == "text" else synth.lcg_ascii(total, 7)
+    if args.workload == "e8sa":
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import cases
+        parts = [cases.fixture_path("sample5.ref"), cases.fixture_path("sample4.ref")]
+        assert all(parts), "e8sa needs test/sample5.ref and test/sample4.ref (staged by __graft_entry__.build())"
+        base = np.concatenate([np.fromfile(p, dtype=np.uint8) for p in parts])
+        host = np.tile(base, total // base.size + 1)[:total].copy()
+    else:
+        host = synth.text_like(total, 2025) if args.workload == "text" else synth.lcg_ascii(total, 7)
     d_in = torch.from_numpy(host).to(dev)
     ctx = Context(local, args.batch)
     bound = int(ctx.L.cjs_bz2_compress_bound(total))
@@ -170,12 +180,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8", "data": "synthetic" if args.workload != "e8sa" else "reference test fixtures, tiled",
             "config": {"workload": "synthetic enwik8-shaped text (compressjs_amd.synth.text_like, seed 2025), "
                                    "%d bytes per GPU, bzip2 -%d, %d-byte blocks; BASELINE.json configs[2]"
                                    % (args.size, args.level, args.level * 100000 - 19)
                        if args.workload == "text" else
                        "LCG(n, seed 7) random printable ASCII, %d bytes per GPU, bzip2 -%d; BASELINE.json configs[3]"
+                       % (args.size, args.level) if args.workload == "lcg" else
+                       "test/sample5.ref || test/sample4.ref tiled to %d bytes per GPU (SURVEY.md 8d E8S-A), bzip2 -%d"
                        % (args.size, args.level),
                        "input_bytes": total, "compressed_bytes": len(comp),
                        "blocks_in_flight": args.batch, "sharding": "blocks/%d" % world,

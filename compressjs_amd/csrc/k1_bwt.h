@@ -6,7 +6,6 @@
 #define K1_STAT_LARGE 32    // stats[32..63] : large groups registered in round r
 #define K1_STAT_ACTPOS 64   // stats[64..95] : positions still in unsorted groups entering round r
 #define K1_STAT_LIST 96     // stats[96..103]: sparse-phase list counters [parity][4 size classes]
-#define K1_STAT_LISTPOS 113 // stats[113..114]: rotations covered by the sparse-phase lists [parity]
 #define K1_STATS 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS
 

@@ -886,11 +886,6 @@ __device__ __forceinline__ void sp_append(const K1Buf& B, int parity, bool pred,
     sp_append_class(B.listS[parity], c + 1, B.listSCap, pred && len > SP_TINY && len <= 64u, d);
     sp_append_class(B.listM[parity], c + 2, B.listMCap, pred && len > 64u && len <= K1_MED_MAX, d);
     sp_append_class(B.listL[parity], c + 3, B.listLCap, pred && len > K1_MED_MAX, d);
-    // rotations covered by the lists of the next round: (groups, rotations) unchanged from one round to
-    // the next <=> no group was split <=> none ever will be (k1_run jumps to the tie-break round)
-    u32 cov = pred ? len : 0u;
-    for (u32 off = 32; off; off >>= 1) cov += __shfl_xor(cov, off);
-    if ((threadIdx.x & 63u) == 0 && cov) atomicAdd(B.stats + K1_STAT_LISTPOS + parity, cov);
 }
 
 __device__ __forceinline__ u32 sp_key(const K1Buf& B, const BatchGeom& g, u32 b, u32 n, u32 s, u32 h, u32 hm, int mode) {
@@ -1172,7 +1167,6 @@ __global__ __launch_bounds__(256) void k1_sp_update(K1Buf B, BatchGeom g, int pa
 
 __global__ void k1_sp_reset(K1Buf B, int parity) {
     if (threadIdx.x < 4 && blockIdx.x == 0) B.stats[K1_STAT_LIST + parity * 4 + threadIdx.x] = 0;
-    if (threadIdx.x == 4 && blockIdx.x == 0) B.stats[K1_STAT_LISTPOS + parity] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1322,8 +1316,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     // then so do all later ones (s ~2h s' gives s+h ~h s'+h = s+h ~2h s'+h, i.e. s+2h ~h s'+2h): what is left are
     // identical rotations, and only the tie-break round (descending index) remains to be run.  Periodic and
     // tiled inputs reach that state after a few rounds instead of ceil(log2(n/8)).
-    bool force_final = false;
-    u64 prev_groups = ~0ull, prev_cov = ~0ull;
+    bool force_final = false;                  // (decided in tile rounds only: their two counters are exact)
     for (u64 h = 8;; h <<= 1) {
         const int mode = (h >= max_n || force_final) ? 1 : 0;      // last round: identical rotations by descending index
         if (!sparse) {
@@ -1368,11 +1361,9 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
                 HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats + K1_STAT_LIST, sizeof hs, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK_RET(hipStreamSynchronize(stream));
                 const u32* nx = hs + parity * 4;
-                const u64 groups = (u64)nx[0] + nx[1] + nx[2] + nx[3], cov = hs[K1_STAT_LISTPOS - K1_STAT_LIST + parity];
-                if (k1_trace) fprintf(stderr, "[k1] sparse round %d (h=%llu): next lists %u %u %u %u covering %llu\n", sparse_rounds, (unsigned long long)h, nx[0], nx[1], nx[2], nx[3], (unsigned long long)cov);
+                const u64 groups = (u64)nx[0] + nx[1] + nx[2] + nx[3];
+                if (k1_trace) fprintf(stderr, "[k1] sparse round %d (h=%llu): next lists %u %u %u %u\n", sparse_rounds, (unsigned long long)h, nx[0], nx[1], nx[2], nx[3]);
                 if (groups == 0) { round++; break; }
-                if (groups == prev_groups && cov == prev_cov) force_final = true;     // two rounds without a split
-                prev_groups = groups; prev_cov = cov;
             }
         }
         round++;
