@@ -1308,6 +1308,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     int parity = 0;
     const u64 total_n = (u64)g.nb * max_n;
     static const bool k1_trace = getenv("CJS_K1_TRACE") != nullptr;
+    static const u64 sparse_div = []() -> u64 { const char* e = getenv("CJS_SPARSE_DIV"); const u64 v = e ? strtoull(e, nullptr, 10) : 8; return v ? v : 8; }();
     static const u64 sparse_min = []() -> u64 {              // tests lower this to reach the sparse phase
         const char* e = getenv("CJS_SPARSE_MIN");
         return e ? (u64)strtoull(e, nullptr, 10) : (u64)(1u << 20);
@@ -1341,7 +1342,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
                                       hs[K1_STAT_ACTIVE + round], hs[K1_STAT_ACTIVE + round + 1], hs[K1_STAT_ACTPOS + round], hs[K1_STAT_ACTPOS + round + 1]);
                 if (hs[K1_STAT_ACTIVE + round + 1] == hs[K1_STAT_ACTIVE + round] && actpos == hs[K1_STAT_ACTPOS + round])
                     force_final = true;                        // this round split nothing
-                if (actpos * 8 < total_n) { sparse = true; parity = 0; }
+                if (actpos * sparse_div < total_n) { sparse = true; parity = 0; }
                 else hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0);
             }
         } else {
