@@ -7,6 +7,7 @@
 #define K1_STAT_ACTPOS 64   // stats[64..95] : positions still in unsorted groups entering round r
 #define K1_STAT_LIST 96     // stats[96..103]: sparse-phase list counters [parity][4 size classes]
 #define K1_STATS 128
+#define K1_SPREAD 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS
 
 // HIP-event timing of one kernel's launches (k1_scatter), filled by k1_run when enabled.
@@ -38,6 +39,8 @@ struct K1Buf {
     const u32* nlen;  // [nb]           block lengths
     u32* tileHist;    // [nb][rtiles][256]
     u32* stats;       // [K1_STATS]
+    u32* spread;      // [32 rounds][2][K1_SPREAD]  per-round (group starts, rotations in groups), spread over
+                      //                            K1_SPREAD words: ~10^5 tiles adding to ONE word cost 1 ms per launch
     uint2* large;     // [largeCap]     (block, start position)
     u32 largeCap;
     u64* listT[2];    // sparse phase: descriptors of groups of <= 8 rotations (cur/next)

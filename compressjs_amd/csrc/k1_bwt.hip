@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     const u32 n = B.nlen[b];
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && gid < K1_STATS) B.stats[gid] = 0;
+    if (b == 0) for (u32 i = gid; i < 32u * 2u * K1_SPREAD; i += gridDim.x * blockDim.x) B.spread[i] = 0;
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
         u32 w;
@@ -369,12 +370,18 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
     // suffix indices of the tile, fetched while the bitmap words are on their way
     const u32* SA = B.SA + (size_t)b * g.stride;
     u32 pre_s[K1_HT / 256];
+    __syncthreads();
+    // suffix indices only of the 64-position chunks that hold a position of an unsorted group: late rounds
+    // touch a few percent of them (the bitmap words are in LDS now; 8 workgroups per CU hide the extra hop)
 #pragma unroll
     for (int it = 0; it < K1_HT / 256; it++) {
-        const u32 p = base + w * (K1_HT / 4u) + (u32)it * 64u + lane;
-        pre_s[it] = p < n ? SA[p] : 0u;
+        const u32 q0 = w * (K1_HT / 4u) + (u32)it * 64u;
+        const u32 wi = q0 >> 5;
+        const u64 c64 = (u64)hc[wi] | ((u64)hc[wi + 1] << 32);
+        const u64 cnx = (c64 >> 1) | ((u64)(hc[wi + 2] & 1u) << 63);
+        const u32 p = base + q0 + lane;
+        pre_s[it] = (~(c64 & cnx)) != 0 && p < n ? SA[p] : 0u;
     }
-    __syncthreads();
     if (w == 0) {
         const u32 word = hn[lane];
         int v = word ? (int)(lane * 32u + 31u - (u32)__clz((int)word)) : -1;
@@ -436,8 +443,9 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
     __syncthreads();
     if (tid == 0) {
         B.FN[fidx] = (u8)((red[0] ? 1 : 0) | (red[1] ? 2 : 0));
-        if (red[0]) atomicAdd(&B.stats[K1_STAT_ACTIVE + slot_out], red[0]);
-        if (red[1]) atomicAdd(&B.stats[K1_STAT_ACTPOS + slot_out], red[1]);
+        const u32 sp = (t * 29u + b) & (K1_SPREAD - 1u);
+        if (red[0]) atomicAdd(&B.spread[((size_t)slot_out * 2 + 0) * K1_SPREAD + sp], red[0]);
+        if (red[1]) atomicAdd(&B.spread[((size_t)slot_out * 2 + 1) * K1_SPREAD + sp], red[1]);
     }
     // descriptor lists for a possible switch to the sparse phase after this round (the tile's
     // bitmap words are already in LDS; a separate pass over the bitmaps cost 0.9 ms)
@@ -1215,6 +1223,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += 2 * al256((size_t)g.nb * g.htiles);                 // FC FN
     tot += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);       // tileHist
     tot += al256(K1_STATS * 4);
+    tot += al256(32 * 2 * K1_SPREAD * 4);                      // spread
     tot += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     tot += 2 * al256((size_t)g.nb * (g.stride / 2) * 8);       // listT cur/next
     tot += 2 * al256((size_t)g.nb * (g.stride / 8) * 8);       // listS cur/next
@@ -1237,6 +1246,7 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.FN = (u8*)p; p += al256((size_t)g.nb * g.htiles);
     B.tileHist = (u32*)p; p += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);
     B.stats = (u32*)p; p += al256(K1_STATS * 4);
+    B.spread = (u32*)p; p += al256(32 * 2 * K1_SPREAD * 4);
     B.large = (uint2*)p; p += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     B.largeCap = g.nb * (g.htiles + 1);
     B.listTCap = g.nb * (g.stride / 2);
@@ -1318,14 +1328,18 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     // identical rotations, and only the tie-break round (descending index) remains to be run.  Periodic and
     // tiled inputs reach that state after a few rounds instead of ceil(log2(n/8)).
     bool force_final = false;                  // (decided in tile rounds only: their two counters are exact)
+    u64 prev_actpos = 0;                       // rotations in unsorted groups before the current round (0: not known yet)
     for (u64 h = 8;; h <<= 1) {
         const int mode = (h >= max_n || force_final) ? 1 : 0;      // last round: identical rotations by descending index
         if (!sparse) {
             const bool try_sparse = mode == 0 && total_n >= sparse_min;
+            // descriptor lists for a switch to the sparse phase are only worth emitting when the switch is near:
+            // the unsorted share roughly halves per round, so emit once it was below 1/4 before this round (unknown before round 0: emit)
+            const bool emit_lists = try_sparse && prev_actpos * 4 < total_n;
             HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
             hipLaunchKernelGGL(k1_refine, gridHX, dim3(256), 0, stream, B, g, (u32)h, mode, round);
             hipLaunchKernelGGL(k1_sort_large, dim3(large_grid), dim3(1024), 0, stream, B, g, (u32)h, mode, round);
-            hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, round + 1, try_sparse ? 1 : 0);
+            hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, round + 1, emit_lists ? 1 : 0);
             { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
             if (try_sparse) {
                 // How much is still unsorted?  One small read-back per tile round: a list-driven
@@ -1334,15 +1348,23 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
                 // faster one (measured on tiled/periodic inputs), so switch below 1/8.  The lists
                 // were already filled by k1_update_ranks; they are dropped if we stay.
                 u32 hs[K1_STATS];
-                HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats, sizeof hs, hipMemcpyDeviceToHost, stream));
+                static thread_local u32 spr[2 * 2 * K1_SPREAD];
+                HIP_CHECK_RET(hipMemcpyAsync(spr, B.spread + (size_t)round * 2 * K1_SPREAD, sizeof spr, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK_RET(hipStreamSynchronize(stream));
+                for (int rr = 0; rr < 2; rr++) {
+                    u32 a = 0, c = 0;
+                    for (u32 i = 0; i < K1_SPREAD; i++) { a += spr[(rr * 2 + 0) * K1_SPREAD + i]; c += spr[(rr * 2 + 1) * K1_SPREAD + i]; }
+                    hs[K1_STAT_ACTIVE + round + rr] = a;
+                    hs[K1_STAT_ACTPOS + round + rr] = c;
+                }
                 const u64 actpos = hs[K1_STAT_ACTPOS + round + 1];
                 if (actpos == 0) { round++; break; }           // everything sorted: no tie round needed
                 if (k1_trace) fprintf(stderr, "[k1] tile round %d (h=%llu): groups %u -> %u, rotations in groups %u -> %u\n", round, (unsigned long long)h,
                                       hs[K1_STAT_ACTIVE + round], hs[K1_STAT_ACTIVE + round + 1], hs[K1_STAT_ACTPOS + round], hs[K1_STAT_ACTPOS + round + 1]);
                 if (hs[K1_STAT_ACTIVE + round + 1] == hs[K1_STAT_ACTIVE + round] && actpos == hs[K1_STAT_ACTPOS + round])
                     force_final = true;                        // this round split nothing
-                if (actpos * sparse_div < total_n) { sparse = true; parity = 0; }
+                prev_actpos = actpos;
+                if (emit_lists && actpos * sparse_div < total_n) { sparse = true; parity = 0; }
                 else hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0);
             }
         } else {
