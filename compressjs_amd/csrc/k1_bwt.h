@@ -34,6 +34,7 @@ struct K1Buf {
     u32* KB;          // [nb][stride]   keys of large groups (pong)
     u32* HC;          // [nb][hstride]  head bitmap, current
     u32* HN;          // [nb][hstride]  head bitmap, next
+    u32* HX;          // [nb][hstride]  head bitmap after the 8-byte sort (input of k1_deep)
     u8* FC;           // [nb][htiles]   tile flags, current: bit0 = an unsorted group starts here,
     u8* FN;           //                                     bit1 = holds a position of an unsorted group
     const u32* nlen;  // [nb]           block lengths

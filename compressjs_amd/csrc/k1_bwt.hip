@@ -707,6 +707,227 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1-deep: groups resolved by comparing the TEXT, before any rank exists.
+//
+// After the 8-byte radix sort most unsorted groups of text-like input are tiny (pairs, triples: a
+// phrase and its copies) and tie for the next 10..200 bytes.  Prefix doubling pays one random rank
+// gather and one random rank scatter per tied rotation and ROUND for them, out of a rank array that
+// is far larger than L2.  Here the same tile/ownership scheme as k1_refine compacts the rotations of
+// the owned groups into LDS and then iterates ENTIRELY inside the workgroup: iteration i keys every
+// still-tied rotation s with the 8 text bytes at (s + 8 + 8i) mod n (the block's 900 kB of text sit
+// in the XCD's L2, see xcd_block_tile), ranks it inside its group by counting, permutes, and splits the
+// group where neighbouring keys differ.  No global traffic between iterations, no ranks.  Groups are
+// classes of "equal first 8+8i bytes" exactly as a doubling round would produce them, only finer, so
+// whatever is still tied after `iters` iterations (long repeats, identical rotations) or was too big
+// (> K1_DEEP_BIG rotations after two iterations, > K1_HT at all) is left to the doubling rounds, whose
+// invariant "a group at round h shares >= h bytes" holds for the finer partition as well.
+// Cyclic mode only (rotations; T_ext wraps).  Replaces no reference code of its own: it is a faster
+// route to the order BWT.js:372-417 defines.
+// ---------------------------------------------------------------------------------------------
+#define K1_DEEP_BIG 64u
+
+__device__ __forceinline__ u64 load_be64(const u8* p) {
+    u64 v;
+    __builtin_memcpy(&v, p, 8);
+    return __builtin_bswap64(v);
+}
+
+// DHT = suffix-array positions owned by one workgroup of DNT threads (window 2*DHT).  <1024, 256> mirrors
+// k1_refine; <256, 64> is one WAVE per tile: its barriers are wave-local, so a tile whose groups tie for
+// 20 iterations does not stall on three other waves 20 times, and 16 independent tiles per CU overlap
+// their text loads.
+template <int DHT, int DNT>
+__global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iters) {
+    constexpr int DWIN = 2 * DHT, DWW = DWIN / 32 + 2, DCW = DWIN / 32, NW = DNT / 64, SL = DWIN / DNT;
+    static_assert(DCW <= 64 && DWW <= DNT, "one wave scans the compact bitmap");
+    u32 b, t;
+    if (!xcd_block_tile(g.nb, b, t)) return;
+    const u32 n = B.nlen[b];
+    const u32 base = t * (u32)DHT;
+    if (base >= n || n < 64u) return;
+    __shared__ u32 hw[DWW + 2];
+    __shared__ int prevh[DWW + 2], nexth[DWW + 2];
+    __shared__ u64 ck[DWIN];
+    __shared__ u32 cv[DWIN];
+    __shared__ u16 cp[DWIN];
+    __shared__ u32 hb[DCW + 2];
+    __shared__ int cprev[DCW], cnext[DCW];
+    __shared__ u32 chunkoff[DWIN / 64 + 1];
+    __shared__ u32 anyact[2];
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32* HX = B.HX + (size_t)b * g.hstride;
+    u32* HN = B.HN + (size_t)b * g.hstride;
+    u32* SA = B.SA + (size_t)b * g.stride;
+    const u8* T = B.T + (size_t)b * g.tstride;
+    const u32 wbase = base >> 5;
+    if (tid < DWW) hw[tid] = HX[wbase + tid];
+    if (tid < DCW + 2) hb[tid] = tid < DCW ? 0u : 0xFFFFFFFFu;
+    if (tid < 2) anyact[tid] = 0;
+    __syncthreads();
+    if (tid < DWW) {
+        int pv = -1;
+        for (int i = (int)tid - 1; i >= 0; i--) {
+            const u32 wd = hw[i];
+            if (wd) { pv = i * 32 + 31 - __clz((int)wd); break; }
+        }
+        prevh[tid] = pv;
+        int nx = K1_INF;
+        for (int i = (int)tid + 1; i < DWW; i++) {
+            const u32 wd = hw[i];
+            if (wd) { nx = i * 32 + __ffs((int)wd) - 1; break; }
+        }
+        nexth[tid] = nx;
+    }
+    __syncthreads();
+    const u64 lt = lanemask_lt();
+    const u32 spill_end = (hw[DHT / 32] & 1u) ? (u32)DHT
+                        : (nexth[DHT / 32 - 1] < K1_INF ? (u32)nexth[DHT / 32 - 1] : (u32)DWIN);
+    // pass 1: owned positions per 64-position chunk (ownership as in refine_tile)
+    for (int it = 0; it < SL; it++) {
+        const u32 ci = (u32)it * (u32)NW + w;
+        const u32 q0 = ci * 64u;
+        u32 c64 = 0;
+        if (q0 < spill_end && !chunk_all_sorted(hw, q0)) {            // wave-uniform
+            const u32 q = q0 + lane;
+            const PosClass c = classify(hw, prevh, nexth, q);
+            const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
+            const bool owned = c.head >= 0 && c.head < DHT && size >= 2 && size <= DHT && base + q < n;
+            c64 = (u32)__popcll(__ballot(owned));
+        }
+        if (lane == 0) chunkoff[ci] = c64;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (u32 ci = 0; ci < DWIN / 64; ci++) { const u32 c = chunkoff[ci]; chunkoff[ci] = run; run += c; }
+        chunkoff[DWIN / 64] = run;
+    }
+    __syncthreads();
+    const u32 m = chunkoff[DWIN / 64];
+    if (m == 0) return;
+    // pass 2: compact the owned rotations; head bits over the compact index
+    for (int it = 0; it < SL; it++) {
+        const u32 ci = (u32)it * (u32)NW + w;
+        const u32 q0 = ci * 64u;
+        if (q0 >= spill_end || chunk_all_sorted(hw, q0)) continue;    // wave-uniform
+        const u32 q = q0 + lane;
+        const PosClass c = classify(hw, prevh, nexth, q);
+        const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
+        const bool owned = c.head >= 0 && c.head < DHT && size >= 2 && size <= DHT && base + q < n;
+        const u64 bal = __ballot(owned);
+        if (owned) {
+            const u32 e = chunkoff[ci] + (u32)__popcll(bal & lt);
+            cv[e] = SA[base + q];
+            cp[e] = (u16)q;
+            if (c.is_head) atomicOr(&hb[e >> 5], 1u << (e & 31u));
+        }
+    }
+    if (tid < DCW) {                                                // compact slots >= m count as sorted
+        const u32 lo = tid * 32u;
+        if (lo + 32u > m) atomicOr(&hb[tid], lo >= m ? 0xFFFFFFFFu : 0xFFFFFFFFu << (m - lo));
+    }
+    __syncthreads();
+    for (u32 iter = 0; iter < iters; iter++) {
+        // word-level neighbours of the compact head bitmap (one wave: DCW == 64 words)
+        if (w == 0) {
+            const u32 word = lane < (u32)DCW ? hb[lane] : 0xFFFFFFFFu;
+            int v = word ? (int)(lane * 32u + 31u - (u32)__clz((int)word)) : -1;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(v, (unsigned)off);
+                if ((int)lane >= off) v = v > u ? v : u;
+            }
+            int ex = __shfl_up(v, 1u);
+            if (lane == 0) ex = -1;
+            if (lane < (u32)DCW) cprev[lane] = ex;
+            int f = word ? (int)(lane * 32u + (u32)__ffs((int)word) - 1u) : 64 * 32;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_down(f, (unsigned)off);
+                if ((int)lane + off < 64) f = f < u ? f : u;
+            }
+            int nx = __shfl_down(f, 1u);
+            if (lane == 63u) nx = 64 * 32;
+            if (lane < (u32)DCW) cnext[lane] = nx;
+        }
+        __syncthreads();
+        u32 dm = (8u + 8u * iter) % n;
+        u64 key[SL];
+        u32 val[SL], gsl[SL];                     // group start | length << 16 (0: not active)
+        bool mine = false;
+#pragma unroll
+        for (int it = 0; it < SL; it++) {
+            const u32 e0 = (u32)it * (u32)DNT + w * 64u;
+            gsl[it] = 0;
+            if (e0 >= m || chunk_all_sorted(hb, e0)) continue;        // wave-uniform
+            const u32 e = e0 + lane;
+            const u32 wq = e >> 5, bq = e & 31u;
+            const u32 word = hb[wq];
+            const u32 low = word & (0xFFFFFFFFu >> (31u - bq));
+            const int head = low ? (int)(wq * 32u + 31u - (u32)__clz((int)low)) : cprev[wq];
+            const u32 high = bq == 31u ? 0u : (word & (0xFFFFFFFEu << bq));
+            const int endp = high ? (int)(wq * 32u + (u32)__ffs((int)high) - 1u) : cnext[wq];
+            const u32 gl = (u32)(endp - head);
+            if (e < m && head >= 0 && gl >= 2u && (gl <= K1_DEEP_BIG || iter < 2u)) {
+                const u32 s = cv[e];
+                u32 p = s + dm;
+                if (p >= n) p -= n;
+                const u64 k = load_be64(T + p);
+                key[it] = k;
+                val[it] = s;
+                gsl[it] = (u32)head | (gl << 16);
+                ck[e] = k;
+                mine = true;
+            }
+        }
+        if (mine) anyact[iter & 1u] = 1u;
+        __syncthreads();
+        if (!anyact[iter & 1u]) break;                                // nothing left to compare in this tile
+        if (tid == 0) anyact[(iter + 1u) & 1u] = 0u;
+        u32 ns[SL];
+#pragma unroll
+        for (int it = 0; it < SL; it++) {
+            if (!gsl[it]) continue;
+            const u32 e = (u32)it * (u32)DNT + tid;
+            const u32 gs = gsl[it] & 0xFFFFu, ge = gs + (gsl[it] >> 16);
+            const u64 k = key[it];
+            u32 r = 0;
+            for (u32 j = gs; j < ge; j++) {
+                const u64 kj = ck[j];
+                r += (kj < k || (kj == k && j < e)) ? 1u : 0u;
+            }
+            ns[it] = gs + r;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SL; it++)
+            if (gsl[it]) { ck[ns[it]] = key[it]; cv[ns[it]] = val[it]; }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SL; it++) {
+            const u32 e0 = (u32)it * (u32)DNT + w * 64u;
+            if (e0 >= m) continue;                                    // wave-uniform
+            const u32 e = e0 + lane;
+            const bool nh = gsl[it] && e != (gsl[it] & 0xFFFFu) && ck[e] != ck[e - 1u];
+            const u64 bal = __ballot(nh);
+            if (bal && lane == 0) {
+                if ((u32)bal) atomicOr(&hb[e0 >> 5], (u32)bal);
+                if ((u32)(bal >> 32)) atomicOr(&hb[(e0 >> 5) + 1u], (u32)(bal >> 32));
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // write back: the suffix indices in their new order, and the heads that are new
+    for (u32 e = tid; e < m; e += DNT) {
+        const u32 q = cp[e];
+        const u32 p = base + q;
+        SA[p] = cv[e];
+        const bool nowh = (hb[e >> 5] >> (e & 31u)) & 1u;
+        const bool was = (hw[q >> 5] >> (q & 31u)) & 1u;
+        if (nowh && !was) atomicOr(&HN[p >> 5], 1u << (p & 31u));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // groups of > K1_HT rotations: one 1024-thread workgroup per group, 3 stable 7-bit LSD passes
 // through global memory (keys < 2^20)
 // ---------------------------------------------------------------------------------------------
@@ -1219,7 +1440,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     const size_t e = (size_t)g.nb * g.stride;
     size_t tot = 0;
     tot += 5 * al256(e * 4);                                   // SA SB ISA KA KB
-    tot += 2 * al256((size_t)g.nb * g.hstride * 4);            // HC HN
+    tot += 3 * al256((size_t)g.nb * g.hstride * 4);            // HC HN HX
     tot += 2 * al256((size_t)g.nb * g.htiles);                 // FC FN
     tot += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);       // tileHist
     tot += al256(K1_STATS * 4);
@@ -1242,6 +1463,7 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.KB = (u32*)p; p += al256(e * 4);
     B.HC = (u32*)p; p += al256((size_t)g.nb * g.hstride * 4);
     B.HN = (u32*)p; p += al256((size_t)g.nb * g.hstride * 4);
+    B.HX = (u32*)p; p += al256((size_t)g.nb * g.hstride * 4);
     B.FC = (u8*)p; p += al256((size_t)g.nb * g.htiles);
     B.FN = (u8*)p; p += al256((size_t)g.nb * g.htiles);
     B.tileHist = (u32*)p; p += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);
@@ -1309,13 +1531,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         }
     }
     hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g);
-    hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, 0, 0);
-    { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
     const size_t hbytes = (size_t)g.nb * g.hstride * 4;
-    int round = 0;
-    const u32 large_grid = g.nb * 4 < 1024 ? (g.nb * 4 < 64 ? 64 : g.nb * 4) : 1024;
-    bool sparse = false;
-    int parity = 0;
     const u64 total_n = (u64)g.nb * max_n;
     static const bool k1_trace = getenv("CJS_K1_TRACE") != nullptr;
     static const u64 sparse_div = []() -> u64 { const char* e = getenv("CJS_SPARSE_DIV"); const u64 v = e ? strtoull(e, nullptr, 10) : 8; return v ? v : 8; }();
@@ -1323,13 +1539,43 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const char* e = getenv("CJS_SPARSE_MIN");
         return e ? (u64)strtoull(e, nullptr, 10) : (u64)(1u << 20);
     }();
+    // K1-deep: iterations of 8 text bytes each (0 switches it off; default 32 = ties up to 264 bytes)
+    static const u32 deep_iters = []() -> u32 { const char* e = getenv("CJS_DEEP_ITERS"); return e ? (u32)strtoul(e, nullptr, 10) : 32u; }();
+    static const u32 deep_tile = []() -> u32 { const char* e = getenv("CJS_DEEP_TILE"); return e ? (u32)strtoul(e, nullptr, 10) : 256u; }();
+    const bool deep = deep_iters > 0 && !B.linear;
+    if (deep) {
+        HIP_CHECK_RET(hipMemcpyAsync(B.HX, B.HN, hbytes, hipMemcpyDeviceToDevice, stream));
+        if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters);
+        else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters);
+    }
+    // with K1-deep in front most inputs arrive here nearly sorted: the first rank pass then also emits the
+    // descriptor lists, and the doubling rounds start in the sparse phase (or not at all)
+    const bool early = deep && total_n >= sparse_min;
+    hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, 0, early ? 1 : 0);
+    { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
+    int round = 0;
+    const u32 large_grid = g.nb * 4 < 1024 ? (g.nb * 4 < 64 ? 64 : g.nb * 4) : 1024;
+    bool sparse = false, all_sorted = false;
+    int parity = 0;
     // If a doubling round splits no group, the classes "equal h-prefix" and "equal 2h-prefix" coincide, and
     // then so do all later ones (s ~2h s' gives s+h ~h s'+h = s+h ~2h s'+h, i.e. s+2h ~h s'+2h): what is left are
     // identical rotations, and only the tie-break round (descending index) remains to be run.  Periodic and
     // tiled inputs reach that state after a few rounds instead of ceil(log2(n/8)).
     bool force_final = false;                  // (decided in tile rounds only: their two counters are exact)
     u64 prev_actpos = 0;                       // rotations in unsorted groups before the current round (0: not known yet)
-    for (u64 h = 8;; h <<= 1) {
+    if (early) {
+        static thread_local u32 spr0[2 * K1_SPREAD];
+        HIP_CHECK_RET(hipMemcpyAsync(spr0, B.spread, sizeof spr0, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK_RET(hipStreamSynchronize(stream));
+        u64 a = 0, c = 0;
+        for (u32 i = 0; i < K1_SPREAD; i++) { a += spr0[i]; c += spr0[K1_SPREAD + i]; }
+        if (k1_trace) fprintf(stderr, "[k1] after the 8-byte sort + deep: %llu unsorted groups, %llu rotations in them (of %llu)\n",
+                              (unsigned long long)a, (unsigned long long)c, (unsigned long long)total_n);
+        if (c == 0) all_sorted = true;
+        else if (c * sparse_div < total_n) { sparse = true; parity = 0; }
+        else { hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0); prev_actpos = c; }
+    }
+    for (u64 h = 8; !all_sorted; h <<= 1) {
         const int mode = (h >= max_n || force_final) ? 1 : 0;      // last round: identical rotations by descending index
         if (!sparse) {
             const bool try_sparse = mode == 0 && total_n >= sparse_min;
