@@ -725,6 +725,7 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
 // route to the order BWT.js:372-417 defines.
 // ---------------------------------------------------------------------------------------------
 #define K1_DEEP_BIG 64u
+#define K1_DEEP_LANE 8u         // groups up to this size: one lane each (phase 2)
 
 __device__ __forceinline__ u64 load_be64(const u8* p) {
     u64 v;
@@ -754,6 +755,9 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
     __shared__ int cprev[DCW], cnext[DCW];
     __shared__ u32 chunkoff[DWIN / 64 + 1];
     __shared__ u32 anyact[2];
+    __shared__ u16 gd[DWIN];           // phase 2: bytes the members of the group starting here are known to share
+    __shared__ u16 glist[DWIN / 2];    // phase 2: start | length << 12 of the groups of this pass
+    __shared__ u32 gcount;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* HX = B.HX + (size_t)b * g.hstride;
     u32* HN = B.HN + (size_t)b * g.hstride;
@@ -827,8 +831,8 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
         if (lo + 32u > m) atomicOr(&hb[tid], lo >= m ? 0xFFFFFFFFu : 0xFFFFFFFFu << (m - lo));
     }
     __syncthreads();
-    for (u32 iter = 0; iter < iters; iter++) {
-        // word-level neighbours of the compact head bitmap (one wave: DCW == 64 words)
+    // word-level neighbours of the compact head bitmap (one wave: DCW <= 64 words)
+    auto scan_words = [&]() {
         if (w == 0) {
             const u32 word = lane < (u32)DCW ? hb[lane] : 0xFFFFFFFFu;
             int v = word ? (int)(lane * 32u + 31u - (u32)__clz((int)word)) : -1;
@@ -848,11 +852,17 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
             if (lane == 63u) nx = 64 * 32;
             if (lane < (u32)DCW) cnext[lane] = nx;
         }
+    };
+    // ---- phase 1: all groups together, 8 bytes per iteration, while a group of more than K1_DEEP_LANE
+    //      rotations is still being worked on (rank by counting inside the group: any size up to DHT)
+    u32 iter = 0;
+    for (; iter < iters; iter++) {
+        scan_words();
         __syncthreads();
-        u32 dm = (8u + 8u * iter) % n;
+        const u32 dm = (8u + 8u * iter) % n;
         u64 key[SL];
         u32 val[SL], gsl[SL];                     // group start | length << 16 (0: not active)
-        bool mine = false;
+        bool big = false;
 #pragma unroll
         for (int it = 0; it < SL; it++) {
             const u32 e0 = (u32)it * (u32)DNT + w * 64u;
@@ -867,21 +877,29 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
             const int endp = high ? (int)(wq * 32u + (u32)__ffs((int)high) - 1u) : cnext[wq];
             const u32 gl = (u32)(endp - head);
             if (e < m && head >= 0 && gl >= 2u && (gl <= K1_DEEP_BIG || iter < 2u)) {
-                const u32 s = cv[e];
-                u32 p = s + dm;
-                if (p >= n) p -= n;
-                const u64 k = load_be64(T + p);
-                key[it] = k;
-                val[it] = s;
+                val[it] = cv[e];
                 gsl[it] = (u32)head | (gl << 16);
-                ck[e] = k;
-                mine = true;
+                big = big || gl > K1_DEEP_LANE;
             }
         }
-        if (mine) anyact[iter & 1u] = 1u;
+        if (big) anyact[iter & 1u] = 1u;
         __syncthreads();
-        if (!anyact[iter & 1u]) break;                                // nothing left to compare in this tile
+        if (!anyact[iter & 1u]) break;                                // only lane-sized groups left (or none)
         if (tid == 0) anyact[(iter + 1u) & 1u] = 0u;
+        // all text loads of the iteration in flight together, then the LDS stores
+#pragma unroll
+        for (int it = 0; it < SL; it++) {
+            key[it] = 0;
+            if (gsl[it]) {
+                u32 p = val[it] + dm;
+                if (p >= n) p -= n;
+                key[it] = load_be64(T + p);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < SL; it++)
+            if (gsl[it]) ck[(u32)it * (u32)DNT + tid] = key[it];
+        __syncthreads();
         u32 ns[SL];
 #pragma unroll
         for (int it = 0; it < SL; it++) {
@@ -914,6 +932,89 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
             }
         }
         __syncthreads();
+    }
+    // ---- phase 2: groups of <= K1_DEEP_LANE rotations, one LANE each.  The lane walks the text of all
+    //      members at once, 16 bytes per step (every load of a step in flight together), until they stop
+    //      being all equal; then it sorts the members by the 8 bytes that differ and splits the group.
+    //      Sub-groups that still tie come back in the next pass with their own depth (gd[]).
+    const u32 capd = 8u + 8u * iters;
+    for (u32 e = tid; e < (u32)DWIN; e += DNT) gd[e] = (u16)(8u + 8u * iter);
+    for (u32 pass = 0; pass < 64u; pass++) {
+        __syncthreads();
+        scan_words();
+        if (tid == 0) gcount = 0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < SL; it++) {
+            const u32 e0 = (u32)it * (u32)DNT + w * 64u;
+            if (e0 >= m || chunk_all_sorted(hb, e0)) continue;        // wave-uniform
+            const u32 e = e0 + lane;
+            const u32 wq = e >> 5, bq = e & 31u;
+            const u32 word = hb[wq];
+            const bool ishead = (word >> bq) & 1u;
+            const u32 high = bq == 31u ? 0u : (word & (0xFFFFFFFEu << bq));
+            const int endp = high ? (int)(wq * 32u + (u32)__ffs((int)high) - 1u) : cnext[wq];
+            const u32 gl = (u32)endp - e;
+            const bool take = ishead && e < m && gl >= 2u && gl <= K1_DEEP_LANE && gd[e] < capd;
+            const u64 bal = __ballot(take);
+            if (bal == 0) continue;                                   // wave-uniform
+            u32 gb = 0;
+            if (lane == 0) gb = atomicAdd(&gcount, (u32)__popcll(bal));
+            gb = __shfl(gb, 0);
+            if (take) glist[gb + (u32)__popcll(bal & lt)] = (u16)(e | (gl << 12));
+        }
+        __syncthreads();
+        const u32 ng = gcount;
+        if (ng == 0) break;
+        for (u32 gi = tid; gi < ng; gi += DNT) {
+            const u32 ent = glist[gi];
+            const u32 gs = ent & 0xFFFu, gl = ent >> 12;
+            u32 d = gd[gs];
+            u32 pp[K1_DEEP_LANE];
+            const u32 dm = d < n ? d : d % n;
+#pragma unroll
+            for (int i = 0; i < (int)K1_DEEP_LANE; i++) {
+                pp[i] = 0;
+                if ((u32)i < gl) { u32 q = cv[gs + i] + dm; if (q >= n) q -= n; pp[i] = q; }
+            }
+            u64 ka[K1_DEEP_LANE], kb[K1_DEEP_LANE];
+            bool tie = false, useb = false;
+            for (;;) {
+#pragma unroll
+                for (int i = 0; i < (int)K1_DEEP_LANE; i++) {
+                    ka[i] = 0; kb[i] = 0;
+                    if ((u32)i < gl) { ka[i] = load_be64(T + pp[i]); kb[i] = load_be64(T + pp[i] + 8); }
+                }
+                bool eqa = true, eqb = true;
+#pragma unroll
+                for (int i = 1; i < (int)K1_DEEP_LANE; i++)
+                    if ((u32)i < gl) { eqa = eqa && ka[i] == ka[0]; eqb = eqb && kb[i] == kb[0]; }
+                if (!eqa) { d += 8u; break; }
+                if (!eqb) { d += 16u; useb = true; break; }
+                d += 16u;
+                if (d >= capd) { tie = true; break; }
+#pragma unroll
+                for (int i = 0; i < (int)K1_DEEP_LANE; i++) { pp[i] += 16u; if (pp[i] >= n) pp[i] -= n; }
+            }
+            if (tie) { gd[gs] = (u16)capd; continue; }                // left to the doubling rounds
+#pragma unroll
+            for (int i = 0; i < (int)K1_DEEP_LANE; i++)
+                if ((u32)i < gl) ck[gs + i] = useb ? kb[i] : ka[i];
+            for (u32 i = 1; i < gl; i++) {                            // insertion sort of (ck, cv)[gs .. gs+gl)
+                const u64 x = ck[gs + i];
+                const u32 v = cv[gs + i];
+                u32 j = i;
+                while (j > 0 && ck[gs + j - 1u] > x) { ck[gs + j] = ck[gs + j - 1u]; cv[gs + j] = cv[gs + j - 1u]; j--; }
+                ck[gs + j] = x;
+                cv[gs + j] = v;
+            }
+            u64 bits = 0;
+            for (u32 i = 1; i < gl; i++) if (ck[gs + i] != ck[gs + i - 1u]) bits |= 1ull << i;
+            for (u32 i = 0; i < gl; i++) gd[gs + i] = (u16)(d < capd ? d : capd);
+            bits <<= (gs & 31u);
+            if ((u32)bits) atomicOr(&hb[gs >> 5], (u32)bits);
+            if ((u32)(bits >> 32)) atomicOr(&hb[(gs >> 5) + 1u], (u32)(bits >> 32));
+        }
     }
     __syncthreads();
     // write back: the suffix indices in their new order, and the heads that are new
@@ -1540,7 +1641,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         return e ? (u64)strtoull(e, nullptr, 10) : (u64)(1u << 20);
     }();
     // K1-deep: iterations of 8 text bytes each (0 switches it off; default 32 = ties up to 264 bytes)
-    static const u32 deep_iters = []() -> u32 { const char* e = getenv("CJS_DEEP_ITERS"); return e ? (u32)strtoul(e, nullptr, 10) : 32u; }();
+    static const u32 deep_iters = []() -> u32 { const char* e = getenv("CJS_DEEP_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 32u; return v > 4000u ? 4000u : v; }();
     static const u32 deep_tile = []() -> u32 { const char* e = getenv("CJS_DEEP_TILE"); return e ? (u32)strtoul(e, nullptr, 10) : 256u; }();
     const bool deep = deep_iters > 0 && !B.linear;
     if (deep) {

@@ -308,3 +308,44 @@ def test_decoder_differential_fuzz_vs_oracle(emu_ctx):
     import decode_fuzz
     L, h = emu_ctx
     assert decode_fuzz.fuzz(L, h, seed=20260925, cases=150) == 150
+
+
+@pytest.mark.parametrize("env_add", [{}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "2"}, {"CJS_DEEP_ITERS": "0"}])
+def test_deep_refinement_of_suffix_sort(env_add):
+    """K1-deep resolves groups by comparing the text inside LDS before any rank exists; what it leaves
+    (long repeats, identical rotations, groups that stay big) goes to the doubling rounds, which then start
+    in the sparse phase or are skipped.  Both kernels (wave / workgroup per tile), a short iteration cap and
+    'off' against the oracle, on inputs that end in each of the three continuations."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle, stagelib
+from compressjs_amd import synth
+L = C.CDLL(stagelib.build_emu())
+L.cjs_bwt_cyclic.restype = C.c_int32
+L.cjs_bwt_cyclic.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+passage = synth.text_like(700, 3)
+cases = [np.concatenate([synth.text_like(9000, 1), passage, synth.text_like(5000, 2), passage, synth.runs_mixed(3000, 1), passage]),
+         synth.enwik_like(40000, 7), synth.lcg_ascii(5000, 3), synth.runs_mixed(12000, 5), synth.periodic(6000),
+         np.tile(synth.text_like(1000, 5), 9), np.zeros(3000, np.uint8), synth.text_like(65, 2), synth.periodic(70),
+         np.tile(synth.text_like(300, 8), 30)]
+res = []
+for d in cases:
+    d = np.ascontiguousarray(d)
+    u = np.zeros(d.size, np.uint8); p = C.c_uint32(0)
+    assert L.cjs_bwt_cyclic(d.ctypes.data, u.ctypes.data, d.size, C.byref(p)) == 0
+    uo, po = oracle.bwt_cyclic(d)
+    assert p.value == po and (u == uo).all(), d.size
+    res.append((L.cjs_dbg_k1_rounds(), L.cjs_dbg_k1_sparse_rounds()))
+print("ok", res)
+''' % (stagelib.ROOT, os.path.join(stagelib.ROOT, "tests"))
+    env = dict(os.environ, CJS_SPARSE_MIN="100", **env_add)
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode()
+    assert out.startswith("ok")
+    if not env_add:
+        rounds = eval(out[2:])
+        assert rounds[1] == (0, 0) and rounds[2] == (0, 0), rounds      # phrase-reuse text, random: no doubling round at all
+        assert rounds[0][1] >= 1, rounds                                  # 700-byte repeats: left to the (sparse) doubling rounds

@@ -353,3 +353,30 @@ def test_two_streams_with_host_threads_same_bytes():
         env = dict(os.environ, CJS_STREAMS=ns)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
     assert outs[0] == outs[1] == outs[2], outs
+
+
+def test_deep_refinement_variants_same_bytes(ctx):
+    """K1-deep (text-comparison refinement in front of the doubling rounds) is a faster route to the same
+    order: off (CJS_DEEP_ITERS=0), the default wave-per-tile kernel, the workgroup-per-tile kernel and a short
+    iteration cap (most ties left to the sparse phase) must all give the same bytes on phrase-reuse text, and
+    those bytes must be the oracle's on the leading blocks."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from compressjs_amd import synth\n"
+        "from compressjs_amd.bzip2 import Context\n"
+        "d = np.concatenate([synth.enwik_like(24_000_000, 2025), synth.runs_mixed(1_000_000, 2), synth.periodic(900_000, b'abcab'),\n"
+        "                    np.tile(synth.text_like(70_000, 3), 20)])\n"
+        "c = Context(0, 32)\n"
+        "print(hashlib.sha256(c.compress(d, 9)).hexdigest(), hashlib.sha256(c.compress(d[:9_000_000], 4)).hexdigest())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_add in ({"CJS_DEEP_ITERS": "0"}, {}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "3"}):
+        env = dict(os.environ, **env_add)
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
+    assert outs[0] == outs[1] == outs[2] == outs[3], outs
+    d = synth.enwik_like(24_000_000, 2025)
+    a = ctx.compress(d[:2_700_000], 9)
+    assert a == oracle.bz2_compress(d[:2_700_000], 9)
