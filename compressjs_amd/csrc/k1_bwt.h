@@ -6,6 +6,7 @@
 #define K1_STAT_LARGE 32    // stats[32..63] : large groups registered in round r
 #define K1_STAT_ACTPOS 64   // stats[64..95] : positions still in unsorted groups entering round r
 #define K1_STAT_LIST 96     // stats[96..103]: sparse-phase list counters [parity][4 size classes]
+#define K1_DEEP_SUB 64u     // k1_deep list sub-regions per XCD region (power of two)
 #define K1_STATS 128
 #define K1_SPREAD 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS
@@ -40,6 +41,7 @@ struct K1Buf {
     const u32* nlen;  // [nb]           block lengths
     u32* tileHist;    // [nb][rtiles][256]
     u32* stats;       // [K1_STATS]
+    u32* deepCnt;     // [2 classes][8 XCD regions][K1_DEEP_SUB]  entries in each k1_deep list sub-region
     u32* spread;      // [32 rounds][2][K1_SPREAD]  per-round (group starts, rotations in groups), spread over
                       //                            K1_SPREAD words: ~10^5 tiles adding to ONE word cost 1 ms per launch
     uint2* large;     // [largeCap]     (block, start position)

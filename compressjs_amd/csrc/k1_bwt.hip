@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     const u32 n = B.nlen[b];
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && gid < K1_STATS) B.stats[gid] = 0;
+    if (b == 0) for (u32 i = gid; i < 2u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
     if (b == 0) for (u32 i = gid; i < 32u * 2u * K1_SPREAD; i += gridDim.x * blockDim.x) B.spread[i] = 0;
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
@@ -733,12 +734,64 @@ __device__ __forceinline__ u64 load_be64(const u8* p) {
     return __builtin_bswap64(v);
 }
 
+// Phase 2 of k1_deep, one lane: the (<= M) members of a group, all known to share their first d bytes, are
+// walked W*8 bytes per step with every load of the step in flight together (M*W = 16 loads), until a word
+// differs between them.  On return true, keys[i] holds each member's 8 bytes at the first differing word and
+// d the number of bytes that members with EQUAL keys share; false: still all equal at capd (left alone).
+// T_ext wraps for K1_TPAD = 64 bytes, so a step may read [p, p + 64) for any p < n without reducing mod n.
+template <int M, int W>
+__device__ __forceinline__ bool deep_walk(const u8* T, u32 n, const u32* members, u32 mstride, u32 gl, u32& d, u32 capd,
+                                          u64* keys, u32 kstride) {
+    static_assert(W * 8 <= K1_TPAD, "one step must stay inside the wrapped tail of T_ext");
+    u32 pp[M];
+    const u32 dm = d < n ? d : d % n;
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        pp[i] = 0;
+        if ((u32)i < gl) { u32 q = members[(u32)i * mstride] + dm; if (q >= n) q -= n; pp[i] = q; }
+    }
+    for (;;) {
+        u64 k[M][W];
+#pragma unroll
+        for (int i = 0; i < M; i++)
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                k[i][j] = 0;
+                if ((u32)i < gl) k[i][j] = load_be64(T + pp[i] + 8 * j);
+            }
+        int jd = -1;
+#pragma unroll
+        for (int j = W - 1; j >= 0; j--) {
+            bool eq = true;
+#pragma unroll
+            for (int i = 1; i < M; i++)
+                if ((u32)i < gl) eq = eq && k[i][j] == k[0][j];
+            if (!eq) jd = j;
+        }
+        if (jd >= 0) {
+            d += 8u * (u32)(jd + 1);
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                u64 x = k[i][0];
+#pragma unroll
+                for (int j = 1; j < W; j++) if (j == jd) x = k[i][j];
+                if ((u32)i < gl) keys[(u32)i * kstride] = x;
+            }
+            return true;
+        }
+        d += 8u * W;
+        if (d >= capd) return false;
+#pragma unroll
+        for (int i = 0; i < M; i++) { pp[i] += 8u * W; if (pp[i] >= n) pp[i] -= n; }
+    }
+}
+
 // DHT = suffix-array positions owned by one workgroup of DNT threads (window 2*DHT).  <1024, 256> mirrors
 // k1_refine; <256, 64> is one WAVE per tile: its barriers are wave-local, so a tile whose groups tie for
 // 20 iterations does not stall on three other waves 20 times, and 16 independent tiles per CU overlap
 // their text loads.
 template <int DHT, int DNT>
-__global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iters) {
+__global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iters, u32 dbg) {
     constexpr int DWIN = 2 * DHT, DWW = DWIN / 32 + 2, DCW = DWIN / 32, NW = DNT / 64, SL = DWIN / DNT;
     static_assert(DCW <= 64 && DWW <= DNT, "one wave scans the compact bitmap");
     u32 b, t;
@@ -755,9 +808,6 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
     __shared__ int cprev[DCW], cnext[DCW];
     __shared__ u32 chunkoff[DWIN / 64 + 1];
     __shared__ u32 anyact[2];
-    __shared__ u16 gd[DWIN];           // phase 2: bytes the members of the group starting here are known to share
-    __shared__ u16 glist[DWIN / 2];    // phase 2: start | length << 12 of the groups of this pass
-    __shared__ u32 gcount;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* HX = B.HX + (size_t)b * g.hstride;
     u32* HN = B.HN + (size_t)b * g.hstride;
@@ -856,7 +906,7 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
     // ---- phase 1: all groups together, 8 bytes per iteration, while a group of more than K1_DEEP_LANE
     //      rotations is still being worked on (rank by counting inside the group: any size up to DHT)
     u32 iter = 0;
-    for (; iter < iters; iter++) {
+    for (; iter < iters && !(dbg & 1u); iter++) {
         scan_words();
         __syncthreads();
         const u32 dm = (8u + 8u * iter) % n;
@@ -933,89 +983,6 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
         }
         __syncthreads();
     }
-    // ---- phase 2: groups of <= K1_DEEP_LANE rotations, one LANE each.  The lane walks the text of all
-    //      members at once, 16 bytes per step (every load of a step in flight together), until they stop
-    //      being all equal; then it sorts the members by the 8 bytes that differ and splits the group.
-    //      Sub-groups that still tie come back in the next pass with their own depth (gd[]).
-    const u32 capd = 8u + 8u * iters;
-    for (u32 e = tid; e < (u32)DWIN; e += DNT) gd[e] = (u16)(8u + 8u * iter);
-    for (u32 pass = 0; pass < 64u; pass++) {
-        __syncthreads();
-        scan_words();
-        if (tid == 0) gcount = 0;
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < SL; it++) {
-            const u32 e0 = (u32)it * (u32)DNT + w * 64u;
-            if (e0 >= m || chunk_all_sorted(hb, e0)) continue;        // wave-uniform
-            const u32 e = e0 + lane;
-            const u32 wq = e >> 5, bq = e & 31u;
-            const u32 word = hb[wq];
-            const bool ishead = (word >> bq) & 1u;
-            const u32 high = bq == 31u ? 0u : (word & (0xFFFFFFFEu << bq));
-            const int endp = high ? (int)(wq * 32u + (u32)__ffs((int)high) - 1u) : cnext[wq];
-            const u32 gl = (u32)endp - e;
-            const bool take = ishead && e < m && gl >= 2u && gl <= K1_DEEP_LANE && gd[e] < capd;
-            const u64 bal = __ballot(take);
-            if (bal == 0) continue;                                   // wave-uniform
-            u32 gb = 0;
-            if (lane == 0) gb = atomicAdd(&gcount, (u32)__popcll(bal));
-            gb = __shfl(gb, 0);
-            if (take) glist[gb + (u32)__popcll(bal & lt)] = (u16)(e | (gl << 12));
-        }
-        __syncthreads();
-        const u32 ng = gcount;
-        if (ng == 0) break;
-        for (u32 gi = tid; gi < ng; gi += DNT) {
-            const u32 ent = glist[gi];
-            const u32 gs = ent & 0xFFFu, gl = ent >> 12;
-            u32 d = gd[gs];
-            u32 pp[K1_DEEP_LANE];
-            const u32 dm = d < n ? d : d % n;
-#pragma unroll
-            for (int i = 0; i < (int)K1_DEEP_LANE; i++) {
-                pp[i] = 0;
-                if ((u32)i < gl) { u32 q = cv[gs + i] + dm; if (q >= n) q -= n; pp[i] = q; }
-            }
-            u64 ka[K1_DEEP_LANE], kb[K1_DEEP_LANE];
-            bool tie = false, useb = false;
-            for (;;) {
-#pragma unroll
-                for (int i = 0; i < (int)K1_DEEP_LANE; i++) {
-                    ka[i] = 0; kb[i] = 0;
-                    if ((u32)i < gl) { ka[i] = load_be64(T + pp[i]); kb[i] = load_be64(T + pp[i] + 8); }
-                }
-                bool eqa = true, eqb = true;
-#pragma unroll
-                for (int i = 1; i < (int)K1_DEEP_LANE; i++)
-                    if ((u32)i < gl) { eqa = eqa && ka[i] == ka[0]; eqb = eqb && kb[i] == kb[0]; }
-                if (!eqa) { d += 8u; break; }
-                if (!eqb) { d += 16u; useb = true; break; }
-                d += 16u;
-                if (d >= capd) { tie = true; break; }
-#pragma unroll
-                for (int i = 0; i < (int)K1_DEEP_LANE; i++) { pp[i] += 16u; if (pp[i] >= n) pp[i] -= n; }
-            }
-            if (tie) { gd[gs] = (u16)capd; continue; }                // left to the doubling rounds
-#pragma unroll
-            for (int i = 0; i < (int)K1_DEEP_LANE; i++)
-                if ((u32)i < gl) ck[gs + i] = useb ? kb[i] : ka[i];
-            for (u32 i = 1; i < gl; i++) {                            // insertion sort of (ck, cv)[gs .. gs+gl)
-                const u64 x = ck[gs + i];
-                const u32 v = cv[gs + i];
-                u32 j = i;
-                while (j > 0 && ck[gs + j - 1u] > x) { ck[gs + j] = ck[gs + j - 1u]; cv[gs + j] = cv[gs + j - 1u]; j--; }
-                ck[gs + j] = x;
-                cv[gs + j] = v;
-            }
-            u64 bits = 0;
-            for (u32 i = 1; i < gl; i++) if (ck[gs + i] != ck[gs + i - 1u]) bits |= 1ull << i;
-            for (u32 i = 0; i < gl; i++) gd[gs + i] = (u16)(d < capd ? d : capd);
-            bits <<= (gs & 31u);
-            if ((u32)bits) atomicOr(&hb[gs >> 5], (u32)bits);
-            if ((u32)(bits >> 32)) atomicOr(&hb[(gs >> 5) + 1u], (u32)(bits >> 32));
-        }
-    }
     __syncthreads();
     // write back: the suffix indices in their new order, and the heads that are new
     for (u32 e = tid; e < m; e += DNT) {
@@ -1025,6 +992,155 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
         const bool nowh = (hb[e >> 5] >> (e & 31u)) & 1u;
         const bool was = (hw[q >> 5] >> (q & 31u)) & 1u;
         if (nowh && !was) atomicOr(&HN[p >> 5], 1u << (p & 31u));
+    }
+    // ---- phase 2 is list driven (k1_deep_pairs / k1_deep_small): descriptors of the groups of 2..K1_DEEP_LANE
+    //      rotations that are left, with the depth they are known to share, appended to the list region of
+    //      this block's XCD (one atomic per wave and class).  cprev/cnext are those of the last scan_words().
+    const u32 depth = 8u + 8u * iter;
+    if (depth >= 8u + 8u * iters || (dbg & 2u)) return;
+    __syncthreads();
+    scan_words();
+    __syncthreads();
+    // 8 XCD regions x K1_DEEP_SUB sub-regions (chosen by the tile index) per class, each with its own counter: 10^5..10^6
+    // waves appending to 16 counter words serialise on them (measured: +2.5 ms for this kernel)
+    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB), xr = (b & 7u) * K1_DEEP_SUB + (t & (K1_DEEP_SUB - 1u));
+    u64 balc[2][SL];
+    u32 glv[SL];
+    u32 tot0 = 0, tot1 = 0;
+#pragma unroll
+    for (int it = 0; it < SL; it++) {
+        const u32 e0 = (u32)it * (u32)DNT + w * 64u;
+        balc[0][it] = 0; balc[1][it] = 0; glv[it] = 0;
+        if (e0 >= m || chunk_all_sorted(hb, e0)) continue;            // wave-uniform
+        const u32 e = e0 + lane;
+        const u32 wq = e >> 5, bq = e & 31u;
+        const u32 word = hb[wq];
+        const bool ishead = (word >> bq) & 1u;
+        const u32 high = bq == 31u ? 0u : (word & (0xFFFFFFFEu << bq));
+        const int endp = high ? (int)(wq * 32u + (u32)__ffs((int)high) - 1u) : cnext[wq];
+        const u32 gl = (u32)endp - e;
+        const bool take = ishead && e < m && gl >= 2u && gl <= K1_DEEP_LANE;
+        glv[it] = take ? gl : 0u;
+        balc[0][it] = __ballot(take && gl == 2u);
+        balc[1][it] = __ballot(take && gl > 2u);
+        tot0 += (u32)__popcll(balc[0][it]);
+        tot1 += (u32)__popcll(balc[1][it]);
+    }
+    u32 gb0 = 0, gb1 = 0;
+    if (lane == 0) {
+        if (tot0) gb0 = atomicAdd(&B.deepCnt[xr], tot0);
+        if (tot1) gb1 = atomicAdd(&B.deepCnt[8u * K1_DEEP_SUB + xr], tot1);
+    }
+    gb0 = __shfl(gb0, 0);
+    gb1 = __shfl(gb1, 0);
+#pragma unroll
+    for (int it = 0; it < SL; it++) {
+        const u32 e = (u32)it * (u32)DNT + tid;
+        if (glv[it]) {
+            const int cls = glv[it] == 2u ? 0 : 1;
+            const u32 idx = (cls ? gb1 : gb0) + (u32)__popcll(balc[cls][it] & lt);
+            if (idx < rcap)
+                B.listT[cls][(size_t)xr * rcap + idx] = ((u64)b << 52) | ((u64)(base + cp[e]) << 26) | ((u64)depth << 4) | (u64)(glv[it] - 1u);
+        }
+        gb0 += (u32)__popcll(balc[0][it]);
+        gb1 += (u32)__popcll(balc[1][it]);
+    }
+}
+
+#define DP_B(d) ((u32)((d) >> 52))
+#define DP_START(d) ((u32)(((d) >> 26) & 0x3FFFFFFu))
+#define DP_DEPTH(d) ((u32)(((d) >> 4) & 0xFFFFu))
+#define DP_LEN(d) (((u32)(d) & 15u) + 1u)
+
+// Pairs: one lane each, no LDS.  Workgroup L serves the list region of XCD L & 7 (the region holds the groups
+// of the blocks whose tiles ran on that XCD, in roughly block order, so their text is in that L2).
+__global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 capd) {
+    // gridDim.x is a multiple of 8 * K1_DEEP_SUB: workgroup -> (XCD region, sub-region, slice of the sub-region)
+    const u32 xr = (blockIdx.x & 7u) * K1_DEEP_SUB + ((blockIdx.x >> 3) & (K1_DEEP_SUB - 1u));
+    const u32 r = blockIdx.x / (8u * K1_DEEP_SUB), nr = gridDim.x / (8u * K1_DEEP_SUB);
+    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB);
+    u32 cnt = B.deepCnt[xr];
+    if (cnt > rcap) cnt = rcap;
+    const u64* L = B.listT[0] + (size_t)xr * rcap;
+    for (u32 gi = r * 256u + threadIdx.x; gi < cnt; gi += nr * 256u) {
+        const u64 dsc = L[gi];
+        const u32 b = DP_B(dsc), start = DP_START(dsc);
+        u32 d = DP_DEPTH(dsc);
+        const u32 n = B.nlen[b];
+        const u8* T = B.T + (size_t)b * g.tstride;
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32 mem[2];
+        u64 keys[2];
+        mem[0] = SA[0];
+        mem[1] = SA[1];
+        if (deep_walk<2, 8>(T, n, mem, 1u, 2u, d, capd, keys, 1u)) {
+            if (keys[0] > keys[1]) { SA[0] = mem[1]; SA[1] = mem[0]; }
+            atomicOr(&B.HN[(size_t)b * g.hstride + ((start + 1u) >> 5)], 1u << ((start + 1u) & 31u));
+        }
+    }
+}
+
+// Groups of 3..K1_DEEP_LANE rotations: one lane each, members in a per-lane LDS column.  The lane walks the text
+// of all members until a word differs, sorts them by that word, and goes on depth-first with every run of
+// equal keys (own depth per run) until the group is resolved or a run ties up to capd (left as it is).
+__global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 capd) {
+    __shared__ u64 lk[K1_DEEP_LANE * 256];
+    __shared__ u32 lv[K1_DEEP_LANE * 256];
+    __shared__ u16 ld[K1_DEEP_LANE * 256];
+    const u32 tid = threadIdx.x;
+    const u32 xr = (blockIdx.x & 7u) * K1_DEEP_SUB + ((blockIdx.x >> 3) & (K1_DEEP_SUB - 1u));
+    const u32 r = blockIdx.x / (8u * K1_DEEP_SUB), nr = gridDim.x / (8u * K1_DEEP_SUB);
+    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB);
+    u32 cnt = B.deepCnt[8u * K1_DEEP_SUB + xr];
+    if (cnt > rcap) cnt = rcap;
+    const u64* L = B.listT[1] + (size_t)xr * rcap;
+    u64* ck = lk + tid;
+    u32* cv = lv + tid;
+    u16* cd = ld + tid;
+    for (u32 gi = r * 256u + tid; gi < cnt; gi += nr * 256u) {
+        const u64 dsc = L[gi];
+        const u32 b = DP_B(dsc), start = DP_START(dsc), gl = DP_LEN(dsc);
+        const u32 n = B.nlen[b];
+        const u8* T = B.T + (size_t)b * g.tstride;
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32 mem[K1_DEEP_LANE];
+#pragma unroll
+        for (int i = 0; i < (int)K1_DEEP_LANE; i++) mem[i] = (u32)i < gl ? SA[i] : 0u;     // all loads in flight together
+#pragma unroll
+        for (int i = 0; i < (int)K1_DEEP_LANE; i++)
+            if ((u32)i < gl) { cv[(u32)i * 256u] = mem[i]; cd[(u32)i * 256u] = (u16)DP_DEPTH(dsc); }
+        u32 heads = 1u, done = 0u;
+        for (;;) {
+            u32 a = 0, e = 0;
+            while (a < gl) {                                          // first run of >= 2 that is not given up
+                const u32 rest = (heads >> (a + 1u)) & ((1u << (gl - a - 1u)) - 1u);
+                e = rest ? a + (u32)__ffs((int)rest) : gl;
+                if (e - a >= 2u && !((done >> a) & 1u)) break;
+                a = e;
+            }
+            if (a >= gl) break;
+            const u32 len = e - a;
+            u32 d = cd[a * 256u];
+            const bool split = len == 2u ? deep_walk<2, 8>(T, n, cv + a * 256u, 256u, len, d, capd, ck + a * 256u, 256u)
+                             : len <= 4u ? deep_walk<4, 4>(T, n, cv + a * 256u, 256u, len, d, capd, ck + a * 256u, 256u)
+                                         : deep_walk<(int)K1_DEEP_LANE, 2>(T, n, cv + a * 256u, 256u, len, d, capd, ck + a * 256u, 256u);
+            if (!split) { done |= 1u << a; continue; }
+            for (u32 i = a + 1u; i < e; i++) {                        // insertion sort of (ck, cv)[a .. e)
+                const u64 x = ck[i * 256u];
+                const u32 v = cv[i * 256u];
+                u32 j = i;
+                while (j > a && ck[(j - 1u) * 256u] > x) { ck[j * 256u] = ck[(j - 1u) * 256u]; cv[j * 256u] = cv[(j - 1u) * 256u]; j--; }
+                ck[j * 256u] = x;
+                cv[j * 256u] = v;
+            }
+            for (u32 i = a + 1u; i < e; i++) if (ck[i * 256u] != ck[(i - 1u) * 256u]) heads |= 1u << i;
+            for (u32 i = a; i < e; i++) cd[i * 256u] = (u16)(d < 0xFFFFu ? d : 0xFFFFu);
+        }
+        for (u32 i = 0; i < gl; i++) SA[i] = cv[i * 256u];
+        const u64 bits = (u64)(heads & ~1u) << (start & 31u);
+        u32* HN = B.HN + (size_t)b * g.hstride + (start >> 5);
+        if ((u32)bits) atomicOr(&HN[0], (u32)bits);
+        if ((u32)(bits >> 32)) atomicOr(&HN[1], (u32)(bits >> 32));
     }
 }
 
@@ -1545,9 +1661,10 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += 2 * al256((size_t)g.nb * g.htiles);                 // FC FN
     tot += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);       // tileHist
     tot += al256(K1_STATS * 4);
+    tot += al256(2 * 8 * K1_DEEP_SUB * 4);                     // deepCnt
     tot += al256(32 * 2 * K1_SPREAD * 4);                      // spread
     tot += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
-    tot += 2 * al256((size_t)g.nb * (g.stride / 2) * 8);       // listT cur/next
+    tot += 2 * al256((size_t)((g.nb + 7u) & ~7u) * (g.stride / 2) * 8);       // listT cur/next (also the 8 per-XCD regions of k1_deep)
     tot += 2 * al256((size_t)g.nb * (g.stride / 8) * 8);       // listS cur/next
     tot += 2 * al256((size_t)g.nb * (g.stride / 64) * 8);      // listM cur/next
     tot += 2 * al256((size_t)g.nb * (g.stride / K1_MED_MAX + 1) * 8);   // listL cur/next
@@ -1569,10 +1686,11 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.FN = (u8*)p; p += al256((size_t)g.nb * g.htiles);
     B.tileHist = (u32*)p; p += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);
     B.stats = (u32*)p; p += al256(K1_STATS * 4);
+    B.deepCnt = (u32*)p; p += al256(2 * 8 * K1_DEEP_SUB * 4);
     B.spread = (u32*)p; p += al256(32 * 2 * K1_SPREAD * 4);
     B.large = (uint2*)p; p += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     B.largeCap = g.nb * (g.htiles + 1);
-    B.listTCap = g.nb * (g.stride / 2);
+    B.listTCap = ((g.nb + 7u) & ~7u) * (g.stride / 2);
     B.listSCap = g.nb * (g.stride / 8);
     B.listMCap = g.nb * (g.stride / 64);
     B.listT[0] = (u64*)p; p += al256((size_t)B.listTCap * 8);
@@ -1643,11 +1761,16 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     // K1-deep: iterations of 8 text bytes each (0 switches it off; default 32 = ties up to 264 bytes)
     static const u32 deep_iters = []() -> u32 { const char* e = getenv("CJS_DEEP_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 32u; return v > 4000u ? 4000u : v; }();
     static const u32 deep_tile = []() -> u32 { const char* e = getenv("CJS_DEEP_TILE"); return e ? (u32)strtoul(e, nullptr, 10) : 256u; }();
+    static const u32 deep_dbg = []() -> u32 { const char* e = getenv("CJS_DEEP_DBG"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();   // timing experiments: 1 = no phase 1, 2 = no phase 2
     const bool deep = deep_iters > 0 && !B.linear;
     if (deep) {
         HIP_CHECK_RET(hipMemcpyAsync(B.HX, B.HN, hbytes, hipMemcpyDeviceToDevice, stream));
-        if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters);
-        else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters);
+        if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters, deep_dbg);
+        else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg);
+        const u32 lane_unit = 8u * K1_DEEP_SUB;              // one workgroup per (XCD region, sub-region) at least
+        const u32 lane_grid = g.nb * 32u <= lane_unit ? lane_unit : (g.nb * 32u >= 4096u ? 4096u : (g.nb * 32u + lane_unit - 1u) / lane_unit * lane_unit);
+        hipLaunchKernelGGL(k1_deep_pairs, dim3(lane_grid), dim3(256), 0, stream, B, g, 8u + 8u * deep_iters);
+        hipLaunchKernelGGL(k1_deep_small, dim3(lane_grid), dim3(256), 0, stream, B, g, 8u + 8u * deep_iters);
     }
     // with K1-deep in front most inputs arrive here nearly sorted: the first rank pass then also emits the
     // descriptor lists, and the doubling rounds start in the sparse phase (or not at all)

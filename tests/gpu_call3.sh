@@ -1,0 +1,20 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 120 python tests/gpu_deep_probe.py gen
+cat > /tmp/q.py <<'PY'
+import sqlite3, sys, glob
+for f in sorted(glob.glob(sys.argv[1] + '/*_results.db')):
+    db = sqlite3.connect(f); cur = db.cursor()
+    n = cur.execute("select count(*) from kernels where name like 'k34_tables%'").fetchone()[0]
+    tot = cur.execute("select sum(end-start) from kernels").fetchone()[0]
+    print(f.split('/')[-1], 'steps', n, 'total ms/step %.3f' % (tot / 1e6 / n))
+    for r in cur.execute("select name, count(*), sum(end-start) from kernels where name like '%k1_deep%' or name like 'k1_update%' or name like 'k1_sp_%' or name like 'k1_refine%' group by name order by 3 desc"):
+        print('   %-50s calls/step %5.1f  ms/step %.3f' % (r[0][:50], r[1] / n, r[2] / 1e6 / n))
+PY
+for dbg in 0 1 2 3; do
+  cd /tmp && CJS_DEEP_DBG=$dbg timeout 200 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_dbg -o dbg$dbg -- python $GRAFT_REPO_ROOT/tests/gpu_deep_probe.py run enwik text > $GRAFT_REPO_ROOT/gpurun_out/dbg$dbg.log 2>&1
+  grep "^.iters" $GRAFT_REPO_ROOT/gpurun_out/dbg$dbg.log
+done
+python /tmp/q.py $GRAFT_REPO_ROOT/gpurun_out/prof_dbg

@@ -2,7 +2,7 @@
 `gen` caches the synthetic streams under /tmp; `run` compresses each 4x and prints the best device time, the
 K1 round counts and a digest of the stream, which must not depend on CJS_DEEP_ITERS / CJS_DEEP_TILE."""
 import sys, os, bz2, hashlib
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from compressjs_amd import synth
 
@@ -11,7 +11,7 @@ def gen():
     np.save('/tmp/enwik.npy', synth.enwik_like(N, 2025))
     np.save('/tmp/text.npy', synth.text_like(N, 2025))
     for f in ('sample5.ref', 'sample3.ref'):
-        p = os.path.join('oracle', '_ref', 'fixtures', f)
+        p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'fixtures', f)
         if os.path.exists(p):
             d = np.fromfile(p, dtype=np.uint8)
             np.save('/tmp/%s.npy' % f.split('.')[0], np.tile(d, max(1, 50_000_000 // d.size)))
