@@ -742,7 +742,7 @@ __device__ __forceinline__ u64 load_be64(const u8* p) {
 template <int M, int W>
 __device__ __forceinline__ bool deep_walk(const u8* T, u32 n, const u32* members, u32 mstride, u32 gl, u32& d, u32 capd,
                                           u64* keys, u32 kstride) {
-    static_assert(W * 8 <= K1_TPAD, "one step must stay inside the wrapped tail of T_ext");
+    static_assert(W * 8 <= K1_TPAD && W % 2 == 0, "one step must stay inside the wrapped tail of T_ext");
     u32 pp[M];
     const u32 dm = d < n ? d : d % n;
 #pragma unroll
@@ -755,9 +755,14 @@ __device__ __forceinline__ bool deep_walk(const u8* T, u32 n, const u32* members
 #pragma unroll
         for (int i = 0; i < M; i++)
 #pragma unroll
-            for (int j = 0; j < W; j++) {
-                k[i][j] = 0;
-                if ((u32)i < gl) k[i][j] = load_be64(T + pp[i] + 8 * j);
+            for (int j = 0; j < W; j += 2) {                          // 16 bytes per load instruction
+                k[i][j] = 0; k[i][j + 1] = 0;
+                if ((u32)i < gl) {
+                    u64 v[2];
+                    __builtin_memcpy(v, T + pp[i] + 8 * j, 16);
+                    k[i][j] = __builtin_bswap64(v[0]);
+                    k[i][j + 1] = __builtin_bswap64(v[1]);
+                }
             }
         int jd = -1;
 #pragma unroll
