@@ -728,10 +728,26 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
 #define K1_DEEP_BIG 64u
 #define K1_DEEP_LANE 8u         // groups up to this size: one lane each (phase 2)
 
-__device__ __forceinline__ u64 load_be64(const u8* p) {
+// W big-endian 64-bit words of text starting at byte p of T (any alignment), through DWORD-ALIGNED loads plus
+// v_alignbyte.  PMC (TCP_TOTAL_CACHE_ACCESSES): a byte-misaligned 16-byte load costs the vector L1 ~4 accesses,
+// and the lane kernels below were bound by exactly that (one access per clock and CU).  Reads 8W + 4 bytes from
+// p & ~3; the block slots of T_ext are 128 bytes longer than the longest block, so this stays inside the slot.
+template <int W>
+__device__ __forceinline__ void load_be_words(const u8* T, u32 p, u64* out) {
+    const u32 sh = p & 3u;
+    u32 d[2 * W + 1];
+    __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), (2 * W + 1) * 4);
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const u32 w0 = __builtin_amdgcn_alignbyte(d[2 * j + 1], d[2 * j], sh);
+        const u32 w1 = __builtin_amdgcn_alignbyte(d[2 * j + 2], d[2 * j + 1], sh);
+        out[j] = ((u64)__builtin_bswap32(w0) << 32) | (u64)__builtin_bswap32(w1);
+    }
+}
+__device__ __forceinline__ u64 load_be64(const u8* T, u32 p) {
     u64 v;
-    __builtin_memcpy(&v, p, 8);
-    return __builtin_bswap64(v);
+    load_be_words<1>(T, p, &v);
+    return v;
 }
 
 // Phase 2 of k1_deep, one lane: the (<= M) members of a group, all known to share their first d bytes, are
@@ -742,7 +758,7 @@ __device__ __forceinline__ u64 load_be64(const u8* p) {
 template <int M, int W>
 __device__ __forceinline__ bool deep_walk(const u8* T, u32 n, const u32* members, u32 mstride, u32 gl, u32& d, u32 capd,
                                           u64* keys, u32 kstride) {
-    static_assert(W * 8 <= K1_TPAD && W % 2 == 0, "one step must stay inside the wrapped tail of T_ext");
+    static_assert(W * 8 <= K1_TPAD, "one step must stay inside the wrapped tail of T_ext");
     u32 pp[M];
     const u32 dm = d < n ? d : d % n;
 #pragma unroll
@@ -753,17 +769,11 @@ __device__ __forceinline__ bool deep_walk(const u8* T, u32 n, const u32* members
     for (;;) {
         u64 k[M][W];
 #pragma unroll
-        for (int i = 0; i < M; i++)
+        for (int i = 0; i < M; i++) {
 #pragma unroll
-            for (int j = 0; j < W; j += 2) {                          // 16 bytes per load instruction
-                k[i][j] = 0; k[i][j + 1] = 0;
-                if ((u32)i < gl) {
-                    u64 v[2];
-                    __builtin_memcpy(v, T + pp[i] + 8 * j, 16);
-                    k[i][j] = __builtin_bswap64(v[0]);
-                    k[i][j + 1] = __builtin_bswap64(v[1]);
-                }
-            }
+            for (int j = 0; j < W; j++) k[i][j] = 0;
+            if ((u32)i < gl) load_be_words<W>(T, pp[i], k[i]);
+        }
         int jd = -1;
 #pragma unroll
         for (int j = W - 1; j >= 0; j--) {
@@ -948,7 +958,7 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
             if (gsl[it]) {
                 u32 p = val[it] + dm;
                 if (p >= n) p -= n;
-                key[it] = load_be64(T + p);
+                key[it] = load_be64(T, p);
             }
         }
 #pragma unroll

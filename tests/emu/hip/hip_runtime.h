@@ -222,6 +222,9 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
 static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
+static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned s) {
+    return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8u * (s & 3u)));
+}
 template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return emu_shfl_(v, lane); }
 static inline long long clock64() { return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
