@@ -833,7 +833,29 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
     if (tid < DCW + 2) hb[tid] = tid < DCW ? 0u : 0xFFFFFFFFu;
     if (tid < 2) anyact[tid] = 0;
     __syncthreads();
-    if (tid < DWW) {
+    if constexpr (DWW <= 64) {
+        // previous / next head outside each bitmap word by two wave scans (the tile kernel is issue-bound:
+        // PMC SQ_ACTIVE_INST_ANY x 4 waves per SIMD ~ its wave cycles; the serial per-lane walks cost more)
+        if (w == 0) {
+            const u32 word = lane < (u32)DWW ? hw[lane] : 0u;
+            int v = word ? (int)(lane * 32u + 31u - (u32)__clz((int)word)) : -1;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(v, (unsigned)off);
+                if ((int)lane >= off) v = v > u ? v : u;
+            }
+            int ex = __shfl_up(v, 1u);
+            if (lane == 0) ex = -1;
+            if (lane < (u32)DWW) prevh[lane] = ex;
+            int f = word ? (int)(lane * 32u + (u32)__ffs((int)word) - 1u) : K1_INF;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_down(f, (unsigned)off);
+                if ((int)lane + off < 64) f = f < u ? f : u;
+            }
+            int nx = __shfl_down(f, 1u);
+            if (lane == 63u) nx = K1_INF;
+            if (lane < (u32)DWW) nexth[lane] = nx;
+        }
+    } else if (tid < DWW) {
         int pv = -1;
         for (int i = (int)tid - 1; i >= 0; i--) {
             const u32 wd = hw[i];
@@ -851,19 +873,26 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
     const u64 lt = lanemask_lt();
     const u32 spill_end = (hw[DHT / 32] & 1u) ? (u32)DHT
                         : (nexth[DHT / 32 - 1] < K1_INF ? (u32)nexth[DHT / 32 - 1] : (u32)DWIN);
-    // pass 1: owned positions per 64-position chunk (ownership as in refine_tile)
+    // pass 1: owned positions per 64-position chunk (ownership as in refine_tile); their suffix indices are
+    // fetched here, all chunks in flight together
+    u64 obal[SL];
+    u32 osa[SL], ohead = 0;
+#pragma unroll
     for (int it = 0; it < SL; it++) {
         const u32 ci = (u32)it * (u32)NW + w;
         const u32 q0 = ci * 64u;
-        u32 c64 = 0;
+        obal[it] = 0;
+        osa[it] = 0;
         if (q0 < spill_end && !chunk_all_sorted(hw, q0)) {            // wave-uniform
             const u32 q = q0 + lane;
             const PosClass c = classify(hw, prevh, nexth, q);
             const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
             const bool owned = c.head >= 0 && c.head < DHT && size >= 2 && size <= DHT && base + q < n;
-            c64 = (u32)__popcll(__ballot(owned));
+            obal[it] = __ballot(owned);
+            if (owned) osa[it] = SA[base + q];
+            if (c.is_head) ohead |= 1u << it;
         }
-        if (lane == 0) chunkoff[ci] = c64;
+        if (lane == 0) chunkoff[ci] = (u32)__popcll(obal[it]);
     }
     __syncthreads();
     if (tid == 0) {
@@ -875,21 +904,14 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
     const u32 m = chunkoff[DWIN / 64];
     if (m == 0) return;
     // pass 2: compact the owned rotations; head bits over the compact index
+#pragma unroll
     for (int it = 0; it < SL; it++) {
+        if (!((obal[it] >> lane) & 1ull)) continue;
         const u32 ci = (u32)it * (u32)NW + w;
-        const u32 q0 = ci * 64u;
-        if (q0 >= spill_end || chunk_all_sorted(hw, q0)) continue;    // wave-uniform
-        const u32 q = q0 + lane;
-        const PosClass c = classify(hw, prevh, nexth, q);
-        const int size = (c.head >= 0 && c.endp < K1_INF) ? c.endp - c.head : K1_INF;
-        const bool owned = c.head >= 0 && c.head < DHT && size >= 2 && size <= DHT && base + q < n;
-        const u64 bal = __ballot(owned);
-        if (owned) {
-            const u32 e = chunkoff[ci] + (u32)__popcll(bal & lt);
-            cv[e] = SA[base + q];
-            cp[e] = (u16)q;
-            if (c.is_head) atomicOr(&hb[e >> 5], 1u << (e & 31u));
-        }
+        const u32 e = chunkoff[ci] + (u32)__popcll(obal[it] & lt);
+        cv[e] = osa[it];
+        cp[e] = (u16)(ci * 64u + lane);
+        if ((ohead >> it) & 1u) atomicOr(&hb[e >> 5], 1u << (e & 31u));
     }
     if (tid < DCW) {                                                // compact slots >= m count as sorted
         const u32 lo = tid * 32u;
