@@ -1182,6 +1182,32 @@ __global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 c
 }
 
 // ---------------------------------------------------------------------------------------------
+// How many rotations are still in unsorted groups under HN?  (position p is settled iff p and p + 1 are heads;
+// bits at and beyond n are set.)  One bitmap word per thread; per-workgroup sums go to round slot 31 of `spread`.
+// When the answer is 0 -- random data after the radix sort, phrase-reuse text after K1-deep -- the rank pass
+// (10^8 random 4-byte stores, 1.1 ms) and every doubling round are skipped.
+// ---------------------------------------------------------------------------------------------
+#define K1_COUNT_SLOT 31
+__global__ __launch_bounds__(256) void k1_count_unsorted(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.y, n = B.nlen[b];
+    const u32 wi = blockIdx.x * 256u + threadIdx.x;
+    const u32* HN = B.HN + (size_t)b * g.hstride;
+    u32 c = 0;
+    if (wi * 32u < n) {
+        const u32 h = HN[wi], hx = HN[wi + 1u];
+        c = (u32)__popc(~(h & ((h >> 1) | (hx << 31))));
+    }
+    for (u32 off = 32; off; off >>= 1) c += __shfl_xor(c, off);
+    __shared__ u32 part[4];
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(&B.spread[((size_t)K1_COUNT_SLOT * 2 + 1) * K1_SPREAD + ((blockIdx.x * 29u + b) & (K1_SPREAD - 1u))], t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // groups of > K1_HT rotations: one 1024-thread workgroup per group, 3 stable 7-bit LSD passes
 // through global memory (keys < 2^20)
 // ---------------------------------------------------------------------------------------------
@@ -1809,14 +1835,29 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         hipLaunchKernelGGL(k1_deep_pairs, dim3(lane_grid), dim3(256), 0, stream, B, g, 8u + 8u * deep_iters);
         hipLaunchKernelGGL(k1_deep_small, dim3(lane_grid), dim3(256), 0, stream, B, g, 8u + 8u * deep_iters);
     }
-    // with K1-deep in front most inputs arrive here nearly sorted: the first rank pass then also emits the
-    // descriptor lists, and the doubling rounds start in the sparse phase (or not at all)
     const bool early = deep && total_n >= sparse_min;
-    hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, 0, early ? 1 : 0);
-    { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
+    bool sparse = false, all_sorted = false;
+    u64 unsorted0 = 0;                         // rotations in unsorted groups before the first rank pass (when counted)
+    if (!B.linear && total_n >= sparse_min) {
+        // nothing left to sort?  (one tiny kernel + a 512-byte read-back; the rank pass it can save costs 1.1 ms per 10^8)
+        static thread_local u32 cnt0[K1_SPREAD];
+        hipLaunchKernelGGL(k1_count_unsorted, dim3((g.hstride + 255u) / 256u, g.nb), dim3(256), 0, stream, B, g);
+        HIP_CHECK_RET(hipMemcpyAsync(cnt0, B.spread + ((size_t)K1_COUNT_SLOT * 2 + 1) * K1_SPREAD, sizeof cnt0, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK_RET(hipStreamSynchronize(stream));
+        u64 c = 0;
+        for (u32 i = 0; i < K1_SPREAD; i++) c += cnt0[i];
+        if (k1_trace) fprintf(stderr, "[k1] rotations in unsorted groups before the first rank pass: %llu (of %llu)\n", (unsigned long long)c, (unsigned long long)total_n);
+        all_sorted = c == 0;
+        unsorted0 = c;
+    }
+    // K1-deep ran and little is left: the first rank pass also emits the descriptor lists and the doubling rounds START sparse
+    const bool sparse0 = early && !all_sorted && unsorted0 * sparse_div < total_n;
+    if (!all_sorted) {
+        hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, 0, sparse0 ? 1 : 0);
+        { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
+    }
     int round = 0;
     const u32 large_grid = g.nb * 4 < 1024 ? (g.nb * 4 < 64 ? 64 : g.nb * 4) : 1024;
-    bool sparse = false, all_sorted = false;
     int parity = 0;
     // If a doubling round splits no group, the classes "equal h-prefix" and "equal 2h-prefix" coincide, and
     // then so do all later ones (s ~2h s' gives s+h ~h s'+h = s+h ~2h s'+h, i.e. s+2h ~h s'+2h): what is left are
@@ -1824,18 +1865,8 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     // tiled inputs reach that state after a few rounds instead of ceil(log2(n/8)).
     bool force_final = false;                  // (decided in tile rounds only: their two counters are exact)
     u64 prev_actpos = 0;                       // rotations in unsorted groups before the current round (0: not known yet)
-    if (early) {
-        static thread_local u32 spr0[2 * K1_SPREAD];
-        HIP_CHECK_RET(hipMemcpyAsync(spr0, B.spread, sizeof spr0, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK_RET(hipStreamSynchronize(stream));
-        u64 a = 0, c = 0;
-        for (u32 i = 0; i < K1_SPREAD; i++) { a += spr0[i]; c += spr0[K1_SPREAD + i]; }
-        if (k1_trace) fprintf(stderr, "[k1] after the 8-byte sort + deep: %llu unsorted groups, %llu rotations in them (of %llu)\n",
-                              (unsigned long long)a, (unsigned long long)c, (unsigned long long)total_n);
-        if (c == 0) all_sorted = true;
-        else if (c * sparse_div < total_n) { sparse = true; parity = 0; }
-        else { hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0); prev_actpos = c; }
-    }
+    if (sparse0) { sparse = true; parity = 0; }
+    else if (early && !all_sorted) prev_actpos = unsorted0;
     for (u64 h = 8; !all_sorted; h <<= 1) {
         const int mode = (h >= max_n || force_final) ? 1 : 0;      // last round: identical rotations by descending index
         if (!sparse) {
