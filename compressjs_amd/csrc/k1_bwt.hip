@@ -241,7 +241,7 @@ __global__ __launch_bounds__(K1_STH) void k1_scatter(K1Buf B, BatchGeom g, const
 // ---------------------------------------------------------------------------------------------
 // group heads after the 8-byte sort
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g) {
+__global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g, u32 lomask) {
     u32 b, t;
     if (!xcd_block_tile(g.nb, b, t)) return;
     const u32 n = B.nlen[b];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k1_init_heads(K1Buf B, BatchGeom g) {
         u32 phi = __shfl_up(hi, 1u), plo = __shfl_up(lo, 1u);
         if (lane == 0 && p > 0 && p < n) { phi = KH[p - 1]; plo = load_be32(T + SA[p - 1] + 4); }
         bool head = true;
-        if (p < n && p > 0) head = (hi != phi) || (lo != plo);
+        if (p < n && p > 0) head = (hi != phi) || (((lo ^ plo) & lomask) != 0u);
         const u64 bal = __ballot(head);
         if (lane == 0) {
             HN[(p >> 5)] = (u32)bal;
@@ -806,7 +806,7 @@ __device__ __forceinline__ bool deep_walk(const u8* T, u32 n, const u32* members
 // 20 iterations does not stall on three other waves 20 times, and 16 independent tiles per CU overlap
 // their text loads.
 template <int DHT, int DNT>
-__global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iters, u32 dbg) {
+__global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iters, u32 dbg, u32 d0) {
     constexpr int DWIN = 2 * DHT, DWW = DWIN / 32 + 2, DCW = DWIN / 32, NW = DNT / 64, SL = DWIN / DNT;
     static_assert(DCW <= 64 && DWW <= DNT, "one wave scans the compact bitmap");
     u32 b, t;
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
     for (; iter < iters && !(dbg & 1u); iter++) {
         scan_words();
         __syncthreads();
-        const u32 dm = (8u + 8u * iter) % n;
+        const u32 dm = (d0 + 8u * iter) % n;
         u64 key[SL];
         u32 val[SL], gsl[SL];                     // group start | length << 16 (0: not active)
         bool big = false;
@@ -1033,8 +1033,8 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
     // ---- phase 2 is list driven (k1_deep_pairs / k1_deep_small): descriptors of the groups of 2..K1_DEEP_LANE
     //      rotations that are left, with the depth they are known to share, appended to the list region of
     //      this block's XCD (one atomic per wave and class).  cprev/cnext are those of the last scan_words().
-    const u32 depth = 8u + 8u * iter;
-    if (depth >= 8u + 8u * iters || (dbg & 2u)) return;
+    const u32 depth = d0 + 8u * iter;
+    if (depth >= d0 + 8u * iters || (dbg & 2u)) return;
     __syncthreads();
     scan_words();
     __syncthreads();
@@ -1790,13 +1790,18 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const u32 initx = (g.hstride + 255) / 256;
     hipLaunchKernelGGL(k1_init, dim3(initx, g.nb), dim3(256), 0, stream, B, g);
     // 8 LSD passes over (key, index) pairs; buffers alternate (KB,SB), (KA,SA), ... and end in (KA,SA)
-    for (int p = 0; p < 8; p++) {
+    // CJS_SORT_BYTES = 6..8 bytes of every rotation sorted by the radix passes (default 7, measured below; linear mode always 8): with fewer, the
+    // low digits of stage 1 are skipped, groups are "equal first d0 bytes", K1-deep starts at depth d0 and the doubling rounds at h = d0
+    static const u32 sort_bytes = []() -> u32 { const char* e = getenv("CJS_SORT_BYTES"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 7u; return v < 6u || v > 8u ? 7u : v; }();
+    const u32 d0 = B.linear ? 8u : sort_bytes;
+    const int p0 = (int)(8u - d0);
+    for (int p = p0; p < 8; p++) {
         const u32* kin = (p & 1) ? B.KB : B.KA;
         const u32* vin = (p & 1) ? B.SB : B.SA;
         u32* kout = (p & 1) ? B.KA : B.KB;
         u32* vout = (p & 1) ? B.SA : B.SB;
         const int shift = 8 * (p & 3);
-        if (p == 0) hipLaunchKernelGGL(k1_hist<true>, gridS, dim3(K1_STH), 0, stream, B, g, kin, shift, stiles);
+        if (p == p0) hipLaunchKernelGGL(k1_hist<true>, gridS, dim3(K1_STH), 0, stream, B, g, kin, shift, stiles);
         else hipLaunchKernelGGL(k1_hist<false>, gridS, dim3(K1_STH), 0, stream, B, g, kin, shift, stiles);
         hipLaunchKernelGGL(k1_scan, dim3(g.nb), dim3(1024), 0, stream, B, g, stiles);
         K1Prof* pr = B.prof;
@@ -1804,7 +1809,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const u32 slot = pr && pr->enabled ? __atomic_fetch_add(&pr->used, 1u, __ATOMIC_RELAXED) : K1_PROF_MAX;
         const bool timed = slot < K1_PROF_MAX;
         if (timed) (void)hipEventRecord(pr->ev[2 * slot], stream);
-        if (p == 0) hipLaunchKernelGGL((k1_scatter<true, false>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
+        if (p == p0) hipLaunchKernelGGL((k1_scatter<true, false>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
         else if (p == 3) hipLaunchKernelGGL((k1_scatter<false, true>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
         else hipLaunchKernelGGL((k1_scatter<false, false>), gridS, dim3(K1_STH), sdyn, stream, B, g, kin, vin, kout, vout, shift, stiles);
         if (timed) {
@@ -1812,7 +1817,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             __atomic_fetch_add(&pr->elements, (u64)g.nb * max_n, __ATOMIC_RELAXED);
         }
     }
-    hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g, d0 == 8u ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * (8u - d0)));
     const size_t hbytes = (size_t)g.nb * g.hstride * 4;
     const u64 total_n = (u64)g.nb * max_n;
     static const bool k1_trace = getenv("CJS_K1_TRACE") != nullptr;
@@ -1828,12 +1833,12 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const bool deep = deep_iters > 0 && !B.linear;
     if (deep) {
         HIP_CHECK_RET(hipMemcpyAsync(B.HX, B.HN, hbytes, hipMemcpyDeviceToDevice, stream));
-        if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters, deep_dbg);
-        else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg);
+        if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters, deep_dbg, d0);
+        else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg, d0);
         const u32 lane_unit = 8u * K1_DEEP_SUB;              // one workgroup per (XCD region, sub-region) at least
         const u32 lane_grid = g.nb * 32u <= lane_unit ? lane_unit : (g.nb * 32u >= 4096u ? 4096u : (g.nb * 32u + lane_unit - 1u) / lane_unit * lane_unit);
-        hipLaunchKernelGGL(k1_deep_pairs, dim3(lane_grid), dim3(256), 0, stream, B, g, 8u + 8u * deep_iters);
-        hipLaunchKernelGGL(k1_deep_small, dim3(lane_grid), dim3(256), 0, stream, B, g, 8u + 8u * deep_iters);
+        hipLaunchKernelGGL(k1_deep_pairs, dim3(lane_grid), dim3(256), 0, stream, B, g, d0 + 8u * deep_iters);
+        hipLaunchKernelGGL(k1_deep_small, dim3(lane_grid), dim3(256), 0, stream, B, g, d0 + 8u * deep_iters);
     }
     const bool early = deep && total_n >= sparse_min;
     bool sparse = false, all_sorted = false;
@@ -1867,7 +1872,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     u64 prev_actpos = 0;                       // rotations in unsorted groups before the current round (0: not known yet)
     if (sparse0) { sparse = true; parity = 0; }
     else if (early && !all_sorted) prev_actpos = unsorted0;
-    for (u64 h = 8; !all_sorted; h <<= 1) {
+    for (u64 h = d0; !all_sorted; h <<= 1) {
         const int mode = (h >= max_n || force_final) ? 1 : 0;      // last round: identical rotations by descending index
         if (!sparse) {
             const bool try_sparse = mode == 0 && total_n >= sparse_min;

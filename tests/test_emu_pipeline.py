@@ -310,12 +310,14 @@ def test_decoder_differential_fuzz_vs_oracle(emu_ctx):
     assert decode_fuzz.fuzz(L, h, seed=20260925, cases=150) == 150
 
 
-@pytest.mark.parametrize("env_add", [{}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "2"}, {"CJS_DEEP_ITERS": "0"}])
+@pytest.mark.parametrize("env_add", [{}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "2"}, {"CJS_DEEP_ITERS": "0"},
+                                     {"CJS_SORT_BYTES": "8"}, {"CJS_SORT_BYTES": "6"}, {"CJS_SORT_BYTES": "6", "CJS_DEEP_ITERS": "0"}])
 def test_deep_refinement_of_suffix_sort(env_add):
     """K1-deep resolves groups by comparing the text inside LDS before any rank exists; what it leaves
     (long repeats, identical rotations, groups that stay big) goes to the doubling rounds, which then start
     in the sparse phase or are skipped.  Both kernels (wave / workgroup per tile), a short iteration cap and
-    'off' against the oracle, on inputs that end in each of the three continuations."""
+    'off' against the oracle, on inputs that end in each of the three continuations; and the radix sort over 6 / 7 (default) / 8
+    bytes (CJS_SORT_BYTES: K1-deep and the doubling rounds start at that depth)."""
     import os
     import subprocess
     import sys

@@ -358,7 +358,8 @@ def test_two_streams_with_host_threads_same_bytes():
 def test_deep_refinement_variants_same_bytes(ctx):
     """K1-deep (text-comparison refinement in front of the doubling rounds) is a faster route to the same
     order: off (CJS_DEEP_ITERS=0), the default wave-per-tile kernel, the workgroup-per-tile kernel and a short
-    iteration cap (most ties left to the sparse phase) must all give the same bytes on phrase-reuse text, and
+    iteration cap (most ties left to the sparse phase), and the radix sort over 6 / 7 / 8 bytes (CJS_SORT_BYTES) must all give
+    the same bytes on phrase-reuse text, and
     those bytes must be the oracle's on the leading blocks."""
     import subprocess
     import sys
@@ -373,10 +374,11 @@ def test_deep_refinement_variants_same_bytes(ctx):
         "print(hashlib.sha256(c.compress(d, 9)).hexdigest(), hashlib.sha256(c.compress(d[:9_000_000], 4)).hexdigest())\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env_add in ({"CJS_DEEP_ITERS": "0"}, {}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "3"}):
+    for env_add in ({"CJS_DEEP_ITERS": "0"}, {}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "3"}, {"CJS_SORT_BYTES": "8"},
+                    {"CJS_SORT_BYTES": "6"}, {"CJS_SORT_BYTES": "8", "CJS_DEEP_ITERS": "0"}):
         env = dict(os.environ, **env_add)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
-    assert outs[0] == outs[1] == outs[2] == outs[3], outs
+    assert all(o == outs[0] for o in outs), outs
     d = synth.enwik_like(24_000_000, 2025)
     a = ctx.compress(d[:2_700_000], 9)
     assert a == oracle.bz2_compress(d[:2_700_000], 9)
