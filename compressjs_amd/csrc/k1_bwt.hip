@@ -6,8 +6,13 @@
 // realises this total order yields identical bytes, so this file does not port SA-IS.  It runs,
 // for all blocks of a batch at once:
 //
-//   1. LSD radix sort of rotation indices by their first 8 bytes (8 stable 8-bit passes;
+//   1. LSD radix sort of rotation indices by their first 7 (CJS_SORT_BYTES = 6..8) bytes (stable 8-bit passes;
 //      per-tile LDS histograms, wave-ballot ranking, bucket scatter).
+//   1b. K1-deep (cyclic mode): the groups of text-like input are mostly tiny and tie for tens of bytes; they are
+//      resolved by comparing the TEXT -- 8 bytes per in-LDS iteration while groups above 8 rotations are being
+//      worked on (k1_deep), then one lane per group (k1_deep_pairs, k1_deep_small).  No ranks involved; what is
+//      left (long repeats, identical rotations, big groups) goes on to step 2, and if nothing is left
+//      (k1_count_unsorted) steps 2 and 3 are skipped.
 //   2. Group refinement by prefix doubling (Larsson-Sadakane style, cyclic): positions of the
 //      suffix array that still tie form "groups" marked in a head bitmap; each round sorts every
 //      unsorted group by the rank of the rotation h positions ahead.  Groups of <= 2048 rotations
