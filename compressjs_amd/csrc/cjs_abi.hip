@@ -297,6 +297,8 @@ struct cjs_ctx {
     StreamState* d_ss;         // stream cursor + combined CRC, shared by all sub-batches
     void* k0ws;                // K0 workspace (grows with the input length)
     size_t k0ws_bytes;
+    void* planws;              // K0 workspace of cjs_bz2_plan: its own, so that a later compress call on this
+    size_t planws_bytes;       // context cannot re-carve or free what `plan` points into
     void* din;  size_t din_bytes;      // staging for the host-buffer entry point
     void* dout; size_t dout_bytes;
     hipEvent_t ev0, ev1;
@@ -360,7 +362,7 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
         if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]);
         if (c->sub[i]) (void)hipStreamDestroy(c->sub[i]);
     }
-    (void)hipFree(c->d_ss); (void)hipFree(c->k0ws); (void)hipFree(c->din); (void)hipFree(c->dout);
+    (void)hipFree(c->d_ss); (void)hipFree(c->k0ws); (void)hipFree(c->planws); (void)hipFree(c->din); (void)hipFree(c->dout);
     if (c->evReady) (void)hipEventDestroy(c->evReady);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -526,16 +528,18 @@ extern "C" int64_t cjs_bz2_plan(cjs_ctx* c, const void* d_in, uint64_t in_len, i
 #define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
     TRYR(hipSetDevice(c->device));
     const u32 cap = (u32)level * 100000u - 19u;
-    int rc = grow(&c->k0ws, &c->k0ws_bytes, k0_bytes(in_len, cap));
+    c->plan_level = 0;                               // no valid plan while this one is being made
+    c->plan_blocks = 0;
+    int rc = grow(&c->planws, &c->planws_bytes, k0_bytes(in_len, cap));
     if (rc) return rc;
-    k0_carve(c->plan, (const u8*)d_in, in_len, cap, c->k0ws);
-    c->plan_level = level;
+    k0_carve(c->plan, (const u8*)d_in, in_len, cap, c->planws);
     rc = k0_prepass(c->plan, cap, c->stream);
     if (rc) return rc;
     u32 nblocks = 0;
     TRYR(hipMemcpyAsync(&nblocks, c->plan.nBlocks, 4, hipMemcpyDeviceToHost, c->stream));
     TRYR(hipStreamSynchronize(c->stream));
     c->plan_blocks = nblocks;
+    c->plan_level = level;
     return (int64_t)nblocks;
 #undef TRYR
 }
@@ -544,7 +548,7 @@ extern "C" int64_t cjs_bz2_encode_blocks(cjs_ctx* c, uint32_t first, uint32_t co
                                          uint64_t seg_cap, uint32_t* crc_fold, uint32_t* n_done) {
     if (!c || !d_seg || !c->plan_level || ((uintptr_t)d_seg & 3) || seg_cap < 64) return CJS_E_ARG;
     if (first > c->plan_blocks) return CJS_E_ARG;
-    if (first + count > c->plan_blocks) count = c->plan_blocks - first;
+    if (count > c->plan_blocks - first) count = c->plan_blocks - first;   // no uint32 wrap for count = 0xFFFFFFFF ("all remaining")
     hipError_t e;
     int rc;
 #define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e

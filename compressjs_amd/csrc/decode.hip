@@ -36,7 +36,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static int dec_alloc(DecState& S, u32 slots) {
     if (S.slab) { (void)hipFree(S.slab); S.slab = nullptr; }
-    S.slots = slots;
+    S.slots = 0;                                  // nothing usable until the new slab exists
     const size_t n = slots;
     size_t tot = 0;
     const size_t o_tt = tot;        tot += al(n * DEC_STRIDE);
@@ -59,6 +59,7 @@ static int dec_alloc(DecState& S, u32 slots) {
     const size_t o_outoff = tot;    tot += al(n * 8);
     const size_t o_crc = tot;       tot += al(n * 4);
     TRYH(hipMalloc(&S.slab, tot));
+    S.slots = slots;
     u8* b = (u8*)S.slab;
     { const u32* keep_in = S.D.in32; const u64 keep_zc = S.D.zeroChunk; memset(&S.D, 0, sizeof S.D); S.D.in32 = keep_in; S.D.zeroChunk = keep_zc; }
     S.D.tt = b + o_tt; S.D.ttStride = DEC_STRIDE;
@@ -82,12 +83,33 @@ static int dec_alloc(DecState& S, u32 slots) {
 // One k7_decode wave set per block is latency-bound, so throughput comes from the number of blocks in flight
 // (4 per CU fit); 5.7 MB of HBM per slot.
 #define DEC_MAX_SLOTS 4096u
+// The slab never shrinks while the context lives, so its size is capped: CJS_DEC_MAX_SLOTS (env), else what fits
+// a quarter of the HBM that is free right now (a 400 MB level-1 stream, or a small stream stuffed with fake
+// block magics, has thousands of candidates: 4096 slots would pin 23 GB).  Fewer slots only mean more batches.
+static u32 dec_slot_limit(u32 min_slots) {
+    static const u32 env_cap = []() -> u32 { const char* e = getenv("CJS_DEC_MAX_SLOTS"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();
+    u32 lim = DEC_MAX_SLOTS;
+    if (env_cap) lim = env_cap;
+    else {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) {
+            const size_t per = (size_t)DEC_STRIDE * 6 + 4160 * 4 + DEC_TILES * 1040 + DEC_MAXSPL * 12 + 4096;
+            const size_t fit = fr / 4 / per;
+            if (fit < lim) lim = (u32)fit;
+        }
+    }
+    return lim < min_slots ? min_slots : lim;
+}
 static int dec_fit_slots(DecState& S, u32 min_slots, size_t ncand) {
-    u32 want = (u32)std::min<size_t>(DEC_MAX_SLOTS, ncand);
+    u32 want = (u32)std::min<size_t>(dec_slot_limit(min_slots), ncand);
     if (want < min_slots) want = min_slots;
     if (want <= S.slots) return CJS_OK;
     want = (want + 63u) & ~63u;
-    return dec_alloc(S, want);
+    for (;;) {                                   // out of memory: halve, down to the minimum the caller can work with
+        const int rc = dec_alloc(S, want);
+        if (rc == CJS_OK || want <= ((min_slots + 63u) & ~63u)) return rc;
+        want = ((want / 2 > min_slots ? want / 2 : min_slots) + 63u) & ~63u;
+    }
 }
 
 void dec_free(DecState* S) {

@@ -42,6 +42,10 @@ __global__ __launch_bounds__(256) void k6_scan(u32* tileHist, u32 ntiles) {
     }
 }
 
+// RAW = false: inverse links pred[next(t)] = t for the list ranking.  RAW = true: the successor map itself,
+// nxt[t] = LF[t] + C[T[t]] (+1 below pidx), exactly what the reference's loop computes (may be n): only for the
+// serial fallback below.
+template <bool RAW>
 __global__ __launch_bounds__(256) void k6_next(const u8* T, u32 n, u32 pidx, const u32* tileHist, u32* pred) {
     __shared__ u32 wh[4][256];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
@@ -80,49 +84,79 @@ __global__ __launch_bounds__(256) void k6_next(const u8* T, u32 n, u32 pidx, con
             // other successor is unique.
             const bool last = t + 1u == pidx;
             if (t < pidx) t++;
-            if (!last && t < n) pred[t] = i;
+            if (RAW) pred[i] = t;
+            else if (!last && t < n) pred[t] = i;
         }
     }
 }
 
+// A position nothing links to (pred still ~0: only possible for a (T, pidx) pair no BWT produces) becomes a
+// self-loop of rank n; ranks saturate at n, so exactly the positions on the chain that starts at node 0 end up
+// with R < n, all distinct.
 __global__ __launch_bounds__(256) void k6_init(u32 n, const u32* pred, u32* P, u32* R) {
     const u32 t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n) return;
-    P[t] = t == 0 ? 0u : pred[t];
-    R[t] = t == 0 ? 0u : 1u;
+    const u32 p = pred[t];
+    P[t] = t == 0 ? 0u : (p == 0xFFFFFFFFu ? t : p);
+    R[t] = t == 0 ? 0u : (p == 0xFFFFFFFFu ? n : 1u);
 }
 __global__ __launch_bounds__(256) void k6_jump(u32 n, const u32* Pin, const u32* Rin, u32* Pout, u32* Rout) {
     const u32 t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n) return;
     const u32 p = Pin[t];
-    Rout[t] = Rin[t] + Rin[p];
+    const u32 r = Rin[t] + Rin[p];
+    Rout[t] = r < n ? r : n;
     Pout[t] = Pin[p];
 }
-__global__ __launch_bounds__(256) void k6_emit(const u8* T, u32 n, const u32* R, u8* U) {
+__global__ __launch_bounds__(256) void k6_emit(const u8* T, u32 n, const u32* R, u8* U, u32* onChain) {
     const u32 t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n) return;
-    const u32 r = R[t];
-    if (r < n) U[n - 1u - r] = T[t];       // r >= n only for a (T, pidx) pair no BWT produces
-
+    const u32 r = t < n ? R[t] : n;
+    if (r < n) U[n - 1u - r] = T[t];
+    const u64 bal = __ballot(r < n);
+    if ((threadIdx.x & 63u) == 0 && bal) atomicAdd(onChain, (u32)__popcll(bal));
+}
+// The LF mapping of a real BWT is one cycle through all n positions.  For any other (T, pidx) the reference's
+// loop (lib/BWT.js:359-362) still takes n steps from t = 0: this kernel repeats it literally (one lane).  When t
+// leaves [0, n) the reference's arithmetic turns to NaN and every remaining U[i] = T[NaN] stores 0.
+__global__ void k6_serial(const u8* T, u32 n, const u32* nxt, u8* U) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 t = 0;
+    bool dead = false;
+    for (u32 i = n; i-- > 0;) {
+        if (dead) { U[i] = 0; continue; }
+        U[i] = T[t];
+        t = nxt[t];
+        if (t >= n) dead = true;
+    }
 }
 
-// device pointers; ws needs 5*n*4 + ntiles*1024 bytes
+// device pointers; ws needs 5*n*4 + ntiles*1024 + 256 bytes
 int k6_unbwt_linear(const u8* dT, u8* dU, u32 n, u32 pidx, void* ws, hipStream_t stream) {
     const u32 ntiles = (n + K6_TILE - 1) / K6_TILE, nb = (n + 255) / 256;
     u32* pred = (u32*)ws;
     u32* P0 = pred + n; u32* R0 = P0 + n; u32* P1 = R0 + n; u32* R1 = P1 + n;
     u32* tileHist = R1 + n;
-    HIP_CHECK_RET(hipMemsetAsync(pred, 0, (size_t)n * 4, stream));
+    u32* onChain = tileHist + (size_t)ntiles * 256;
+    HIP_CHECK_RET(hipMemsetAsync(pred, 0xFF, (size_t)n * 4, stream));
+    HIP_CHECK_RET(hipMemsetAsync(onChain, 0, 4, stream));
     hipLaunchKernelGGL(k6_hist, dim3(ntiles), dim3(256), 0, stream, dT, n, tileHist);
     hipLaunchKernelGGL(k6_scan, dim3(1), dim3(256), 0, stream, tileHist, ntiles);
-    hipLaunchKernelGGL(k6_next, dim3(ntiles), dim3(256), 0, stream, dT, n, pidx, (const u32*)tileHist, pred);
+    hipLaunchKernelGGL(k6_next<false>, dim3(ntiles), dim3(256), 0, stream, dT, n, pidx, (const u32*)tileHist, pred);
     hipLaunchKernelGGL(k6_init, dim3(nb), dim3(256), 0, stream, n, (const u32*)pred, P0, R0);
     u32 *Pi = P0, *Ri = R0, *Po = P1, *Ro = R1;
     for (u32 span = 1; span < n; span <<= 1) {
         hipLaunchKernelGGL(k6_jump, dim3(nb), dim3(256), 0, stream, n, (const u32*)Pi, (const u32*)Ri, Po, Ro);
         u32* t = Pi; Pi = Po; Po = t; t = Ri; Ri = Ro; Ro = t;
     }
-    hipLaunchKernelGGL(k6_emit, dim3(nb), dim3(256), 0, stream, dT, n, (const u32*)Ri, dU);
+    hipLaunchKernelGGL(k6_emit, dim3(nb), dim3(256), 0, stream, dT, n, (const u32*)Ri, dU, onChain);
+    u32 got = 0;
+    HIP_CHECK_RET(hipMemcpyAsync(&got, onChain, 4, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK_RET(hipStreamSynchronize(stream));
+    if (got != n) {
+        // not one n-cycle (corrupt BWTC stream, or a caller's arbitrary (T, pidx)): the reference's walk, literally
+        hipLaunchKernelGGL(k6_next<true>, dim3(ntiles), dim3(256), 0, stream, dT, n, pidx, (const u32*)tileHist, pred);
+        hipLaunchKernelGGL(k6_serial, dim3(1), dim3(64), 0, stream, dT, n, (const u32*)pred, dU);
+    }
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
             u32 mw = s_mtf[lane], cnt = 0, tokv = 0, nt = 0;
             const bool is0 = lane == 0;
             int st = 0;
-            u32 runN = 0;                  // RUNA/RUNB symbols of the run in progress
+            u32 runN = 0;                  // RUNA/RUNB symbols since the run (re)started: the reference's runPos == 1 << runN, 0 = no run pending
             long long runT = 0;
             u32 consumed = 0;
             u64 cwait = 0;
@@ -327,16 +327,21 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                 u32 cur = lo;
                 for (;;) {
                     const u32 k = lit ? (u32)__builtin_ctzll(lit) : hi;       // next literal, or the end of the row
-                    if (k > cur) {                                             // run symbols [cur, k): indices runN.. of the run
+                    if (k > cur) {                                             // run symbols [cur, k) of the row
+                        // The reference's int32 runPos (:314-337) reaches 0 after 32 run symbols; the next one finds
+                        // !runPos and restarts with t = 0, and a literal that follows a multiple of 32 run symbols finds
+                        // runPos == 0 and flushes nothing.  runN = run symbols since the last (re)start, 0..31.
                         const u32 len = k - cur;
                         const u64 seg = len == 64u ? ~0ull : ((1ull << len) - 1ull);
-                        if (runN < 32u) {
-                            const u64 sa = ((mA >> cur) & seg) << runN, sb = ((mB >> cur) & seg) << runN;
-                            // int32 runPos of the reference: index 31 weighs -2^31, indices >= 32 weigh 0
-                            runT += (long long)(sa & 0x7fffffffull) + 2ll * (long long)(sb & 0x7fffffffull)
-                                    - (long long)(((sa >> 31) & 1ull) << 31) - 2ll * (long long)(((sb >> 31) & 1ull) << 31);
+                        const u64 sa = (mA >> cur) & seg, sb = (mB >> cur) & seg;
+                        if (runN + len < 32u) {
+                            runT += (long long)(sa << runN) + 2ll * (long long)(sb << runN);
+                            runN += len;
+                        } else {
+                            const u32 rp = (runN + len) & 31u, skip = len - rp;   // only the symbols after the last restart count
+                            runT = rp ? (long long)(sa >> skip) + 2ll * (long long)(sb >> skip) : 0ll;
+                            runN = rp;
                         }
-                        runN += len;
                     }
                     if (!lit) break;
                     lit &= lit - 1;
@@ -344,7 +349,6 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                     const u32 sym = (u32)__builtin_amdgcn_readlane((int)symv, (int)k);
                     if (runN) {                                                // :340-347
                         runN = 0;
-                        if (runT < 0) { st = DEC_DATA_ERROR; break; }          // the reference never terminates here
                         if ((long long)cnt + runT > (long long)DEC_CAP) { st = DEC_DATA_ERROR; break; }
                         if (runT) {
                             const u32 uc = (u32)__builtin_amdgcn_readlane((int)mw, 0) & 0xffu;

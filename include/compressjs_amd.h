@@ -39,10 +39,14 @@ int64_t cjs_bwtc_compress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int 
 
 /* Sharded encoding for multi-GPU runs (blocks are independent once the RLE1 split is known):
  * cjs_bz2_plan   = the readBlock chain of lib/Bzip2.js:913-922 over the whole (device) input;
- *                  returns the number of blocks and keeps the split in the context.
+ *                  returns the number of blocks and keeps the split in the context, in a workspace of
+ *                  its own: it stays valid across other calls on the context until the next
+ *                  cjs_bz2_plan.  d_in must stay alive and unmodified until the last
+ *                  cjs_bz2_encode_blocks that uses the plan (the plan points into it).
  * cjs_bz2_encode_blocks = compressBlock (lib/Bzip2.js:735-876) for blocks [first, first+count):
  *                  bare bit stream in d_seg starting at bit 0 (no "BZh" header, no trailer);
- *                  returns its length in BITS; *crc_fold = XOR_i rotl^(count-1-i)(blockCRC_i). */
+ *                  returns its length in BITS; *crc_fold = XOR_i rotl^(count-1-i)(blockCRC_i).
+ *                  count is clamped to the blocks that exist (0xFFFFFFFF = "all remaining"). */
 int64_t cjs_bz2_plan(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level);
 int64_t cjs_bz2_encode_blocks(cjs_ctx* ctx, uint32_t first, uint32_t count, void* d_seg,
                               uint64_t seg_cap, uint32_t* crc_fold, uint32_t* n_done);
@@ -59,6 +63,9 @@ int32_t cjs_profile_read(cjs_ctx* ctx, float* total_ms, uint32_t* launches, uint
 #define CJS_E_ARG (-22)
 #define CJS_E_NOGPU (-23)
 
+/* The four BWT.* entry points below handle ONE block per call with n <= 2^20 - 1 = 1 048 575 bytes (CJS_E_ARG
+ * above that: suffix positions are packed into 20 bits by the refinement kernels; bzip2 blocks are <= 900 000).
+ * The reference has no such limit; js/index.js hands larger n to the reference package when it is installed. */
 /* = BWT.bwtransform2(T, U, n, 256) -> pidx            (reference: lib/BWT.js:372-417) */
 int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx);
 /* = BWT.bwtransform(T, U, A, n, 256) -> pidx           (reference: lib/BWT.js:328-350, :153-192) */

@@ -75,7 +75,18 @@ Bzip2.table = function(input, callback, multistream) {               // lib/Bzip
 };
 
 var BWT = Object.create(null);
+// The BWT.* entry points sort ONE block per call and take n <= 2^20 - 1 (the bzip2 path never needs more than
+// 900 000; positions are packed into 20 bits in the refinement kernels).  The reference has no such limit, so a
+// larger n goes to the reference package when it is installed next to this one, else it is a RangeError that
+// says so (the C ABI reports CJS_E_ARG, -22).
+var BWT_MAX_N = (1 << 20) - 1;
+function tooBig(name, n, args) {
+  if (n <= BWT_MAX_N) return false;
+  if (reference) return true;
+  throw new RangeError('BWT.' + name + ': n = ' + n + ' exceeds the ' + BWT_MAX_N + '-byte block limit of the MI355X path (install the reference compressjs next to this package for larger inputs)');
+}
 BWT.bwtransform2 = function(T, U, n, alphabetSize) {                  // lib/BWT.js:372
+  if (tooBig('bwtransform2', n)) return reference.BWT.bwtransform2(T, U, n, alphabetSize);
   if (alphabetSize && alphabetSize > 256) {
     if (reference) return reference.BWT.bwtransform2(T, U, n, alphabetSize);
     throw new Error('only byte alphabets are accelerated');
@@ -87,6 +98,7 @@ BWT.bwtransform2 = function(T, U, n, alphabetSize) {                  // lib/BWT
   return pidx;
 };
 BWT.bwtransform = function(T, U, A, n, alphabetSize) {               // lib/BWT.js:328
+  if (tooBig('bwtransform', n)) return reference.BWT.bwtransform(T, U, A, n, alphabetSize);
   if (alphabetSize && alphabetSize > 256) {
     if (reference) return reference.BWT.bwtransform(T, U, A, n, alphabetSize);
     throw new Error('only byte alphabets are accelerated');
@@ -98,6 +110,7 @@ BWT.bwtransform = function(T, U, A, n, alphabetSize) {               // lib/BWT.
   return pidx;
 };
 BWT.suffixsort = function(T, SA, n, alphabetSize) {                  // lib/BWT.js:305
+  if (tooBig('suffixsort', n)) return reference.BWT.suffixsort(T, SA, n, alphabetSize);
   if (alphabetSize && alphabetSize > 256) {
     if (reference) return reference.BWT.suffixsort(T, SA, n, alphabetSize);
     throw new Error('only byte alphabets are accelerated');
@@ -109,6 +122,7 @@ BWT.suffixsort = function(T, SA, n, alphabetSize) {                  // lib/BWT.
   return 0;
 };
 BWT.unbwtransform = function(T, U, LF, n, pidx) {                   // lib/BWT.js:352 (LF: scratch, unused here)
+  if (tooBig('unbwtransform', n)) return reference.BWT.unbwtransform(T, U, LF, n, pidx);
   need();
   var t = inputBytes(T), u = Buffer.alloc(Math.max(n, 1));
   addon.unbwtransform(t, u, n, pidx);

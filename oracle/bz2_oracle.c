@@ -177,6 +177,7 @@ void orc_unbwt_linear(const uint8_t *T, uint8_t *U, uint32_t n, uint32_t pidx) {
     t = 0;
     for (int c = 0; c < 256; c++) { t += C[c]; C[c] = t - C[c]; }
     for (i = (int32_t)n - 1, t = 0; i >= 0; i--) {
+        if (t >= n) { U[i] = 0; continue; }                         /* JS: T[n] is undefined, t turns NaN, U[i] = T[NaN] stores 0 */
         U[i] = T[t];
         t = LF[t] + C[U[i]];
         t += (t < pidx) ? 1 : 0;

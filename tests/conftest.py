@@ -17,3 +17,11 @@ def pytest_configure(config):
 def golden():
     with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
         return json.load(f)["vectors"]
+
+
+@pytest.fixture(scope="session")
+def golden_big():
+    """Digests of the reference's own output (node 12, /root/reference) on the full 10^8-byte bench streams
+    (tests/golden/make_golden_big.py)."""
+    with open(os.path.join(ROOT, "tests", "golden", "golden_big.json")) as f:
+        return json.load(f)["vectors"]

@@ -66,6 +66,12 @@ def fuzz(L, h, seed, cases):
         data = gen_input(rng)
         s = oracle.bz2_compress(data, int(rng.randint(1, 10)))
         ms = bool(rng.randint(0, 2))
+        if k % 8 == 5:
+            # hand-made block with stretches of 1..70 RUNA/RUNB symbols: the int32 runPos wrap of lib/Bzip2.js:314-347
+            import decode_cases
+            syms = "".join("".join(rng.choice(["A", "B"], size=int(rng.choice([1, 5, 30, 31, 32, 33, 63, 64, 65, 70]))).tolist()) + "L"
+                           for _ in range(int(rng.randint(1, 4))))
+            s = decode_cases.craft_runs(syms[:-1] if rng.randint(0, 2) else syms, bytes(rng.randint(97, 99, size=int(rng.randint(0, 3))).tolist()))
         if rng.randint(0, 4) == 0:
             s = s + oracle.bz2_compress(gen_input(rng), int(rng.randint(1, 10)))
         for _ in range(int(rng.randint(0, 3))):

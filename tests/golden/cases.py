@@ -66,6 +66,11 @@ CASES = {
     "zeros300k": (("bytes", b"\0" * 300000), [1, 9]),
 }
 
+# BWT.unbwtransform on (T, pidx) pairs that are NOT the BWT of anything (LF mapping with several cycles, chains
+# that run off the end): the reference still walks n steps (lib/BWT.js:359-362); id -> pidx values
+UNBWT_CASES = {"banana": [0, 1, 2, 3, 6], "mary9": [1, 17, 200], "text1k": [1, 500, 1000], "ab500": [1, 2, 999],
+               "bytes40": [1, 5000], "a1000": [1, 1000], "abc_tie": [0, 3, 6], "text100k": [77777]}
+
 # inputs used for stage-level (BWT) vectors
 BWT_CASES = ["sample0", "sample1", "sample3", "a1", "a4", "ab500", "abc_tie", "banana", "mary9",
              "bytes40", "text1k", "text100k", "periodic_ab_100k", "lcg99981", "runs300k"]

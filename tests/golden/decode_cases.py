@@ -44,6 +44,38 @@ def _setbyte(s, i, v):
     return bytes(b)
 
 
+def craft_runs(syms, crc_of=b"b"):
+    """A hand-made one-block stream over the alphabet {a, b}: `syms` is a string of 'A' (RUNA), 'B' (RUNB)
+    and 'L' (the literal at MTF index 1), end-of-block is appended.  Two tables, all four codes 2 bits long.
+    Exercises the reference's int32 `runPos <<= 1` wrap (lib/Bzip2.js:314-347): 32 run symbols bring runPos
+    to 0, so the run is dropped or restarted.  The block/stream CRC is that of `crc_of`."""
+    bits = []
+
+    def put(n, v):
+        for i in range(n - 1, -1, -1):
+            bits.append((v >> i) & 1)
+    for ch in b"BZh9":
+        put(8, ch)
+    crc = oracle.crc32(np.frombuffer(crc_of, dtype=np.uint8))
+    put(48, 0x314159265359); put(32, crc); put(1, 0); put(24, 0)
+    put(16, 1 << (15 - 6)); put(16, (1 << 14) | (1 << 13))           # bytes 0x61, 0x62
+    nsym = len(syms) + 1
+    put(3, 2); put(15, (nsym + 49) // 50)
+    for _ in range((nsym + 49) // 50):
+        put(1, 0)                                                     # selector MTF index 0
+    for _ in range(2):
+        put(5, 2)
+        for _ in range(4):
+            put(1, 0)
+    for ch in syms:
+        put(2, {"A": 0, "B": 1, "L": 2}[ch])
+    put(2, 3)
+    put(48, 0x177245385090); put(32, crc)
+    while len(bits) % 8:
+        bits.append(0)
+    return np.packbits(np.array(bits, dtype=np.uint8)).tobytes()
+
+
 def streams():
     """-> list of (id, bytes or None (fixture missing), multistream)"""
     out = []
@@ -119,6 +151,13 @@ def streams():
         bit = int(rng.randint(32 + 105, len(big) * 8 - 90))
         add("flip:lib:text100k:%d" % bit, _flip(big, bit))
     add("setbyte:groups0", _setbyte(a, 20, 0))
+    # runs of 31 / 32 / 33 / 64 / 65 RUNA-RUNB symbols: the reference's runPos wraps to 0 at 32 (lib/Bzip2.js:314-347)
+    for name, syms, want in (("31A+L", "A" * 31 + "L", b"b"), ("32A+L", "A" * 32 + "L", b"b"), ("33A+L", "A" * 33 + "L", b"b"),
+                             ("32A", "A" * 32, b""), ("32B+L", "B" * 32 + "L", b"b"), ("L+32A", "L" + "A" * 32, b"b"),
+                             ("64A+L", "A" * 64 + "L", b"b"), ("65A+L", "A" * 65 + "L", b"b"),
+                             ("33mixed+L", "AB" * 16 + "B" + "L", b"b"), ("40A+L+35B", "A" * 40 + "L" + "B" * 35, b"b"),
+                             ("3A+L", "AAA" + "L", b"aaab"), ("70mixed", "ABBA" * 17 + "AB", b"b"), ("L+33A", "L" + "A" * 33, b"bb")):
+        add("craft:runs:%s" % name, craft_runs(syms, want))
     return out
 
 

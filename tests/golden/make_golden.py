@@ -64,6 +64,8 @@ def main():
             jobs.append(dict(id="%s:bwt2" % cid, kind="bwt2", input=p))
             jobs.append(dict(id="%s:bwt" % cid, kind="bwt", input=p))
             jobs.append(dict(id="%s:sa" % cid, kind="sa", input=p))
+        for pidx in cases.UNBWT_CASES.get(cid, []):
+            jobs.append(dict(id="%s:unbwt:%d" % (cid, pidx), kind="unbwt", input=p, pidx=pidx))
         if cid in ("sample0", "sample1", "sample3", "empty", "a1000", "text100k"):
             jobs.append(dict(id="%s:bwtc:9" % cid, kind="bwtc", input=p, level=9))
         for bc, lv in (("text950k", 9), ("text100k", 7), ("bytes40", 6), ("runs300k", 8), ("lcg250000", 9),

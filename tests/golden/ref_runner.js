@@ -44,6 +44,12 @@ jobs.forEach(function(j) {
                                  : cjs.BWT.bwtransform(T, U, new Int32Array(n), n, 256);
     r.n = n; r.pidx = pidx; r.u_sha256 = sha(U); r.in_sha256 = sha(T);
     if (n <= 256) { r.u_hex = U.toString('hex'); r.in_hex = T.toString('hex'); }
+  } else if (j.kind === 'unbwt') {
+    // BWT.unbwtransform on an ARBITRARY (T, pidx) pair (not necessarily a BWT): lib/BWT.js:352-363
+    var Tu = fs.readFileSync(j.input), nu = Tu.length, Uu = Buffer.alloc(nu);
+    cjs.BWT.unbwtransform(Tu, Uu, new Int32Array(nu), nu, j.pidx);
+    r.n = nu; r.pidx = j.pidx; r.u_sha256 = sha(Uu); r.in_sha256 = sha(Tu);
+    if (nu <= 256) r.u_hex = Uu.toString('hex');
   } else if (j.kind === 'sa') {
     var T2 = fs.readFileSync(j.input), SA = new Int32Array(T2.length);
     cjs.BWT.suffixsort(T2, SA, T2.length, 256);

@@ -183,6 +183,16 @@ def test_inverse_linear_bwt_by_list_ranking():
     out = np.zeros(6, np.uint8)
     assert L.cjs_unbwt_linear(datas[0].ctypes.data, out.ctypes.data, 6, 7) == -22              # pidx > n
     assert L.cjs_unbwt_linear(datas[0].ctypes.data, out.ctypes.data, 6, 2) == 0                # inconsistent pair: no fault
+    # (T, pidx) pairs that are the BWT of nothing (several LF cycles, chains that leave [0, n)): the reference's n-step
+    # walk, literally (reference-made vectors in golden.json pin the oracle on exactly these pairs)
+    for cid, pidxs in cases.UNBWT_CASES.items():
+        d = np.ascontiguousarray(cases.case_input(cid))
+        if d.size > 2000:
+            continue
+        for p in pidxs:
+            out = np.full(d.size, 0xEE, np.uint8)
+            assert L.cjs_unbwt_linear(d.ctypes.data, out.ctypes.data, d.size, p) == 0
+            assert np.array_equal(out, oracle.unbwt_linear(d, p)), (cid, p)
 
 
 def test_allocator_entry_vs_reference_vectors(golden):

@@ -123,6 +123,13 @@ def test_stage_vectors(golden):
         u, p = oracle.bwt_linear(d)
         assert p == golden[k]["pidx"] and _sha(u) == golden[k]["u_sha256"], k
         assert (oracle.unbwt_linear(u, p) == d).all()
+    n_unbwt = 0
+    for k in [k for k in golden if k.split(":")[1:2] == ["unbwt"]]:      # (T, pidx) pairs that are no BWT at all: lib/BWT.js:359-362
+        cid, _, pidx = k.split(":")
+        d = cases.case_input(cid)
+        assert _sha(oracle.unbwt_linear(d, int(pidx))) == golden[k]["u_sha256"], k
+        n_unbwt += 1
+    assert n_unbwt == sum(len(v) for v in cases.UNBWT_CASES.values())
     for k in _keys(golden, "sa"):
         d = cases.case_input(k.split(":")[0])
         if d is None:
