@@ -7,9 +7,23 @@
 #define K1_STAT_ACTPOS 64   // stats[64..95] : positions still in unsorted groups entering round r
 #define K1_STAT_LIST 96     // stats[96..103]: sparse-phase list counters [parity][4 size classes]
 #define K1_DEEP_SUB 64u     // k1_deep list sub-regions per XCD region (power of two)
+#define K1_STAT_FRONT_BIG 104  // stats[104]: buckets of the sample-sort front end that did not fit LDS
 #define K1_STATS 128
 #define K1_SPREAD 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS
+
+// sample-sort front end (k1_front.hip)
+#ifndef K1F_NB
+#define K1F_NB 1024         // buckets per block (power of two; measured: 512 x 4096-rotation buckets 8.5 ms, 1024 x 2048 4.1 ms for k1f_bsort)
+#endif
+#ifndef K1F_OVS
+#define K1F_OVS 16          // samples per bucket
+#endif
+#define K1F_S (K1F_NB * K1F_OVS)
+#ifndef K1F_C
+#define K1F_C 2048          // rotations a bucket-sort workgroup holds in LDS
+#endif
+#define K1F_PT 8192         // rotations per partition tile
 
 // HIP-event timing of one kernel's launches (k1_scatter), filled by k1_run when enabled.
 #define K1_PROF_MAX 4096
@@ -39,7 +53,9 @@ struct K1Buf {
     u8* FC;           // [nb][htiles]   tile flags, current: bit0 = an unsorted group starts here,
     u8* FN;           //                                     bit1 = holds a position of an unsorted group
     const u32* nlen;  // [nb]           block lengths
-    u32* tileHist;    // [nb][rtiles][256]
+    u32* tileHist;    // [nb][rtiles][256]  (front end: [nb][ptiles][K1F_NB])
+    u64* fsplit;      // [nb][K1F_NB]       front end: bucket d holds the keys in [fsplit[d-1], fsplit[d])
+    u32* fstart;      // [nb][K1F_NB+1]     front end: first suffix-array position of every bucket
     u32* stats;       // [K1_STATS]
     u32* deepCnt;     // [2 classes][8 XCD regions][K1_DEEP_SUB]  entries in each k1_deep list sub-region
     u32* spread;      // [32 rounds][2][K1_SPREAD]  per-round (group starts, rotations in groups), spread over
@@ -61,3 +77,6 @@ size_t k1_workspace_bytes(const BatchGeom& g);
 void k1_carve(K1Buf& B, const BatchGeom& g, void* ws);
 // enqueue the whole K1 pipeline on `stream`; max_n = largest block length in the batch
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
+// k1_front.hip: rotations of every block sorted by their first 8 bytes into B.SA, group heads into B.HN
+int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
+size_t k1_front_tilehist_words(const BatchGeom& g);   // u32 per block the front end needs in tileHist

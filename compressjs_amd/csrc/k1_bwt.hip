@@ -1721,13 +1721,20 @@ __global__ __launch_bounds__(256) void k1_finish_linear(K1Buf B, BatchGeom g, in
 // ---------------------------------------------------------------------------------------------
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+static inline size_t k1_tilehist_words(const BatchGeom& g) {
+    const size_t a = (size_t)k1_stiles(g) * 256, f = k1_front_tilehist_words(g);
+    return a > f ? a : f;
+}
+
 size_t k1_workspace_bytes(const BatchGeom& g) {
     const size_t e = (size_t)g.nb * g.stride;
     size_t tot = 0;
     tot += 5 * al256(e * 4);                                   // SA SB ISA KA KB
     tot += 3 * al256((size_t)g.nb * g.hstride * 4);            // HC HN HX
     tot += 2 * al256((size_t)g.nb * g.htiles);                 // FC FN
-    tot += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);       // tileHist
+    tot += al256((size_t)g.nb * k1_tilehist_words(g) * 4);     // tileHist
+    tot += al256((size_t)g.nb * K1F_NB * 8);                   // fsplit
+    tot += al256((size_t)g.nb * (K1F_NB + 1) * 4);             // fstart
     tot += al256(K1_STATS * 4);
     tot += al256(2 * 8 * K1_DEEP_SUB * 4);                     // deepCnt
     tot += al256(32 * 2 * K1_SPREAD * 4);                      // spread
@@ -1752,7 +1759,9 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.HX = (u32*)p; p += al256((size_t)g.nb * g.hstride * 4);
     B.FC = (u8*)p; p += al256((size_t)g.nb * g.htiles);
     B.FN = (u8*)p; p += al256((size_t)g.nb * g.htiles);
-    B.tileHist = (u32*)p; p += al256((size_t)g.nb * k1_stiles(g) * 256 * 4);
+    B.tileHist = (u32*)p; p += al256((size_t)g.nb * k1_tilehist_words(g) * 4);
+    B.fsplit = (u64*)p; p += al256((size_t)g.nb * K1F_NB * 8);
+    B.fstart = (u32*)p; p += al256((size_t)g.nb * (K1F_NB + 1) * 4);
     B.stats = (u32*)p; p += al256(K1_STATS * 4);
     B.deepCnt = (u32*)p; p += al256(2 * 8 * K1_DEEP_SUB * 4);
     B.spread = (u32*)p; p += al256(32 * 2 * K1_SPREAD * 4);
@@ -1798,8 +1807,22 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     // CJS_SORT_BYTES = 6..8 bytes of every rotation sorted by the radix passes (default 7, measured below; linear mode always 8): with fewer, the
     // low digits of stage 1 are skipped, groups are "equal first d0 bytes", K1-deep starts at depth d0 and the doubling rounds at h = d0
     static const u32 sort_bytes = []() -> u32 { const char* e = getenv("CJS_SORT_BYTES"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 7u; return v < 6u || v > 8u ? 7u : v; }();
-    const u32 d0 = B.linear ? 8u : sort_bytes;
-    const int p0 = (int)(8u - d0);
+    // CJS_FRONT=0: the seven LSD passes below (kept as the reference path for A/B runs); default: the sample-sort
+    // front end of k1_front.hip (one partition pass + in-LDS bucket sorts), which always sorts 8 bytes
+    static const bool front = []() { const char* e = getenv("CJS_FRONT"); return !e || atoi(e) != 0; }();
+    const u32 d0 = (B.linear || front) ? 8u : sort_bytes;
+    const int p0 = front ? 8 : (int)(8u - d0);
+    if (front) {
+        const int rc = k1_front_run(B, g, max_n, stream);
+        if (rc) return rc;
+        if (getenv("CJS_K1_TRACE")) {
+            u32 fs[8];
+            HIP_CHECK_RET(hipMemcpyAsync(fs, B.stats + K1_STAT_FRONT_BIG, sizeof fs, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK_RET(hipStreamSynchronize(stream));
+            fprintf(stderr, "[k1] front end: %u oversize buckets; k1f_bsort stage clocks/256 (K1F_TRACE builds): load %u  sample %u  partition %u  leaves %u  flush %u\n",
+                    fs[0], fs[1], fs[2], fs[3], fs[4], fs[5]);
+        }
+    }
     for (int p = p0; p < 8; p++) {
         const u32* kin = (p & 1) ? B.KB : B.KA;
         const u32* vin = (p & 1) ? B.SB : B.SA;
@@ -1822,7 +1845,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             __atomic_fetch_add(&pr->elements, (u64)g.nb * max_n, __ATOMIC_RELAXED);
         }
     }
-    hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g, d0 == 8u ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * (8u - d0)));
+    if (!front) hipLaunchKernelGGL(k1_init_heads, gridHX, dim3(256), 0, stream, B, g, d0 == 8u ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8u * (8u - d0)));
     const size_t hbytes = (size_t)g.nb * g.hstride * 4;
     const u64 total_n = (u64)g.nb * max_n;
     static const bool k1_trace = getenv("CJS_K1_TRACE") != nullptr;

@@ -361,3 +361,62 @@ print("ok", res)
         rounds = eval(out[2:])
         assert rounds[1] == (0, 0) and rounds[2] == (0, 0), rounds      # phrase-reuse text, random: no doubling round at all
         assert rounds[0][1] >= 1, rounds                                  # 700-byte repeats: left to the (sparse) doubling rounds
+
+
+def _bwt_batch(L, blocks):
+    cap = max(b.size for b in blocks)
+    T = np.zeros(len(blocks) * cap, np.uint8)
+    nl = np.zeros(len(blocks), np.uint32)
+    for i, b in enumerate(blocks):
+        T[i * cap:i * cap + b.size] = b
+        nl[i] = b.size
+    U = np.zeros_like(T)
+    pidx = np.zeros(len(blocks), np.uint32)
+    L.cjs_bwt_cyclic_batch.restype = C.c_int32
+    L.cjs_bwt_cyclic_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    assert L.cjs_bwt_cyclic_batch(T.ctypes.data, nl.ctypes.data, len(blocks), cap, U.ctypes.data, pidx.ctypes.data) == 0
+    return [(U[i * cap:i * cap + b.size], int(pidx[i])) for i, b in enumerate(blocks)]
+
+
+def _front_blocks():
+    rng = np.random.RandomState(7)
+    heavy = synth.text_like(60000, 9).copy()                 # one 8-byte key in ~1 % of the positions, not enough quantiles
+    for p in rng.randint(0, heavy.size - 8, size=500):
+        heavy[p:p + 8] = np.frombuffer(b"QQQQZZZZ", np.uint8)
+    return [synth.text_like(70000, 11), synth.enwik_like(50000, 12), synth.lcg_ascii(40000, 3),
+            synth.periodic(45001, b"ab"), synth.periodic(30011, b"the quick brown fox jumps over the lazy dog\n"),
+            np.zeros(20000, np.uint8), synth.runs_mixed(50000, 4), heavy,
+            rng.randint(0, 256, size=33000).astype(np.uint8), rng.randint(97, 99, size=25000).astype(np.uint8),
+            np.full(5000, 255, np.uint8), synth.text_like(4097, 1), synth.text_like(4096, 2)]
+
+
+@pytest.mark.parametrize("variant", ["default", "tiny_buckets", "lsd_passes"])
+def test_sample_sort_front_end(variant):
+    """k1_front.hip (sample-sort front end of the suffix sort) on blocks large enough to be partitioned: text,
+    random, periodic (pure buckets), runs, a moderately heavy key; `tiny_buckets` is a build with a 256-rotation
+    bucket capacity and 2 samples per bucket, so that the oversize path runs all the time; `lsd_passes` is the
+    CJS_FRONT=0 path.  BWT + origPtr of every block against the oracle."""
+    env = dict(os.environ)
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'));"
+            "sys.path.insert(0, os.path.join(%r, 'tests', 'golden'));"
+            "import test_emu_pipeline as t; t._front_check(%r)" % (ROOT, ROOT, ROOT, variant))
+    if variant == "lsd_passes":
+        env["CJS_FRONT"] = "0"
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _front_check(variant):
+    so = stagelib.build_emu()
+    if variant == "tiny_buckets":
+        so = os.path.join(ROOT, "tests", "emu", "libcjs_emu_tiny.so")
+        import subprocess
+        subprocess.check_call(["sh", os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL,
+                              env=dict(os.environ, EMU_OUT=so, EMU_DEFS="-DK1F_C=256 -DK1F_OVS=2"))
+    L = C.CDLL(so)
+    blocks = _front_blocks()
+    for (u, p), b in zip(_bwt_batch(L, blocks), blocks):
+        uo, po = oracle.bwt_cyclic(b)
+        assert p == po and np.array_equal(u, uo), (variant, b.size, bytes(b[:16]))
