@@ -5,13 +5,25 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete bzip2 -9 compression (Bzip2.compressFile equivalent, lib/Bzip2.js:879)
-of the synthetic enwik8-shaped stream (BASELINE.json configs[2]: 10^8 bytes per GPU, ~112
-blocks of 899 981 bytes; compressjs_amd.synth.enwik_like: words + wiki markup + phrase reuse,
-calibrated so that bzip2 -9 reaches enwik8's ratio 0.29), input resident in HBM when the timed region starts, complete .bz2
-stream resident in HBM (rank 0) when it ends.  Weak scaling: N GPUs compress an N x 10^8-byte
-stream; blocks are sharded, the encoded segments are gathered to rank 0 (compressjs_amd/dist.py).
-Prints ONE JSON line (rank 0)."""
+One "step" = one complete bzip2 -9 compression (Bzip2.compressFile equivalent, lib/Bzip2.js:879) of a
+10^8-byte stream per GPU (BASELINE.json configs[2]; ~112 blocks of 899 981 bytes), input resident in HBM
+when the timed region starts, complete .bz2 stream resident in HBM (rank 0) when it ends.  Workloads
+(tests/workloads.py): enwik (default: synthetic enwik8-shaped text with phrase reuse), e8sa (SURVEY.md 8d E8S-A:
+the reference's test/sample5.ref || sample4.ref tiled), lcg (configs[3]: random printable ASCII), text, e8sb.
+Weak scaling: N GPUs compress an N x 10^8-byte stream; blocks are sharded, the encoded segments are gathered
+to rank 0 (compressjs_amd/dist.py).  Prints ONE JSON line (rank 0).
+
+What the line carries besides the driver's contract:
+  config.bit_exact_vs_reference_digest   sha256 of the WHOLE stream == what the reference itself (node 12) produced
+                                         on the same bytes (tests/golden/golden_big.json), all 112 blocks
+  config.pcie_inclusive_mb_s             the same step through cjs_bz2_compress (host buffer in, host buffer out)
+  roofline                               dominant kernel, timed with HIP events on the library's stream in a
+                                         single-stream pass after the timed region; traffic from the committed
+                                         PMC pass of this build (profiles/r02_pmc_traffic.json), e2e = 16 B/B
+  cpu_baseline                           kind "reference": Bzip2.compressFile of cscott/compressjs under node 12 on
+                                         the SAME 10^8 bytes, 1 thread, timed in the build container (the reference
+                                         does not exist on the GPU box); all_cores = nproc node processes on equal
+                                         slices; port = the C restatement (oracle/) timed live on this box."""
 from __future__ import annotations
 
 import argparse
@@ -23,25 +35,30 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+DOMINANT = "k1f_bsort"          # kernel the roofline object is about (k1_front.hip)
+# ALGORITHMIC bytes of one k1f_bsort launch per rotation (DESIGN.md section 3, K1 front end): 4 (index read) +
+# 8 (key bytes of the rotation's text) + 4 (suffix-array entry written); head bits are 1/8 byte.
+DOMINANT_ALG_BYTES = 16.0
+E2E_ALG_BYTES = 16.0            # 14 + 4 rho + c bytes per input byte, nominal 16 for enwik8-shaped text
 
-def cpu_baseline(data: np.ndarray, level: int, sample_bytes: int):
-    """The oracle (C port of the reference algorithm) timed on ONE host core on the first
+
+def port_baseline(data: np.ndarray, level: int, sample_bytes: int):
+    """The oracle (C restatement of the reference algorithm) timed on ONE host core of THIS box on the first
     `sample_bytes` of the same stream.  Checker code: only this leg may call it."""
     import oracle
     sample = data[:sample_bytes]
     t0 = time.perf_counter()
     out = oracle.bz2_compress(sample, level)
     dt = time.perf_counter() - t0
-    return dict(value=round(sample.size / dt / 1e6, 4), unit="MB/s", cores=1, kind="port",
-                sample="first %d bytes of the same stream, 1 thread, oracle/bz2_oracle.c; "
-                       "the reference itself (node 12, 1 thread) measured 0.378 MB/s on this "
-                       "path in the build container (BASELINE.md)" % sample.size), out
+    return dict(value=round(sample.size / dt / 1e6, 4), unit="MB/s", cores=1,
+                sample="first %d bytes of the same stream, oracle/bz2_oracle.c, this box" % sample.size), out
 
 
 def main():
@@ -51,10 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=100_000_000, help="input bytes per GPU")
     ap.add_argument("--level", type=int, default=9)
-    ap.add_argument("--workload", default="enwik", choices=["enwik", "text", "lcg", "e8sa"],
-                    help="enwik (default): synthetic words+markup with phrase reuse calibrated to enwik8's bzip2 -9 ratio 0.29; "
-                         "text: the same without phrase reuse (ratio 0.38, an easier suffix structure); lcg: random printable ASCII (configs[3]); "
-                         "e8sa: test/sample5.ref || test/sample4.ref tiled (SURVEY.md 8d E8S-A; needs the staged fixtures)")
+    ap.add_argument("--workload", default="enwik", choices=["enwik", "text", "lcg", "e8sa", "e8sb"])
     ap.add_argument("--cpu-sample", type=int, default=12_000_000)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--batch", type=int, default=128, help="bzip2 blocks in flight (over all streams)")
@@ -79,21 +93,12 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from compressjs_amd import synth
+    import workloads
     from compressjs_amd.bzip2 import Context
     from compressjs_amd.dist import sharded_compress
 
     total = args.size * world
-    if args.workload == "e8sa":
-        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-        import cases
-        parts = [cases.fixture_path("sample5.ref"), cases.fixture_path("sample4.ref")]
-        assert all(parts), "e8sa needs test/sample5.ref and test/sample4.ref (staged by __graft_entry__.build())"
-        base = np.concatenate([np.fromfile(p, dtype=np.uint8) for p in parts])
-        host = np.tile(base, total // base.size + 1)[:total].copy()
-    else:
-        host = (synth.text_like(total, 2025) if args.workload == "text" else
-                synth.enwik_like(total, 2025) if args.workload == "enwik" else synth.lcg_ascii(total, 7))
+    host = workloads.stream(args.workload, total)
     d_in = torch.from_numpy(host).to(dev)
     ctx = Context(local, args.batch)
     bound = int(ctx.L.cjs_bz2_compress_bound(total))
@@ -111,7 +116,6 @@ def main():
 
     for _ in range(args.warmup):
         out = step()
-    ctx.L.cjs_profile_enable(ctx.h, 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -124,10 +128,6 @@ def main():
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    import ctypes as C
-    pms, pl, pe = C.c_float(0), C.c_uint32(0), C.c_uint64(0)
-    ctx.L.cjs_profile_read(ctx.h, C.byref(pms), C.byref(pl), C.byref(pe))
-    ctx.L.cjs_profile_enable(ctx.h, 0)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -135,76 +135,118 @@ def main():
     elapsed = float(elapsed.item())
 
     if rank == 0:
+        import ctypes as C
         comp = out.cpu().numpy().tobytes()
-        verified = None
-        cpu = None
+        sha = hashlib.sha256(comp).hexdigest()
+        # ---- parity of the WHOLE stream: the digest the reference itself produced on these bytes -------------
+        gold = {}
+        gpath = os.path.join(ROOT, "tests", "golden", "golden_big.json")
+        if os.path.exists(gpath):
+            gold = json.load(open(gpath))["vectors"]
+        gkey = "%s:%d:bz2:%d" % (args.workload, total, args.level)
+        g = gold.get(gkey)
+        vs_ref = None
+        if g is not None:
+            assert hashlib.sha256(host.tobytes()).hexdigest() == g["in_sha256"], "workload generator drifted from the reference-made golden"
+            vs_ref = bool(sha == g["out_sha256"] and len(comp) == g["out_len"])
+        verified, port, pcie = None, None, None
         if not args.no_verify:
             import bz2
-            # independent decoder, bounded to keep the default run short
+            # independent decoder (libbz2), bounded to keep the default run short
             limit = min(total, 200_000_000)
-            dec = bz2.BZ2Decompressor()
-            got = dec.decompress(comp, limit)
-            verified = bool(got == host[:limit].tobytes())
+            verified = bool(bz2.BZ2Decompressor().decompress(comp, limit) == host[:limit].tobytes())
             # the whole stream through the GPU decoder (K7-K9), compared on the device
             back = torch.empty(total + 64, dtype=torch.uint8, device=dev)
             nback = ctx.decompress_device(out, back)
             verified = verified and nback == total and bool(torch.equal(back[:total], d_in[:total]))
             del back
-            cpu, ref = cpu_baseline(host, args.level, min(args.cpu_sample, total))
-            # parity of the leading blocks against the oracle (bit-exact): blocks are encoded
-            # independently of what follows, so the oracle's stream of the sample is a prefix of
-            # the full stream except for its last block and trailer.
+            # localiser: the leading blocks bit for bit against the oracle (says WHICH block differs if the digest does)
+            port, ref = port_baseline(host, args.level, min(args.cpu_sample, total))
             nfull = (min(args.cpu_sample, total) // (args.level * 100000)) - 1
             if nfull > 0:
                 import oracle
-                nbytes = 0
                 pref = sum(b["bit_len"] for _, b in zip(range(nfull), oracle.block_stages(host[:min(args.cpu_sample, total)], args.level)))
                 nbytes = (32 + pref) // 8
                 verified = verified and comp[:nbytes] == ref[:nbytes]
-        n_launch = max(int(pl.value), 1)
-        avg_ms = pms.value / n_launch
-        # Dominant kernel: k1_scatter, one stable 8-bit LSD pass over the (key32, index) pair of every
-        # rotation of the batch.  ALGORITHMIC bytes per launch = (4+4 read + 4+4 written) = 16 B per
-        # block byte; duration = mean of the HIP-event pairs recorded around
-        # every launch on the library's own stream during the timed steps.
-        alg_bytes = 16.0 * (pe.value / n_launch if pe.value else args.size)
+            if world == 1:
+                # host buffer in -> .bz2 in host memory through the C ABI (SURVEY.md 8d's end-to-end definition)
+                hbuf = np.zeros(bound, dtype=np.uint8)             # caller-owned output buffer, pages touched
+                tt, nn = [], 0
+                for _ in range(4):
+                    a = time.perf_counter()
+                    nn = int(ctx.L.cjs_bz2_compress(ctx.h, host.ctypes.data, host.size, args.level, hbuf.ctypes.data, hbuf.size))
+                    tt.append(time.perf_counter() - a)
+                assert nn == len(comp) and hashlib.sha256(hbuf[:nn].tobytes()).hexdigest() == sha
+                tt = tt[1:]
+                pcie = round(total / min(tt) / 1e6, 1)
+        # ---- roofline leg: the dominant kernel alone on the GPU (one stream), HIP events around every launch ---
+        avg_ms, launches, elements = 0.0, 0, 0
+        if world == 1:
+            os.environ["CJS_STREAMS"] = "1"
+            ctx1 = Context(local, args.batch)
+            ctx1.compress_device(d_in, d_out, args.level)
+            ctx1.L.cjs_profile_enable(ctx1.h, 1)
+            for _ in range(3):
+                ctx1.compress_device(d_in, d_out, args.level)
+            pms, pl, pe = C.c_float(0), C.c_uint32(0), C.c_uint64(0)
+            ctx1.L.cjs_profile_read(ctx1.h, C.byref(pms), C.byref(pl), C.byref(pe))
+            ctx1.L.cjs_profile_enable(ctx1.h, 0)
+            ctx1.close()
+            launches, elements = int(pl.value), int(pe.value)
+            avg_ms = pms.value / max(launches, 1)
+        alg_bytes = DOMINANT_ALG_BYTES * (elements / launches if launches else args.size)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch from the PMC passes of this same command (profiles/r01_pmc_v6_fetch_write.csv:
-        # separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; KiB units; FETCH_SIZE doubled as the
-        # MI355X guide prescribes for coalesced streaming reads on gfx950).  Only valid for the
-        # default workload/size; null otherwise.
+        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE passes of THIS build on THIS workload, collected by
+        # tests/gpu_round_end.sh into profiles/r02_pmc_traffic.json (separate --pmc runs; FETCH_SIZE doubled as the
+        # MI355X guide prescribes for gfx950).  null when no pass for this workload/size is committed.
         traffic = None
-        if args.workload == "enwik" and args.size == 100_000_000 and world == 1:
-            traffic = round((2 * 416.8e6 + 866.2e6), 0)         # profiles/r01_pmc_v6_fetch_write.csv
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            ent = tj.get("%s:%d" % (args.workload, args.size), {}).get(DOMINANT)
+            if ent:
+                traffic = ent["traffic_bytes_per_launch"]
+        wall = elapsed / args.steps
+        ref_line = None
+        if g is not None:
+            ac = gold.get("%s:%d:allcores:%d" % (args.workload, total, args.level)) or gold.get("enwik:%d:allcores:%d" % (total, args.level))
+            ref_line = {"value": g["mb_per_s"], "unit": "MB/s", "cores": 1, "kind": "reference",
+                        "sample": "Bzip2.compressFile(buf, null, %d) of cscott/compressjs under node 12 on the whole %d-byte "
+                                  "stream of this run (same sha256 in and out), %.1f s, timed in the build container "
+                                  "(tests/golden/make_golden_big.py); /root/reference does not exist on the GPU box"
+                                  % (args.level, g["in_len"], g["seconds"]),
+                        "all_cores": None if not ac else {"value": ac["sum_mb_per_s"], "unit": "MB/s", "processes": ac["processes"],
+                                                          "sample": "%d node processes on equal slices of the enwik stream, summed" % ac["processes"]},
+                        "port": port}
+        elif port is not None:
+            ref_line = dict(port, kind="port")
         line = {
             "metric": "bzip2 -9 compress MB/s on enwik8-shaped input",
             "value": round(total * args.steps / elapsed / 1e6, 2),
             "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(wall * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic" if args.workload != "e8sa" else "reference test fixtures, tiled",
-            "config": {"workload": "synthetic enwik8-shaped text (compressjs_amd.synth.text_like, seed 2025), "
-                                   "%d bytes per GPU, bzip2 -%d, %d-byte blocks; BASELINE.json configs[2]"
-                                   % (args.size, args.level, args.level * 100000 - 19)
-                       if args.workload == "text" else
-                       "synthetic enwik8-shaped text with phrase reuse calibrated to enwik8's bzip2 -9 ratio "
-                       "(compressjs_amd.synth.enwik_like, seed 2025), %d bytes per GPU, bzip2 -%d; BASELINE.json configs[2]"
-                       % (args.size, args.level) if args.workload == "enwik" else
-                       "LCG(n, seed 7) random printable ASCII, %d bytes per GPU, bzip2 -%d; BASELINE.json configs[3]"
-                       % (args.size, args.level) if args.workload == "lcg" else
-                       "test/sample5.ref || test/sample4.ref tiled to %d bytes per GPU (SURVEY.md 8d E8S-A), bzip2 -%d"
-                       % (args.size, args.level),
+            "dtype": "u8",
+            "data": "synthetic" if args.workload not in ("e8sa", "e8sb") else "reference test fixtures, " + ("tiled" if args.workload == "e8sa" else "order-2 Markov"),
+            "config": {"workload": "%s, %d bytes per GPU, bzip2 -%d, %d-byte blocks; BASELINE.json configs[%d]"
+                                   % (workloads.DESCRIPTIONS[args.workload], args.size, args.level, args.level * 100000 - 19,
+                                      3 if args.workload == "lcg" else 2),
                        "input_bytes": total, "compressed_bytes": len(comp),
                        "blocks_in_flight": args.batch, "sharding": "blocks/%d" % world,
                        "device_ms_per_step": round(dev_ms / args.steps, 3),
+                       "bit_exact_vs_reference_digest": vs_ref,
                        "bit_exact_vs_oracle_prefix_and_roundtrip": verified,
-                       "sha256": hashlib.sha256(comp).hexdigest()},
-            "roofline": {"bound": "hbm", "kernel": "k1_scatter", "achieved": round(achieved, 2),
+                       "pcie_inclusive_mb_s": pcie,
+                       "sha256": sha},
+            "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 2),
                          "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
-                         "avg_launch_ms": round(avg_ms, 4), "launches": int(pl.value),
-                         "alg_bytes_per_launch": alg_bytes, "traffic": traffic},
-            "cpu_baseline": cpu,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                         "alg_bytes_per_launch": alg_bytes, "traffic": traffic,
+                         "e2e": {"alg_bytes_per_input_byte": E2E_ALG_BYTES,
+                                 "achieved": round(E2E_ALG_BYTES * total / wall / 1e9, 2),
+                                 "frac": round(E2E_ALG_BYTES * total / wall / 8e12, 5)}},
+            "cpu_baseline": ref_line,
         }
         print(json.dumps(line))
     if world > 1:

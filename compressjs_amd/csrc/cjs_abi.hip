@@ -8,6 +8,8 @@
 #include <vector>
 #include <atomic>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <string.h>
 #include <stdlib.h>
 
@@ -325,16 +327,20 @@ extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
     memset(c, 0, sizeof *c);
     c->device = device;
     c->batch_blocks = batch_blocks ? batch_blocks : 128;
-    // CJS_STREAMS=2: two streams, each driven by its own host thread (issue_blocks): latency-bound kernels of
-    // one half of the batch (k34_tables: one workgroup per block, the sparse rounds, the small scans) overlap
-    // with the bandwidth-bound ones of the other.  Measured, 10^8 B text: 1 stream 15.99 ms, 2 streams 15.36-
-    // 15.61 ms, 3 streams 18.8 ms.  The default stays 1: with overlapping kernels neither HIP events nor
-    // rocprof give a per-launch duration that means anything for the roofline of the dominant kernel.
-    c->nstreams = 1;
+    // Two streams by default, each driven by its own host thread (issue_blocks): the latency-bound kernels of one half of
+    // the batch (k34_tables: one workgroup per block, the sparse rounds, the small scans, K1's read-backs) overlap with
+    // the bandwidth-bound ones of the other.  Measured, 10^8 bytes, ms per step with 1 / 2 / 3 / 4 streams: enwik
+    // 14.86 / 14.35 / 14.73 / 17.72, E8S-A 23.94 / 21.45 / 21.90 / 27.48, random ASCII 12.81 / 12.07 / 12.58 / 15.35.
+    // CJS_STREAMS=1 gives every kernel the GPU to itself: what per-kernel timings (bench.py's roofline leg, rocprof
+    // summaries) are taken with.
+    c->nstreams = batch_blocks && batch_blocks < 32 ? 1 : 2;
     if (const char* ev = getenv("CJS_STREAMS")) {
         const int v = atoi(ev);
         if (v >= 1 && v <= CJS_NSTREAMS) c->nstreams = (u32)v;
     }
+#ifdef CJS_CPU_DEBUG_BUILD
+    c->nstreams = 1;                             // the CPU logic-debug build runs kernels as fibers of one thread
+#endif
     c->sub_blocks = (c->batch_blocks + c->nstreams - 1) / c->nstreams;
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
     BatchGeom g = make_geom(c->sub_blocks, 9u * 100000u - 19u);
@@ -494,6 +500,167 @@ extern "C" int64_t cjs_bz2_compress_device(cjs_ctx* c, const void* d_in, uint64_
 #undef TRYR
 }
 
+// Host buffers in, host buffers out, input longer than ~1.5 batches: the input is cut into SEGMENTS of about one batch
+// of blocks.  A segment is planned as an input of its own (a bzip2 block always starts with a fresh RLE1 state,
+// lib/Bzip2.js:636-667, so planning from a block start is exact); all of its blocks but the last are encoded, and
+// the next segment starts where that last, possibly incomplete, block started.  Two helper threads move data on
+// their own non-blocking streams: the uploader keeps H2D a segment ahead of the encoder, the downloader copies the
+// bytes of the stream that are final (everything before the bit cursor) while the next segment is being encoded.
+namespace {
+struct SegCopy {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t uploaded = 0;          // input bytes resident in HBM
+    uint64_t want = 0;              // downloader: copy the stream up to this byte
+    bool quit = false;
+    int err = 0;
+};
+}
+
+static int64_t compress_segmented(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out, uint64_t out_cap,
+                                  uint64_t seg_bytes) {
+    hipError_t e;
+#define TRYR(x) if ((e = (x)) != hipSuccess) { rc = CJS_E_HIP - (int)e; goto done; }
+    const u32 cap = (u32)level * 100000u - 19u;
+    int64_t rc = 0;
+    SegCopy sc;
+    hipStream_t sIn = nullptr, sOut = nullptr;
+    std::thread up, down;
+    uint64_t copied = 0;            // bytes of the stream already in `out` (downloader's own)
+    const int dev = c->device;
+    u8* din = (u8*)c->din;
+    u8* dout = (u8*)c->dout;
+    const uint64_t dout_cap = c->dout_bytes;
+    float total_ms = 0.f;
+    u32 total_blocks = 0;
+    Pipe P0;
+    memset(&P0, 0, sizeof P0);
+    P0.ss = c->d_ss;
+    P0.out = (u32*)dout;
+    P0.outCapBytes = dout_cap & ~(uint64_t)3;
+    if (hipStreamCreateWithFlags(&sIn, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&sOut, hipStreamNonBlocking) != hipSuccess) {
+        if (sIn) (void)hipStreamDestroy(sIn);
+        return CJS_E_HIP;
+    }
+    up = std::thread([&]() {
+        if (hipSetDevice(dev) != hipSuccess) { std::lock_guard<std::mutex> g(sc.mu); sc.err = CJS_E_NOGPU; sc.cv.notify_all(); return; }
+        const uint64_t chunk = (uint64_t)32 << 20;
+        for (uint64_t off = 0; off < in_len; off += chunk) {
+            const uint64_t len = in_len - off < chunk ? in_len - off : chunk;
+            hipError_t e2 = hipMemcpyAsync(din + off, in + off, len, hipMemcpyHostToDevice, sIn);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(sIn);
+            std::lock_guard<std::mutex> g(sc.mu);
+            if (e2 != hipSuccess) { sc.err = CJS_E_HIP - (int)e2; sc.cv.notify_all(); return; }
+            sc.uploaded = off + len;
+            sc.cv.notify_all();
+            if (sc.quit) return;
+        }
+    });
+    down = std::thread([&]() {
+        if (hipSetDevice(dev) != hipSuccess) return;
+        for (;;) {
+            uint64_t to;
+            {
+                std::unique_lock<std::mutex> g(sc.mu);
+                sc.cv.wait(g, [&]() { return sc.quit || sc.want > copied; });
+                if (sc.want <= copied) return;          // quit and nothing left
+                to = sc.want;
+            }
+            if (to > out_cap) { std::lock_guard<std::mutex> g(sc.mu); sc.err = CJS_E_NOSPACE; return; }
+            hipError_t e2 = hipMemcpyAsync(out + copied, dout + copied, to - copied, hipMemcpyDeviceToHost, sOut);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(sOut);
+            if (e2 != hipSuccess) { std::lock_guard<std::mutex> g(sc.mu); sc.err = CJS_E_HIP - (int)e2; return; }
+            copied = to;
+        }
+    });
+    {
+        hipStream_t st = c->stream;
+        int rci = k5_stream_begin(P0, level, st);
+        if (rci) { rc = rci; goto done; }
+        uint64_t s = 0;
+        u32 seg = 0;
+        while (s < in_len || (in_len == 0 && seg == 0)) {
+            uint64_t eoff = s + seg_bytes < in_len ? s + seg_bytes : in_len;
+            {   // wait until the uploader has brought the segment in
+                std::unique_lock<std::mutex> g(sc.mu);
+                sc.cv.wait(g, [&]() { return sc.err || sc.uploaded >= eoff; });
+                if (sc.err) { rc = sc.err; goto done; }
+            }
+            void** kws = seg & 1 ? &c->planws : &c->k0ws;            // alternate: the previous segment's tables may still be read
+            size_t* kwb = seg & 1 ? &c->planws_bytes : &c->k0ws_bytes;
+            if (seg & 1) { c->plan_level = 0; c->plan_blocks = 0; }  // a cjs_bz2_plan result does not survive this call
+            rci = grow(kws, kwb, k0_bytes(eoff - s, cap));
+            if (rci) { rc = rci; goto done; }
+            K0Buf K;
+            k0_carve(K, din + s, eoff - s, cap, *kws);
+            TRYR(hipEventRecord(c->ev0, st));
+            rci = k0_prepass(K, cap, st);
+            if (rci) { rc = rci; goto done; }
+            TRYR(hipEventRecord(c->evReady, st));
+            u32 nblocks = 0;
+            TRYR(hipMemcpyAsync(&nblocks, K.nBlocks, 4, hipMemcpyDeviceToHost, st));
+            TRYR(hipStreamSynchronize(st));
+            u32 keep = nblocks;
+            uint64_t next = in_len;
+            if (eoff < in_len) {
+                if (nblocks < 2) { seg_bytes *= 2; continue; }       // run-heavy input: one block swallowed the segment
+                keep = nblocks - 1;
+                uint64_t bs = 0;
+                TRYR(hipMemcpy(&bs, K.blkStart + keep, 8, hipMemcpyDeviceToHost));
+                next = s + bs;
+            }
+            rci = issue_blocks(c, K, cap, 0, keep, dout, dout_cap);
+            if (rci) { rc = rci; goto done; }
+            TRYR(hipEventRecord(c->ev1, st));
+            StreamState hs;
+            TRYR(hipMemcpyAsync(&hs, c->d_ss, sizeof hs, hipMemcpyDeviceToHost, st));
+            TRYR(hipStreamSynchronize(st));
+            float ms = 0.f;
+            TRYR(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+            total_ms += ms;
+            total_blocks += keep;
+            if (hs.overflow) { rc = CJS_E_NOSPACE; goto done; }
+            {   // everything before the bit cursor is final
+                std::lock_guard<std::mutex> g(sc.mu);
+                if (sc.err) { rc = sc.err; goto done; }
+                sc.want = hs.bits >> 3;
+                sc.cv.notify_all();
+            }
+            s = next;
+            seg++;
+            if (in_len == 0) break;
+        }
+        rci = k5_stream_end(P0, st);
+        if (rci) { rc = rci; goto done; }
+        StreamState hs;
+        TRYR(hipMemcpyAsync(&hs, c->d_ss, sizeof hs, hipMemcpyDeviceToHost, st));
+        TRYR(hipStreamSynchronize(st));
+        if (hs.overflow) { rc = CJS_E_NOSPACE; goto done; }
+        rc = (int64_t)((hs.bits + 7) >> 3);
+        if ((uint64_t)rc > out_cap) { rc = CJS_E_NOSPACE; goto done; }
+        {
+            std::lock_guard<std::mutex> g(sc.mu);
+            sc.want = (uint64_t)rc;
+            sc.cv.notify_all();
+        }
+    }
+done:
+    {
+        std::lock_guard<std::mutex> g(sc.mu);
+        sc.quit = true;
+        sc.cv.notify_all();
+    }
+    if (up.joinable()) up.join();
+    if (down.joinable()) down.join();
+    (void)hipStreamDestroy(sIn);
+    (void)hipStreamDestroy(sOut);
+    if (rc >= 0 && sc.err) rc = sc.err;
+    c->last_ms = total_ms;
+    c->last_blocks = total_blocks;
+    return rc;
+#undef TRYR
+}
+
 extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
                                     uint64_t out_cap) {
     if (!c || (!in && in_len) || !out) return CJS_E_ARG;
@@ -506,6 +673,11 @@ extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_l
     if (rc) return rc;
     rc = grow(&c->dout, &c->dout_bytes, need);
     if (rc) return rc;
+    // one batch of blocks per segment; CJS_SEG_BYTES (tests) overrides.  Inputs of up to a batch and a half go in one
+    // piece: half-size batches cost more (16.9 vs 14.2 ms per 10^8 bytes) than overlapping their copies would save.
+    static const uint64_t seg_env = []() -> uint64_t { const char* ev = getenv("CJS_SEG_BYTES"); return ev ? strtoull(ev, nullptr, 10) : 0; }();
+    const uint64_t seg_bytes = seg_env ? seg_env : (uint64_t)c->batch_blocks * ((u32)level * 100000u - 19u);
+    if (in_len > seg_bytes + seg_bytes / 2) return compress_segmented(c, in, in_len, level, out, out_cap, seg_bytes);
     if (in_len) TRYR(hipMemcpyAsync(c->din, in, in_len, hipMemcpyHostToDevice, c->stream));
     const int64_t n = cjs_bz2_compress_device(c, c->din, in_len, level, c->dout, c->dout_bytes);
     if (n < 0) return n;

@@ -420,3 +420,29 @@ def _front_check(variant):
     for (u, p), b in zip(_bwt_batch(L, blocks), blocks):
         uo, po = oracle.bwt_cyclic(b)
         assert p == po and np.array_equal(u, uo), (variant, b.size, bytes(b[:16]))
+
+
+def test_segmented_host_pipeline():
+    """cjs_bz2_compress on inputs longer than 1.5 segments: planned and encoded segment by segment (upload / encode /
+    download overlapped by two helper threads).  CJS_SEG_BYTES=250000 makes a segment ~2.5 level-1 blocks, so the
+    "drop the last block and restart there" seam, the segment-doubling path (runs: one block swallows a segment) and the
+    incremental download all run; the stream must equal the oracle's."""
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'));"
+            "sys.path.insert(0, os.path.join(%r, 'tests', 'golden'));"
+            "import test_emu_pipeline as t; t._segmented_check()" % (ROOT, ROOT, ROOT))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CJS_SEG_BYTES="250000"), capture_output=True,
+                       text=True, timeout=3000)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _segmented_check():
+    L = _lib.load(stagelib.build_emu())
+    h = L.cjs_create(0, 4)
+    try:
+        for d, lv in ((synth.text_like(1_200_000, 21), 1), (synth.runs_mixed(1_500_000, 6), 1), (np.zeros(3_000_000, np.uint8), 1),
+                      (synth.lcg_ascii(700_001, 3), 2), (synth.text_like(380_000, 2), 1)):
+            assert _compress((L, h), d, lv) == oracle.bz2_compress(d, lv), (d.size, lv)
+    finally:
+        L.cjs_destroy(h)
