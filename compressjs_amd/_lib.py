@@ -12,8 +12,8 @@ LIB_PATH = os.environ.get("COMPRESSJS_AMD_LIB") or os.path.join(_HERE, "libcompr
 _lib = None
 
 # every symbol include/compressjs_amd.h declares (tests check the .so exports all of them)
-SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_bz2_compress_bound", "cjs_bz2_compress",
-           "cjs_bz2_compress_device", "cjs_bz2_plan", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
+SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_bz2_compress_bound", "cjs_bz2_compress",
+           "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
            "cjs_bwtc_compress_bound",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
            "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
@@ -49,6 +49,8 @@ def load(path: str | None = None):
     vp = C.c_void_p
     L.cjs_create.restype = vp
     L.cjs_create.argtypes = [C.c_int, C.c_uint32]
+    L.cjs_device_count.restype = C.c_int32
+    L.cjs_device_count.argtypes = []
     L.cjs_destroy.restype = None
     L.cjs_destroy.argtypes = [vp]
     L.cjs_bz2_compress_bound.restype = C.c_int64
@@ -110,6 +112,8 @@ def load(path: str | None = None):
     L.cjs_bz2_last_detail.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.cjs_shift_bits.restype = C.c_int32
     L.cjs_shift_bits.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp]
+    L.cjs_bz2_compress_multi.restype = C.c_int64
+    L.cjs_bz2_compress_multi.argtypes = [C.POINTER(vp), C.c_uint32, vp, C.c_uint64, C.c_int, vp, C.c_uint64]
     L.cjs_bwtc_decompress.restype = C.c_int64
     L.cjs_bwtc_decompress.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_int64)]
     L.cjs_bwtc_last_size.restype = C.c_int64

@@ -163,6 +163,19 @@ class Context:
         return int(self.L.cjs_last_block_count(self.h))
 
 
+def compress_multi(contexts, data, level: int = 9) -> bytes:
+    """Bzip2.compressFile over several GPUs from one process (cjs_bz2_compress_multi): `contexts` = Context objects on
+    different devices; segments of about one batch of blocks go round-robin to them.  Same bytes as one context."""
+    d = np.ascontiguousarray(data, dtype=np.uint8)
+    L = contexts[0].L
+    cap = int(L.cjs_bz2_compress_bound(d.size))
+    out = contexts[0]._staging(cap)
+    hs = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    n = L.cjs_bz2_compress_multi(hs, len(contexts), d.ctypes.data, d.size, int(level), out.ctypes.data, cap)
+    _lib.check(n, "cjs_bz2_compress_multi")
+    return out[:n].tobytes()
+
+
 _default_ctx = None
 
 

@@ -8,6 +8,7 @@
 #include <vector>
 #include <atomic>
 #include <thread>
+#include <functional>
 #include <mutex>
 #include <condition_variable>
 #include <string.h>
@@ -319,6 +320,12 @@ struct cjs_ctx {
 };
 
 extern "C" void cjs_destroy(cjs_ctx* c);
+
+extern "C" int32_t cjs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 0) return 0;
+    return n;
+}
 
 extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
     if (ensure_device()) return nullptr;
@@ -685,6 +692,158 @@ extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_l
     TRYR(hipMemcpy(out, c->dout, (size_t)n, hipMemcpyDeviceToHost));
     return n;
 #undef TRYR
+}
+
+// ---- Bzip2.compressFile over several GPUs of one node, from ONE process (the Node addon's path to N devices) -----
+// The input is cut at the nominal segment ends E_k = (k+1) * seg_bytes; segment k goes to device k mod n.  Each device
+// thread uploads only its windows [E_(k-1) - W, E_k) of the input (all uploads start at once), then waits for s_k, the
+// start of the first block of its segment - published by segment k-1 as soon as THAT segment is planned (K0 pre-pass,
+// ~0.3 ms), not encoded - plans [s_k, E_k) as an input of its own (blocks start with a fresh RLE1 state), publishes
+// s_(k+1) = start of its last, incomplete block, and encodes the others from bit 0 into a buffer of its own.  When all
+// bit lengths are known the segments are shifted on their devices to their bit offsets and copied side by side into the
+// caller's buffer (parallel D2H, no peer traffic); the bytes two segments share are OR-ed on the host, which also folds
+// the combined CRC (linear over GF(2)) and writes header and trailer.  A block that reaches further back than the window
+// margin W (run-heavy input) makes the call fall back to one device.  = SURVEY.md 8(e) without torch.distributed.
+namespace {
+struct MSeg {
+    uint64_t w0 = 0, e = 0;         // window start, nominal end (absolute input offsets)
+    uint64_t s = 0;                 // first byte of the segment's first block
+    bool s_known = false;
+    uint64_t bits = 0, off = 0;
+    u32 fold = 0, count = 0;
+    u8* dseg = nullptr;             // device: the segment's bit stream from bit 0
+    uint64_t dseg_cap = 0;
+    u8 first = 0, last = 0;         // seam bytes (shifted)
+};
+static inline u32 rotl32(u32 v, u32 k) { k &= 31u; return k ? (v << k) | (v >> (32u - k)) : v; }
+}
+
+extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint8_t* in, uint64_t in_len, int level,
+                                          uint8_t* out, uint64_t out_cap) {
+    if (!ctxs || n == 0 || !ctxs[0] || (!in && in_len) || !out) return CJS_E_ARG;
+    if (level < 1 || level > 9) return CJS_E_LEVEL;
+    for (u32 i = 0; i < n; i++) if (!ctxs[i]) return CJS_E_ARG;
+    const u32 cap = (u32)level * 100000u - 19u;
+    static const uint64_t seg_env = []() -> uint64_t { const char* ev = getenv("CJS_SEG_BYTES"); return ev ? strtoull(ev, nullptr, 10) : 0; }();
+    const uint64_t seg_bytes = seg_env ? seg_env : (uint64_t)ctxs[0]->batch_blocks * cap;
+    const uint64_t nseg = (in_len + seg_bytes - 1) / seg_bytes;
+    if (n == 1 || nseg <= 1) return cjs_bz2_compress(ctxs[0], in, in_len, level, out, out_cap);
+    const uint64_t W = (uint64_t)4 * (cap + 19u);
+    std::vector<MSeg> S(nseg);
+    for (uint64_t k = 0; k < nseg; k++) {
+        S[k].e = (k + 1) * seg_bytes < in_len ? (k + 1) * seg_bytes : in_len;
+        const uint64_t pe = k ? S[k - 1].e : 0;
+        S[k].w0 = pe > W ? pe - W : 0;
+    }
+    S[0].s = 0; S[0].s_known = true;
+    std::mutex mu;
+    std::condition_variable cv;
+    int err = 0;                    // first error; 1 = fall back to one device
+    auto fail = [&](int code) { std::lock_guard<std::mutex> g(mu); if (!err) err = code; cv.notify_all(); };
+    // phase 1 of one segment on its context
+    auto encode_seg = [&](uint64_t k) {
+        cjs_ctx* c = ctxs[k % n];
+        MSeg& g = S[k];
+        if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); return; }
+        const uint64_t wlen = g.e - g.w0;
+        int rc = grow(&c->din, &c->din_bytes, wlen + 64);
+        if (rc) { fail(rc); return; }
+        hipError_t e2 = hipMemcpyAsync(c->din, in + g.w0, wlen, hipMemcpyHostToDevice, c->stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+        if (e2 != hipSuccess) { fail(CJS_E_HIP - (int)e2); return; }
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { return err || g.s_known; });
+            if (err) return;
+        }
+        if (g.s < g.w0) { fail(1); return; }                          // the block reaches further back than the window
+        const int64_t nb = cjs_bz2_plan(c, (const u8*)c->din + (g.s - g.w0), g.e - g.s, level);
+        if (nb < 0) { fail((int)nb); return; }
+        u32 keep = (u32)nb;
+        if (g.e < in_len) {
+            if (nb < 2) { fail(1); return; }                          // one block swallowed the segment
+            keep = (u32)nb - 1u;
+            uint64_t bs = 0;
+            if (hipMemcpy(&bs, c->plan.blkStart + keep, 8, hipMemcpyDeviceToHost) != hipSuccess) { fail(CJS_E_HIP); return; }
+            std::lock_guard<std::mutex> lk(mu);
+            S[k + 1].s = g.s + bs;
+            S[k + 1].s_known = true;
+            cv.notify_all();
+        }
+        g.dseg_cap = ((uint64_t)cjs_bz2_compress_bound(g.e - g.s) + 3) & ~(uint64_t)3;
+        if (hipMalloc((void**)&g.dseg, g.dseg_cap) != hipSuccess) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); return; }
+        u32 fold = 0, cnt = 0;
+        const int64_t bits = cjs_bz2_encode_blocks(c, 0, keep, g.dseg, g.dseg_cap, &fold, &cnt);
+        if (bits < 0) { fail((int)bits); return; }
+        g.bits = (uint64_t)bits; g.fold = fold; g.count = cnt;
+    };
+    // phase 2: shift to the bit offset, copy the inner bytes into place, fetch the two seam bytes
+    auto place_seg = [&](uint64_t k) {
+        cjs_ctx* c = ctxs[k % n];
+        MSeg& g = S[k];
+        if (!g.bits) return;
+        if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); return; }
+        const uint64_t nbytes = (g.bits + 7) >> 3, sh = g.off & 7u;
+        const uint64_t fb = g.off >> 3, lb = (g.off + g.bits - 1) >> 3, span = lb - fb + 1;
+        int rc = grow(&c->dout, &c->dout_bytes, nbytes + 64);
+        if (rc) { fail(rc); return; }
+        rc = cjs_shift_bits(c, g.dseg, nbytes, (u32)sh, (u8*)c->dout);
+        if (rc) { fail(rc); return; }
+        hipError_t e2 = hipMemcpy(&g.first, c->dout, 1, hipMemcpyDeviceToHost);
+        if (e2 == hipSuccess) e2 = hipMemcpy(&g.last, (u8*)c->dout + span - 1, 1, hipMemcpyDeviceToHost);
+        if (e2 == hipSuccess && span > 2) e2 = hipMemcpy(out + fb + 1, (u8*)c->dout + 1, span - 2, hipMemcpyDeviceToHost);
+        if (e2 != hipSuccess) fail(CJS_E_HIP - (int)e2);
+    };
+    auto run_all = [&](const std::function<void(uint64_t)>& fn) {
+#ifdef CJS_CPU_DEBUG_BUILD
+        for (uint64_t k = 0; k < nseg && !err; k++) fn(k);            // the CPU logic-debug build runs kernels on one thread
+#else
+        std::vector<std::thread> th;
+        for (u32 d = 0; d < n; d++)
+            th.emplace_back([&, d]() { for (uint64_t k = d; k < nseg && !err; k += n) fn(k); });
+        for (auto& t : th) t.join();
+#endif
+    };
+    run_all(encode_seg);
+    int64_t result = 0;
+    if (!err) {
+        uint64_t pos = 32;
+        u32 crc = 0;
+        for (uint64_t k = 0; k < nseg; k++) {
+            S[k].off = pos;
+            pos += S[k].bits;
+            crc = rotl32(crc, S[k].count) ^ S[k].fold;                // lib/Bzip2.js:917 over the segment's blocks
+        }
+        const uint64_t end = pos + 80, total = (end + 7) >> 3;
+        if (total > out_cap) err = CJS_E_NOSPACE;
+        else {
+            for (uint64_t k = 0; k < nseg; k++)
+                if (S[k].bits) { out[S[k].off >> 3] = 0; out[(S[k].off + S[k].bits - 1) >> 3] = 0; }
+            for (uint64_t b = pos >> 3; b < total; b++) out[b] = 0;
+            run_all(place_seg);
+            if (!err) {
+                out[0] = 'B'; out[1] = 'Z'; out[2] = 'h'; out[3] = (u8)('0' + level);       // lib/Bzip2.js:903-906
+                for (uint64_t k = 0; k < nseg; k++)
+                    if (S[k].bits) { out[S[k].off >> 3] |= S[k].first; out[(S[k].off + S[k].bits - 1) >> 3] |= S[k].last; }
+                // end-of-stream magic + combined CRC at bit `pos` (lib/Bzip2.js:925-926), zero-padded to a byte
+                const u8 tr[10] = {0x17, 0x72, 0x45, 0x38, 0x50, 0x90, (u8)(crc >> 24), (u8)(crc >> 16), (u8)(crc >> 8), (u8)crc};
+                const u32 sh = (u32)(pos & 7u);
+                for (u32 i = 0; i < 10; i++) {
+                    out[(pos >> 3) + i] |= (u8)(tr[i] >> sh);
+                    if (sh) out[(pos >> 3) + i + 1] |= (u8)(tr[i] << (8u - sh));
+                }
+                result = (int64_t)total;
+            }
+        }
+    }
+    for (uint64_t k = 0; k < nseg; k++)
+        if (S[k].dseg) { (void)hipSetDevice(ctxs[k % n]->device); (void)hipFree(S[k].dseg); }
+    if (err == 1) return cjs_bz2_compress(ctxs[0], in, in_len, level, out, out_cap);
+    if (err) return err;
+    u32 blocks = 0;
+    for (uint64_t k = 0; k < nseg; k++) blocks += S[k].count;
+    ctxs[0]->last_blocks = blocks;
+    return result;
 }
 
 // ---- sharded encoding (multi-GPU): plan once, then encode a block range bit-aligned at 0 ----------

@@ -148,6 +148,16 @@ int64_t cjs_bwtc_decompress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, ui
 int64_t cjs_bwtc_last_size(cjs_ctx* ctx);
 int64_t cjs_bwtc_fetch(cjs_ctx* ctx, uint8_t* out, uint64_t out_cap);
 
+/* HIP devices visible to the process (0: none; the product has no CPU path). */
+int32_t cjs_device_count(void);
+/* = Bzip2.compressFile over SEVERAL GPUs of one node from one process (the N-API addon's path to N
+ * devices, the reference's single entry point lib/Bzip2.js:879 staying the only call): ctxs[i] = contexts created
+ * on different devices (the same device twice is allowed: tests).  The input is cut into segments of about one batch of
+ * blocks, segment k is uploaded to, planned and encoded on device k mod n, the segments' bit streams are shifted to
+ * their offsets on the devices and copied side by side into `out` (parallel D2H); same bytes as cjs_bz2_compress. */
+int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint8_t* in, uint64_t in_len, int level,
+                               uint8_t* out, uint64_t out_cap);
+
 /* multi-GPU seam helper: d_out[0 .. nbytes] = d_in[0 .. nbytes) shifted right by s (0..7) bits (MSB first).
  * Used when a rank's bit-0-aligned segment (cjs_bz2_encode_blocks) is placed at its offset in the stream. */
 int32_t cjs_shift_bits(cjs_ctx* ctx, const uint8_t* d_in, uint64_t nbytes, uint32_t s, uint8_t* d_out);

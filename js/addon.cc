@@ -20,6 +20,8 @@ static cjs_ctx* (*p_create)(int, uint32_t);
 static void (*p_destroy)(cjs_ctx*);
 static int64_t (*p_bound)(uint64_t);
 static int64_t (*p_compress)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t);
+static int64_t (*p_compress_multi)(cjs_ctx**, uint32_t, const uint8_t*, uint64_t, int, uint8_t*, uint64_t);
+static int32_t (*p_device_count)(void);
 static int32_t (*p_bwt)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
 static int32_t (*p_bwtlin)(const uint8_t*, uint8_t*, uint32_t, uint32_t*);
 static int32_t (*p_sufsort)(const uint8_t*, int32_t*, uint32_t);
@@ -37,7 +39,12 @@ static int64_t (*p_bwtc_fetch)(cjs_ctx*, uint8_t*, uint64_t);
 static int64_t (*p_bwtc_bound)(uint64_t);
 static int64_t (*p_bwtc)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t);
 static void* g_lib;
-static cjs_ctx* g_ctx;
+static cjs_ctx* g_ctx;                       // context on the first configured device: every single-device entry point
+static std::vector<cjs_ctx*> g_ctxs;         // one context per configured device (g_ctxs[0] == g_ctx)
+// configuration: configure({devices, blocksInFlight}) of js/index.js, or COMPRESSJS_AMD_DEVICES ("all", "0,1,2,3")
+// and COMPRESSJS_AMD_BLOCKS in the environment; default: device 0, 128 blocks in flight (what bench.py uses)
+static std::vector<int> g_devices;
+static uint32_t g_blocks = 0;
 static std::string g_err;
 
 static bool load_lib(const char* path) {
@@ -48,6 +55,8 @@ static bool load_lib(const char* path) {
     p_destroy = (void (*)(cjs_ctx*))dlsym(g_lib, "cjs_destroy");
     p_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bz2_compress_bound");
     p_compress = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bz2_compress");
+    p_compress_multi = (int64_t(*)(cjs_ctx**, uint32_t, const uint8_t*, uint64_t, int, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bz2_compress_multi");
+    p_device_count = (int32_t(*)(void))dlsym(g_lib, "cjs_device_count");
     p_bwt = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t*))dlsym(g_lib, "cjs_bwt_cyclic");
     p_bwtlin = (int32_t(*)(const uint8_t*, uint8_t*, uint32_t, uint32_t*))dlsym(g_lib, "cjs_bwt_linear");
     p_sufsort = (int32_t(*)(const uint8_t*, int32_t*, uint32_t))dlsym(g_lib, "cjs_suffixsort");
@@ -64,7 +73,7 @@ static bool load_lib(const char* path) {
     p_bwtc_fetch = (int64_t(*)(cjs_ctx*, uint8_t*, uint64_t))dlsym(g_lib, "cjs_bwtc_fetch");
     p_bwtc_bound = (int64_t(*)(uint64_t))dlsym(g_lib, "cjs_bwtc_compress_bound");
     p_bwtc = (int64_t(*)(cjs_ctx*, const uint8_t*, uint64_t, int, uint8_t*, uint64_t, int64_t))dlsym(g_lib, "cjs_bwtc_compress");
-    if (!p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_hufflen || !p_dec || !p_decblk || !p_table || !p_lastsize || !p_fetch || !p_detail || !p_bwtc_dec || !p_bwtc_lastsize || !p_bwtc_fetch || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
+    if (!p_compress_multi || !p_device_count || !p_create || !p_destroy || !p_bound || !p_compress || !p_bwt || !p_bwtlin || !p_sufsort || !p_unbwt || !p_hufflen || !p_dec || !p_decblk || !p_table || !p_lastsize || !p_fetch || !p_detail || !p_bwtc_dec || !p_bwtc_lastsize || !p_bwtc_fetch || !p_bwtc || !p_bwtc_bound) { g_err = "missing symbols"; return false; }
     return true;
 }
 
@@ -106,11 +115,65 @@ static napi_value LastError(napi_env env, napi_callback_info) {
     return r;
 }
 
+static void drop_ctxs() {
+    for (cjs_ctx* c : g_ctxs) p_destroy(c);
+    g_ctxs.clear();
+    g_ctx = nullptr;
+}
+
+static void config_from_env() {
+    if (g_devices.empty()) {
+        const char* e = getenv("COMPRESSJS_AMD_DEVICES");
+        if (e && !strcmp(e, "all")) { const int n = p_device_count(); for (int i = 0; i < n; i++) g_devices.push_back(i); }
+        else if (e) { for (const char* p = e; *p;) { char* q; const long v = strtol(p, &q, 10); if (q == p) break; g_devices.push_back((int)v); p = *q == ',' ? q + 1 : q; } }
+        if (g_devices.empty()) g_devices.push_back(0);
+    }
+    if (!g_blocks) {
+        const char* e = getenv("COMPRESSJS_AMD_BLOCKS");
+        const long v = e ? strtol(e, nullptr, 10) : 0;
+        g_blocks = v >= 1 && v <= 4096 ? (uint32_t)v : 128u;
+    }
+}
+
 static bool ensure_ctx(napi_env env) {
     if (!g_lib) { napi_throw_error(env, nullptr, ("libcompressjs_amd.so not loaded: " + g_err).c_str()); return false; }
-    if (!g_ctx) g_ctx = p_create(0, 32);
-    if (!g_ctx) { throw_code(env, -23, "cjs_create"); return false; }
+    if (g_ctx) return true;
+    config_from_env();
+    for (int d : g_devices) {
+        cjs_ctx* c = p_create(d, g_blocks);
+        if (!c) { drop_ctxs(); throw_code(env, -23, "cjs_create"); return false; }
+        g_ctxs.push_back(c);
+    }
+    g_ctx = g_ctxs[0];
     return true;
+}
+
+// configure(devices: number[] | null, blocksInFlight: number | 0): takes effect for the next call (contexts are rebuilt)
+static napi_value Configure(napi_env env, napi_callback_info info) {
+    size_t argc = 2; napi_value argv[2];
+    napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
+    if (!g_lib) { napi_throw_error(env, nullptr, ("libcompressjs_amd.so not loaded: " + g_err).c_str()); return nullptr; }
+    std::vector<int> devs;
+    bool isarr = false;
+    if (argc >= 1 && napi_is_array(env, argv[0], &isarr) == napi_ok && isarr) {
+        uint32_t n = 0; napi_get_array_length(env, argv[0], &n);
+        for (uint32_t i = 0; i < n; i++) { napi_value v; int32_t d = 0; napi_get_element(env, argv[0], i, &v); napi_get_value_int32(env, v, &d); devs.push_back(d); }
+    }
+    int32_t blocks = 0;
+    if (argc >= 2) napi_get_value_int32(env, argv[1], &blocks);
+    const int have = p_device_count();
+    for (int d : devs) if (d < 0 || d >= have) { napi_throw_range_error(env, nullptr, "configure: no such HIP device"); return nullptr; }
+    if (blocks < 0 || blocks > 4096) { napi_throw_range_error(env, nullptr, "configure: blocksInFlight must be 1..4096"); return nullptr; }
+    drop_ctxs();
+    if (!devs.empty()) g_devices = devs;
+    if (blocks) g_blocks = (uint32_t)blocks;
+    napi_value r; napi_create_int32(env, have, &r);
+    return r;
+}
+
+static napi_value DeviceCount(napi_env env, napi_callback_info) {
+    napi_value r; napi_create_int32(env, g_lib ? p_device_count() : 0, &r);
+    return r;
 }
 
 static napi_value Compress(napi_env env, napi_callback_info info) {
@@ -126,7 +189,9 @@ static napi_value Compress(napi_env env, napi_callback_info info) {
     // staging kept across calls: a fresh malloc would fault in every page the D2H copy touches
     static std::vector<uint8_t> stage;
     if (stage.size() < cap) stage.resize(cap);
-    const int64_t n = p_compress(g_ctx, in, len, level, stage.data(), cap);
+    // several devices configured: segments of the input go round-robin to them (cjs_bz2_compress_multi)
+    const int64_t n = g_ctxs.size() > 1 ? p_compress_multi(g_ctxs.data(), (uint32_t)g_ctxs.size(), in, len, level, stage.data(), cap)
+                                        : p_compress(g_ctx, in, len, level, stage.data(), cap);
     if (n < 0) return throw_code(env, n, "cjs_bz2_compress");
     napi_value out; void* dst;
     napi_create_buffer_copy(env, (size_t)n, stage.data(), &dst, &out);
@@ -348,6 +413,8 @@ static napi_value Init(napi_env env, napi_value exports) {
         {"huffLengths", nullptr, HuffLengths, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"suffixsort", nullptr, SuffixSort, nullptr, nullptr, nullptr, napi_default, nullptr},
         {"bwtcCompress", nullptr, BwtcCompress, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"configure", nullptr, Configure, nullptr, nullptr, nullptr, napi_default, nullptr},
+        {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
     };
     napi_define_properties(env, exports, sizeof d / sizeof d[0], d);
     return exports;

@@ -153,7 +153,20 @@ BWTC.decompressFile = function(inStream, outStream) {               // lib/BWTC.
   return deliver(addon.bwtcDecompress(bytes), outStream);
 };
 
-var out = { version: '0.1.0-mi355x', Bzip2: Object.freeze(Bzip2), BWT: Object.freeze(BWT), BWTC: Object.freeze(BWTC),
+// Not in the reference (which is single-threaded JavaScript): which GPUs Bzip2.compressFile uses and how many bzip2
+// blocks are in flight per GPU.  configure({devices: [0, 1, 2, 3], blocksInFlight: 128}); devices: 'all' = every visible
+// one.  Also settable without code through COMPRESSJS_AMD_DEVICES ("all" | "0,1,...") and COMPRESSJS_AMD_BLOCKS.  With
+// more than one device the input's segments go round-robin to the devices (cjs_bz2_compress_multi, SURVEY.md 8e);
+// the bytes returned are the same.  Returns the number of visible devices.
+function configure(opts) {
+  need();
+  opts = opts || {};
+  var devs = opts.devices;
+  if (devs === 'all') { devs = []; for (var i = 0, n = addon.deviceCount(); i < n; i++) devs.push(i); }
+  return addon.configure(Array.isArray(devs) ? devs : null, opts.blocksInFlight | 0);
+}
+
+var out = { version: '0.2.0-mi355x', configure: configure, deviceCount: function() { need(); return addon.deviceCount(); }, Bzip2: Object.freeze(Bzip2), BWT: Object.freeze(BWT), BWTC: Object.freeze(BWTC),
             // not in the reference's main.js facade; the reference reaches it by path (test/huffman.js:3)
             HuffmanAllocator: Object.freeze(HuffmanAllocator) };
 if (reference) {

@@ -34,4 +34,11 @@ try { cjs.Bzip2.decompressFile(Buffer.from('BZx9')); res.badmagic = 'no throw'; 
 res.sized = cjs.Bzip2.decompressFile(cjs.Bzip2.compressFile(Buffer.from('hello hello')), 11).length;
 res.bwtc_roundtrip = sha(cjs.BWTC.decompressFile(cjs.BWTC.compressFile(lcg, null, 7))) === sha(lcg);
 try { cjs.Bzip2.compressFile(Buffer.from('x'), null, 0); res.badlevel = 'no throw'; } catch (e) { res.badlevel = e.message; }
+// several contexts (here: the same GPU three times) behind the one entry point: same bytes (cjs_bz2_compress_multi)
+res.devices = cjs.deviceCount();
+var big = Buffer.alloc(3000000); for (var q = 0; q < big.length; q++) big[q] = lcg[(q * 7) % n] ^ (q >> 13 & 15);
+var one = sha(cjs.Bzip2.compressFile(big, null, 1));
+cjs.configure({ devices: [0, 0, 0], blocksInFlight: 8 });
+res.multi_same = sha(cjs.Bzip2.compressFile(big, null, 1)) === one;
+cjs.configure({ devices: [0], blocksInFlight: 128 });
 console.log(JSON.stringify(res));

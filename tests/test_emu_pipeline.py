@@ -444,5 +444,17 @@ def _segmented_check():
         for d, lv in ((synth.text_like(1_200_000, 21), 1), (synth.runs_mixed(1_500_000, 6), 1), (np.zeros(3_000_000, np.uint8), 1),
                       (synth.lcg_ascii(700_001, 3), 2), (synth.text_like(380_000, 2), 1)):
             assert _compress((L, h), d, lv) == oracle.bz2_compress(d, lv), (d.size, lv)
+        # the same inputs over three contexts (cjs_bz2_compress_multi: segment k on context k mod 3, windows, bit-shifted
+        # placement, seam bytes, trailer); zeros / runs take its fall-back to one device
+        hs = [L.cjs_create(0, 4) for _ in range(3)]
+        arr = (C.c_void_p * 3)(*hs)
+        for d, lv in ((synth.text_like(1_200_000, 21), 1), (synth.lcg_ascii(700_001, 3), 2), (np.zeros(3_000_000, np.uint8), 1),
+                      (synth.runs_mixed(1_500_000, 6), 1), (synth.text_like(380_000, 2), 1), (synth.enwik_like(900_000, 4), 1)):
+            cap = int(L.cjs_bz2_compress_bound(d.size))
+            out = np.full(cap, 0xAA, np.uint8)                  # stale bytes: the call must write every byte it returns
+            n = L.cjs_bz2_compress_multi(arr, 3, d.ctypes.data, d.size, lv, out.ctypes.data, cap)
+            assert n > 0 and out[:n].tobytes() == oracle.bz2_compress(d, lv), (d.size, lv, n)
+        for x in hs:
+            L.cjs_destroy(x)
     finally:
         L.cjs_destroy(h)

@@ -33,6 +33,25 @@ def test_node_dropin_digests(golden):
     assert r["unbwt"] == "banana"                          # BWT.unbwtransform, lib/BWT.js:352-363
     assert r["stream_len"] > 30
     assert r["badlevel"] == "Invalid block size multiplier"
+    assert r["devices"] >= 1 and r["multi_same"] is True     # configure({devices, blocksInFlight}) -> cjs_bz2_compress_multi
+
+
+def test_reference_acceptance_suite_against_the_dropin():
+    """The reference's OWN mocha files, unchanged - test/bwtest.js, suftest.js, huffman.js, bzip2-basic.js,
+    bzip2-block.js, bzip2-table.js and the bzip2 / bwtc round trips of file.js (all levels x sample0..5) - with
+    require('../') resolving to js/index.js (js/run_reference_tests.js: describe/it stand-in + resolution hook).
+    The files are staged under oracle/_ref/reftests by __graft_entry__.build(); they are not in the repository."""
+    rt = os.path.join(ROOT, "oracle", "_ref", "reftests")
+    if shutil.which("node") is None or not os.path.exists(os.path.join(ROOT, "build", "compressjs_amd.node")):
+        pytest.skip("node or the addon is not available on this box")
+    assert os.path.exists(os.path.join(rt, "test", "bwtest.js")), \
+        "reference test files not staged (run __graft_entry__.build() in the build container)"
+    r = subprocess.run(["node", os.path.join(ROOT, "js", "run_reference_tests.js"), rt], cwd=ROOT, capture_output=True, timeout=1500)
+    out = r.stdout.decode().strip().splitlines()
+    assert out, r.stderr.decode()[-2000:]
+    res = json.loads(out[-1])
+    assert res["failed"] == 0 and r.returncode == 0, res["failures"][:10]
+    assert res["files"] == 7 and res["passed"] >= 150, res                 # 120 file.js round trips + the stage tests
 
 
 def test_cli_round_trip(tmp_path):
