@@ -24,7 +24,7 @@ static int ensure_device() {
 static int32_t bwt_batch_impl(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                               uint8_t* U, uint32_t* pidx, int reps, float* ms_out, int linear = 0,
                               int32_t* SAout = nullptr) {
-    if (!T || !U || !nlen || !pidx || nb == 0 || cap == 0 || cap > (1u << 20) - 1) return CJS_E_ARG;
+    if (!T || !U || !nlen || !pidx || nb == 0 || cap == 0 || cap > (1u << 22) - 1) return CJS_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
     BatchGeom g = make_geom(nb, cap);
@@ -199,7 +199,7 @@ extern "C" int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint
 extern "C" int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                                         int upto, cjs_dbg_stage_out* o) {
     void* dout = nullptr;
-    if (!T || !nlen || !o || nb == 0 || cap == 0 || cap > (1u << 20) - 1) return CJS_E_ARG;
+    if (!T || !nlen || !o || nb == 0 || cap == 0 || cap > (1u << 22) - 1) return CJS_E_ARG;
     int rc = ensure_device();
     if (rc) return rc;
     BatchGeom g = make_geom(nb, cap);

@@ -630,7 +630,7 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
             u32 s, k;
             if (it < K1_HT / 256) { s = pre_s[it]; k = pre_k[it]; }   // own half: prefetched (static index)
             else { s = SA[base + q]; k = rot_key(ISA, n, s, h, hm, mode, B.linear); }
-            ck[e] = ((u32)c.head << 20) | k;
+            ck[e] = ((u32)c.head << 22) | k;                        // head < K1_HT = 2^10, key < n < 2^22
             cv[e] = s;
             cp[e] = (u16)q;
             csz[e] = (u16)size;
@@ -650,7 +650,7 @@ __device__ __forceinline__ void refine_tile(const K1Buf& B, const BatchGeom& g, 
             ns[it] = 0xFFFFFFFFu;
             if (e < m && csz[e] <= K1_SMALL) {
                 const u32 key = ck[e];
-                const u32 gs = e - ((u32)cp[e] - (key >> 20));
+                const u32 gs = e - ((u32)cp[e] - (key >> 22));
                 const u32 ge = gs + csz[e];
                 u32 r = 0;
                 for (u32 j = gs; j < ge; j++) {
@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(1024) void k1_sort_large(K1Buf B, BatchGeom g, u32 
         if (lane == 0) { if (myl) atomicAdd(&s_side[0], myl); if (myg) atomicAdd(&s_side[1], myg); }
         __syncthreads();
         const u32 nlt = s_side[0], ngt = s_side[1];
-        if (nlt <= K1_MAJ_SIDE && ngt <= K1_MAJ_SIDE && (nlt + ngt) * 4u < L) {
+        if (n < (1u << 21) && nlt <= K1_MAJ_SIDE && ngt <= K1_MAJ_SIDE && (nlt + ngt) * 4u < L) {   // (key << 11 | index) needs keys < 2^21
             const u32 neq = L - nlt - ngt;
             u32 runE = 0, runL = 0, runG = 0;
             for (u32 c0 = 0; c0 < L; c0 += 1024) {
@@ -1363,6 +1363,10 @@ __global__ __launch_bounds__(1024) void k1_sort_large(K1Buf B, BatchGeom g, u32 
             seg_radix_pass(KB, SB, KA, SA, L, 0, wh, dtot);
             seg_radix_pass(KA, SA, KB, SB, L, 7, wh, dtot);
             seg_radix_pass(KB, SB, KA, SA, L, 14, wh, dtot);
+            if (n >= (1u << 21)) {                                      // BWT.* entry points on blocks of 2^21 .. 2^22-1 bytes
+                seg_radix_pass(KA, SA, KB, SB, L, 21, wh, dtot);
+                seg_radix_pass(KB, SB, KA, SA, L, 28, wh, dtot);
+            }
         }
         __syncthreads();
         for (u32 i = tid + 1; i < L; i += 1024)
@@ -1610,6 +1614,10 @@ __global__ __launch_bounds__(1024) void k1_sp_large(K1Buf B, BatchGeom g, u32 h,
         seg_radix_pass(KB, SB, KA, SA, len, 0, wh, dtot);
         seg_radix_pass(KA, SA, KB, SB, len, 7, wh, dtot);
         seg_radix_pass(KB, SB, KA, SA, len, 14, wh, dtot);
+        if (n >= (1u << 21)) {
+            seg_radix_pass(KA, SA, KB, SB, len, 21, wh, dtot);
+            seg_radix_pass(KB, SB, KA, SA, len, 28, wh, dtot);
+        }
         // ranks (into SB) and the still-tied sub-groups, 1024 positions at a time
         for (u32 i0 = 0; i0 < len; i0 += 1024) {
             const u32 i = i0 + tid;
@@ -1809,7 +1817,10 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     static const u32 sort_bytes = []() -> u32 { const char* e = getenv("CJS_SORT_BYTES"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 7u; return v < 6u || v > 8u ? 7u : v; }();
     // CJS_FRONT=0: the seven LSD passes below (kept as the reference path for A/B runs); default: the sample-sort
     // front end of k1_front.hip (one partition pass + in-LDS bucket sorts), which always sorts 8 bytes
-    static const bool front = []() { const char* e = getenv("CJS_FRONT"); return !e || atoi(e) != 0; }();
+    // (blocks of more than ~1.1 million bytes - only the BWT.* entry points see them - would overflow most of its
+    // K1F_NB x K1F_C bucket slots: they take the LSD passes)
+    static const bool front_env = []() { const char* e = getenv("CJS_FRONT"); return !e || atoi(e) != 0; }();
+    const bool front = front_env && (u64)max_n * 16u <= (u64)K1F_NB * K1F_C * 9u;
     const u32 d0 = (B.linear || front) ? 8u : sort_bytes;
     const int p0 = front ? 8 : (int)(8u - d0);
     if (front) {

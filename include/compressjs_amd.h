@@ -63,9 +63,10 @@ int32_t cjs_profile_read(cjs_ctx* ctx, float* total_ms, uint32_t* launches, uint
 #define CJS_E_ARG (-22)
 #define CJS_E_NOGPU (-23)
 
-/* The four BWT.* entry points below handle ONE block per call with n <= 2^20 - 1 = 1 048 575 bytes (CJS_E_ARG
- * above that: suffix positions are packed into 20 bits by the refinement kernels; bzip2 blocks are <= 900 000).
- * The reference has no such limit; js/index.js hands larger n to the reference package when it is installed. */
+/* The four BWT.* entry points below handle ONE block per call with n <= 2^22 - 1 = 4 194 303 bytes (CJS_E_ARG
+ * above that: ranks are packed into 22 bits by the refinement kernels; bzip2 blocks are <= 900 000 and the
+ * reference's own tests go up to test/sample5.ref = 2 130 640).  The reference has no such limit; js/index.js
+ * hands larger n to the reference package when it is installed. */
 /* = BWT.bwtransform2(T, U, n, 256) -> pidx            (reference: lib/BWT.js:372-417) */
 int32_t cjs_bwt_cyclic(const uint8_t* T, uint8_t* U, uint32_t n, uint32_t* pidx);
 /* = BWT.bwtransform(T, U, A, n, 256) -> pidx           (reference: lib/BWT.js:328-350, :153-192) */

@@ -75,11 +75,11 @@ Bzip2.table = function(input, callback, multistream) {               // lib/Bzip
 };
 
 var BWT = Object.create(null);
-// The BWT.* entry points sort ONE block per call and take n <= 2^20 - 1 (the bzip2 path never needs more than
-// 900 000; positions are packed into 20 bits in the refinement kernels).  The reference has no such limit, so a
+// The BWT.* entry points sort ONE block per call and take n <= 2^22 - 1 (the bzip2 path never needs more than
+// 900 000, the reference's tests 2 130 640; ranks are packed into 22 bits in the refinement kernels).  The reference has no such limit, so a
 // larger n goes to the reference package when it is installed next to this one, else it is a RangeError that
 // says so (the C ABI reports CJS_E_ARG, -22).
-var BWT_MAX_N = (1 << 20) - 1;
+var BWT_MAX_N = (1 << 22) - 1;
 function tooBig(name, n, args) {
   if (n <= BWT_MAX_N) return false;
   if (reference) return true;

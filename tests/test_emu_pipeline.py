@@ -166,6 +166,18 @@ def test_linear_bwt_and_suffix_array(golden):
         assert p.value == po and np.array_equal(u, uo)
 
 
+def test_bwt_entry_points_above_one_megabyte():
+    """BWT.bwtransform / suffixsort on a block of more than 2^20 bytes (the reference's test/bwtest.js and suftest.js
+    go up to sample5.ref = 2 130 640): ranks packed into 22 bits, the LSD passes instead of the sample-sort front end."""
+    L = _lib.load(stagelib.EMU_SO)
+    d = np.ascontiguousarray(synth.text_like((1 << 20) + 70_001, 9))
+    u = np.zeros(d.size, np.uint8)
+    p = C.c_uint32(0)
+    assert L.cjs_bwt_linear(d.ctypes.data, u.ctypes.data, d.size, C.byref(p)) == 0
+    uo, po = oracle.bwt_linear(d)
+    assert p.value == po and np.array_equal(u, uo)
+
+
 def test_inverse_linear_bwt_by_list_ranking():
     """BWT.unbwtransform (lib/BWT.js:352-363) as counting-sort LF links + list ranking (K6): inverts
     the oracle's bwtransform, and agrees with the oracle's serial LF walk."""
