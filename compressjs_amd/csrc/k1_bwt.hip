@@ -287,11 +287,13 @@ __device__ __forceinline__ u64 sp_desc(u32 b, u32 start, u32 len) {
 // `Hglob`.  Staged per size class in LDS, then appended to the parity-0 lists with one global
 // atomic per class and workgroup.  Every thread of the workgroup must call it.
 __device__ __forceinline__ void emit_group_descriptors(const K1Buf& B, const BatchGeom& g, u32 b, u32 base, u32 n,
-                                                       const u32* hwords, u32 nwords, const u32* Hglob) {
+                                                       const u32* hwords, u32 nwords, const u32* Hglob, u32 classmask = 0xFu) {
     __shared__ u64 stT[K1_HT / 2], stS[K1_HT / 8], stM[K1_HT / 64 + 1], stL[4];
     __shared__ u32 cntc[4], basec[4];
+    __shared__ u32 medrot;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     if (tid < 4) cntc[tid] = 0;
+    if (tid == 0) medrot = 0;
     __syncthreads();
     for (int it = 0; it < K1_HT / 256; it++) {
         const u32 q0 = w * (K1_HT / 4u) + it * 64u;
@@ -333,14 +335,15 @@ __device__ __forceinline__ void emit_group_descriptors(const K1Buf& B, const Bat
         if (starts) {
             const u32 len = endq - q;
             const u64 d = sp_desc(b, base + q, len);
-            if (len <= 8u) stT[atomicAdd(&cntc[0], 1u)] = d;
-            else if (len <= 64u) stS[atomicAdd(&cntc[1], 1u)] = d;
-            else if (len <= K1_MED_MAX) stM[atomicAdd(&cntc[2], 1u)] = d;
-            else { const u32 li = atomicAdd(&cntc[3], 1u); if (li < 4u) stL[li] = d; }
+            if (len <= 8u) { if (classmask & 1u) stT[atomicAdd(&cntc[0], 1u)] = d; }
+            else if (len <= 64u) { if (classmask & 2u) stS[atomicAdd(&cntc[1], 1u)] = d; }
+            else if (len <= K1_MED_MAX) { if (classmask & 4u) { stM[atomicAdd(&cntc[2], 1u)] = d; atomicAdd(&medrot, len); } }
+            else if (classmask & 8u) { const u32 li = atomicAdd(&cntc[3], 1u); if (li < 4u) stL[li] = d; }
         }
     }
     __syncthreads();
     if (tid < 4 && cntc[tid]) basec[tid] = atomicAdd(&B.stats[K1_STAT_LIST + tid], cntc[tid]);
+    if (tid == 0 && medrot) atomicAdd(&B.stats[K1_STAT_MEDROT], medrot);
     __syncthreads();
     for (u32 i = tid; i < cntc[0]; i += 256) if (basec[0] + i < B.listTCap) B.listT[0][basec[0] + i] = stT[i];
     for (u32 i = tid; i < cntc[1]; i += 256) if (basec[1] + i < B.listSCap) B.listS[0][basec[1] + i] = stS[i];
@@ -1096,7 +1099,8 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
 
 // Pairs: one lane each, no LDS.  Workgroup L serves the list region of XCD L & 7 (the region holds the groups
 // of the blocks whose tiles ran on that XCD, in roughly block order, so their text is in that L2).
-__global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 capd) {
+__global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 capd_short, u32 capd_long, u32 medrot_max) {
+    const u32 capd = B.stats[K1_STAT_MEDROT] > medrot_max ? capd_short : capd_long;
     // gridDim.x is a multiple of 8 * K1_DEEP_SUB: workgroup -> (XCD region, sub-region, slice of the sub-region)
     const u32 xr = (blockIdx.x & 7u) * K1_DEEP_SUB + ((blockIdx.x >> 3) & (K1_DEEP_SUB - 1u));
     const u32 r = blockIdx.x / (8u * K1_DEEP_SUB), nr = gridDim.x / (8u * K1_DEEP_SUB);
@@ -1125,7 +1129,8 @@ __global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 c
 // Groups of 3..K1_DEEP_LANE rotations: one lane each, members in a per-lane LDS column.  The lane walks the text
 // of all members until a word differs, sorts them by that word, and goes on depth-first with every run of
 // equal keys (own depth per run) until the group is resolved or a run ties up to capd (left as it is).
-__global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 capd) {
+__global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 capd_short, u32 capd_long, u32 medrot_max) {
+    const u32 capd = B.stats[K1_STAT_MEDROT] > medrot_max ? capd_short : capd_long;
     __shared__ u64 lk[K1_DEEP_LANE * 256];
     __shared__ u32 lv[K1_DEEP_LANE * 256];
     __shared__ u16 ld[K1_DEEP_LANE * 256];
@@ -1193,6 +1198,185 @@ __global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 c
 // (10^8 random 4-byte stores, 1.1 ms) and every doubling round are skipped.
 // ---------------------------------------------------------------------------------------------
 #define K1_COUNT_SLOT 31
+// ---------------------------------------------------------------------------------------------
+// K1-deep, medium groups: groups of 9 .. K1_MED_MAX rotations that the tile kernel leaves (it ranks by counting,
+// O(length^2), and therefore gives groups above 64 rotations two iterations and groups above 256 none) are refined
+// by comparing the text as well, list driven: k1_emit_medium turns the head bitmap into descriptors, every
+// k1_dm_round sorts each listed group by the 8 text bytes at the round's depth (one workgroup per group, bitonic
+// network on 64-bit keys in LDS), marks the new heads, hands sub-groups of 2..8 rotations to the lane kernels'
+// lists and sub-groups of 9 and more to the next round's list.  On the enwik8-shaped stream this is what was left
+// after K1-deep (417 groups, 118 000 rotations per 10^8): with them resolved k1_count_unsorted finds nothing and the
+// whole rank machinery (k1_update_ranks: 10^8 random stores, 1.1 ms) is skipped; on HTML-like input (E8S-A) the
+// medium groups are 30 % of all rotations.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sp_append_class(u64* list, u32* counter, u32 cap, bool pred, u64 d);   // below (sparse phase)
+
+__global__ __launch_bounds__(256) void k1_emit_medium(K1Buf B, BatchGeom g) {
+    u32 b, t;
+    if (!xcd_block_tile(g.nb, b, t)) return;
+    const u32 n = B.nlen[b];
+    const u32 base = t * K1_HT;
+    if (base >= n) return;
+    __shared__ u32 hn[K1_HT / 32 + 4];
+    const u32* HN = B.HN + (size_t)b * g.hstride;
+    if (threadIdx.x < K1_HT / 32 + 4) hn[threadIdx.x] = HN[(base >> 5) + threadIdx.x];
+    __syncthreads();
+    emit_group_descriptors(B, g, b, base, n, hn, K1_HT / 32 + 4, HN, 4u);        // 65 .. K1_MED_MAX only: smaller groups went through
+                                                                                // the tile kernel's iterations: what is left of them ties beyond its cap
+}
+
+__device__ __forceinline__ void cmpx64(u64* ck, u32* cv, u32 lo, u32 hi) {
+    const u64 a = ck[lo], c2 = ck[hi];
+    if (a > c2) {
+        ck[lo] = c2; ck[hi] = a;
+        const u32 va = cv[lo]; cv[lo] = cv[hi]; cv[hi] = va;
+    }
+}
+
+// groups of 9..64 rotations listed for this round: one WAVE each, members in lanes, ranked by counting with the candidates
+// broadcast through v_readlane (as the leaves of k1f_bsort): equal counts = equal keys = one sub-group
+__global__ __launch_bounds__(256) void k1_dm_round_small(K1Buf B, BatchGeom g, u32 depth, u32 medrot_max, int parity) {
+    if (B.stats[K1_STAT_MEDROT] > medrot_max) return;      // see k1_dm_round
+    const u32 tid = threadIdx.x, lane = tid & 63u;
+    u32 cs = B.stats[K1_STAT_LIST + parity * 4 + 1];
+    if (cs > B.listSCap) cs = B.listSCap;
+    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB);
+    const u64 lt = lanemask_lt();
+    for (u32 gi = blockIdx.x * 4u + (tid >> 6); gi < cs; gi += gridDim.x * 4u) {       // wave-uniform
+        const u64 d = B.listS[parity][gi];
+        const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
+        const u32 n = B.nlen[b];
+        const u8* T = B.T + (size_t)b * g.tstride;
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        const u32 dm = depth % n;
+        const bool valid = lane < len;
+        const u32 s = valid ? SA[lane] : 0u;
+        u32 p = s + dm;
+        if (p >= n) p -= n;
+        const u64 ke = valid ? load_be64(T, p) : 0ull;
+        const int clo = (int)(u32)ke, chi = (int)(u32)(ke >> 32);
+        const u64 k0 = ((u64)(u32)__builtin_amdgcn_readlane(chi, 0) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, 0);
+        u32* cnx = B.stats + K1_STAT_LIST + (parity ^ 1) * 4;
+        if (__ballot(valid && ke != k0) == 0ull) {                      // these 8 bytes tie for the whole group: nothing to sort (wave-uniform)
+            sp_append_class(B.listS[parity ^ 1], cnx + 1, B.listSCap, lane == 0, d);
+            continue;
+        }
+        u32 less = 0;
+        for (u32 t = 0; t < len; t++) {
+            const u64 kt = ((u64)(u32)__builtin_amdgcn_readlane(chi, (int)t) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, (int)t);
+            less += kt < ke ? 1u : 0u;
+        }
+        const u64 same = match_any(less, 7, valid);
+        const u32 eqb = (u32)__popcll(same & lt), sublen0 = (u32)__popcll(same);
+        if (valid) SA[less + eqb] = s;
+        const bool head = valid && eqb == 0;                           // this member opens the sub-group at position `less`
+        const u32 sublen = head ? sublen0 : 0u;
+        if (head && less) atomicOr(&B.HN[(size_t)b * g.hstride + ((start + less) >> 5)], 1u << ((start + less) & 31u));
+        const u32 xr = (b & 7u) * K1_DEEP_SUB + ((start >> 10) & (K1_DEEP_SUB - 1u));
+        const u64 dd = ((u64)b << 52) | ((u64)(start + less) << 26) | ((u64)(depth + 8u) << 4) | (u64)(sublen - 1u);
+        sp_append_class(B.listT[0] + (size_t)xr * rcap, &B.deepCnt[xr], rcap, sublen == 2u, dd);
+        sp_append_class(B.listT[1] + (size_t)xr * rcap, &B.deepCnt[8u * K1_DEEP_SUB + xr], rcap, sublen > 2u && sublen <= K1_DEEP_LANE, dd);
+        sp_append_class(B.listS[parity ^ 1], cnx + 1, B.listSCap, sublen > K1_DEEP_LANE, sp_desc(b, start + less, sublen));
+    }
+}
+
+// medrot_max: with more rotations than this in listed groups (HTML-like input: 30 % of all rotations sit in groups of
+// 65..4096 that mostly tie for hundreds of bytes) the text rounds cost more than the rank rounds they would replace
+// (measured on E8S-A: +11 ms against -7 ms), so every kernel of the stage returns at once: decided on the device, the
+// host does not wait for the count.
+__global__ __launch_bounds__(256) void k1_dm_round(K1Buf B, BatchGeom g, u32 depth, u32 medrot_max, int parity) {
+    if (B.stats[K1_STAT_MEDROT] > medrot_max) return;
+    __shared__ u64 ck[K1_MED_MAX];
+    __shared__ u32 cv[K1_MED_MAX];
+    __shared__ u32 hb[K1_MED_MAX / 32 + 2];
+    __shared__ u32 differs;
+    const u32 tid = threadIdx.x;
+    u32 cm = B.stats[K1_STAT_LIST + parity * 4 + 2];
+    if (cm > B.listMCap) cm = B.listMCap;
+    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB);
+    for (u32 gi = blockIdx.x; gi < cm; gi += gridDim.x) {
+        const u64 d = B.listM[parity][gi];
+        const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
+        const u32 n = B.nlen[b];
+        const u8* T = B.T + (size_t)b * g.tstride;
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        const u32 dm = depth % n;
+        for (u32 i = tid; i < len; i += 256) {
+            const u32 s = SA[i];
+            u32 p = s + dm;
+            if (p >= n) p -= n;
+            cv[i] = s;
+            ck[i] = load_be64(T, p);
+        }
+        for (u32 i = tid; i < K1_MED_MAX / 32 + 2; i += 256) hb[i] = 0;
+        if (tid == 0) differs = 0;
+        __syncthreads();
+        {
+            const u64 k0 = ck[0];
+            bool df = false;
+            for (u32 i = tid; i < len; i += 256) df = df || ck[i] != k0;
+            if (df) differs = 1;
+        }
+        __syncthreads();
+        if (!differs) {                                        // these 8 bytes tie for the whole group: nothing to sort, next round
+            u32* cq = B.stats + K1_STAT_LIST + (parity ^ 1) * 4;
+            if (tid < 64) sp_append_class(B.listM[parity ^ 1], cq + 2, B.listMCap, tid == 0, d);
+            __syncthreads();
+            continue;
+        }
+        u32 M = 128;
+        while (M < len) M <<= 1;
+        for (u32 k = 2; k <= M; k <<= 1) {
+            const u32 hk = k >> 1;
+            for (u32 i = tid; i < (M >> 1); i += 256) {
+                const u32 blk = i / hk, off = i - blk * hk;
+                const u32 lo = blk * k + off, hi = blk * k + (k - 1u - off);
+                if (hi < len) cmpx64(ck, cv, lo, hi);
+            }
+            __syncthreads();
+            for (u32 j = k >> 2; j > 0; j >>= 1) {
+                for (u32 i = tid; i < (M >> 1); i += 256) {
+                    const u32 lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
+                    const u32 hi = lo | j;
+                    if (hi < len) cmpx64(ck, cv, lo, hi);
+                }
+                __syncthreads();
+            }
+        }
+        for (u32 i = tid; i <= len; i += 256) {
+            const bool head = i == 0 || i == len || ck[i] != ck[i - 1];
+            if (head) atomicOr(&hb[i >> 5], 1u << (i & 31u));
+        }
+        __syncthreads();
+        u32* HN = B.HN + (size_t)b * g.hstride;
+        const u32 xr = (b & 7u) * K1_DEEP_SUB + ((start >> 10) & (K1_DEEP_SUB - 1u));
+        for (u32 i0 = 0; i0 < len; i0 += 256) {                // uniform trip count (wave-wide appends)
+            const u32 i = i0 + tid;
+            u32 sublen = 0;
+            if (i < len) {
+                SA[i] = cv[i];
+                if ((hb[i >> 5] >> (i & 31u)) & 1u) {          // a head: the sub-group runs to the next head
+                    if (i) atomicOr(&HN[(start + i) >> 5], 1u << ((start + i) & 31u));
+                    u32 wj = i >> 5;
+                    u32 mm = (i & 31u) == 31u ? 0u : (hb[wj] & (0xFFFFFFFEu << (i & 31u)));
+                    while (!mm) mm = hb[++wj];
+                    sublen = wj * 32u + (u32)__ffs((int)mm) - 1u - i;
+                }
+            }
+            // 2..8 rotations: the lane kernels' lists (pairs / small), with the depth they are now known to share
+            const u64 dd = ((u64)b << 52) | ((u64)(start + i) << 26) | ((u64)(depth + 8u) << 4) | (u64)(sublen - 1u);
+            sp_append_class(B.listT[0] + (size_t)xr * rcap, &B.deepCnt[xr], rcap, sublen == 2u, dd);
+            sp_append_class(B.listT[1] + (size_t)xr * rcap, &B.deepCnt[8u * K1_DEEP_SUB + xr], rcap, sublen > 2u && sublen <= K1_DEEP_LANE, dd);
+            // 9 and more: the next round
+            const u64 ds = sp_desc(b, start + i, sublen);
+            u32* c = B.stats + K1_STAT_LIST + (parity ^ 1) * 4;
+            sp_append_class(B.listS[parity ^ 1], c + 1, B.listSCap, sublen > K1_DEEP_LANE && sublen <= 64u, ds);
+            sp_append_class(B.listM[parity ^ 1], c + 2, B.listMCap, sublen > 64u, ds);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void k1_count_unsorted(K1Buf B, BatchGeom g) {
     const u32 b = blockIdx.y, n = B.nlen[b];
     const u32 wi = blockIdx.x * 256u + threadIdx.x;
@@ -1874,10 +2058,32 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         HIP_CHECK_RET(hipMemcpyAsync(B.HX, B.HN, hbytes, hipMemcpyDeviceToDevice, stream));
         if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters, deep_dbg, d0);
         else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg, d0);
+        // medium groups (9 .. K1_MED_MAX rotations) by text, 8 bytes per round; what they shed goes to the lane kernels' lists.
+        // CJS_DEEP_MED = rounds (default 8: depths d0 .. d0 + 56; 0 switches the stage off)
+        static const u32 med_rounds = []() -> u32 { const char* e = getenv("CJS_DEEP_MED"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v > 64u ? 64u : v; }();
+        // the stage (and the long walks of the lane kernels) only when at most 1/32 of the rotations sit in medium groups
+        static const u32 med_div = []() -> u32 { const char* e = getenv("CJS_DEEP_MED_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 32u; return v ? v : 32u; }();
+        const u32 medrot_max = (u32)(total_n / med_div);
+        if (med_rounds) {
+            hipLaunchKernelGGL(k1_emit_medium, gridHX, dim3(256), 0, stream, B, g);
+            const u32 mgrid = g.nb * 16u < 256u ? 256u : (g.nb * 16u > 2048u ? 2048u : g.nb * 16u);
+            for (u32 r = 0; r < med_rounds; r++) {
+                hipLaunchKernelGGL(k1_dm_round, dim3(mgrid), dim3(256), 0, stream, B, g, d0 + 8u * r, medrot_max, (int)(r & 1u));
+                hipLaunchKernelGGL(k1_dm_round_small, dim3(mgrid), dim3(256), 0, stream, B, g, d0 + 8u * r, medrot_max, (int)(r & 1u));
+                hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, (int)(r & 1u));
+            }
+            hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, (int)(med_rounds & 1u));   // groups the last round listed stay marked in the bitmap: the rank rounds find them
+        }
+        // lane kernels: CJS_DEEP_LANE_CAP = bytes a pair / small group is walked before it is left to the rank rounds
+        // (default 4096 in the "few leftovers" regime decided by medrot_max: boilerplate passages of the text streams tie
+        // for up to ~3 KB; on E8S-A the long walks cost +2.2 ms and the pairs still tie)
+        static const u32 lane_cap = []() -> u32 { const char* e = getenv("CJS_DEEP_LANE_CAP"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 4096u; return v > 60000u ? 60000u : v; }();
+        const u32 capd0 = d0 + 8u * deep_iters;
+        const u32 capd = med_rounds && lane_cap > capd0 ? lane_cap : capd0;
         const u32 lane_unit = 8u * K1_DEEP_SUB;              // one workgroup per (XCD region, sub-region) at least
         const u32 lane_grid = g.nb * 32u <= lane_unit ? lane_unit : (g.nb * 32u >= 4096u ? 4096u : (g.nb * 32u + lane_unit - 1u) / lane_unit * lane_unit);
-        hipLaunchKernelGGL(k1_deep_pairs, dim3(lane_grid), dim3(256), 0, stream, B, g, d0 + 8u * deep_iters);
-        hipLaunchKernelGGL(k1_deep_small, dim3(lane_grid), dim3(256), 0, stream, B, g, d0 + 8u * deep_iters);
+        hipLaunchKernelGGL(k1_deep_pairs, dim3(lane_grid), dim3(256), 0, stream, B, g, capd0, capd, medrot_max);
+        hipLaunchKernelGGL(k1_deep_small, dim3(lane_grid), dim3(256), 0, stream, B, g, capd0, capd, medrot_max);
     }
     const bool early = deep && total_n >= sparse_min;
     bool sparse = false, all_sorted = false;
@@ -1910,6 +2116,12 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     bool force_final = false;                  // (decided in tile rounds only: their two counters are exact)
     u64 prev_actpos = 0;                       // rotations in unsorted groups before the current round (0: not known yet)
     if (sparse0) { sparse = true; parity = 0; }
+    if (sparse0 && k1_trace) {
+        u32 hs[4];
+        HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats + K1_STAT_LIST, sizeof hs, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK_RET(hipStreamSynchronize(stream));
+        fprintf(stderr, "[k1] groups left after K1-deep: %u of <= 8 rotations, %u of 9..64, %u of 65..%u, %u larger\n", hs[0], hs[1], hs[2], (u32)K1_MED_MAX, hs[3]);
+    }
     else if (early && !all_sorted) prev_actpos = unsorted0;
     for (u64 h = d0; !all_sorted; h <<= 1) {
         const int mode = (h >= max_n || force_final) ? 1 : 0;      // last round: identical rotations by descending index
