@@ -8,8 +8,9 @@ bzip2 blocks are independent once the input-dependent RLE1 split is known (SURVE
      starts at bit 0 (cjs_bz2_encode_blocks);
   3. one all_gather of (bits, crc_fold, block count) per rank -- 24 bytes each -- gives every
      rank its absolute bit offset; each rank shifts its own segment by (offset mod 8) bits;
-  4. the shifted segments are gathered to rank 0 (RCCL over xGMI; payload = compressed bytes
-     only) which ORs them together at their byte offsets, writes "BZh<level>" and the
+  4. the shifted segments go to rank 0 at their own lengths - grouped send/recv (RCCL has no
+     gatherv), all peers' xGMI links into the root in use at once; payload = compressed bytes
+     only - which ORs them together at their byte offsets, writes "BZh<level>" and the
      end-of-stream magic + combined CRC (lib/Bzip2.js:903-906, 917, 925-927).
 
 The combined CRC is linear over GF(2): S' = rotl^k(S) ^ P with P the shard's fold, so shards
@@ -104,17 +105,25 @@ def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch
     mark("all_gather")
     my_off = offs[rank]
     nbytes = (bits + 7) // 8
-    maxlen = max((b + 7) // 8 for b, _, _ in meta) + 1
-    padded = torch.zeros(maxlen, dtype=torch.uint8, device=dev)
-    ctx.shift_bits(seg, nbytes, my_off % 8, padded)               # one pass (k5_shift_bits); shift_bits() below is the spec
+    shifted = torch.zeros(nbytes + 1, dtype=torch.uint8, device=dev)
+    ctx.shift_bits(seg, nbytes, my_off % 8, shifted)              # one pass (k5_shift_bits); shift_bits() below is the spec
     mark("shift")
-    if world > 1:
-        gl = [torch.zeros(maxlen, dtype=torch.uint8, device=cdev) for _ in range(world)] if rank == 0 else None
-        dist.gather(padded.to(cdev), gl, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    lens = [(b + 7) // 8 + 1 for b, _, _ in meta]                  # every segment travels at its own length (RCCL has no gatherv:
+    if world > 1:                                                 # grouped send/recv, all peers' links into the root used at once)
+        root = dist.get_global_rank(group, 0) if group is not None else 0
         if rank == 0:
+            gl = [shifted] + [torch.empty(lens[r], dtype=torch.uint8, device=cdev) for r in range(1, world)]
+            ops = [dist.P2POp(dist.irecv, gl[r], dist.get_global_rank(group, r) if group is not None else r, group=group)
+                   for r in range(1, world)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
             gl = [t.to(dev) for t in gl]
+        else:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, shifted.to(cdev), root, group=group)]):
+                req.wait()
+            gl = None
     else:
-        gl = [padded]
+        gl = [shifted]
     mark("gather")
     if rank != 0:
         return None

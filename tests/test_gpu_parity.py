@@ -15,6 +15,7 @@ import workloads
 from compressjs_amd import BWT, Bzip2, _lib, synth
 from compressjs_amd.bzip2 import Context
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -412,3 +413,69 @@ def test_deep_refinement_variants_same_bytes(ctx):
     d = synth.enwik_like(24_000_000, 2025)
     a = ctx.compress(d[:2_700_000], 9)
     assert a == oracle.bz2_compress(d[:2_700_000], 9)
+
+
+def test_segmented_host_path_same_bytes(ctx):
+    """cjs_bz2_compress on an input of more than 1.5 batches: segment-wise upload / plan / encode / download
+    (compress_segmented) must give the bytes of the one-piece device-resident path."""
+    import torch
+    d = np.concatenate([synth.text_like(150_000_000, 41), synth.runs_mixed(30_000_000, 9), synth.lcg_ascii(80_000_000, 5)])
+    a = ctx.compress(d, 9)
+    d_in = torch.from_numpy(d).cuda()
+    d_out = torch.zeros((int(ctx.L.cjs_bz2_compress_bound(d.size)) + 3) & ~3, dtype=torch.uint8, device="cuda")
+    n = ctx.compress_device(d_in, d_out, 9)
+    assert n == len(a) and _sha(d_out[:n].cpu().numpy().tobytes()) == _sha(a)
+    assert a[:200_000] == oracle.bz2_compress(d[:3_000_000], 9)[:200_000]
+
+
+def test_multi_context_fan_out_same_bytes():
+    """cjs_bz2_compress_multi (what the Node addon calls with several devices configured): three contexts - here on the
+    same GPU - take the segments round-robin; windows, chained planning, bit-shifted placement, seam bytes, trailer."""
+    from compressjs_amd.bzip2 import compress_multi
+    cs = [Context(0, 16) for _ in range(3)]
+    one = Context(0, 128)
+    try:
+        for d, lv in ((synth.enwik_like(70_000_000, 8), 9), (synth.runs_mixed(40_000_000, 3), 9), (synth.lcg_ascii(9_000_000, 2), 1),
+                      (np.zeros(50_000_000, np.uint8), 9)):
+            assert _sha(compress_multi(cs, d, lv)) == _sha(one.compress(d, lv)), (d.size, lv)
+    finally:
+        for c in cs + [one]:
+            c.close()
+
+
+def _gloo_rank(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from compressjs_amd import synth as sy
+    from compressjs_amd.bzip2 import Context as Cx
+    from compressjs_amd.dist import sharded_compress
+    c = Cx(0, 32)
+    d = np.concatenate([sy.text_like(9_000_000, 21), sy.runs_mixed(2_000_000, 2)])
+    out = sharded_compress(c, torch.from_numpy(d).cuda(), 9)
+    if rank == 0:
+        q.put(out.cpu().numpy().tobytes())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_sharing_the_gpu_real_library():
+    """compressjs_amd/dist.py with the REAL library: two processes on GPU 0, gloo for the collectives (RCCL needs one
+    GPU per rank): plan, block ranges, 24-byte all_gather, seam shift kernel, variable-length send/recv, assembly."""
+    import torch.multiprocessing as mp
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    port = 29700 + os.getpid() % 2000
+    procs = [mctx.Process(target=_gloo_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    d = np.concatenate([synth.text_like(9_000_000, 21), synth.runs_mixed(2_000_000, 2)])
+    assert got == oracle.bz2_compress(d, 9)
