@@ -58,7 +58,8 @@ struct K1Buf {
     u64* fsplit;      // [nb][K1F_NB]       front end: bucket d holds the keys in [fsplit[d-1], fsplit[d])
     u32* fstart;      // [nb][K1F_NB+1]     front end: first suffix-array position of every bucket
     u32* stats;       // [K1_STATS]
-    u32* deepCnt;     // [2 classes][8 XCD regions][K1_DEEP_SUB]  entries in each k1_deep list sub-region
+    u32* deepCnt;     // [2 passes][2 classes][8 XCD regions][K1_DEEP_SUB]  entries in each k1_deep list sub-region
+                      //   (pass 1: what the tile kernel and the medium rounds listed; pass 2: what tied up to the short cap)
     u32* spread;      // [32 rounds][2][K1_SPREAD]  per-round (group starts, rotations in groups), spread over
                       //                            K1_SPREAD words: ~10^5 tiles adding to ONE word cost 1 ms per launch
     uint2* large;     // [largeCap]     (block, start position)

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     const u32 n = B.nlen[b];
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && gid < K1_STATS) B.stats[gid] = 0;
-    if (b == 0) for (u32 i = gid; i < 2u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
+    if (b == 0) for (u32 i = gid; i < 4u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
     if (b == 0) for (u32 i = gid; i < 32u * 2u * K1_SPREAD; i += gridDim.x * blockDim.x) B.spread[i] = 0;
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
@@ -1099,15 +1099,30 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
 
 // Pairs: one lane each, no LDS.  Workgroup L serves the list region of XCD L & 7 (the region holds the groups
 // of the blocks whose tiles ran on that XCD, in roughly block order, so their text is in that L2).
-__global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 capd_short, u32 capd_long, u32 medrot_max) {
-    const u32 capd = B.stats[K1_STAT_MEDROT] > medrot_max ? capd_short : capd_long;
+// PASS2 = false: the lists the tile kernel and the medium rounds filled, walked up to `capd` (the short cap); what still
+// ties there is listed again (second set of regions: listS[cls], counters deepCnt[2 * 8 * K1_DEEP_SUB ..]).
+// PASS2 = true: those survivors with the long cap - only if there are at most `limit` of them (decided here, on the
+// device: tiled / periodic inputs have ALL their rotations in such groups, and walking 4 KB for each costs more than
+// the rank rounds that sort them otherwise: 200 kB of text tiled 29 -> 81 ms when tried).
+template <bool PASS2>
+__device__ __forceinline__ bool deep_pass2_wanted(const K1Buf& B, u32 limit) {
+    if (!PASS2) return true;
+    u32 t = 0;
+    for (u32 i = threadIdx.x & 63u; i < 2u * 8u * K1_DEEP_SUB; i += 64u) t += B.deepCnt[2u * 8u * K1_DEEP_SUB + i];
+    for (u32 off = 32; off > 0; off >>= 1) t += __shfl_xor(t, (int)off);
+    return t <= limit;
+}
+
+template <bool PASS2>
+__global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 capd, u32 limit) {
+    if (!deep_pass2_wanted<PASS2>(B, limit)) return;
     // gridDim.x is a multiple of 8 * K1_DEEP_SUB: workgroup -> (XCD region, sub-region, slice of the sub-region)
     const u32 xr = (blockIdx.x & 7u) * K1_DEEP_SUB + ((blockIdx.x >> 3) & (K1_DEEP_SUB - 1u));
     const u32 r = blockIdx.x / (8u * K1_DEEP_SUB), nr = gridDim.x / (8u * K1_DEEP_SUB);
-    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB);
-    u32 cnt = B.deepCnt[xr];
+    const u32 rcap = (PASS2 ? B.listSCap : B.listTCap) / (8u * K1_DEEP_SUB), rcap2 = B.listSCap / (8u * K1_DEEP_SUB);
+    u32 cnt = B.deepCnt[(PASS2 ? 2u * 8u * K1_DEEP_SUB : 0u) + xr];
     if (cnt > rcap) cnt = rcap;
-    const u64* L = B.listT[0] + (size_t)xr * rcap;
+    const u64* L = (PASS2 ? B.listS[0] : B.listT[0]) + (size_t)xr * rcap;
     for (u32 gi = r * 256u + threadIdx.x; gi < cnt; gi += nr * 256u) {
         const u64 dsc = L[gi];
         const u32 b = DP_B(dsc), start = DP_START(dsc);
@@ -1122,6 +1137,9 @@ __global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 c
         if (deep_walk<2, 8>(T, n, mem, 1u, 2u, d, capd, keys, 1u)) {
             if (keys[0] > keys[1]) { SA[0] = mem[1]; SA[1] = mem[0]; }
             atomicOr(&B.HN[(size_t)b * g.hstride + ((start + 1u) >> 5)], 1u << ((start + 1u) & 31u));
+        } else if (!PASS2) {
+            const u32 idx = atomicAdd(&B.deepCnt[2u * 8u * K1_DEEP_SUB + xr], 1u);
+            if (idx < rcap2) B.listS[0][(size_t)xr * rcap2 + idx] = (dsc & ~((u64)0xFFFFu << 4)) | ((u64)(d < 0xFFFFu ? d : 0xFFFFu) << 4);
         }
     }
 }
@@ -1129,18 +1147,19 @@ __global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 c
 // Groups of 3..K1_DEEP_LANE rotations: one lane each, members in a per-lane LDS column.  The lane walks the text
 // of all members until a word differs, sorts them by that word, and goes on depth-first with every run of
 // equal keys (own depth per run) until the group is resolved or a run ties up to capd (left as it is).
-__global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 capd_short, u32 capd_long, u32 medrot_max) {
-    const u32 capd = B.stats[K1_STAT_MEDROT] > medrot_max ? capd_short : capd_long;
+template <bool PASS2>
+__global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 capd, u32 limit) {
+    if (!deep_pass2_wanted<PASS2>(B, limit)) return;
     __shared__ u64 lk[K1_DEEP_LANE * 256];
     __shared__ u32 lv[K1_DEEP_LANE * 256];
     __shared__ u16 ld[K1_DEEP_LANE * 256];
     const u32 tid = threadIdx.x;
     const u32 xr = (blockIdx.x & 7u) * K1_DEEP_SUB + ((blockIdx.x >> 3) & (K1_DEEP_SUB - 1u));
     const u32 r = blockIdx.x / (8u * K1_DEEP_SUB), nr = gridDim.x / (8u * K1_DEEP_SUB);
-    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB);
-    u32 cnt = B.deepCnt[8u * K1_DEEP_SUB + xr];
+    const u32 rcap = (PASS2 ? B.listSCap : B.listTCap) / (8u * K1_DEEP_SUB), rcap2 = B.listSCap / (8u * K1_DEEP_SUB);
+    u32 cnt = B.deepCnt[(PASS2 ? 3u : 1u) * 8u * K1_DEEP_SUB + xr];
     if (cnt > rcap) cnt = rcap;
-    const u64* L = B.listT[1] + (size_t)xr * rcap;
+    const u64* L = (PASS2 ? B.listS[1] : B.listT[1]) + (size_t)xr * rcap;
     u64* ck = lk + tid;
     u32* cv = lv + tid;
     u16* cd = ld + tid;
@@ -1171,7 +1190,14 @@ __global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 c
             const bool split = len == 2u ? deep_walk<2, 8>(T, n, cv + a * 256u, 256u, len, d, capd, ck + a * 256u, 256u)
                              : len <= 4u ? deep_walk<4, 4>(T, n, cv + a * 256u, 256u, len, d, capd, ck + a * 256u, 256u)
                                          : deep_walk<(int)K1_DEEP_LANE, 2>(T, n, cv + a * 256u, 256u, len, d, capd, ck + a * 256u, 256u);
-            if (!split) { done |= 1u << a; continue; }
+            if (!split) {
+                done |= 1u << a;
+                if (!PASS2) {                                         // ties up to the short cap: listed for the second pass
+                    const u32 idx = atomicAdd(&B.deepCnt[3u * 8u * K1_DEEP_SUB + xr], 1u);
+                    if (idx < rcap2) B.listS[1][(size_t)xr * rcap2 + idx] = ((u64)b << 52) | ((u64)(start + a) << 26) | ((u64)(d < 0xFFFFu ? d : 0xFFFFu) << 4) | (u64)(len - 1u);
+                }
+                continue;
+            }
             for (u32 i = a + 1u; i < e; i++) {                        // insertion sort of (ck, cv)[a .. e)
                 const u64 x = ck[i * 256u];
                 const u32 v = cv[i * 256u];
@@ -1928,7 +1954,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += al256((size_t)g.nb * K1F_NB * 8);                   // fsplit
     tot += al256((size_t)g.nb * (K1F_NB + 1) * 4);             // fstart
     tot += al256(K1_STATS * 4);
-    tot += al256(2 * 8 * K1_DEEP_SUB * 4);                     // deepCnt
+    tot += al256(4 * 8 * K1_DEEP_SUB * 4);                     // deepCnt (two passes)
     tot += al256(32 * 2 * K1_SPREAD * 4);                      // spread
     tot += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     tot += 2 * al256((size_t)((g.nb + 7u) & ~7u) * (g.stride / 2) * 8);       // listT cur/next (also the 8 per-XCD regions of k1_deep)
@@ -1955,7 +1981,7 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.fsplit = (u64*)p; p += al256((size_t)g.nb * K1F_NB * 8);
     B.fstart = (u32*)p; p += al256((size_t)g.nb * (K1F_NB + 1) * 4);
     B.stats = (u32*)p; p += al256(K1_STATS * 4);
-    B.deepCnt = (u32*)p; p += al256(2 * 8 * K1_DEEP_SUB * 4);
+    B.deepCnt = (u32*)p; p += al256(4 * 8 * K1_DEEP_SUB * 4);
     B.spread = (u32*)p; p += al256(32 * 2 * K1_SPREAD * 4);
     B.large = (uint2*)p; p += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     B.largeCap = g.nb * (g.htiles + 1);
@@ -2075,15 +2101,19 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, (int)(med_rounds & 1u));   // groups the last round listed stay marked in the bitmap: the rank rounds find them
         }
         // lane kernels: CJS_DEEP_LANE_CAP = bytes a pair / small group is walked before it is left to the rank rounds
-        // (default 4096 in the "few leftovers" regime decided by medrot_max: boilerplate passages of the text streams tie
-        // for up to ~3 KB; on E8S-A the long walks cost +2.2 ms and the pairs still tie)
+        // (default 4096: boilerplate passages of the text streams tie for up to ~3 KB; 0 = no second pass)
         static const u32 lane_cap = []() -> u32 { const char* e = getenv("CJS_DEEP_LANE_CAP"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 4096u; return v > 60000u ? 60000u : v; }();
         const u32 capd0 = d0 + 8u * deep_iters;
-        const u32 capd = med_rounds && lane_cap > capd0 ? lane_cap : capd0;
         const u32 lane_unit = 8u * K1_DEEP_SUB;              // one workgroup per (XCD region, sub-region) at least
         const u32 lane_grid = g.nb * 32u <= lane_unit ? lane_unit : (g.nb * 32u >= 4096u ? 4096u : (g.nb * 32u + lane_unit - 1u) / lane_unit * lane_unit);
-        hipLaunchKernelGGL(k1_deep_pairs, dim3(lane_grid), dim3(256), 0, stream, B, g, capd0, capd, medrot_max);
-        hipLaunchKernelGGL(k1_deep_small, dim3(lane_grid), dim3(256), 0, stream, B, g, capd0, capd, medrot_max);
+        hipLaunchKernelGGL(k1_deep_pairs<false>, dim3(lane_grid), dim3(256), 0, stream, B, g, capd0, 0u);
+        hipLaunchKernelGGL(k1_deep_small<false>, dim3(lane_grid), dim3(256), 0, stream, B, g, capd0, 0u);
+        if (lane_cap > capd0) {
+            // second pass over what tied up to capd0, with the long cap, when at most 1 rotation group in 256 positions is left
+            const u32 limit = (u32)(total_n / 256u);
+            hipLaunchKernelGGL(k1_deep_pairs<true>, dim3(lane_grid), dim3(256), 0, stream, B, g, lane_cap, limit);
+            hipLaunchKernelGGL(k1_deep_small<true>, dim3(lane_grid), dim3(256), 0, stream, B, g, lane_cap, limit);
+        }
     }
     const bool early = deep && total_n >= sparse_min;
     bool sparse = false, all_sorted = false;
