@@ -10,6 +10,7 @@
 #define K1_STAT_MEDROT 112     // stats[112]: rotations in the groups k1_emit_medium listed (65..K1_MED_MAX rotations each)
 #define K1_STAT_FRONT_BIG 104  // stats[104]: buckets of the sample-sort front end that did not fit LDS
 #define K1_STATS 128
+#define K1_DM_SUB 64u      // sub-lists per class of the medium rounds (one counter each: a single counter serialises millions of appends)
 #define K1_SPREAD 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS
 
@@ -62,6 +63,7 @@ struct K1Buf {
                       //   (pass 1: what the tile kernel and the medium rounds listed; pass 2: what tied up to the short cap)
     u32* spread;      // [32 rounds][2][K1_SPREAD]  per-round (group starts, rotations in groups), spread over
                       //                            K1_SPREAD words: ~10^5 tiles adding to ONE word cost 1 ms per launch
+    u32* dmCnt;       // [2 parities][2 classes (9..64, 65..K1_MED_MAX)][K1_DM_SUB]  entries of the medium rounds' sub-lists
     uint2* large;     // [largeCap]     (block, start position)
     u32 largeCap;
     u64* listT[2];    // sparse phase: descriptors of groups of <= 8 rotations (cur/next)

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && gid < K1_STATS) B.stats[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 4u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
+    if (b == 0 && gid < 4u * K1_DM_SUB) B.dmCnt[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 32u * 2u * K1_SPREAD; i += gridDim.x * blockDim.x) B.spread[i] = 0;
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
@@ -1264,12 +1265,17 @@ __device__ __forceinline__ void cmpx64(u64* ck, u32* cv, u32 lo, u32 hi) {
 __global__ __launch_bounds__(256) void k1_dm_round_small(K1Buf B, BatchGeom g, u32 depth, u32 medrot_max, int parity) {
     if (B.stats[K1_STAT_MEDROT] > medrot_max) return;      // see k1_dm_round
     const u32 tid = threadIdx.x, lane = tid & 63u;
-    u32 cs = B.stats[K1_STAT_LIST + parity * 4 + 1];
-    if (cs > B.listSCap) cs = B.listSCap;
+    // wave W serves sub-list W % K1_DM_SUB (gridDim.x * 4 is a multiple of K1_DM_SUB) and appends to the same sub-list of the next round
+    const u32 W = blockIdx.x * 4u + (tid >> 6), sub = W & (K1_DM_SUB - 1u), capS = B.listSCap / K1_DM_SUB;
+    u32 cs = B.dmCnt[((u32)parity * 2u + 0u) * K1_DM_SUB + sub];
+    if (cs > capS) cs = capS;
+    const u64* Lin = B.listS[parity] + (size_t)sub * capS;
+    u64* LoutS = B.listS[parity ^ 1] + (size_t)sub * capS;
+    u32* coutS = B.dmCnt + (((u32)parity ^ 1u) * 2u + 0u) * K1_DM_SUB + sub;
     const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB);
     const u64 lt = lanemask_lt();
-    for (u32 gi = blockIdx.x * 4u + (tid >> 6); gi < cs; gi += gridDim.x * 4u) {       // wave-uniform
-        const u64 d = B.listS[parity][gi];
+    for (u32 gi = W / K1_DM_SUB; gi < cs; gi += gridDim.x * 4u / K1_DM_SUB) {           // wave-uniform
+        const u64 d = Lin[gi];
         const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
         const u32 n = B.nlen[b];
         const u8* T = B.T + (size_t)b * g.tstride;
@@ -1282,9 +1288,8 @@ __global__ __launch_bounds__(256) void k1_dm_round_small(K1Buf B, BatchGeom g, u
         const u64 ke = valid ? load_be64(T, p) : 0ull;
         const int clo = (int)(u32)ke, chi = (int)(u32)(ke >> 32);
         const u64 k0 = ((u64)(u32)__builtin_amdgcn_readlane(chi, 0) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, 0);
-        u32* cnx = B.stats + K1_STAT_LIST + (parity ^ 1) * 4;
         if (__ballot(valid && ke != k0) == 0ull) {                      // these 8 bytes tie for the whole group: nothing to sort (wave-uniform)
-            sp_append_class(B.listS[parity ^ 1], cnx + 1, B.listSCap, lane == 0, d);
+            sp_append_class(LoutS, coutS, capS, lane == 0, d);
             continue;
         }
         u32 less = 0;
@@ -1302,7 +1307,7 @@ __global__ __launch_bounds__(256) void k1_dm_round_small(K1Buf B, BatchGeom g, u
         const u64 dd = ((u64)b << 52) | ((u64)(start + less) << 26) | ((u64)(depth + 8u) << 4) | (u64)(sublen - 1u);
         sp_append_class(B.listT[0] + (size_t)xr * rcap, &B.deepCnt[xr], rcap, sublen == 2u, dd);
         sp_append_class(B.listT[1] + (size_t)xr * rcap, &B.deepCnt[8u * K1_DEEP_SUB + xr], rcap, sublen > 2u && sublen <= K1_DEEP_LANE, dd);
-        sp_append_class(B.listS[parity ^ 1], cnx + 1, B.listSCap, sublen > K1_DEEP_LANE, sp_desc(b, start + less, sublen));
+        sp_append_class(LoutS, coutS, capS, sublen > K1_DEEP_LANE, sp_desc(b, start + less, sublen));
     }
 }
 
@@ -1310,18 +1315,26 @@ __global__ __launch_bounds__(256) void k1_dm_round_small(K1Buf B, BatchGeom g, u
 // 65..4096 that mostly tie for hundreds of bytes) the text rounds cost more than the rank rounds they would replace
 // (measured on E8S-A: +11 ms against -7 ms), so every kernel of the stage returns at once: decided on the device, the
 // host does not wait for the count.
-__global__ __launch_bounds__(256) void k1_dm_round(K1Buf B, BatchGeom g, u32 depth, u32 medrot_max, int parity) {
+__global__ __launch_bounds__(256) void k1_dm_round(K1Buf B, BatchGeom g, u32 depth, u32 medrot_max, int parity, int flat) {
     if (B.stats[K1_STAT_MEDROT] > medrot_max) return;
     __shared__ u64 ck[K1_MED_MAX];
     __shared__ u32 cv[K1_MED_MAX];
     __shared__ u32 hb[K1_MED_MAX / 32 + 2];
     __shared__ u32 differs;
     const u32 tid = threadIdx.x;
-    u32 cm = B.stats[K1_STAT_LIST + parity * 4 + 2];
-    if (cm > B.listMCap) cm = B.listMCap;
+    // flat: the list k1_emit_medium wrote (one counter: it appends once per tile); else the sub-lists of the previous round:
+    // workgroup L serves sub-list L % K1_DM_SUB (gridDim.x is a multiple of K1_DM_SUB) and appends to the same one of the next round
+    const u32 sub = blockIdx.x & (K1_DM_SUB - 1u), capS = B.listSCap / K1_DM_SUB, capM = B.listMCap / K1_DM_SUB;
+    u32 cm = flat ? B.stats[K1_STAT_LIST + parity * 4 + 2] : B.dmCnt[((u32)parity * 2u + 1u) * K1_DM_SUB + sub];
+    if (cm > (flat ? B.listMCap : capM)) cm = flat ? B.listMCap : capM;
+    const u64* Lin = flat ? B.listM[parity] : B.listM[parity] + (size_t)sub * capM;
+    u64* LoutS = B.listS[parity ^ 1] + (size_t)sub * capS;
+    u64* LoutM = B.listM[parity ^ 1] + (size_t)sub * capM;
+    u32* coutS = B.dmCnt + (((u32)parity ^ 1u) * 2u + 0u) * K1_DM_SUB + sub;
+    u32* coutM = B.dmCnt + (((u32)parity ^ 1u) * 2u + 1u) * K1_DM_SUB + sub;
     const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB);
-    for (u32 gi = blockIdx.x; gi < cm; gi += gridDim.x) {
-        const u64 d = B.listM[parity][gi];
+    for (u32 gi = flat ? blockIdx.x : blockIdx.x / K1_DM_SUB; gi < cm; gi += flat ? gridDim.x : gridDim.x / K1_DM_SUB) {
+        const u64 d = Lin[gi];
         const u32 b = SP_B(d), start = SP_START(d), len = SP_LEN(d);
         const u32 n = B.nlen[b];
         const u8* T = B.T + (size_t)b * g.tstride;
@@ -1345,8 +1358,7 @@ __global__ __launch_bounds__(256) void k1_dm_round(K1Buf B, BatchGeom g, u32 dep
         }
         __syncthreads();
         if (!differs) {                                        // these 8 bytes tie for the whole group: nothing to sort, next round
-            u32* cq = B.stats + K1_STAT_LIST + (parity ^ 1) * 4;
-            if (tid < 64) sp_append_class(B.listM[parity ^ 1], cq + 2, B.listMCap, tid == 0, d);
+            if (tid < 64) sp_append_class(LoutM, coutM, capM, tid == 0, d);
             __syncthreads();
             continue;
         }
@@ -1395,9 +1407,8 @@ __global__ __launch_bounds__(256) void k1_dm_round(K1Buf B, BatchGeom g, u32 dep
             sp_append_class(B.listT[1] + (size_t)xr * rcap, &B.deepCnt[8u * K1_DEEP_SUB + xr], rcap, sublen > 2u && sublen <= K1_DEEP_LANE, dd);
             // 9 and more: the next round
             const u64 ds = sp_desc(b, start + i, sublen);
-            u32* c = B.stats + K1_STAT_LIST + (parity ^ 1) * 4;
-            sp_append_class(B.listS[parity ^ 1], c + 1, B.listSCap, sublen > K1_DEEP_LANE && sublen <= 64u, ds);
-            sp_append_class(B.listM[parity ^ 1], c + 2, B.listMCap, sublen > 64u, ds);
+            sp_append_class(LoutS, coutS, capS, sublen > K1_DEEP_LANE && sublen <= 64u, ds);
+            sp_append_class(LoutM, coutM, capM, sublen > 64u, ds);
         }
         __syncthreads();
     }
@@ -1897,6 +1908,9 @@ __global__ __launch_bounds__(256) void k1_sp_update(K1Buf B, BatchGeom g, int pa
     }
 }
 
+__global__ void k1_dm_reset(K1Buf B, int parity) {            // the sub-list counters of one parity (medium rounds)
+    if (threadIdx.x < 2u * K1_DM_SUB && blockIdx.x == 0) B.dmCnt[(u32)parity * 2u * K1_DM_SUB + threadIdx.x] = 0;
+}
 __global__ void k1_sp_reset(K1Buf B, int parity) {
     if (threadIdx.x < 4 && blockIdx.x == 0) B.stats[K1_STAT_LIST + parity * 4 + threadIdx.x] = 0;
 }
@@ -1955,6 +1969,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += al256((size_t)g.nb * (K1F_NB + 1) * 4);             // fstart
     tot += al256(K1_STATS * 4);
     tot += al256(4 * 8 * K1_DEEP_SUB * 4);                     // deepCnt (two passes)
+    tot += al256(2 * 2 * K1_DM_SUB * 4);                       // dmCnt
     tot += al256(32 * 2 * K1_SPREAD * 4);                      // spread
     tot += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     tot += 2 * al256((size_t)((g.nb + 7u) & ~7u) * (g.stride / 2) * 8);       // listT cur/next (also the 8 per-XCD regions of k1_deep)
@@ -1982,6 +1997,7 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.fstart = (u32*)p; p += al256((size_t)g.nb * (K1F_NB + 1) * 4);
     B.stats = (u32*)p; p += al256(K1_STATS * 4);
     B.deepCnt = (u32*)p; p += al256(4 * 8 * K1_DEEP_SUB * 4);
+    B.dmCnt = (u32*)p; p += al256(2 * 2 * K1_DM_SUB * 4);
     B.spread = (u32*)p; p += al256(32 * 2 * K1_SPREAD * 4);
     B.large = (uint2*)p; p += al256((size_t)g.nb * (g.htiles + 1) * sizeof(uint2));
     B.largeCap = g.nb * (g.htiles + 1);
@@ -2092,13 +2108,15 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const u32 medrot_max = (u32)(total_n / med_div);
         if (med_rounds) {
             hipLaunchKernelGGL(k1_emit_medium, gridHX, dim3(256), 0, stream, B, g);
-            const u32 mgrid = g.nb * 16u < 256u ? 256u : (g.nb * 16u > 2048u ? 2048u : g.nb * 16u);
+            u32 mgrid = g.nb * 16u < 256u ? 256u : (g.nb * 16u > 2048u ? 2048u : g.nb * 16u);
+            mgrid = (mgrid + K1_DM_SUB - 1u) / K1_DM_SUB * K1_DM_SUB;
             for (u32 r = 0; r < med_rounds; r++) {
-                hipLaunchKernelGGL(k1_dm_round, dim3(mgrid), dim3(256), 0, stream, B, g, d0 + 8u * r, medrot_max, (int)(r & 1u));
-                hipLaunchKernelGGL(k1_dm_round_small, dim3(mgrid), dim3(256), 0, stream, B, g, d0 + 8u * r, medrot_max, (int)(r & 1u));
-                hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, (int)(r & 1u));
+                hipLaunchKernelGGL(k1_dm_round, dim3(mgrid), dim3(256), 0, stream, B, g, d0 + 8u * r, medrot_max, (int)(r & 1u), r == 0 ? 1 : 0);
+                if (r) hipLaunchKernelGGL(k1_dm_round_small, dim3(mgrid), dim3(256), 0, stream, B, g, d0 + 8u * r, medrot_max, (int)(r & 1u));
+                hipLaunchKernelGGL(k1_dm_reset, dim3(1), dim3(128), 0, stream, B, (int)(r & 1u));
             }
-            hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, (int)(med_rounds & 1u));   // groups the last round listed stay marked in the bitmap: the rank rounds find them
+            hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0);   // k1_emit_medium's counters; groups the last round listed stay marked in the bitmap
+            hipLaunchKernelGGL(k1_dm_reset, dim3(1), dim3(128), 0, stream, B, (int)(med_rounds & 1u));
         }
         // lane kernels: CJS_DEEP_LANE_CAP = bytes a pair / small group is walked before it is left to the rank rounds
         // (default 4096: boilerplate passages of the text streams tie for up to ~3 KB; 0 = no second pass)
