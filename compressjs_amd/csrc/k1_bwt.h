@@ -7,6 +7,7 @@
 #define K1_STAT_ACTPOS 64   // stats[64..95] : positions still in unsorted groups entering round r
 #define K1_STAT_LIST 96     // stats[96..103]: sparse-phase list counters [parity][4 size classes]
 #define K1_DEEP_SUB 64u     // k1_deep list sub-regions per XCD region (power of two)
+#define K1_STAT_BIGROT 116     // stats[116..123]: rotations in 8-byte groups of more than 64 members, counted by k1f_bsort (8 spread words)
 #define K1_STAT_MEDROT 112     // stats[112]: rotations in the groups k1_emit_medium listed (65..K1_MED_MAX rotations each)
 #define K1_STAT_FRONT_BIG 104  // stats[104]: buckets of the sample-sort front end that did not fit LDS
 #define K1_STATS 128

@@ -815,7 +815,13 @@ __device__ __forceinline__ bool deep_walk(const u8* T, u32 n, const u32* members
 // 20 iterations does not stall on three other waves 20 times, and 16 independent tiles per CU overlap
 // their text loads.
 template <int DHT, int DNT>
-__global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iters, u32 dbg, u32 d0) {
+__global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iters, u32 dbg, u32 d0, u32 bigrot_max) {
+    {   // predictor (decided on the device): with this many rotations in big 8-byte groups (HTML-like input) most ties
+        // are long repeats that 264 bytes of text do not settle, and the stage only costs (E8S-A: 24.5 ms with it, 22.6 without)
+        u32 bg = 0;
+        for (u32 i = 0; i < 8u; i++) bg += B.stats[K1_STAT_BIGROT + i];
+        if (bg > bigrot_max) return;
+    }
     constexpr int DWIN = 2 * DHT, DWW = DWIN / 32 + 2, DCW = DWIN / 32, NW = DNT / 64, SL = DWIN / DNT;
     static_assert(DCW <= 64 && DWW <= DNT, "one wave scans the compact bitmap");
     u32 b, t;
@@ -2053,11 +2059,13 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const int rc = k1_front_run(B, g, max_n, stream);
         if (rc) return rc;
         if (getenv("CJS_K1_TRACE")) {
-            u32 fs[8];
+            u32 fs[20];
             HIP_CHECK_RET(hipMemcpyAsync(fs, B.stats + K1_STAT_FRONT_BIG, sizeof fs, hipMemcpyDeviceToHost, stream));
             HIP_CHECK_RET(hipStreamSynchronize(stream));
-            fprintf(stderr, "[k1] front end: %u oversize buckets; k1f_bsort stage clocks/256 (K1F_TRACE builds): load %u  sample %u  partition %u  leaves %u  flush %u\n",
-                    fs[0], fs[1], fs[2], fs[3], fs[4], fs[5]);
+            u64 bg = 0;
+            for (u32 i = 0; i < 8u; i++) bg += fs[K1_STAT_BIGROT - K1_STAT_FRONT_BIG + i];
+            fprintf(stderr, "[k1] front end: %u oversize buckets, %llu of %llu rotations in 8-byte groups above 64; k1f_bsort stage clocks/256 (K1F_TRACE builds): load %u  sample %u  partition %u  leaves %u  flush %u\n",
+                    fs[0], (unsigned long long)bg, (unsigned long long)g.nb * max_n, fs[1], fs[2], fs[3], fs[4], fs[5]);
         }
     }
     for (int p = p0; p < 8; p++) {
@@ -2098,8 +2106,12 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const bool deep = deep_iters > 0 && !B.linear;
     if (deep) {
         HIP_CHECK_RET(hipMemcpyAsync(B.HX, B.HN, hbytes, hipMemcpyDeviceToDevice, stream));
-        if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters, deep_dbg, d0);
-        else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg, d0);
+        // CJS_DEEP_BIG_DIV: K1-deep's tile kernel returns at once when more than 1/DIV of the rotations sit in 8-byte groups of more
+        // than 64 members (counted by k1f_bsort; with CJS_FRONT=0 the count is 0 and the stage always runs)
+        static const u32 big_div = []() -> u32 { const char* e = getenv("CJS_DEEP_BIG_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();
+        const u32 bigrot_max = (u32)(total_n / big_div);
+        if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters, deep_dbg, d0, bigrot_max);
+        else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg, d0, bigrot_max);
         // medium groups (9 .. K1_MED_MAX rotations) by text, 8 bytes per round; what they shed goes to the lane kernels' lists.
         // CJS_DEEP_MED = rounds (default 8: depths d0 .. d0 + 56; 0 switches the stage off)
         static const u32 med_rounds = []() -> u32 { const char* e = getenv("CJS_DEEP_MED"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v > 64u ? 64u : v; }();

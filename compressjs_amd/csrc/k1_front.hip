@@ -260,6 +260,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort(K1Buf B, BatchGeom g) {
     if (pure || cnt == 1u) {
         for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
         k1f_write_heads(HN, start, end, [&](u32 p) { return p == start; });
+        if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (see k1_run: K1-deep predictor)
         return;
     }
     __shared__ u64 key[K1F_C];
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort(K1Buf B, BatchGeom g) {
         // ---- oversize bucket (unlucky sampling or a moderately heavy key): stable LSD passes through global memory,
         //      one digit byte gathered from the text per pass, ping-pong between the bucket's slices of SB and SA.
         //      Wave 0 scatters row by row (stable by construction); rare, so simple.
-        if (tid == 0) atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
+        if (tid == 0) { atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u); atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt); }
         u32* bufs[2] = {(u32*)SB, SA};
         int cur = 0;
         for (u32 pass = 0; pass < 8u; pass++) {
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort(K1Buf B, BatchGeom g) {
         const u32 m = (u32)__builtin_amdgcn_readfirstlane((int)cnt2[lf]), o = (u32)__builtin_amdgcn_readfirstlane((int)off2[lf]);   // wave-uniform, in SGPRs
         if (m == 0) continue;
         const bool pure2 = K > 1u && lf > 0u && lf + 1u < K && sp2[lf] == sp2[lf - 1u] + 1u;    // one key only
+        if (m > 64u && lane == 0) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], m);            // a leaf this big is (mostly) one key
         if (pure2 || m == 1u) {
             for (u32 j = lane; j < m; j += 64u) SA[o + j] = idx[perm[o + j]];
             if (lane == 0) atomicOr(&hbits[o >> 5], 1u << (o & 31u));
