@@ -5,6 +5,8 @@ struct bwtc_coder;
 extern "C" uint64_t bwtc_bound(uint64_t in_len);
 bwtc_coder* bwtc_begin(uint8_t* out, uint64_t cap, int64_t file_size, int level);
 void bwtc_block(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* used8, const uint16_t* sym, uint32_t nsym);
+void bwtc_block_triples(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* used8, const uint32_t* sylt,
+                        const uint32_t* tot, uint32_t ntri);
 int64_t bwtc_end(bwtc_coder* c);
 
 // Decoder side (BWTC.decompressFile, lib/BWTC.js:141-233): serial range decoder + models on the host;

@@ -250,9 +250,8 @@ bwtc_coder* bwtc_begin(uint8_t* out, uint64_t cap, int64_t file_size, int level)
     return c;
 }
 
-// one block: `used8` = 256-bit set of byte values present, `sym`/`nsym` = RUNA(0)/RUNB(1)/index+1
-// stream of the MTF'd BWT output (no end-of-block symbol), lib/BWTC.js:42-135
-void bwtc_block(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* used8, const uint16_t* sym, uint32_t nsym) {
+// block header: short-block flag + length, primary index, used-symbol tree (lib/BWTC.js:42-79); returns alphabetSize
+static uint32_t bwtc_block_header(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* used8) {
     RangeEnc& rc = c->rc;
     if (length == c->blockSize) rc.encodeFreq(1, 0, 3);                      // :47-49
     else { rc.encodeFreq(1, 1, 3); c->len.encode(rc, length); }              // :51-53
@@ -273,6 +272,14 @@ void bwtc_block(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* u
             rc.encodeFreq(1, v == 0 ? 0 : (v == full ? 2 : 1), 3);
         }
     }
+    return alphabetSize;
+}
+
+// one block: `used8` = 256-bit set of byte values present, `sym`/`nsym` = RUNA(0)/RUNB(1)/index+1
+// stream of the MTF'd BWT output (no end-of-block symbol), lib/BWTC.js:42-135
+void bwtc_block(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* used8, const uint16_t* sym, uint32_t nsym) {
+    RangeEnc& rc = c->rc;
+    const uint32_t alphabetSize = bwtc_block_header(c, length, pidx, used8);
     if (c->level <= 5) {                                                     // :107 `fast`
         static thread_local DefSum dm;
         dm.init(alphabetSize + 1, false);
@@ -282,6 +289,15 @@ void bwtc_block(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* u
     Fenwick m;
     m.init(alphabetSize + 1, 0xFF00, 0x0100);                                // :105-106
     for (uint32_t i = 0; i < nsym; i++) m.encode(rc, sym[i]);                // :109-133
+}
+
+// levels 6..9 with the FenwickModel run on the GPU (k10_bwtc_model.hip): what is left is RangeCoder.encodeFreq
+// (lib/RangeCoder.js:79-89) over the model's (sy_f, lt_f, tot_f) triples, in order
+void bwtc_block_triples(bwtc_coder* c, uint32_t length, uint32_t pidx, const uint32_t* used8, const uint32_t* sylt,
+                        const uint32_t* tot, uint32_t ntri) {
+    RangeEnc& rc = c->rc;
+    (void)bwtc_block_header(c, length, pidx, used8);
+    for (uint32_t i = 0; i < ntri; i++) rc.encodeFreq(sylt[i] & 0xFFFFu, sylt[i] >> 16, tot[i]);
 }
 
 int64_t bwtc_end(bwtc_coder* c) {

@@ -285,6 +285,11 @@ done:
                              // (Huffman optimiser, scans, sparse sort rounds) overlap the
                              // bandwidth-bound stages of the others
 
+// BWTC: what the coder thread needs of one group of sub-batches (kept in the context: fresh 100 MB vectors per call would
+// be page-faulted in by the D2H copies)
+struct BwtcBlockJob { u32 len, pidx, nsym, ntri; u32 used[8]; size_t off; };
+struct BwtcGroupJob { std::vector<BwtcBlockJob> blocks; std::vector<u32> a, t; std::vector<u16> sym; bool busy = false; };
+
 struct cjs_ctx {
     int device;
     hipStream_t stream;        // stream 0: pre-pass, framing, timing events
@@ -317,6 +322,7 @@ struct cjs_ctx {
     DecState* dec;
     float dec_ms;
     std::vector<u8>* bwtc_out;  // result of the last cjs_bwtc_decompress
+    BwtcGroupJob* bwtc_jobs[2]; // double buffer between the GPU stages and the coder thread of cjs_bwtc_compress
 };
 
 extern "C" void cjs_destroy(cjs_ctx* c);
@@ -382,6 +388,8 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
     k1_prof_destroy(c->prof);
     dec_free(c->dec);
     delete c->bwtc_out;
+    delete c->bwtc_jobs[0];
+    delete c->bwtc_jobs[1];
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -934,43 +942,127 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
     const u64 nblocks = (in_len + bs - 1) / bs;
     BatchGeom g = make_geom(c->sub_blocks, bs);
     coder = bwtc_begin(out, out_cap, declared_size, level);
-    std::vector<u32> nl(c->sub_blocks), hpos(c->sub_blocks), hpidx(c->sub_blocks), hused((size_t)c->sub_blocks * 8);
-    std::vector<u16> hA;
+    // levels 6..9: the adaptive FenwickModel of every block runs on the GPU too (K10, one wave per block: a serial
+    // recurrence, ~170 ms per launch whatever the number of blocks), the host keeps the range coder.
+    // CJS_BWTC_GPU_MODEL=0: model on the host as in round 1 (A/B runs).
+    static const bool gpu_model = []() { const char* ev = getenv("CJS_BWTC_GPU_MODEL"); return !ev || atoi(ev) != 0; }();
+    const bool tri = gpu_model && level >= 6;
+    // Sub-batches are processed in GROUPS of one per stream: their GPU stages are issued back to back on different
+    // streams (the K10 launches of a group overlap), then everything the coder needs is copied to host vectors and
+    // handed to the coder thread, which works through group g while the GPU runs group g + 1.
+    typedef BwtcBlockJob BlockJob;
+    typedef BwtcGroupJob GroupJob;
+    for (int i = 0; i < 2; i++) { if (!c->bwtc_jobs[i]) c->bwtc_jobs[i] = new GroupJob(); c->bwtc_jobs[i]->busy = false; }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<GroupJob*> queue;
+    bool done_issuing = false;
+    std::thread coder_thread([&]() {
+        for (;;) {
+            GroupJob* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&]() { return done_issuing || !queue.empty(); });
+                if (queue.empty()) return;
+                job = queue.front();
+                queue.erase(queue.begin());
+            }
+            for (const BlockJob& bj : job->blocks) {
+                if (tri) bwtc_block_triples(coder, bj.len, bj.pidx, bj.used, job->a.data() + bj.off, job->t.data() + bj.off, bj.ntri);
+                else bwtc_block(coder, bj.len, bj.pidx, bj.used, job->sym.data() + bj.off, bj.nsym);
+            }
+            { std::lock_guard<std::mutex> lk(mu); job->busy = false; cv.notify_all(); }
+        }
+    });
+    auto stop_coder = [&]() {
+        { std::lock_guard<std::mutex> lk(mu); done_issuing = true; cv.notify_all(); }
+        if (coder_thread.joinable()) coder_thread.join();
+    };
+#undef TRYR
+#define TRYR(x) if ((e = (x)) != hipSuccess) { stop_coder(); (void)bwtc_end(coder); return CJS_E_HIP - (int)e; }
+    const u32 ns = c->nstreams;
+    std::vector<u32> nl((size_t)c->sub_blocks * ns), hpos((size_t)c->sub_blocks * ns), hpidx((size_t)c->sub_blocks * ns),
+        hused((size_t)c->sub_blocks * ns * 8), hntri((size_t)c->sub_blocks * ns);
+    TRYR(hipStreamSynchronize(st));                                // the input is resident
     TRYR(hipEventRecord(c->ev0, st));
     float gpu_ms = 0.f;
-    for (u64 first = 0; first < nblocks; first += c->sub_blocks) {
-        const u32 nb = (u32)(nblocks - first < c->sub_blocks ? nblocks - first : c->sub_blocks);
-        Pipe P;
-        pipe_carve(P, g, c->ws[0]);
-        P.g.nb = nb;
-        P.k1.largeCap = nb * (g.htiles + 1);
-        P.k1.linear = 1;
-        u32 max_n = 0;
-        for (u32 b = 0; b < nb; b++) {
-            const u64 off = (first + b) * bs;
-            nl[b] = (u32)(in_len - off < bs ? in_len - off : bs);
-            if (nl[b] > max_n) max_n = nl[b];
+    for (u64 first = 0; first < nblocks; first += (u64)c->sub_blocks * ns) {
+        Pipe Ps[CJS_NSTREAMS];
+        u32 nbs[CJS_NSTREAMS] = {0, 0, 0, 0};
+        for (u32 si = 0; si < ns; si++) {
+            const u64 f = first + (u64)si * c->sub_blocks;
+            if (f >= nblocks) break;
+            const u32 nb = (u32)(nblocks - f < c->sub_blocks ? nblocks - f : c->sub_blocks);
+            nbs[si] = nb;
+            hipStream_t ss = c->sub[si];
+            Pipe& P = Ps[si];
+            pipe_carve(P, g, c->ws[si]);
+            P.g.nb = nb;
+            P.k1.largeCap = nb * (g.htiles + 1);
+            P.k1.linear = 1;
+            u32* nls = nl.data() + (size_t)si * c->sub_blocks;
+            u32 max_n = 0;
+            for (u32 b = 0; b < nb; b++) {
+                const u64 off = (f + b) * bs;
+                nls[b] = (u32)(in_len - off < bs ? in_len - off : bs);
+                if (nls[b] > max_n) max_n = nls[b];
+            }
+            // T_ext rows: block bytes followed by zeros (linear mode pads with the smallest symbol)
+            TRYR(hipMemsetAsync(P.T, 0, (size_t)nb * g.tstride, ss));
+            const u32 full = (nls[nb - 1] == bs) ? nb : nb - 1;
+            if (full) TRYR(hipMemcpy2DAsync(P.T, g.tstride, (const u8*)c->din + f * bs, bs, bs, full, hipMemcpyDeviceToDevice, ss));
+            if (full < nb) TRYR(hipMemcpyAsync(P.T + (size_t)full * g.tstride, (const u8*)c->din + (f + full) * bs, nls[nb - 1], hipMemcpyDeviceToDevice, ss));
+            TRYR(hipMemcpyAsync(P.nlen, nls, nb * 4, hipMemcpyHostToDevice, ss));
+            rc = k1_run(P.k1, P.g, max_n, ss);
+            if (!rc) rc = k2_run(P, max_n, ss);
+            if (!rc && tri) rc = k10_model_run(P, P.k1.SB, P.k1.KA, P.ngroups, ss);
+            if (rc) { stop_coder(); (void)bwtc_end(coder); return rc; }
+            const size_t o = (size_t)si * c->sub_blocks;
+            if (tri) TRYR(hipMemcpyAsync(hntri.data() + o, P.ngroups, nb * 4, hipMemcpyDeviceToHost, ss));
+            TRYR(hipMemcpyAsync(hpos.data() + o, P.pos, nb * 4, hipMemcpyDeviceToHost, ss));
+            TRYR(hipMemcpyAsync(hpidx.data() + o, P.pidx, nb * 4, hipMemcpyDeviceToHost, ss));
+            TRYR(hipMemcpyAsync(hused.data() + o * 8, P.used, (size_t)nb * 32, hipMemcpyDeviceToHost, ss));
         }
-        // T_ext rows: block bytes followed by zeros (linear mode pads with the smallest symbol)
-        TRYR(hipMemsetAsync(P.T, 0, (size_t)nb * g.tstride, st));
-        const u32 full = (nl[nb - 1] == bs) ? nb : nb - 1;
-        if (full) TRYR(hipMemcpy2DAsync(P.T, g.tstride, (const u8*)c->din + first * bs, bs, bs, full, hipMemcpyDeviceToDevice, st));
-        if (full < nb) TRYR(hipMemcpyAsync(P.T + (size_t)full * g.tstride, (const u8*)c->din + (first + full) * bs, nl[nb - 1], hipMemcpyDeviceToDevice, st));
-        TRYR(hipMemcpyAsync(P.nlen, nl.data(), nb * 4, hipMemcpyHostToDevice, st));
-        rc = k1_run(P.k1, P.g, max_n, st);
-        if (!rc) rc = k2_run(P, max_n, st);
-        if (rc) { (void)bwtc_end(coder); return rc; }
-        TRYR(hipMemcpyAsync(hpos.data(), P.pos, nb * 4, hipMemcpyDeviceToHost, st));
-        TRYR(hipMemcpyAsync(hpidx.data(), P.pidx, nb * 4, hipMemcpyDeviceToHost, st));
-        TRYR(hipMemcpyAsync(hused.data(), P.used, (size_t)nb * 32, hipMemcpyDeviceToHost, st));
-        TRYR(hipStreamSynchronize(st));
-        for (u32 b = 0; b < nb; b++) {
-            const u32 nsym = hpos[b] - 1;                          // K2 appends bzip2's EOB; BWTC has none
-            hA.resize((size_t)nsym + 1);
-            if (nsym) TRYR(hipMemcpy(hA.data(), P.A + (size_t)b * g.stride, (size_t)nsym * 2, hipMemcpyDeviceToHost));
-            bwtc_block(coder, nl[b], hpidx[b], hused.data() + (size_t)b * 8, hA.data(), nsym);
+        GroupJob* job = nullptr;
+        {   // a buffer the coder thread is done with
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&]() { return !c->bwtc_jobs[0]->busy || !c->bwtc_jobs[1]->busy; });
+            job = !c->bwtc_jobs[0]->busy ? c->bwtc_jobs[0] : c->bwtc_jobs[1];
+            job->busy = true;
         }
+        job->blocks.clear();
+        size_t total = 0;
+        for (u32 si = 0; si < ns && nbs[si]; si++) {
+            TRYR(hipStreamSynchronize(c->sub[si]));
+            const size_t o = (size_t)si * c->sub_blocks;
+            for (u32 b = 0; b < nbs[si]; b++) {
+                BlockJob bj;
+                bj.len = nl[o + b]; bj.pidx = hpidx[o + b];
+                bj.nsym = hpos[o + b] - 1;                         // K2 appends bzip2's EOB; BWTC has none
+                bj.ntri = tri ? hntri[o + b] : 0;
+                memcpy(bj.used, hused.data() + (o + b) * 8, 32);
+                bj.off = total;
+                total += (tri ? bj.ntri : bj.nsym) + 1;
+                job->blocks.push_back(bj);
+            }
+        }
+        if (tri) { if (job->a.size() < total) { job->a.resize(total); job->t.resize(total); } } else if (job->sym.size() < total) job->sym.resize(total);
+        size_t k = 0;
+        for (u32 si = 0; si < ns && nbs[si]; si++)
+            for (u32 b = 0; b < nbs[si]; b++, k++) {
+                const BlockJob& bj = job->blocks[k];
+                Pipe& P = Ps[si];
+                if (tri && bj.ntri) {
+                    TRYR(hipMemcpyAsync(job->a.data() + bj.off, P.k1.SB + (size_t)b * g.stride, (size_t)bj.ntri * 4, hipMemcpyDeviceToHost, c->sub[si]));
+                    TRYR(hipMemcpyAsync(job->t.data() + bj.off, P.k1.KA + (size_t)b * g.stride, (size_t)bj.ntri * 4, hipMemcpyDeviceToHost, c->sub[si]));
+                } else if (!tri && bj.nsym) {
+                    TRYR(hipMemcpyAsync(job->sym.data() + bj.off, P.A + (size_t)b * g.stride, (size_t)bj.nsym * 2, hipMemcpyDeviceToHost, c->sub[si]));
+                }
+            }
+        for (u32 si = 0; si < ns && nbs[si]; si++) TRYR(hipStreamSynchronize(c->sub[si]));
+        { std::lock_guard<std::mutex> lk(mu); queue.push_back(job); cv.notify_all(); }
     }
+    stop_coder();
     TRYR(hipEventRecord(c->ev1, st));
     TRYR(hipStreamSynchronize(st));
     TRYR(hipEventElapsedTime(&gpu_ms, c->ev0, c->ev1));

@@ -234,12 +234,20 @@ static inline void __builtin_amdgcn_s_sleep(int) { emu::yield_(); }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 template <class T> static inline void __hip_atomic_store(T* p, T v, int, int) { *(volatile T*)p = v; }
 template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *(volatile T*)p; }
-// DPP: only wave_shr:1 (0x138) is used by the kernels: lane l reads lane l-1, lane 0 keeps `old`
-static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
-    if (ctrl != 0x138) abort();
+// DPP: wave_shr:1 (0x138): lane l reads lane l-1, lane 0 keeps `old`; row_shr:n (0x111..0x11f): lane l reads lane l-n of
+// its row of 16, lanes whose source falls outside the row keep `old` (bound_ctrl false) or get 0 (bound_ctrl true)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
     const int l = emu::lane();
-    const int v = emu_shfl_(src, l > 0 ? l - 1 : 0);
-    return l > 0 ? v : old;
+    if (ctrl == 0x138) {
+        const int v = emu_shfl_(src, l > 0 ? l - 1 : 0);
+        return l > 0 ? v : old;
+    }
+    if (ctrl >= 0x111 && ctrl <= 0x11f) {
+        const int n = ctrl - 0x110, r = l & 15;
+        const int v = emu_shfl_(src, r >= n ? l - n : l);
+        return r >= n ? v : (bound_ctrl ? 0 : old);
+    }
+    abort();
 }
 template <class T> static inline T __builtin_amdgcn_readfirstlane(T v) {
     unsigned long long act = __ballot(1);

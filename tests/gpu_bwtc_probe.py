@@ -1,11 +1,20 @@
-"""BWTC -9 timing (BASELINE.json configs[4]): python tests/gpu_bwtc_probe.py"""
-import sys, os, time
-sys.path.insert(0, os.getcwd())
-from compressjs_amd import synth
+"""BWTC -9 (BASELINE.json configs[4]) rate, host buffers in and out (not a test): python tests/gpu_bwtc_probe.py [workload] [size]
+CJS_BWTC_GPU_MODEL=0 runs the adaptive model on the host as in round 1."""
+import sys, os, time, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np
+import workloads
 from compressjs_amd.bzip2 import Context
+wl = sys.argv[1] if len(sys.argv) > 1 else 'e8sa'
+n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000
+d = workloads.stream(wl, n)
 ctx = Context(0, 128)
-for n in (20_000_000, 100_000_000):
-    d = synth.text_like(n, 2025)
-    ctx.bwtc_compress(d[:2_000_000], 9)
-    t = time.perf_counter(); o = ctx.bwtc_compress(d, 9); dt = time.perf_counter() - t
-    print('BWTC -9 text %d -> %d bytes: wall %.3f s = %.1f MB/s (GPU stages + serial host range coder; last_ms %.1f)' % (n, len(o), dt, n / dt / 1e6, ctx.last_device_ms), flush=True)
+tt = []
+for _ in range(3):
+    a = time.perf_counter(); out = ctx.bwtc_compress(d, 9); tt.append(time.perf_counter() - a)
+print('BWTC -9 %s %d B -> %d B: %.3f s = %.1f MB/s (GPU stages %.1f ms; model on %s) sha %s' % (
+    wl, n, len(out), min(tt), n / min(tt) / 1e6, ctx.last_device_ms, 'host' if os.environ.get('CJS_BWTC_GPU_MODEL') == '0' else 'GPU',
+    hashlib.sha256(out).hexdigest()[:16]), flush=True)
+if '--roundtrip' in sys.argv:
+    print('roundtrip', ctx.bwtc_decompress(out) == d.tobytes())
