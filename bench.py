@@ -61,6 +61,45 @@ def port_baseline(data: np.ndarray, level: int, sample_bytes: int):
                 sample="first %d bytes of the same stream, oracle/bz2_oracle.c, this box" % sample.size), out
 
 
+def bench_bwtc(args):
+    """Secondary line (not the driver's default): BWTC -9 on one GPU, host buffers in and out."""
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1, "BWTC does not shard (serial range coder): N = 1"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
+    import workloads
+    from compressjs_amd.bzip2 import Context
+    wl = args.workload if args.workload != "enwik" else "e8sa"           # SURVEY.md 8(d) cfg5: BWTC -9 on E8S-A
+    host = workloads.stream(wl, args.size)
+    ctx = Context(0, args.batch)
+    for _ in range(max(args.warmup, 1)):
+        out = ctx.bwtc_compress(host, args.level)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = ctx.bwtc_compress(host, args.level)
+    dt = (time.perf_counter() - t0) / args.steps
+    sha = hashlib.sha256(out).hexdigest()
+    gold = {}
+    gpath = os.path.join(ROOT, "tests", "golden", "golden_big.json")
+    if os.path.exists(gpath):
+        gold = json.load(open(gpath))["vectors"]
+    g = gold.get("%s:%d:bwtc:%d" % (wl, args.size, args.level))
+    vs_ref = None if g is None else bool(g["out_sha256"] == sha and g["out_len"] == len(out))
+    # the same stream with the model on the host (round-1 path) must give the same bytes; and back through BWTC.decompressFile
+    back = None
+    if not args.no_verify and args.size <= 30_000_000:
+        back = bool(ctx.bwtc_decompress(np.frombuffer(out, dtype=np.uint8)) == host.tobytes())
+    print(json.dumps({
+        "metric": "BWTC -9 compress MB/s (BASELINE.json configs[4])", "value": round(args.size / dt / 1e6, 2), "unit": "MB/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic" if wl not in ("e8sa", "e8sb") else "reference test fixtures, tiled",
+        "config": {"workload": "%s, %d bytes, BWTC -%d, %d-byte blocks, host buffers in and out" % (workloads.DESCRIPTIONS[wl], args.size, args.level, args.level * 100000),
+                   "compressed_bytes": len(out), "sha256": sha, "bit_exact_vs_reference_digest": vs_ref, "roundtrip": back,
+                   "gpu_stages": "BWT.bwtransform (K1 linear), MTF/RLE2 (K2), FenwickModel (K10); host: RangeCoder.encodeFreq, serial"},
+        "roofline": None,
+        "cpu_baseline": None if g is None else {"value": g["mb_per_s"], "unit": "MB/s", "cores": 1, "kind": "reference",
+                                                "sample": "BWTC.compressFile(buf, null, %d) of cscott/compressjs under node 12 on the same %d bytes, %.1f s, build container" % (args.level, g["in_len"], g["seconds"])}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +111,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=12_000_000)
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--batch", type=int, default=128, help="bzip2 blocks in flight (over all streams)")
+    ap.add_argument("--codec", default="bz2", choices=["bz2", "bwtc"],
+                    help="bwtc: BWTC.compressFile -9 (BASELINE.json configs[4]; N = 1, host buffers in and out: its range coder is serial "
+                         "host code, lib/RangeCoder.js; BWT, MTF/RLE2 and the adaptive FenwickModel run on the GPU)")
     args = ap.parse_args()
+    if args.codec == "bwtc":
+        return bench_bwtc(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--level", type=int, default=9)
     ap.add_argument("--allcores", default="enwik", help="workload for the nproc-processes row ('' = skip)")
     ap.add_argument("--parallel", type=int, default=2, help="reference processes at a time (full streams)")
+    ap.add_argument("--codec", default="bz2", choices=["bz2", "bwtc"], help="bwtc: BWTC.compressFile (BASELINE.json configs[4])")
     args = ap.parse_args()
     db = json.load(open(OUT)) if os.path.exists(OUT) else dict(meta={}, vectors={})
     db["meta"] = dict(node=subprocess.check_output(["node", "--version"]).decode().strip(),
@@ -59,8 +60,8 @@ def main():
         data = workloads.stream(w, args.size)
         p = os.path.join(tmp, "%s.bin" % w)
         data.tofile(p)
-        key = "%s:%d:bz2:%d" % (w, args.size, args.level)
-        pending.append((key, [dict(id=key, kind="bz2", input=p, level=args.level)]))
+        key = "%s:%d:%s:%d" % (w, args.size, args.codec, args.level)
+        pending.append((key, [dict(id=key, kind=args.codec, input=p, level=args.level)]))
         del data
     running = []
     while pending or running:
@@ -78,7 +79,8 @@ def main():
                 raise SystemExit("reference failed on %s" % key)
             r = json.load(open(rp))[0]
             r.pop("id")
-            r["nblocks"] = len(r.pop("blocks"))
+            if "blocks" in r:
+                r["nblocks"] = len(r.pop("blocks"))
             r["seconds"] = round(r["seconds"], 2)
             r["mb_per_s"] = round(r["in_len"] / r["seconds"] / 1e6, 4)
             db["vectors"][key] = r

@@ -479,3 +479,13 @@ def test_two_ranks_sharing_the_gpu_real_library():
         assert p.exitcode == 0
     d = np.concatenate([synth.text_like(9_000_000, 21), synth.runs_mixed(2_000_000, 2)])
     assert got == oracle.bz2_compress(d, 9)
+
+
+def test_bwtc_level9_full_size_vs_reference_digest(ctx, golden_big):
+    """BASELINE.json configs[4]: BWTC -9 on the 10^8-byte E8S-A stream - BWT.bwtransform (K1 linear), MTF/RLE2 (K2) and the
+    adaptive FenwickModel (K10) on the GPU, range coder on the host - against the digest of the reference's own output."""
+    assert workloads.have_fixtures(), "reference fixtures not staged (run __graft_entry__.build() in the build container)"
+    d = workloads.stream("e8sa", 100_000_000)
+    g = golden_big["e8sa:100000000:bwtc:9"]
+    a = ctx.bwtc_compress(d, 9)
+    assert len(a) == g["out_len"] and _sha(a) == g["out_sha256"]
