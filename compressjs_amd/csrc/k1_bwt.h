@@ -17,14 +17,15 @@
 
 // sample-sort front end (k1_front.hip)
 #ifndef K1F_NB
-#define K1F_NB 1024         // buckets per block (power of two; measured: 512 x 4096-rotation buckets 8.5 ms, 1024 x 2048 4.1 ms for k1f_bsort)
+#define K1F_NB 2048         // buckets per block (power of two; k1f_bsort / k1f_hist ms per 10^8 rotations: 512 buckets x 4096-rotation slots 8.5 / 0.36,
+                            // 1024 x 2048 3.40 / 0.49, 2048 x 1024 2.72 / 0.64: smaller LDS footprint = more workgroups per CU for a latency-bound kernel)
 #endif
 #ifndef K1F_OVS
-#define K1F_OVS 16          // samples per bucket
+#define K1F_OVS 8           // samples per bucket (K1F_NB * K1F_OVS u64 keys are sorted in LDS by one workgroup: 128 KB)
 #endif
 #define K1F_S (K1F_NB * K1F_OVS)
 #ifndef K1F_C
-#define K1F_C 2048          // rotations a bucket-sort workgroup holds in LDS
+#define K1F_C 1024          // rotations a bucket-sort workgroup holds in LDS
 #endif
 #define K1F_PT 8192         // rotations per partition tile
 

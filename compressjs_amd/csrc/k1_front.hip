@@ -125,6 +125,7 @@ __global__ __launch_bounds__(1024) void k1f_hist(K1Buf B, BatchGeom g, u32 ptile
 
 // per block: bucket starts (fstart[0..K1F_NB], fstart[K1F_NB] = n) and tileHist[t][d] <- first write position
 // of tile t in bucket d
+#if K1F_NB <= 1024
 __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptiles) {
     const u32 b = blockIdx.x;
     const u32 n = B.nlen[b];
@@ -162,6 +163,48 @@ __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptile
         run += c;
     }
 }
+
+#else
+// more buckets than threads: thread t owns buckets t, t + 1024, ...
+__global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptiles) {
+    const u32 b = blockIdx.x;
+    const u32 n = B.nlen[b];
+    const u32 nt = (n + K1F_PT - 1) / K1F_PT;
+    constexpr u32 R = K1F_NB / 1024;
+    __shared__ u32 sh[20];
+    const u32 tid = threadIdx.x;
+    u32* hist = B.tileHist + (size_t)b * ptiles * K1F_NB;
+    u32 sum[R], base[R];
+#pragma unroll
+    for (u32 r = 0; r < R; r++) {
+        const u32 d = tid + r * 1024u;
+        u32 a = 0;
+#pragma unroll 8
+        for (u32 t = 0; t < nt; t++) a += hist[(size_t)t * K1F_NB + d];
+        sum[r] = a;
+    }
+    u32 slab = 0;
+#pragma unroll
+    for (u32 r = 0; r < R; r++) {
+        u32 total;
+        base[r] = slab + block_excl_scan_1024(sum[r], sh, &total);
+        slab += total;
+        B.fstart[(size_t)b * (K1F_NB + 1) + tid + r * 1024u] = base[r];
+    }
+    if (tid == 0) B.fstart[(size_t)b * (K1F_NB + 1) + K1F_NB] = n;
+#pragma unroll
+    for (u32 r = 0; r < R; r++) {
+        const u32 d = tid + r * 1024u;
+        u32 run = base[r];
+#pragma unroll 8
+        for (u32 t = 0; t < nt; t++) {
+            const u32 c = hist[(size_t)t * K1F_NB + d];
+            hist[(size_t)t * K1F_NB + d] = run;
+            run += c;
+        }
+    }
+}
+#endif
 
 __global__ __launch_bounds__(1024) void k1f_scatter(K1Buf B, BatchGeom g, u32 ptiles) {
     u32 b, t;

@@ -436,7 +436,7 @@ def _front_check(variant):
 
 def test_segmented_host_pipeline():
     """cjs_bz2_compress on inputs longer than 1.5 segments: planned and encoded segment by segment (upload / encode /
-    download overlapped by two helper threads).  CJS_SEG_BYTES=250000 makes a segment ~2.5 level-1 blocks, so the
+    download overlapped by two helper threads).  CJS_SEG_BYTES=120000 makes a segment ~1.2 level-1 blocks, so the
     "drop the last block and restart there" seam, the segment-doubling path (runs: one block swallows a segment) and the
     incremental download all run; the stream must equal the oracle's."""
     import subprocess
@@ -444,7 +444,7 @@ def test_segmented_host_pipeline():
     code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'));"
             "sys.path.insert(0, os.path.join(%r, 'tests', 'golden'));"
             "import test_emu_pipeline as t; t._segmented_check()" % (ROOT, ROOT, ROOT))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CJS_SEG_BYTES="250000"), capture_output=True,
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CJS_SEG_BYTES="120000"), capture_output=True,
                        text=True, timeout=3000)
     assert r.returncode == 0, r.stdout + r.stderr
 
@@ -453,15 +453,14 @@ def _segmented_check():
     L = _lib.load(stagelib.build_emu())
     h = L.cjs_create(0, 4)
     try:
-        for d, lv in ((synth.text_like(1_200_000, 21), 1), (synth.runs_mixed(1_500_000, 6), 1), (np.zeros(3_000_000, np.uint8), 1),
-                      (synth.lcg_ascii(700_001, 3), 2), (synth.text_like(380_000, 2), 1)):
+        for d, lv in ((synth.text_like(450_000, 21), 1), (synth.runs_mixed(400_000, 6), 1), (np.zeros(400_000, np.uint8), 1),
+                      (synth.lcg_ascii(300_001, 3), 1), (synth.text_like(185_000, 2), 1)):
             assert _compress((L, h), d, lv) == oracle.bz2_compress(d, lv), (d.size, lv)
         # the same inputs over three contexts (cjs_bz2_compress_multi: segment k on context k mod 3, windows, bit-shifted
         # placement, seam bytes, trailer); zeros / runs take its fall-back to one device
         hs = [L.cjs_create(0, 4) for _ in range(3)]
         arr = (C.c_void_p * 3)(*hs)
-        for d, lv in ((synth.text_like(1_200_000, 21), 1), (synth.lcg_ascii(700_001, 3), 2), (np.zeros(3_000_000, np.uint8), 1),
-                      (synth.runs_mixed(1_500_000, 6), 1), (synth.text_like(380_000, 2), 1), (synth.enwik_like(900_000, 4), 1)):
+        for d, lv in ((synth.text_like(450_000, 21), 1), (np.zeros(400_000, np.uint8), 1), (synth.enwik_like(400_000, 4), 1)):
             cap = int(L.cjs_bz2_compress_bound(d.size))
             out = np.full(cap, 0xAA, np.uint8)                  # stale bytes: the call must write every byte it returns
             n = L.cjs_bz2_compress_multi(arr, 3, d.ctypes.data, d.size, lv, out.ctypes.data, cap)
