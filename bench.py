@@ -10,8 +10,8 @@ One "step" = one complete bzip2 -9 compression (Bzip2.compressFile equivalent, l
 when the timed region starts, complete .bz2 stream resident in HBM (rank 0) when it ends.  Workloads
 (tests/workloads.py): enwik (default: synthetic enwik8-shaped text with phrase reuse), e8sa (SURVEY.md 8d E8S-A:
 the reference's test/sample5.ref || sample4.ref tiled), lcg (configs[3]: random printable ASCII), text, e8sb.
-Weak scaling: N GPUs compress an N x 10^8-byte stream; blocks are sharded, the encoded segments are gathered
-to rank 0 (compressjs_amd/dist.py).  Prints ONE JSON line (rank 0).
+Weak scaling: N GPUs compress an N x 10^8-byte stream; every rank holds its 10^8-byte slice (+ a 3.6 MB margin) only,
+planning is chained through the ranks, the encoded segments are gathered to rank 0 (compressjs_amd/dist.py).  Prints ONE JSON line (rank 0).
 
 What the line carries besides the driver's contract:
   config.bit_exact_vs_reference_digest   sha256 of the WHOLE stream == what the reference itself (node 12) produced
@@ -139,11 +139,16 @@ def main():
 
     import workloads
     from compressjs_amd.bzip2 import Context
-    from compressjs_amd.dist import sharded_compress
+    from compressjs_amd.dist import margin_bytes, sharded_compress_sliced, slice_bounds
 
     total = args.size * world
-    host = workloads.stream(args.workload, total)
-    d_in = torch.from_numpy(host).to(dev)
+    host = workloads.stream(args.workload, total)              # every rank can name the bytes; only its slice goes to its GPU
+    if world == 1:
+        d_in = torch.from_numpy(host).to(dev)
+    else:
+        lo, hi = slice_bounds(total, rank, world)
+        wlo = max(0, lo - margin_bytes(args.level))            # the slice + the tail of the previous rank's slice
+        d_in = torch.from_numpy(host[wlo:hi]).to(dev)
     ctx = Context(local, args.batch)
     bound = int(ctx.L.cjs_bz2_compress_bound(total))
     d_out = torch.zeros((bound + 3) & ~3, dtype=torch.uint8, device=dev)
@@ -156,7 +161,7 @@ def main():
             n = ctx.compress_device(d_in, d_out, args.level)
             return d_out[:n]
         seg.zero_()
-        return sharded_compress(ctx, d_in, args.level, seg=seg)
+        return sharded_compress_sliced(ctx, d_in, wlo, total, args.level, seg=seg, d_all=lambda: torch.from_numpy(host).to(dev))
 
     for _ in range(args.warmup):
         out = step()
@@ -202,8 +207,9 @@ def main():
             # the whole stream through the GPU decoder (K7-K9), compared on the device
             back = torch.empty(total + 64, dtype=torch.uint8, device=dev)
             nback = ctx.decompress_device(out, back)
-            verified = verified and nback == total and bool(torch.equal(back[:total], d_in[:total]))
-            del back
+            whole = d_in if world == 1 else torch.from_numpy(host).to(dev)
+            verified = verified and nback == total and bool(torch.equal(back[:total], whole[:total]))
+            del back, whole
             # localiser: the leading blocks bit for bit against the oracle (says WHICH block differs if the digest does)
             port, ref = port_baseline(host, args.level, min(args.cpu_sample, total))
             nfull = (min(args.cpu_sample, total) // (args.level * 100000)) - 1

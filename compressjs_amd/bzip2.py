@@ -141,6 +141,10 @@ class Context:
         return _lib.check(self.L.cjs_bz2_plan(self.h, d_in.data_ptr(), d_in.numel(), int(level)),
                           "cjs_bz2_plan")
 
+    def plan_block_start(self, k: int) -> int:
+        """First input byte (relative to the planned input) of block k of the current plan."""
+        return _lib.check(self.L.cjs_bz2_plan_block_start(self.h, int(k)), "cjs_bz2_plan_block_start")
+
     def encode_blocks(self, first: int, count: int, d_seg):
         """Encode blocks [first, first+count) of the planned input into d_seg (bit 0 aligned).
         Returns (bits, crc_fold, n_blocks)."""

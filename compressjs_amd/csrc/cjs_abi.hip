@@ -883,6 +883,16 @@ extern "C" int64_t cjs_bz2_plan(cjs_ctx* c, const void* d_in, uint64_t in_len, i
 #undef TRYR
 }
 
+// first input byte (relative to the planned input) of block k of the current plan; k == number of blocks: the input length
+extern "C" int64_t cjs_bz2_plan_block_start(cjs_ctx* c, uint32_t k) {
+    if (!c || !c->plan_level || k > c->plan_blocks) return CJS_E_ARG;
+    if (k == c->plan_blocks) return (int64_t)c->plan.in_len;
+    if (hipSetDevice(c->device) != hipSuccess) return CJS_E_NOGPU;
+    uint64_t v = 0;
+    const hipError_t e = hipMemcpy(&v, c->plan.blkStart + k, 8, hipMemcpyDeviceToHost);
+    return e == hipSuccess ? (int64_t)v : CJS_E_HIP - (int)e;
+}
+
 extern "C" int64_t cjs_bz2_encode_blocks(cjs_ctx* c, uint32_t first, uint32_t count, void* d_seg,
                                          uint64_t seg_cap, uint32_t* crc_fold, uint32_t* n_done) {
     if (!c || !d_seg || !c->plan_level || ((uintptr_t)d_seg & 3) || seg_cap < 64) return CJS_E_ARG;

@@ -62,31 +62,9 @@ def trailer_bytes(bit_pos: int, crc: int):
     return first, v.to_bytes(nbytes, "big"), (end + pad) // 8
 
 
-def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch.Tensor = None):
-    """Compress d_in (the WHOLE stream, resident on every rank) with the blocks sharded over the
-    ranks of `group`.  Returns the complete .bz2 stream as a uint8 tensor on rank 0 (None on
-    the other ranks)."""
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    dev = d_in.device
-    trace = [] if os.environ.get("CJS_DIST_TRACE") else None
-
-    def mark(name):
-        if trace is not None:
-            if dev.type == "cuda":
-                torch.cuda.synchronize(dev)
-            trace.append((name, time.perf_counter()))
-
-    mark("start")
-    nblocks = ctx.plan(d_in, level)
-    mark("plan")
-    first, count = block_range(nblocks, rank, world)
-    if seg is None:
-        per = (nblocks + world - 1) // world
-        seg_cap = per * (level * 100000 * 2 + 32768) + 4096
-        seg = torch.zeros(seg_cap, dtype=torch.uint8, device=dev)
-    bits, fold, cnt = ctx.encode_blocks(first, count, seg)
-    mark("encode")
+def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
+    """Shared tail of both drivers: 24-byte all_gather -> bit offsets and CRC fold; shift own segment; variable-length
+    send/recv to rank 0; rank 0 ORs the segments, writes header and trailer.  Returns the stream on rank 0, else None."""
     # collectives run on the tensors' own device with RCCL ("nccl"); with the gloo backend (CPU tests,
     # or several ranks sharing one GPU) they are staged through host memory
     cdev = dev if (world == 1 or dist.get_backend(group) != "gloo") else torch.device("cpu")
@@ -138,6 +116,115 @@ def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch
     tb = torch.tensor(list(tbytes), dtype=torch.uint8, device=dev)
     final[toff:toff + tb.numel()] |= tb
     mark("assemble")
+    return final[:total]
+
+
+def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch.Tensor = None):
+    """Compress d_in (the WHOLE stream, resident on every rank) with the blocks sharded over the
+    ranks of `group`.  Returns the complete .bz2 stream as a uint8 tensor on rank 0 (None on
+    the other ranks)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    dev = d_in.device
+    trace = [] if os.environ.get("CJS_DIST_TRACE") else None
+
+    def mark(name):
+        if trace is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            trace.append((name, time.perf_counter()))
+
+    mark("start")
+    nblocks = ctx.plan(d_in, level)
+    mark("plan")
+    first, count = block_range(nblocks, rank, world)
+    if seg is None:
+        per = (nblocks + world - 1) // world
+        seg_cap = per * (level * 100000 * 2 + 32768) + 4096
+        seg = torch.zeros(seg_cap, dtype=torch.uint8, device=dev)
+    bits, fold, cnt = ctx.encode_blocks(first, count, seg)
+    mark("encode")
+    out = _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark)
     if trace is not None:
         print("[dist] " + ", ".join("%s %.2f ms" % (n, (t - trace[i][1]) * 1e3) for i, (n, t) in enumerate(trace[1:])), flush=True)
-    return final[:total]
+    return out
+
+
+def slice_bounds(total: int, rank: int, world: int):
+    """Byte range [lo, hi) of the stream that rank `rank` holds in the sliced driver."""
+    per = (total + world - 1) // world
+    return min(rank * per, total), min((rank + 1) * per, total)
+
+
+def margin_bytes(level: int) -> int:
+    """Bytes of the previous rank's slice a rank needs in front of its own (its first block starts in there)."""
+    return 4 * level * 100000
+
+
+def sharded_compress_sliced(ctx, d_win: torch.Tensor, win_lo: int, total: int, level: int, group=None,
+                            seg: torch.Tensor = None, d_all=None):
+    """The same stream as sharded_compress, but every rank holds only ITS slice of the input ("each GPU:
+    H2D its input slice"): d_win = bytes [win_lo, hi) of the stream with hi = slice_bounds(...)[1] and
+    win_lo = max(0, lo - margin_bytes(level)) - the slice plus the tail of the previous rank's slice.
+
+    Planning is chained through the ranks exactly as in cjs_bz2_compress_multi: rank r receives s_r, the first byte of
+    its first block (8 bytes from rank r-1, sent as soon as THAT rank has planned, K0's pre-pass, not encoded), plans
+    [s_r, hi) as an input of its own - a bzip2 block starts with a fresh RLE1 state (lib/Bzip2.js:636-667) -, sends
+    s_(r+1) = the start of its last, incomplete block on, and encodes the others.  The rest (24-byte all_gather, seam
+    shift, variable-length send/recv, assembly) is shared with sharded_compress.  When a block reaches further back than
+    the margin or swallows a whole slice (run-heavy input), all ranks fall back to the replicated driver on `d_all`
+    (callable returning the whole stream as a device tensor, or None: then RuntimeError)."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    dev = d_win.device
+    trace = [] if os.environ.get("CJS_DIST_TRACE") else None
+
+    def mark(name):
+        if trace is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            trace.append((name, time.perf_counter()))
+
+    mark("start")
+    lo, hi = slice_bounds(total, rank, world)
+    cdev = dev if (world == 1 or dist.get_backend(group) != "gloo") else torch.device("cpu")
+    grank = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    BAD = -1
+    s = 0
+    if rank > 0:
+        t = torch.zeros(1, dtype=torch.int64, device=cdev)
+        dist.recv(t, src=grank(rank - 1), group=group)
+        s = int(t.item())
+    bad = s == BAD or (rank > 0 and (s < win_lo or s > hi))
+    keep, nxt = 0, BAD
+    if not bad:
+        nb = ctx.plan(d_win[s - win_lo:], level) if hi > s else 0
+        if hi < total:
+            if nb < 2:
+                bad = True                                   # one block swallowed the slice
+            else:
+                keep = nb - 1
+                nxt = s + ctx.plan_block_start(keep)
+        else:
+            keep, nxt = nb, total
+    if rank + 1 < world:
+        dist.send(torch.tensor([BAD if bad else nxt], dtype=torch.int64, device=cdev), dst=grank(rank + 1), group=group)
+    mark("plan chain")
+    flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=cdev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        if d_all is None:
+            raise RuntimeError("sliced sharding does not apply to this input (a block reaches beyond the margin); use sharded_compress")
+        return sharded_compress(ctx, d_all(), level, group=group)
+    if seg is None:
+        seg = torch.zeros(((hi - lo) + margin_bytes(level)) * 3 // 2 + (1 << 20), dtype=torch.uint8, device=dev)
+    if keep:
+        bits, fold, cnt = ctx.encode_blocks(0, keep, seg)
+    else:
+        bits, fold, cnt = 0, 0, 0
+    mark("encode")
+    out = _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark)
+    if trace is not None:
+        print("[dist] " + ", ".join("%s %.2f ms" % (n, (t - trace[i][1]) * 1e3) for i, (n, t) in enumerate(trace[1:])), flush=True)
+    return out

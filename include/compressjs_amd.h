@@ -48,6 +48,10 @@ int64_t cjs_bwtc_compress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int 
  *                  returns its length in BITS; *crc_fold = XOR_i rotl^(count-1-i)(blockCRC_i).
  *                  count is clamped to the blocks that exist (0xFFFFFFFF = "all remaining"). */
 int64_t cjs_bz2_plan(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level);
+/* first input byte, relative to the planned input, of block k of the current plan (k == block count: its length).  A
+ * driver that holds only a slice of the stream plans from a block start, drops the last, incomplete block and tells the
+ * next slice where that block started (compressjs_amd/dist.py, cjs_bz2_compress_multi). */
+int64_t cjs_bz2_plan_block_start(cjs_ctx* ctx, uint32_t k);
 int64_t cjs_bz2_encode_blocks(cjs_ctx* ctx, uint32_t first, uint32_t count, void* d_seg,
                               uint64_t seg_cap, uint32_t* crc_fold, uint32_t* n_done);
 /* Device time (HIP events on the context's stream) and block count of the last compress call. */

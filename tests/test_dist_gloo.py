@@ -28,8 +28,16 @@ def _worker(rank, world, port, q):
     data = np.concatenate([synth.text_like(230000, 21), synth.runs_mixed(40000, 2)])
     d_in = torch.from_numpy(data.copy())
     out = sharded_compress(ctx, d_in, 1)
+    # the sliced driver: every rank holds its slice + margin only; then an input whose blocks swallow slices (fallback)
+    from compressjs_amd.dist import margin_bytes, sharded_compress_sliced, slice_bounds
+    outs = []
+    for dd in (data, np.concatenate([synth.lcg_ascii(150000, 4), np.zeros(900000, np.uint8)])):
+        lo, hi = slice_bounds(dd.size, rank, world)
+        wlo = max(0, lo - margin_bytes(1))
+        o2 = sharded_compress_sliced(ctx, torch.from_numpy(dd[wlo:hi].copy()), wlo, dd.size, 1, d_all=lambda: torch.from_numpy(dd.copy()))
+        outs.append(o2.numpy().tobytes() if rank == 0 else None)
     if rank == 0:
-        q.put(out.numpy().tobytes())
+        q.put((out.numpy().tobytes(), outs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -43,15 +51,18 @@ def test_sharded_stream_equals_reference_stream():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
-    got = q.get(timeout=600)
+    got, sliced = q.get(timeout=900)
     for p in procs:
-        p.join(timeout=600)
+        p.join(timeout=900)
         assert p.exitcode == 0
     data = np.concatenate([synth.text_like(230000, 21), synth.runs_mixed(40000, 2)])
     assert got == oracle.bz2_compress(data, 1)
+    assert sliced[0] == oracle.bz2_compress(data, 1)                                   # chained planning over three slices
+    runs = np.concatenate([synth.lcg_ascii(150000, 4), np.zeros(900000, np.uint8)])
+    assert sliced[1] == oracle.bz2_compress(runs, 1)                                   # a block swallows a slice: replicated fallback
 
 
 def test_shift_and_trailer_helpers():

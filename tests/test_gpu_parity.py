@@ -453,11 +453,15 @@ def _gloo_rank(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from compressjs_amd import synth as sy
     from compressjs_amd.bzip2 import Context as Cx
-    from compressjs_amd.dist import sharded_compress
+    from compressjs_amd.dist import margin_bytes, sharded_compress, sharded_compress_sliced, slice_bounds
     c = Cx(0, 32)
     d = np.concatenate([sy.text_like(9_000_000, 21), sy.runs_mixed(2_000_000, 2)])
     out = sharded_compress(c, torch.from_numpy(d).cuda(), 9)
+    lo, hi = slice_bounds(d.size, rank, world)                   # the sliced driver: this rank holds [lo - margin, hi) only
+    wlo = max(0, lo - margin_bytes(9))
+    out2 = sharded_compress_sliced(c, torch.from_numpy(d[wlo:hi].copy()).cuda(), wlo, d.size, 9, d_all=lambda: torch.from_numpy(d).cuda())
     if rank == 0:
+        assert torch.equal(out, out2)
         q.put(out.cpu().numpy().tobytes())
     dist.barrier()
     dist.destroy_process_group()
