@@ -111,13 +111,15 @@ __device__ void huff_build_wave(const u32* freq, int S, u8* lens, int* keys, int
     __builtin_amdgcn_wave_barrier();
 }
 
-// LDS plan (static, < 64 KB): the 50 KB staging area for the symbol walks is time-shared with the
+// LDS plan: the 100 KB staging area for the symbol walks (dynamic LDS) is time-shared with the
 // table-build scratch (keys, arr) and the cost histogram, which are never live at the same time.
-#define K34_STAGE_WORDS 800          // 32 groups x 50 symbols x 2 B per wave
-#define K34_GROUPS_PER_CHUNK 32
+// 64 groups per chunk: every lane of a wave walks a group (with 32, half of them only helped staging).
+#define K34_STAGE_WORDS 1600         // 64 groups x 50 symbols x 2 B per wave
+#define K34_GROUPS_PER_CHUNK 64
+#define K34_PRE ((K34_STAGE_WORDS + 63) / 64)
 
-// Walk every 50-symbol group of A: each wave stages 32 groups (1600 symbols) with coalesced
-// 4-byte loads, then lanes 0..31 read their own group back (stride 25 words: conflict free).
+// Walk every 50-symbol group of A: each wave stages 64 groups (3200 symbols) with coalesced
+// 4-byte loads, then every lane reads its own group back (stride 25 words: conflict free per half-wave).
 // `body(gi, sym)` is called for every symbol of group gi by the lane that owns it.
 template <class Body, class Done>
 __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32* stage_w, Body body, Done done) {
@@ -125,13 +127,13 @@ __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32
     const u32* Aw = (const u32*)A;
     const u32 nchunks = (nSel + K34_GROUPS_PER_CHUNK - 1) / K34_GROUPS_PER_CHUNK;
     // software pipeline: the words of chunk c+16 are in flight while chunk c is consumed from LDS
-    u32 pre[13];
+    u32 pre[K34_PRE];
     auto fetch = [&](u32 c) {
         const u32 sym0 = c * K34_GROUPS_PER_CHUNK * CJS_GROUP;
-        const u32 nsym = pos - sym0 < 1600u ? pos - sym0 : 1600u;
+        const u32 nsym = pos - sym0 < 2u * K34_STAGE_WORDS ? pos - sym0 : 2u * K34_STAGE_WORDS;
         const u32 nwords = (nsym + 1u) >> 1;
 #pragma unroll
-        for (int k = 0; k < 13; k++) {
+        for (int k = 0; k < K34_PRE; k++) {
             const u32 j = lane + 64u * (u32)k;
             pre[k] = j < nwords ? Aw[(sym0 >> 1) + j] : 0u;
         }
@@ -140,7 +142,7 @@ __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32
     for (u32 c = w; c < nchunks; c += 16) {
         const u32 g0 = c * K34_GROUPS_PER_CHUNK;
 #pragma unroll
-        for (int k = 0; k < 13; k++) {
+        for (int k = 0; k < K34_PRE; k++) {
             const u32 j = lane + 64u * (u32)k;
             if (j < K34_STAGE_WORDS) stage_w[j] = pre[k];
         }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
     u8* sel = P.sel + (size_t)b * P.selPitch;
     u16* cost = P.selCost + (size_t)b * P.selPitch;
 
-    __shared__ u32 pool[16 * K34_STAGE_WORDS];
+    HIP_DYNAMIC_SHARED(u32, pool)                                                       // [16 * K34_STAGE_WORDS]
     __shared__ u8 lens[CJS_MAX_GROUPS][HB_PITCH];
     __shared__ u32 fr[CJS_MAX_GROUPS][HB_PITCH];
     __shared__ u64 lens64[HB_PITCH];
@@ -289,7 +291,10 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
 }
 
 int k34_run(Pipe P, hipStream_t stream) {
-    hipLaunchKernelGGL(k34_tables, dim3(P.g.nb), dim3(1024), 0, stream, P);
+    const size_t dyn = (size_t)16 * K34_STAGE_WORDS * 4;
+    static const bool lds_ok = hipFuncSetAttribute((const void*)k34_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * K34_STAGE_WORDS * 4)) == hipSuccess;
+    if (!lds_ok) return CJS_E_HIP;
+    hipLaunchKernelGGL(k34_tables, dim3(P.g.nb), dim3(1024), dyn, stream, P);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
