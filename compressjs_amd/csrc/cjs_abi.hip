@@ -1090,7 +1090,7 @@ extern "C" float cjs_last_device_ms(const cjs_ctx* c) { return c ? c->last_ms : 
 extern "C" uint32_t cjs_last_block_count(const cjs_ctx* c) { return c ? c->last_blocks : 0; }
 extern "C" void* cjs_stream(const cjs_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-// Per-kernel timing of the K1 radix scatter (the dominant kernel) with HIP events on the
+// Per-kernel timing of the dominant kernel (k1f_bsort; k1_scatter with CJS_FRONT=0) with HIP events on the
 // library's own stream, for bench.py's roofline leg.
 extern "C" int32_t cjs_profile_enable(cjs_ctx* c, int on) {
     if (!c) return CJS_E_ARG;

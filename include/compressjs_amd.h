@@ -58,7 +58,8 @@ int64_t cjs_bz2_encode_blocks(cjs_ctx* ctx, uint32_t first, uint32_t count, void
 float cjs_last_device_ms(const cjs_ctx* ctx);
 uint32_t cjs_last_block_count(const cjs_ctx* ctx);
 void* cjs_stream(const cjs_ctx* ctx);   /* the hipStream_t the library launches on */
-/* HIP-event timing of every launch of the dominant kernel (K1 radix scatter). */
+/* HIP-event timing of every launch of the dominant kernel (k1f_bsort, the in-LDS bucket sort of the suffix sort's
+ * sample-sort front end; k1_scatter with CJS_FRONT=0): event pairs on the library's own stream, for bench.py's roofline leg. */
 int32_t cjs_profile_enable(cjs_ctx* ctx, int on);
 int32_t cjs_profile_read(cjs_ctx* ctx, float* total_ms, uint32_t* launches, uint64_t* elements);
 
