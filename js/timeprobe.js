@@ -1,0 +1,16 @@
+// node js/timeprobe.js <raw byte file> [level] : wall time of Bzip2.compressFile through the N-API drop-in (not a test).
+'use strict';
+var fs = require('fs'), crypto = require('crypto');
+var cjs = require('./index.js');
+var buf = fs.readFileSync(process.argv[2]);
+var level = +(process.argv[3] || 9);
+var out = cjs.Bzip2.compressFile(buf, null, level);                // warm-up (contexts, staging buffers)
+var best = 1e9;
+for (var i = 0; i < 4; i++) {
+  var t0 = process.hrtime.bigint();
+  out = cjs.Bzip2.compressFile(buf, null, level);
+  var dt = Number(process.hrtime.bigint() - t0) / 1e6;
+  if (dt < best) best = dt;
+}
+console.log(JSON.stringify({ bytes: buf.length, out: out.length, ms: +best.toFixed(2), mb_per_s: +(buf.length / best / 1e3).toFixed(1),
+                             sha256: crypto.createHash('sha256').update(Buffer.from(out)).digest('hex') }));
