@@ -142,14 +142,21 @@ def main():
     from compressjs_amd.dist import margin_bytes, sharded_compress_sliced, slice_bounds
 
     total = args.size * world
-    host = workloads.stream(args.workload, total)              # every rank can name the bytes; only its slice goes to its GPU
+    ctx = Context(local, args.batch)
+    on_device = args.workload == "lcg" and world > 1           # cfg4: every GPU fills its own slice in HBM (LCG jump-ahead)
+    host = None
+    if rank == 0 or not on_device:
+        host = workloads.stream(args.workload, total)          # every rank can name the bytes; only its slice goes to its GPU
     if world == 1:
         d_in = torch.from_numpy(host).to(dev)
     else:
         lo, hi = slice_bounds(total, rank, world)
         wlo = max(0, lo - margin_bytes(args.level))            # the slice + the tail of the previous rank's slice
-        d_in = torch.from_numpy(host[wlo:hi]).to(dev)
-    ctx = Context(local, args.batch)
+        if on_device:
+            d_in = torch.empty(hi - wlo, dtype=torch.uint8, device=dev)
+            ctx.lcg_ascii_device(d_in, 7, first=wlo)
+        else:
+            d_in = torch.from_numpy(host[wlo:hi]).to(dev)
     bound = int(ctx.L.cjs_bz2_compress_bound(total))
     d_out = torch.zeros((bound + 3) & ~3, dtype=torch.uint8, device=dev)
     seg = None
@@ -161,7 +168,13 @@ def main():
             n = ctx.compress_device(d_in, d_out, args.level)
             return d_out[:n]
         seg.zero_()
-        return sharded_compress_sliced(ctx, d_in, wlo, total, args.level, seg=seg, d_all=lambda: torch.from_numpy(host).to(dev))
+        def whole():                                           # only the replicated fall-back (run-heavy input) needs it
+            if host is not None:
+                return torch.from_numpy(host).to(dev)
+            t = torch.empty(total, dtype=torch.uint8, device=dev)
+            ctx.lcg_ascii_device(t, 7, first=0)
+            return t
+        return sharded_compress_sliced(ctx, d_in, wlo, total, args.level, seg=seg, d_all=whole)
 
     for _ in range(args.warmup):
         out = step()

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("COMPRESSJS_AMD_LIB") or os.path.join(_HERE, "libcompr
 _lib = None
 
 # every symbol include/compressjs_amd.h declares (tests check the .so exports all of them)
-SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_bz2_compress_bound", "cjs_bz2_compress",
+SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_lcg_ascii_device", "cjs_bz2_compress_bound", "cjs_bz2_compress",
            "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_plan_block_start", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
            "cjs_bwtc_compress_bound",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
@@ -49,6 +49,8 @@ def load(path: str | None = None):
     vp = C.c_void_p
     L.cjs_create.restype = vp
     L.cjs_create.argtypes = [C.c_int, C.c_uint32]
+    L.cjs_lcg_ascii_device.restype = C.c_int32
+    L.cjs_lcg_ascii_device.argtypes = [vp, vp, C.c_uint64, C.c_uint32, C.c_uint64]
     L.cjs_device_count.restype = C.c_int32
     L.cjs_device_count.argtypes = []
     L.cjs_destroy.restype = None

@@ -141,6 +141,11 @@ class Context:
         return _lib.check(self.L.cjs_bz2_plan(self.h, d_in.data_ptr(), d_in.numel(), int(level)),
                           "cjs_bz2_plan")
 
+    def lcg_ascii_device(self, d_out, seed: int, first: int = 0):
+        """Fill the torch uint8 CUDA tensor d_out with bytes [first, first + len) of LCG(N, seed), on the device."""
+        return _lib.check(self.L.cjs_lcg_ascii_device(self.h, d_out.data_ptr(), d_out.numel(), int(seed) & 0xFFFFFFFF, int(first)),
+                          "cjs_lcg_ascii_device")
+
     def plan_block_start(self, k: int) -> int:
         """First input byte (relative to the planned input) of block k of the current plan."""
         return _lib.check(self.L.cjs_bz2_plan_block_start(self.h, int(k)), "cjs_bz2_plan_block_start")

@@ -1086,6 +1086,42 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
 #undef TRYR
 }
 
+// ---------------------------------------------------------------------------------------------
+// Workload generator of BASELINE.json configs[3] / SURVEY.md 8(c) on the device: bytes [first, first + n) of LCG(N, seed),
+//   s <- s * 1664525 + 1013904223 (mod 2^32), byte = 32 + ((s >>> 16) mod 95),
+// so that every rank of a multi-GPU run fills its own slice in HBM instead of receiving it from the host.  Jump-ahead:
+// s_j = A^j s_0 + C (A^(j-1) + ... + 1); each thread squares its way to the state of its first byte (32 steps), then
+// walks 16 bytes.  Same bytes as compressjs_amd.synth.lcg_ascii (tests).  Not a compression entry point.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lcg_fill(u8* out, u64 n, u32 seed, u64 first) {
+    const u64 t = (u64)blockIdx.x * 256u + threadIdx.x;
+    const u64 i0 = t * 16u;
+    if (i0 >= n) return;
+    // state after j = first + i0 steps: affine map x -> a x + c composed j times by binary powering
+    u64 j = first + i0;
+    u32 ra = 1u, rc = 0u;                    // result map (identity)
+    u32 ba = 1664525u, bc = 1013904223u;     // current power of the base map
+    while (j) {
+        if (j & 1u) { rc = ba * rc + bc; ra = ba * ra; }
+        bc = ba * bc + bc; ba = ba * ba;
+        j >>= 1;
+    }
+    u32 st = ra * seed + rc;
+    const u64 m = n - i0 < 16u ? n - i0 : 16u;
+    for (u64 k = 0; k < m; k++) {
+        st = st * 1664525u + 1013904223u;
+        out[i0 + k] = (u8)(32u + ((st >> 16) % 95u));
+    }
+}
+
+extern "C" int32_t cjs_lcg_ascii_device(cjs_ctx* c, uint8_t* d_out, uint64_t n, uint32_t seed, uint64_t first) {
+    if (!c || (!d_out && n)) return CJS_E_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return CJS_E_NOGPU;
+    if (n) hipLaunchKernelGGL(k_lcg_fill, dim3((unsigned)((n + 4095) / 4096)), dim3(256), 0, c->stream, d_out, n, seed, first);
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? CJS_OK : CJS_E_HIP - (int)e;
+}
+
 extern "C" float cjs_last_device_ms(const cjs_ctx* c) { return c ? c->last_ms : 0.f; }
 extern "C" uint32_t cjs_last_block_count(const cjs_ctx* c) { return c ? c->last_blocks : 0; }
 extern "C" void* cjs_stream(const cjs_ctx* c) { return c ? (void*)c->stream : nullptr; }

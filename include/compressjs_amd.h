@@ -154,6 +154,9 @@ int64_t cjs_bwtc_decompress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, ui
 int64_t cjs_bwtc_last_size(cjs_ctx* ctx);
 int64_t cjs_bwtc_fetch(cjs_ctx* ctx, uint8_t* out, uint64_t out_cap);
 
+/* Workload helper (not a compression entry point): bytes [first, first + n) of LCG(N, seed) - SURVEY.md 8(c), BASELINE.json
+ * configs[3] "random printable ASCII" - written straight into HBM, so that every GPU of a multi-GPU run fills its own slice. */
+int32_t cjs_lcg_ascii_device(cjs_ctx* ctx, uint8_t* d_out, uint64_t n, uint32_t seed, uint64_t first);
 /* HIP devices visible to the process (0: none; the product has no CPU path). */
 int32_t cjs_device_count(void);
 /* = Bzip2.compressFile over SEVERAL GPUs of one node from one process (the N-API addon's path to N

@@ -103,6 +103,16 @@ def test_bwt_kats(emu):
         assert u.tobytes() == out and p.value == idx
 
 
+def test_lcg_generator_on_the_device(emu_ctx):
+    """cjs_lcg_ascii_device (jump-ahead) = synth.lcg_ascii = SURVEY.md 8(c)'s LCG(n, seed), for any slice."""
+    L, h = emu_ctx
+    want = synth.lcg_ascii(70000, 7)
+    for first, n in ((0, 70000), (1, 999), (4097, 12345), (69999, 1), (31, 0)):
+        out = np.full(n + 1, 0xEE, np.uint8)
+        assert L.cjs_lcg_ascii_device(h, out.ctypes.data, n, 7, first) == 0
+        assert np.array_equal(out[:n], want[first:first + n]) and out[n] == 0xEE, (first, n)
+
+
 def test_invalid_level_code(emu_ctx):
     L, h = emu_ctx
     d = np.zeros(4, np.uint8)

@@ -493,3 +493,14 @@ def test_bwtc_level9_full_size_vs_reference_digest(ctx, golden_big):
     g = golden_big["e8sa:100000000:bwtc:9"]
     a = ctx.bwtc_compress(d, 9)
     assert len(a) == g["out_len"] and _sha(a) == g["out_sha256"]
+
+
+def test_lcg_generator_on_the_device(ctx):
+    """cfg4's stream generated in HBM by jump-ahead (cjs_lcg_ascii_device) = synth.lcg_ascii, any slice."""
+    import torch
+    want = synth.lcg_ascii(3_000_000, 7)
+    for first, n in ((0, 3_000_000), (123_457, 1_000_001), (2_999_999, 1)):
+        t = torch.full((n + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+        ctx.lcg_ascii_device(t[:n], 7, first)
+        got = t.cpu().numpy()
+        assert np.array_equal(got[:n], want[first:first + n]) and (got[n:] == 0xEE).all()
