@@ -2,6 +2,10 @@
 #pragma once
 #include "cjs_common.h"
 
+// v_writelane_b32: `old` with lane `lane` replaced by the wave-uniform `val` (clang has no builtin for it; the LLVM
+// intrinsic is reached by its name)
+extern "C" __device__ int cjs_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
 // mask of lanes whose low `nbits` of d equal this lane's (and are valid)
 __device__ __forceinline__ u64 match_any(u32 d, int nbits, bool valid) {
     u64 m = __ballot(valid);

@@ -98,21 +98,73 @@ __device__ __forceinline__ void tab_set(u32& reg, u32 idx, u32 val) {
     if (lane_id() == (idx >> 2)) reg = (reg & ~(0xffu << (8u * (idx & 3u)))) | (val << (8u * (idx & 3u)));
 }
 
-#define K7_RING 4096u        // u16 records in flight between waves 0 and 1
-#define K7_TRING 1024u       // u32 tokens in flight between waves 1 and 2
+#define K7_RING 4096u        // u16 symbols in flight between waves 0 and 1
+#define K7_TROWS 8u          // token rows in flight between waves 1 and 2
+#define K7_WIN 256u          // stream words staged in LDS for the per-lane peeks of wave 0
+#define K7_UNRES 0x100u      // "no length from the table" mark in the chain of code starts
+#define K7_LTBITS 10u        // code lengths up to this many bits come from a table indexed by the next bits
 
 // workgroup-scope publish / observe of a flag in LDS
 __device__ __forceinline__ void lds_publish(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ u32 lds_observe(u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// the 32 stream bits that start at absolute bit q, from the LDS window (MSB-first words)
+__device__ __forceinline__ u32 win_peek(const u32* win, u64 q) {
+    const u32 w = (u32)(q >> 5), s = (u32)q & 31u;
+    const u64 two = ((u64)win[w & (K7_WIN - 1u)] << 32) | win[(w + 1u) & (K7_WIN - 1u)];
+    return (u32)(two >> (32u - s));
+}
+
+// RUNA/RUNB accumulation (:314-337) over a stretch of `len` run symbols given as bit masks (bit k set in sa / sb = the k-th is
+// RUNA / RUNB).  N = run symbols since the run (re)started, T = its value.  The reference's int32 runPos reaches 0 after 32
+// run symbols; the next one finds !runPos and restarts with t = 0, and a literal that follows a multiple of 32 run symbols
+// finds runPos == 0 and flushes nothing: N counts modulo 32.
+struct RunAcc { u32 N; u64 T; };
+__device__ __forceinline__ void run_extend(RunAcc& r, u64 sa, u64 sb, u32 len) {
+    if (r.N + len < 32u) {
+        r.T += (sa << r.N) + 2ull * (sb << r.N);
+        r.N += len;
+    } else {
+        const u32 rp = (r.N + len) & 31u, skip = len - rp;                     // only the symbols after the last restart count
+        r.T = rp ? (sa >> skip) + 2ull * (sb >> skip) : 0ull;
+        r.N = rp;
+    }
+}
+
+// one move-to-front step on the 256-entry list held one entry per lane in four registers (position p = register p >> 6,
+// lane p & 63): returns the entry at idx and moves it to the front (mtf(), lib/Bzip2.js:53-60).  idx is wave-uniform.
+__device__ __forceinline__ u32 mtf_step(u32& l0, u32& l1, u32& l2, u32& l3, u32 idx, u32 lane) {
+    if (idx < 64u) {                                              // the common case: one v_readlane, one DPP shift, one select
+        const u32 src = (u32)__builtin_amdgcn_readlane((int)l0, (int)idx);
+        const u32 sh = (u32)__builtin_amdgcn_update_dpp((int)src, (int)l0, 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 <- src
+        l0 = lane <= idx ? sh : l0;
+        return src;
+    }
+    const u32 q = idx >> 6, r = idx & 63u;
+    const u32 c0 = (u32)__builtin_amdgcn_readlane((int)l0, 63), c1 = (u32)__builtin_amdgcn_readlane((int)l1, 63);
+    const u32 c2 = (u32)__builtin_amdgcn_readlane((int)l2, 63);
+    const u32 src = (u32)__builtin_amdgcn_readlane((int)(q == 1u ? l1 : q == 2u ? l2 : l3), (int)r);
+    const u32 s0 = (u32)__builtin_amdgcn_update_dpp((int)src, (int)l0, 0x138, 0xf, 0xf, false);
+    const u32 s1 = (u32)__builtin_amdgcn_update_dpp((int)c0, (int)l1, 0x138, 0xf, 0xf, false);
+    const u32 s2 = (u32)__builtin_amdgcn_update_dpp((int)c1, (int)l2, 0x138, 0xf, 0xf, false);
+    const u32 s3 = (u32)__builtin_amdgcn_update_dpp((int)c2, (int)l3, 0x138, 0xf, 0xf, false);
+    l0 = s0;
+    if (q == 1u) l1 = lane <= r ? s1 : l1;
+    else if (q == 2u) { l1 = s1; l2 = lane <= r ? s2 : l2; }
+    else { l1 = s1; l2 = s2; l3 = lane <= r ? s3 : l3; }
+    return src;
+}
+
 // Three waves per block, a software pipeline through two LDS rings:
-//   wave 0  parses the block header, then only finds code boundaries: one (table, canonical index)
-//           record per Huffman symbol (lib/Bzip2.js:283-300);
-//   wave 1  turns records into symbols (permute[] gather, 64 at a time), undoes RLE2 and MTF and emits
-//           one (byte, count) token per literal or run (:305-366);
+//   wave 0  parses the block header, then decodes the Huffman symbols one GROUP of 50 at a time (one coding table per
+//           group, lib/Bzip2.js:283-300).  Where the next code starts is a serial recurrence, but how long the code
+//           starting at a given bit is, is not: every lane looks the length up for its own bit offset (64 offsets per
+//           row, a table indexed by the next 10 bits), the chain of code starts is then followed with one v_readlane
+//           per symbol, and the 50 symbols themselves (canonical index, permute[], end-of-block, the checks of
+//           :292-300) are extracted by 50 lanes at once;
+//   wave 1  undoes RLE2 and MTF and emits one (byte, count) token per literal or run (:305-366);
 //   wave 2  expands 64 tokens per step into the block's last column (prefix sum of the counts, one
 //           coalesced byte store per row in the common all-literal case).
-// The two recurrences are serial; splitting them shortens the dependent instruction chain per symbol.
 __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count) {
     const u32 slot = blockIdx.x;
     if (slot >= count) return;
@@ -124,10 +176,14 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
     __shared__ u16 s_perm[6][384];
     __shared__ u32 s_jeob[6];          // canonical index of the end-of-block symbol in every table
     __shared__ u8 s_len[264];
+    __shared__ u8 s_lt[6][1u << K7_LTBITS];   // code length by the next K7_LTBITS bits; 0 = longer than that, or no code
+    __shared__ u32 s_win[K7_WIN];
     __shared__ u16 s_ring[K7_RING];
     __shared__ u32 s_mtf[64];          // initial MTF list (= symToByte), 4 entries per lane
     __shared__ u32 s_head, s_tail, s_done, s_abort, s_symTotal, s_hdr;
-    __shared__ u32 s_tring[K7_TRING];  // (byte | count << 8) tokens between waves 1 and 2
+    __shared__ u32 s_trun[K7_TROWS * 64u];   // per symbol lane: the run flushed in front of it (count | byte << 24) ...
+    __shared__ u32 s_tlit[K7_TROWS * 64u];   // ... and its own literal (byte | 1 << 8), rows in flight between waves 1 and 2
+    __shared__ u32 s_cidx[64];
     __shared__ u32 s_thead, s_ttail, s_tdone;
     __shared__ int s_pstat, s_cstat;
     __shared__ u32 s_cnt, s_origPtr, s_crc;
@@ -139,13 +195,14 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
     __syncthreads();
     BitRd r;
     u32 nSel = 0;
+    int groupCount = 0;
     if (wave == 0) {
         const u64 start = D.cand[first + slot] >> 1;
         br_init(r, D.in32, D.zeroChunk, start + 48);
         int st = 0;
         const u32 crc = br_get(r, 32);
         u32 origPtr = 0, mw = 0;
-        int symTotal = 0, groupCount = 0, symCount = 0;
+        int symTotal = 0, symCount = 0;
         do {
             if (br_get(r, 1)) { st = DEC_OBSOLETE; break; }                    // :174-175
             origPtr = br_get(r, 24);
@@ -229,169 +286,239 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
         } while (0);
         s_mtf[lane] = mw;
         if (lane == 0) { s_pstat = st; s_origPtr = origPtr; s_crc = crc; s_symTotal = (u32)symTotal; s_hdr = st == 0 ? 1u : 0u; }
+        if (st == 0) {
+            // length table: the reference takes the SMALLEST i with (next i bits) <= limit[i] (:290-297); for i <= K7_LTBITS
+            // that is a function of the next K7_LTBITS bits alone
+            for (int g = 0; g < groupCount; g++) {
+                int lim[K7_LTBITS + 1];
+                for (u32 i = 1; i <= K7_LTBITS; i++) lim[i] = s_limLA[g][i];
+                for (u32 idx = lane; idx < (1u << K7_LTBITS); idx += 64u) {
+                    const int v = (int)(idx << (20u - K7_LTBITS));
+                    u32 L = 0;
+                    for (u32 i = K7_LTBITS; i >= 1u; i--) L = v <= lim[i] ? i : L;
+                    s_lt[g][idx] = (u8)L;
+                }
+            }
+        }
     }
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane((int)s_hdr)) {
         if (wave == 0) {
-            // ---- wave 0: code boundaries only --------------------------------------------------------
-            int limLA = -1, st = 0;
-            u32 base = 0, g = 0, jeob = 0, recv = 0;
+            // ---- wave 0: Huffman symbols, one group of 50 per step ------------------------------------
+            int st = 0;
+            u64 P = br_tell(r);            // bit where the current group starts
+            u64 wl = (P >> 11) << 6;       // stream words [wl - K7_WIN, wl) are in s_win; pf = raw words of chunk wl / 64
+            u32 pf = br_load(r, wl >> 6);
             u32 selrow = 0, selnext = gsel[lane];
-            int left = 0;                 // symbols left in the current group of 50
             u32 selector = 0, np = 0;
             u64 nsym = 0, pwait = 0;
             bool eob = false;
-            for (;;) {
-                if (left == 0) {
-                    left = 50;
-                    if (selector >= nSel) { st = DEC_DATA_ERROR; break; }
-                    // selectors live in HBM (16 KB per block would cost LDS residency): a register row of 64 words =
-                    // 512 selectors, the next row requested one row ahead like the stream words
-                    if ((selector & 511u) == 0) { selrow = selnext; selnext = gsel[(((selector >> 9) + 1u) << 6) + lane]; }
-                    g = ((u32)__builtin_amdgcn_readlane((int)selrow, (int)((selector >> 3) & 63u)) >> (4u * (selector & 7u))) & 15u;
-                    selector++;
-                    limLA = lane < 32u ? s_limLA[g][lane] : -1;
-                    base = s_base[g][lane & 31u];
-                    jeob = (u32)__builtin_amdgcn_readfirstlane((int)s_jeob[g]);
-                }
-                left--;
-                nsym++;
-                const u32 v20 = (u32)(r.win >> 44);
-                const u64 m = __ballot((int)v20 <= limLA);
-                if (m == 0) { st = DEC_DATA_ERROR; break; }                    // i > maxLen (:292)
-                const int len = __builtin_ctzll(m);
-                br_consume(r, len);
-                const u32 j = (v20 >> (20 - len)) - (u32)__builtin_amdgcn_readlane((int)base, len);
-                if (j >= 258u) { st = DEC_DATA_ERROR; break; }                 // :299-300 (base <= 2^28: no wrap)
-                recv = lane == (np & 63u) ? (j | (g << 9)) : recv;
-                np++;
-                eob = j == jeob;
-                if (eob || !(np & 63u)) {
-                    const u32 b0 = (np - 1u) & ~63u;                           // first record of this batch
-                    if (b0 + 64u - lds_observe(&s_tail) > K7_RING) {
-                        const u64 w0 = clock64();
-                        while (b0 + 64u - lds_observe(&s_tail) > K7_RING && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(2);
-                        pwait += clock64() - w0;
+            while (!eob) {
+                if (selector >= nSel) { st = DEC_DATA_ERROR; break; }
+                // selectors live in HBM (16 KB per block would cost LDS residency): a register row of 64 words =
+                // 512 selectors, the next row requested one row ahead like the stream words
+                if ((selector & 511u) == 0) { selrow = selnext; selnext = gsel[(((selector >> 9) + 1u) << 6) + lane]; }
+                const u32 g = ((u32)__builtin_amdgcn_readlane((int)selrow, (int)((selector >> 3) & 63u)) >> (4u * (selector & 7u))) & 15u;
+                selector++;
+                const int limLA = lane < 32u ? s_limLA[g][lane] : -1;
+                const u32 jeob = (u32)__builtin_amdgcn_readfirstlane((int)s_jeob[g]);
+                // code starts of the group: pos[i] (relative to P) in lane i of posv, i = 0..50 (pos[50] = end of the group)
+                u32 posv = 0, i = 0, o = 0, rowb = 0;
+                bool nocode = false;
+                for (;;) {
+                    const u64 rowbit = P + rowb;
+                    const u64 need = ((rowbit + 63u) >> 5) + 2u;           // words the peeks of this row (and of the group so far) touch
+                    while (wl < need) {
+                        s_win[((u32)wl + lane) & (K7_WIN - 1u)] = __builtin_bswap32(pf);
+                        wl += 64u;
+                        pf = br_load(r, wl >> 6);
                     }
-                    if (b0 + lane < np) s_ring[(b0 + lane) & (K7_RING - 1u)] = (u16)recv;
                     __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) lds_publish(&s_head, np);
-                    if (eob || lds_observe(&s_abort)) break;
+                    const u32 v20 = win_peek(s_win, rowbit + lane) >> 12;
+                    const u32 L = s_lt[g][v20 >> (20u - K7_LTBITS)];
+                    const u32 dxv = ((L ? L : K7_UNRES) + lane) ^ lane;    // (next code start if a code started at this lane's bit) ^ lane
+                    // the chain of code starts through this row: straight-line steps (a taken branch costs a lone wave more than
+                    // the step itself), steps past the row's end or past symbol 50 change nothing that is read later
+                    for (;;) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            posv = (u32)cjs_writelane((int)(rowb + o), (int)i, (int)posv);
+                            const u32 in = (u32)((int)(o - 64u) >> 31);                    // all ones while o is inside the row
+                            const u32 dx = (u32)__builtin_amdgcn_readlane((int)dxv, (int)o);
+                            i -= in;                                                       // i += 1
+                            o ^= dx & in;                                                  // o = next code start
+                        }
+                        if (o < 64u && i < 50u) continue;
+                        if (o >= K7_UNRES && i <= 50u) {                       // symbol i-1 (at bit o - K7_UNRES of the row): longer than the
+                            const u32 off = o - K7_UNRES;                      // table's reach, or no code at all
+                            const u32 u20 = win_peek(s_win, rowbit + off) >> 12;
+                            const u64 m = __ballot((int)u20 <= limLA);         // lane L = length L (:290-297)
+                            if (m == 0) { nocode = true; i -= 1u; o = off; break; }   // i > maxLen (:292)
+                            o = off + (u32)__builtin_ctzll(m);
+                            if (o < 64u && i < 50u) continue;
+                        }
+                        break;
+                    }
+                    if (nocode || i >= 50u) break;
+                    o -= 64u;
+                    rowb += 64u;
                 }
+                posv = (u32)cjs_writelane((int)(rowb + o), (int)i, (int)posv);
+                if (i > 50u) i = 50u;
+                // lanes < i hold the start of a code whose end is the next lane's start
+                const u32 pn = __shfl_down(posv, 1);
+                const u32 len = pn - posv;
+                const bool have = lane < i;
+                u32 sym = 0;
+                bool badj = false, iseob = false;
+                if (have) {
+                    const u32 c20 = win_peek(s_win, P + posv) >> 12;
+                    const u32 j = (c20 >> (20u - len)) - s_base[g][len];
+                    badj = j >= 258u;                                          // :299-300 (base <= 2^28: no wrap)
+                    sym = s_perm[g][badj ? 0u : j];
+                    iseob = !badj && j == jeob;
+                }
+                u64 mBad = __ballot(badj);
+                if (nocode) mBad |= 1ull << i;
+                const u64 mEob = __ballot(iseob);
+                const u32 e = mEob ? (u32)__builtin_ctzll(mEob) : 64u, b = mBad ? (u32)__builtin_ctzll(mBad) : 64u;
+                u32 cntg = 50u;
+                if (b < e) { st = DEC_DATA_ERROR; cntg = b; }
+                else if (e < 64u) { eob = true; cntg = e + 1u; }
+                nsym += cntg;
+                if (np + cntg - lds_observe(&s_tail) > K7_RING) {
+                    const u64 w0 = clock64();
+                    while (np + cntg - lds_observe(&s_tail) > K7_RING && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(2);
+                    pwait += clock64() - w0;
+                }
+                if (lane < cntg) s_ring[(np + lane) & (K7_RING - 1u)] = (u16)sym;
+                np += cntg;
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) lds_publish(&s_head, np);
+                P += (u32)__builtin_amdgcn_readlane((int)pn, (int)(cntg ? cntg - 1u : 0u));       // end of the last symbol taken
+                if (st || lds_observe(&s_abort)) break;
             }
-            if (lane == 0) { s_pstat = st; s_endbit = br_tell(r); s_nsym = nsym; s_pwait = pwait; lds_publish(&s_done, 1u); }
+            if (lane == 0) { s_pstat = st; s_endbit = P; s_nsym = nsym; s_pwait = pwait; lds_publish(&s_done, 1u); }
         } else if (wave == 1) {
-            // ---- wave 1: records -> symbols -> RLE2 -> MTF -> (byte, count) tokens ---------------------
+            // ---- wave 1: symbols -> RLE2 -> MTF -> per row of 64 symbols a (run, literal) token pair per lane --------
+            // Only the MTF recurrence over the row's literals is serial.  RUNA/RUNB symbols never enter it: a maximal stretch
+            // of them is a bijective base-2 number (:318-335) that every lane ending a stretch takes from two ballots, and the
+            // byte a run repeats is the one the literal before it produced.
             const u32 symTotal = (u32)__builtin_amdgcn_readfirstlane((int)s_symTotal);
-            u32 mw = s_mtf[lane], cnt = 0, tokv = 0, nt = 0;
-            const bool is0 = lane == 0;
+            u32 l0, l1, l2, l3;            // the MTF list in the byte domain (entries are symToByte values), one per lane
+            {
+                const u8* m8 = (const u8*)s_mtf;
+                l0 = m8[lane]; l1 = m8[64u + lane]; l2 = m8[128u + lane]; l3 = m8[192u + lane];
+            }
+            u32 cnt = 0, trow = 0;
             int st = 0;
             u32 runN = 0;                  // RUNA/RUNB symbols since the run (re)started: the reference's runPos == 1 << runN, 0 = no run pending
-            long long runT = 0;
-            u32 consumed = 0;
+            u64 runT = 0;
+            u32 consumed = 0;              // always a multiple of 64 while wave 0 runs
             u64 cwait = 0;
             bool finished = false;
-            // one token per literal or run; 64 tokens are gathered in a register row and handed over at once
-#define K7_TOKEN(byte_, count_) do {                                                              \
-                tokv = lane == (nt & 63u) ? ((u32)(byte_) | ((u32)(count_) << 8)) : tokv;                 \
-                nt++;                                                                                     \
-                if (!(nt & 63u)) {                                                                        \
-                    while (nt - lds_observe(&s_ttail) > K7_TRING && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1); \
-                    s_tring[(nt - 64u + lane) & (K7_TRING - 1u)] = tokv;                                  \
-                    __builtin_amdgcn_wave_barrier();                                                      \
-                    if (lane == 0) lds_publish(&s_thead, nt);                                             \
-                }                                                                                         \
-            } while (0)
+            const u64 lt_mask = (1ull << lane) - 1ull;
             while (!finished) {
+                const u32 b0 = consumed;
                 u32 head = lds_observe(&s_head);
-                if (head == consumed) {
+                if (head - b0 < 64u) {                                         // wait for the whole row unless wave 0 has stopped
                     if (lds_observe(&s_done)) {
                         head = lds_observe(&s_head);
-                        if (head == consumed) break;                           // wave 0 stopped without end-of-block
+                        if (head == b0) break;                                 // wave 0 stopped without end-of-block
                     } else { const u64 w0 = clock64(); __builtin_amdgcn_s_sleep(2); cwait += clock64() - w0; continue; }
                 }
-                const u32 b0 = consumed & ~63u;
-                const u32 hi = head - b0 < 64u ? head - b0 : 64u;              // records [consumed, b0+hi) are ready
-                u32 symv = 0;
-                if (lane < hi) {
-                    const u32 rec = s_ring[(b0 + lane) & (K7_RING - 1u)];
-                    symv = s_perm[rec >> 9][rec & 511u];
-                }
-                // RUNA/RUNB symbols never enter the serial loop: a maximal stretch of them is a bijective
-                // base-2 number (:318-335) whose value falls out of two ballots; the loop below only visits
-                // literals and the end-of-block symbol
-                const u32 lo = consumed - b0;
-                const u64 inb = (hi == 64u ? ~0ull : ((1ull << hi) - 1ull)) & ~((1ull << lo) - 1ull);
-                const u64 mA = __ballot(symv == 0u) & inb, mB = __ballot(symv == 1u) & inb;
-                u64 lit = inb & ~(mA | mB);
-                u32 cur = lo;
-                for (;;) {
-                    const u32 k = lit ? (u32)__builtin_ctzll(lit) : hi;       // next literal, or the end of the row
-                    if (k > cur) {                                             // run symbols [cur, k) of the row
-                        // The reference's int32 runPos (:314-337) reaches 0 after 32 run symbols; the next one finds
-                        // !runPos and restarts with t = 0, and a literal that follows a multiple of 32 run symbols finds
-                        // runPos == 0 and flushes nothing.  runN = run symbols since the last (re)start, 0..31.
-                        const u32 len = k - cur;
-                        const u64 seg = len == 64u ? ~0ull : ((1ull << len) - 1ull);
-                        const u64 sa = (mA >> cur) & seg, sb = (mB >> cur) & seg;
-                        if (runN + len < 32u) {
-                            runT += (long long)(sa << runN) + 2ll * (long long)(sb << runN);
-                            runN += len;
-                        } else {
-                            const u32 rp = (runN + len) & 31u, skip = len - rp;   // only the symbols after the last restart count
-                            runT = rp ? (long long)(sa >> skip) + 2ll * (long long)(sb >> skip) : 0ll;
-                            runN = rp;
-                        }
-                    }
-                    if (!lit) break;
-                    lit &= lit - 1;
-                    cur = k + 1u;
-                    const u32 sym = (u32)__builtin_amdgcn_readlane((int)symv, (int)k);
-                    if (runN) {                                                // :340-347
-                        runN = 0;
-                        if ((long long)cnt + runT > (long long)DEC_CAP) { st = DEC_DATA_ERROR; break; }
-                        if (runT) {
-                            const u32 uc = (u32)__builtin_amdgcn_readlane((int)mw, 0) & 0xffu;
-                            K7_TOKEN(uc, (u32)runT);
-                            cnt += (u32)runT;
-                        }
-                        runT = 0;
-                    }
-                    if (sym > symTotal) { finished = true; break; }            // :349-350
-                    if (cnt >= DEC_CAP) { st = DEC_DATA_ERROR; break; }
-                    {                                                          // mtf(mtfSymbol, sym - 1) :53-60
-                        const u32 idx = sym - 1u, ql = idx >> 2, sh8 = 8u * (idx & 3u);
-                        const u32 src = ((u32)__builtin_amdgcn_readlane((int)mw, (int)ql) >> sh8) & 0xffu;
-                        const u32 lowmask = (1u << sh8) - 1u, keepmask = (~lowmask) << 8;
-                        if (ql == 0) {
-                            const u32 nv = (mw & keepmask) | ((mw & lowmask) << 8) | src;
-                            mw = is0 ? nv : mw;
-                        } else {
-                            const u32 up = (u32)__builtin_amdgcn_update_dpp(0, (int)mw, 0x138, 0xf, 0xf, false);   // wave_shr:1
-                            const u32 carry = is0 ? src : (up >> 24);
-                            const u32 full = (mw << 8) | carry;
-                            const u32 part = (mw & keepmask) | ((mw & lowmask) << 8) | carry;
-                            mw = lane < ql ? full : (lane == ql ? part : mw);
-                        }
-                        K7_TOKEN(src, 1u);
-                        cnt++;
+                const u32 hi = head - b0 < 64u ? head - b0 : 64u;              // symbols [b0, b0+hi) are ready
+                const bool valid = lane < hi;
+                const u32 symv = valid ? s_ring[(b0 + lane) & (K7_RING - 1u)] : 0u;
+                const u32 idxv = symv - 1u;                                    // MTF index of a literal
+                const u64 mE = __ballot(valid && symv > symTotal);             // end of block (:349-350)
+                const u32 eobAt = mE ? (u32)__builtin_ctzll(mE) : 64u;
+                const bool inrow = valid && lane <= eobAt;
+                const bool isL = inrow && symv >= 2u && lane != eobAt;
+                const u64 mA = __ballot(inrow && symv == 0u), mB = __ballot(inrow && symv == 1u), mL = __ballot(isL);
+                const u64 nonrun = mL | (mE ? 1ull << eobAt : 0ull);
+                const bool isN = isL || lane == eobAt;
+                // the run symbols in front of this lane: [start, lane)
+                const u64 below = nonrun & lt_mask;
+                const u32 start = below ? 64u - (u32)__builtin_clzll(below) : 0u;
+                const u32 len = lane - start;
+                const u64 seg = (1ull << len) - 1ull;                          // len <= 63
+                RunAcc ra;
+                ra.N = below ? 0u : runN;
+                ra.T = below ? 0ull : runT;
+                run_extend(ra, (mA >> start) & seg, (mB >> start) & seg, len);
+                const bool fl = isN && ra.N != 0u;                             // :340-347: a pending run is flushed in front of this symbol
+                const u32 flc = fl ? (ra.T > (u64)DEC_CAP ? DEC_CAP + 1u : (u32)ra.T) : 0u;
+                u32 rowsum = flc + (isL ? 1u : 0u);
+                for (int off = 32; off > 0; off >>= 1) rowsum += __shfl_xor(rowsum, off);
+                rowsum = (u32)__builtin_amdgcn_readfirstlane((int)rowsum);
+                if (cnt + rowsum > DEC_CAP) { st = DEC_DATA_ERROR; if (lane == 0) lds_publish(&s_abort, 1u); break; }   // :342, :351
+                cnt += rowsum;
+                // the row's literals, compacted: lane t = MTF index of the t-th literal
+                const u32 rank = (u32)__builtin_popcountll(mL & lt_mask);
+                const u32 nlit = (u32)__builtin_popcountll(mL);
+                const bool far = __ballot(isL && idxv >= 64u) != 0ull;
+                const u32 f0 = (u32)__builtin_amdgcn_readlane((int)l0, 0);       // front of the list before the row's first literal
+                if (isL) s_cidx[rank] = idxv;
+                __builtin_amdgcn_wave_barrier();
+                const u32 cidx = s_cidx[lane];
+                __builtin_amdgcn_wave_barrier();
+                u32 outc = 0;                                                  // lane t = byte of the t-th literal
+                if (!far) {
+                    // mtf(mtfSymbol, sym - 1) :53-60 for an index below 64: one v_readlane, one DPP shift, one select; straight-line
+                    // steps, four per loop branch
+#define K7_MTF_STEP(t_) do {                                                                                       \
+                        const u32 idx_ = (u32)__builtin_amdgcn_readlane((int)cidx, (int)(t_));                     \
+                        const u32 src_ = (u32)__builtin_amdgcn_readlane((int)l0, (int)idx_);                       \
+                        const u32 sh_ = (u32)__builtin_amdgcn_update_dpp((int)src_, (int)l0, 0x138, 0xf, 0xf, false); \
+                        l0 = lane <= idx_ ? sh_ : l0;                                                              \
+                        outc = (u32)cjs_writelane((int)src_, (int)(t_), (int)outc);                                \
+                    } while (0)
+                    u32 t = 0;
+                    for (; t + 4u <= nlit; t += 4u) { K7_MTF_STEP(t); K7_MTF_STEP(t + 1u); K7_MTF_STEP(t + 2u); K7_MTF_STEP(t + 3u); }
+                    if (nlit & 2u) { K7_MTF_STEP(t); K7_MTF_STEP(t + 1u); t += 2u; }
+                    if (nlit & 1u) K7_MTF_STEP(t);
+                } else {
+                    for (u32 t = 0; t < nlit; t++) {
+                        const u32 idx = (u32)__builtin_amdgcn_readlane((int)cidx, (int)t);
+                        const u32 src = mtf_step(l0, l1, l2, l3, idx, lane);
+                        outc = (u32)cjs_writelane((int)src, (int)t, (int)outc);
                     }
                 }
-                if (st) { if (lane == 0) lds_publish(&s_abort, 1u); break; }
+                // back to the row's lanes: own byte for a literal, the byte of the literal before for a run
+                const u32 nb = (u32)__builtin_popcountll(mL & lt_mask);        // literals in front of this lane
+                const u32 own = __shfl(outc, (int)(rank & 63u));
+                const u32 prevb = __shfl(outc, (int)((nb - 1u) & 63u));
+                const u32 rb = nb ? prevb : f0;
+                const u32 tr = fl && ra.T ? (flc | (rb << 24)) : 0u;            // flc < 2^24
+                const u32 tl = isL ? (own | 0x100u) : 0u;
+                while (trow - lds_observe(&s_ttail) >= K7_TROWS && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1);
+                s_trun[(trow & (K7_TROWS - 1u)) * 64u + lane] = tr;
+                s_tlit[(trow & (K7_TROWS - 1u)) * 64u + lane] = tl;
+                __builtin_amdgcn_wave_barrier();
+                trow++;
+                if (lane == 0) lds_publish(&s_thead, trow);
+                if (mE) { finished = true; break; }
+                // the run symbols behind the row's last literal carry over
+                {
+                    const u32 st0 = nonrun ? 64u - (u32)__builtin_clzll(nonrun) : 0u;
+                    const u32 ln = hi - st0;
+                    const u64 sg = ln == 64u ? ~0ull : ((1ull << ln) - 1ull);
+                    RunAcc c;
+                    c.N = nonrun ? 0u : runN;
+                    c.T = nonrun ? 0ull : runT;
+                    run_extend(c, st0 < 64u ? (mA >> st0) & sg : 0ull, st0 < 64u ? (mB >> st0) & sg : 0ull, ln);
+                    runN = c.N;
+                    runT = c.T;
+                }
                 consumed = b0 + hi;
                 if (lane == 0) lds_publish(&s_tail, consumed);
+                if (lds_observe(&s_abort)) break;
             }
             if (!st && !finished) st = -1;                                     // wave 0 reports why it stopped
-            if (st == 0 && (nt & 63u)) {                                       // the last, partial row of tokens
-                const u32 t0 = nt & ~63u;
-                while (t0 + 64u - lds_observe(&s_ttail) > K7_TRING && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1);
-                if (t0 + lane < nt) s_tring[(t0 + lane) & (K7_TRING - 1u)] = tokv;
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) lds_publish(&s_thead, nt);
-            }
             if (lane == 0) { s_cstat = st; s_cnt = cnt; s_cwait = cwait; if (st) lds_publish(&s_abort, 1u); lds_publish(&s_tdone, 1u); }
         } else {
-            // ---- wave 2: tokens -> bytes of the last column, 64 tokens per step -------------------------
+            // ---- wave 2: token rows -> bytes of the last column ------------------------------------------
             u8* out = D.tt + (size_t)slot * D.ttStride;
             u32 taken = 0, opos = 0;
             for (;;) {
@@ -402,23 +529,24 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                         if (head == taken) break;
                     } else { __builtin_amdgcn_s_sleep(2); continue; }
                 }
-                const u32 hi = head - taken < 64u ? head - taken : 64u;        // rows are 64-aligned: taken % 64 == 0
-                const u32 tok = lane < hi ? s_tring[(taken + lane) & (K7_TRING - 1u)] : 0u;
-                const u32 c = tok >> 8, byte = tok & 0xffu;
-                const u32 incl = wave_incl_scan_u32(c);
-                const u32 at = opos + incl - c;
-                if (c == 1u) out[at] = (u8)byte;                               // the common case: one coalesced store per row
-                else if (c && c < 64u) for (u32 i = 0; i < c; i++) out[at + i] = (u8)byte;
+                const u32 tr = s_trun[(taken & (K7_TROWS - 1u)) * 64u + lane], tl = s_tlit[(taken & (K7_TROWS - 1u)) * 64u + lane];
+                const u32 c = tr & 0xffffffu, rb = tr >> 24, f = (tl >> 8) & 1u;
+                const u32 tot = c + f;
+                const u32 incl = wave_incl_scan_u32(tot);
+                const u32 at = opos + incl - tot;
+                if (f) out[at + c] = (u8)tl;                                   // the common case: one coalesced store per row
+                if (c && c < 64u) for (u32 i = 0; i < c; i++) out[at + i] = (u8)rb;
                 u64 big = __ballot(c >= 64u);                                  // long runs: the whole wave fills each of them
                 while (big) {
                     const int l = __builtin_ctzll(big);
                     big &= big - 1;
                     const u32 bc = (u32)__builtin_amdgcn_readlane((int)c, l), bat = (u32)__builtin_amdgcn_readlane((int)at, l);
-                    const u32 bb = (u32)__builtin_amdgcn_readlane((int)byte, l);
+                    const u32 bb = (u32)__builtin_amdgcn_readlane((int)rb, l);
                     for (u32 i = lane; i < bc; i += 64u) out[bat + i] = (u8)bb;
                 }
                 opos += (u32)__builtin_amdgcn_readlane((int)incl, 63);
-                taken += hi;
+                taken++;
+                __builtin_amdgcn_wave_barrier();
                 if (lane == 0) lds_publish(&s_ttail, taken);
             }
         }

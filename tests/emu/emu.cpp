@@ -101,3 +101,7 @@ void run_block(void (*body)(void*), void* arg, dim3 grid, dim3 block, dim3 bidx,
     }
 }
 }  // namespace emu
+
+// devutil.h reaches v_writelane_b32 through the LLVM intrinsic's name; here it is an ordinary function of that name
+extern "C" int cjs_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+extern "C" int cjs_writelane(int val, int lane, int old) { return emu::lane() == (lane & 63) ? val : old; }

@@ -226,7 +226,7 @@ static inline void __builtin_amdgcn_wave_barrier() { emu::wave_sync(); }
 static inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned s) {
     return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (8u * (s & 3u)));
 }
-template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return emu_shfl_(v, lane); }
+template <class T> static inline T __builtin_amdgcn_readlane(T v, int lane) { return emu_shfl_(v, lane & 63); }   // v_readlane_b32 takes the low 6 bits
 static inline long long clock64() { return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
