@@ -45,6 +45,19 @@ __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v) {
     return v;
 }
 
+// inclusive scan / sum over the wave in six DPP adds (rows of 16 by row_shr 1, 2, 4, 8, then row_bcast:15 and row_bcast:31):
+// no LDS crossbar round trips - for a wave that runs alone on its SIMD each __shfl costs ~60 clocks, a DPP add ~8
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // lane 15 of rows 0 and 2 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // lane 31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ u32 wave_sum_dpp(u32 v) { return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(v), 63); }
+
 // exclusive scan over the (up to 1024) threads of a block; every thread must call it.
 // `sh` needs 20 u32 of LDS.  *total receives the block-wide sum.
 __device__ __forceinline__ u32 block_excl_scan_1024(u32 v, u32* sh, u32* total) {

@@ -98,15 +98,22 @@ __device__ __forceinline__ void tab_set(u32& reg, u32 idx, u32 val) {
     if (lane_id() == (idx >> 2)) reg = (reg & ~(0xffu << (8u * (idx & 3u)))) | (val << (8u * (idx & 3u)));
 }
 
-#define K7_RING 4096u        // u16 symbols in flight between waves 0 and 1
-#define K7_TROWS 8u          // token rows in flight between waves 1 and 2
-#define K7_WIN 256u          // stream words staged in LDS for the per-lane peeks of wave 0
+#define K7_GRING 4u          // groups in flight between waves A and B
+#define K7_RROWS 8u          // rows of 64 symbols in flight between waves B, C and D
+#define K7_SYMS 512u
+#define K7_GROWS 18u         // 50 codes of at most 20 bits: 16 rows of 64 bits and a partial one
+#define K7_G_NOCODE 0x1000u  // group record: the symbol after the last one listed has no code
+#define K7_G_NOSEL 0x2000u   // group record: there is no selector for this group
+#define K7_WIN 512u          // stream words staged in LDS for the per-lane peeks of wave 0
 #define K7_UNRES 0x100u      // "no length from the table" mark in the chain of code starts
 #define K7_LTBITS 10u        // code lengths up to this many bits come from a table indexed by the next bits
 
 // workgroup-scope publish / observe of a flag in LDS
 __device__ __forceinline__ void lds_publish(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ u32 lds_observe(u32* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// (the value as ONE lane saw it: every lane of the wave takes the same branch on it)
+__device__ __forceinline__ u32 lds_observe(u32* p) {
+    return (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
 
 // the 32 stream bits that start at absolute bit q, from the LDS window (MSB-first words)
 __device__ __forceinline__ u32 win_peek(const u32* win, u64 q) {
@@ -129,6 +136,13 @@ __device__ __forceinline__ void run_extend(RunAcc& r, u64 sa, u64 sb, u32 len) {
         r.T = rp ? (sa >> skip) + 2ull * (sb >> skip) : 0ull;
         r.N = rp;
     }
+}
+
+// the same with the position given as a window word and a bit offset from it (32-bit arithmetic only)
+__device__ __forceinline__ u32 win_peek32(const u32* win, u32 w0, u32 q) {
+    const u32 w = w0 + (q >> 5), sh = q & 31u;
+    const u64 two = ((u64)win[w & (K7_WIN - 1u)] << 32) | win[(w + 1u) & (K7_WIN - 1u)];
+    return (u32)(two >> (32u - sh));
 }
 
 // one move-to-front step on the 256-entry list held one entry per lane in four registers (position p = register p >> 6,
@@ -155,6 +169,13 @@ __device__ __forceinline__ u32 mtf_step(u32& l0, u32& l1, u32& l2, u32& l3, u32 
     return src;
 }
 
+// section timers of the profiling build (-DK7_PROF; s_memtime costs ~100 clocks per read, so only there)
+#ifdef K7_PROF
+#define K7_T(k_) do { const u64 now_ = clock64(); prof_[k_] += now_ - tl_; tl_ = now_; } while (0)
+#else
+#define K7_T(k_) do { } while (0)
+#endif
+
 // Three waves per block, a software pipeline through two LDS rings:
 //   wave 0  parses the block header, then decodes the Huffman symbols one GROUP of 50 at a time (one coding table per
 //           group, lib/Bzip2.js:283-300).  Where the next code starts is a serial recurrence, but how long the code
@@ -165,7 +186,7 @@ __device__ __forceinline__ u32 mtf_step(u32& l0, u32& l1, u32& l2, u32& l3, u32 
 //   wave 1  undoes RLE2 and MTF and emits one (byte, count) token per literal or run (:305-366);
 //   wave 2  expands 64 tokens per step into the block's last column (prefix sum of the counts, one
 //           coalesced byte store per row in the common all-literal case).
-__global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count) {
+__global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count) {
     const u32 slot = blockIdx.x;
     if (slot >= count) return;
     const u32 lane = lane_id();
@@ -176,22 +197,28 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
     __shared__ u16 s_perm[6][384];
     __shared__ u32 s_jeob[6];          // canonical index of the end-of-block symbol in every table
     __shared__ u8 s_len[264];
-    __shared__ u8 s_lt[6][1u << K7_LTBITS];   // code length by the next K7_LTBITS bits; 0 = longer than that, or no code
+    __shared__ u16 s_lt[6][1u << K7_LTBITS];  // by the next K7_LTBITS bits: length of the code | length of the code after it << 4 (0 = not within these bits, or no code)
     __shared__ u32 s_win[K7_WIN];
-    __shared__ u16 s_ring[K7_RING];
     __shared__ u32 s_mtf[64];          // initial MTF list (= symToByte), 4 entries per lane
-    __shared__ u32 s_head, s_tail, s_done, s_abort, s_symTotal, s_hdr;
-    __shared__ u32 s_trun[K7_TROWS * 64u];   // per symbol lane: the run flushed in front of it (count | byte << 24) ...
-    __shared__ u32 s_tlit[K7_TROWS * 64u];   // ... and its own literal (byte | 1 << 8), rows in flight between waves 1 and 2
-    __shared__ u32 s_cidx[64];
-    __shared__ u32 s_thead, s_ttail, s_tdone;
-    __shared__ int s_pstat, s_cstat;
+    __shared__ u64 s_gmask[K7_GRING][K7_GROWS];   // A -> B: per row of 64 bits of a group, where the steps start ...
+    __shared__ u16 s_spos[64];             // B: the same as a list
+    __shared__ u64 s_gP[K7_GRING];         // ... the bit it starts at ...
+    __shared__ u32 s_ginfo[K7_GRING];      // ... rows | table << 8 | K7_G_* flags | bit where the step after the last one starts << 16
+    __shared__ u16 s_sym[K7_SYMS];         // B: symbols regrouped from groups of 50 into rows of 64
+    __shared__ u16 s_cidx[K7_RROWS][64];   // B -> C: MTF indices of the row's literals, compacted
+    __shared__ u32 s_rrun[K7_RROWS][64];   // B -> D: per symbol lane the run flushed in front of it (count) | literal << 24
+    __shared__ u64 s_rmL[K7_RROWS];        // B -> C, D: mask of the row's literals
+    __shared__ u32 s_rinfo[K7_RROWS];      // B -> C: 1 = some index of the row is 64 or more
+    __shared__ u8 s_out[K7_RROWS][64];     // C -> D: byte of the t-th literal of the row
+    __shared__ u32 s_rf0[K7_RROWS];        // C -> D: front of the MTF list before the row
+    __shared__ u32 s_ghead, s_gtail, s_stop, s_rhead, s_chead, s_dtail, s_adone, s_bdone, s_cdone, s_abort, s_symTotal, s_hdr;
+    __shared__ int s_pstat;
     __shared__ u32 s_cnt, s_origPtr, s_crc;
-    __shared__ u64 s_endbit, s_nsym, s_pwait, s_cwait;
+    __shared__ u64 s_endbit, s_nsym, s_pwait, s_cwait, s_prof[10];
 
     u32* gsel = D.sel + (size_t)slot * 4160u;             // [4096 + 64] words: 32768 selectors, 4 bits each, + one row of slack
     const u64 t_start = clock64();
-    if (threadIdx.x == 0) { s_thead = 0; s_ttail = 0; s_tdone = 0; s_head = 0; s_tail = 0; s_done = 0; s_abort = 0; s_pstat = 0; s_cstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; }
+    if (threadIdx.x == 0) { s_ghead = 0; s_gtail = 0; s_stop = 0; s_rhead = 0; s_chead = 0; s_dtail = 0; s_adone = 0; s_bdone = 0; s_cdone = 0; s_abort = 0; s_pstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; for (int k = 0; k < 10; k++) s_prof[k] = 0; }
     __syncthreads();
     BitRd r;
     u32 nSel = 0;
@@ -288,219 +315,283 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
         if (lane == 0) { s_pstat = st; s_origPtr = origPtr; s_crc = crc; s_symTotal = (u32)symTotal; s_hdr = st == 0 ? 1u : 0u; }
         if (st == 0) {
             // length table: the reference takes the SMALLEST i with (next i bits) <= limit[i] (:290-297); for i <= K7_LTBITS
-            // that is a function of the next K7_LTBITS bits alone
+            // that is a function of the next K7_LTBITS bits alone - and so is the code after it when both fit
             for (int g = 0; g < groupCount; g++) {
                 int lim[K7_LTBITS + 1];
                 for (u32 i = 1; i <= K7_LTBITS; i++) lim[i] = s_limLA[g][i];
                 for (u32 idx = lane; idx < (1u << K7_LTBITS); idx += 64u) {
                     const int v = (int)(idx << (20u - K7_LTBITS));
-                    u32 L = 0;
-                    for (u32 i = K7_LTBITS; i >= 1u; i--) L = v <= lim[i] ? i : L;
-                    s_lt[g][idx] = (u8)L;
+                    u32 L1 = 0, L2 = 0;
+                    for (u32 i = K7_LTBITS; i >= 1u; i--) L1 = v <= lim[i] ? i : L1;
+                    if (L1) {
+                        const int v2 = (int)(((idx << L1) & ((1u << K7_LTBITS) - 1u)) << (20u - K7_LTBITS));
+                        for (u32 i = K7_LTBITS; i >= 1u; i--) L2 = (i + L1 <= K7_LTBITS && v2 <= lim[i]) ? i : L2;
+                    }
+                    s_lt[g][idx] = (u16)(L1 | (L2 << 4));
                 }
             }
         }
     }
     __syncthreads();
     if (__builtin_amdgcn_readfirstlane((int)s_hdr)) {
+        const u64 lt_mask = (1ull << lane) - 1ull;
         if (wave == 0) {
-            // ---- wave 0: Huffman symbols, one group of 50 per step ------------------------------------
-            int st = 0;
+            // ---- wave A: where the Huffman codes of a group of 50 start -------------------------------
             u64 P = br_tell(r);            // bit where the current group starts
             u64 wl = (P >> 11) << 6;       // stream words [wl - K7_WIN, wl) are in s_win; pf = raw words of chunk wl / 64
             u32 pf = br_load(r, wl >> 6);
             u32 selrow = 0, selnext = gsel[lane];
-            u32 selector = 0, np = 0;
-            u64 nsym = 0, pwait = 0;
-            bool eob = false;
-            while (!eob) {
-                if (selector >= nSel) { st = DEC_DATA_ERROR; break; }
-                // selectors live in HBM (16 KB per block would cost LDS residency): a register row of 64 words =
-                // 512 selectors, the next row requested one row ahead like the stream words
-                if ((selector & 511u) == 0) { selrow = selnext; selnext = gsel[(((selector >> 9) + 1u) << 6) + lane]; }
-                const u32 g = ((u32)__builtin_amdgcn_readlane((int)selrow, (int)((selector >> 3) & 63u)) >> (4u * (selector & 7u))) & 15u;
-                selector++;
-                const int limLA = lane < 32u ? s_limLA[g][lane] : -1;
-                const u32 jeob = (u32)__builtin_amdgcn_readfirstlane((int)s_jeob[g]);
-                // code starts of the group: pos[i] (relative to P) in lane i of posv, i = 0..50 (pos[50] = end of the group)
-                u32 posv = 0, i = 0, o = 0, rowb = 0;
-                bool nocode = false;
-                for (;;) {
-                    const u64 rowbit = P + rowb;
-                    const u64 need = ((rowbit + 63u) >> 5) + 2u;           // words the peeks of this row (and of the group so far) touch
-                    while (wl < need) {
-                        s_win[((u32)wl + lane) & (K7_WIN - 1u)] = __builtin_bswap32(pf);
-                        wl += 64u;
-                        pf = br_load(r, wl >> 6);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const u32 v20 = win_peek(s_win, rowbit + lane) >> 12;
-                    const u32 L = s_lt[g][v20 >> (20u - K7_LTBITS)];
-                    const u32 dxv = ((L ? L : K7_UNRES) + lane) ^ lane;    // (next code start if a code started at this lane's bit) ^ lane
-                    // the chain of code starts through this row: straight-line steps (a taken branch costs a lone wave more than
-                    // the step itself), steps past the row's end or past symbol 50 change nothing that is read later
-                    for (;;) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            posv = (u32)cjs_writelane((int)(rowb + o), (int)i, (int)posv);
-                            const u32 in = (u32)((int)(o - 64u) >> 31);                    // all ones while o is inside the row
-                            const u32 dx = (u32)__builtin_amdgcn_readlane((int)dxv, (int)o);
-                            i -= in;                                                       // i += 1
-                            o ^= dx & in;                                                  // o = next code start
-                        }
-                        if (o < 64u && i < 50u) continue;
-                        if (o >= K7_UNRES && i <= 50u) {                       // symbol i-1 (at bit o - K7_UNRES of the row): longer than the
-                            const u32 off = o - K7_UNRES;                      // table's reach, or no code at all
-                            const u32 u20 = win_peek(s_win, rowbit + off) >> 12;
-                            const u64 m = __ballot((int)u20 <= limLA);         // lane L = length L (:290-297)
-                            if (m == 0) { nocode = true; i -= 1u; o = off; break; }   // i > maxLen (:292)
-                            o = off + (u32)__builtin_ctzll(m);
-                            if (o < 64u && i < 50u) continue;
-                        }
-                        break;
-                    }
-                    if (nocode || i >= 50u) break;
-                    o -= 64u;
-                    rowb += 64u;
-                }
-                posv = (u32)cjs_writelane((int)(rowb + o), (int)i, (int)posv);
-                if (i > 50u) i = 50u;
-                // lanes < i hold the start of a code whose end is the next lane's start
-                const u32 pn = __shfl_down(posv, 1);
-                const u32 len = pn - posv;
-                const bool have = lane < i;
-                u32 sym = 0;
-                bool badj = false, iseob = false;
-                if (have) {
-                    const u32 c20 = win_peek(s_win, P + posv) >> 12;
-                    const u32 j = (c20 >> (20u - len)) - s_base[g][len];
-                    badj = j >= 258u;                                          // :299-300 (base <= 2^28: no wrap)
-                    sym = s_perm[g][badj ? 0u : j];
-                    iseob = !badj && j == jeob;
-                }
-                u64 mBad = __ballot(badj);
-                if (nocode) mBad |= 1ull << i;
-                const u64 mEob = __ballot(iseob);
-                const u32 e = mEob ? (u32)__builtin_ctzll(mEob) : 64u, b = mBad ? (u32)__builtin_ctzll(mBad) : 64u;
-                u32 cntg = 50u;
-                if (b < e) { st = DEC_DATA_ERROR; cntg = b; }
-                else if (e < 64u) { eob = true; cntg = e + 1u; }
-                nsym += cntg;
-                if (np + cntg - lds_observe(&s_tail) > K7_RING) {
+            u32 selector = 0, gh = 0;
+            u64 pwait = 0;
+#ifdef K7_PROF
+            u64 prof_[5] = {0, 0, 0, 0, 0}, tl_ = clock64();
+#endif
+            for (;;) {
+                if (lds_observe(&s_stop) || lds_observe(&s_abort)) break;
+                u32 i = 0, g = 0, gend = 0, gexit = 0;
+                u32 flags = 0;
+                if (gh - lds_observe(&s_gtail) >= K7_GRING) {                  // a free record for this group's row masks
                     const u64 w0 = clock64();
-                    while (np + cntg - lds_observe(&s_tail) > K7_RING && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(2);
+                    while (gh - lds_observe(&s_gtail) >= K7_GRING && !lds_observe(&s_stop) && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1);
                     pwait += clock64() - w0;
+                    if (lds_observe(&s_stop) || lds_observe(&s_abort)) break;
                 }
-                if (lane < cntg) s_ring[(np + lane) & (K7_RING - 1u)] = (u16)sym;
-                np += cntg;
+                if (selector >= nSel) flags = K7_G_NOSEL;                      // an error only if wave B gets this far (:286-287)
+                else {
+                    // selectors live in HBM (16 KB per block would cost LDS residency): a register row of 64 words =
+                    // 512 selectors, the next row requested one row ahead like the stream words
+                    if ((selector & 511u) == 0) { selrow = selnext; selnext = gsel[(((selector >> 9) + 1u) << 6) + lane]; }
+                    g = ((u32)__builtin_amdgcn_readlane((int)selrow, (int)((selector >> 3) & 63u)) >> (4u * (selector & 7u))) & 15u;
+                    selector++;
+                    const int limLA = lane < 32u ? s_limLA[g][lane] : -1;
+                    K7_T(0);
+                    const u32 pw = (u32)(P >> 5) & (K7_WIN - 1u), pb = (u32)P & 31u;        // P as a word of the window and a bit in it
+                    {
+                        const u64 need = ((P + 127u) >> 5) + 2u;               // words the peeks of rows 0 and 1 touch
+                        while (wl < need) {
+                            s_win[((u32)wl + lane) & (K7_WIN - 1u)] = __builtin_bswap32(pf);
+                            wl += 64u;
+                            pf = br_load(r, wl >> 6);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    u32 pk = win_peek32(s_win, pw, pb + lane);                  // the 32 bits at this lane's bit of row 0
+                    // The chain of code starts, a row of 64 bits at a time.  One STEP takes the code at the current bit and, when
+                    // the table knows it, the code after it too; all a step does is look up how far it goes (one v_readlane), mark
+                    // its start in the row's mask and advance - a handful of scalar instructions.  Wave B finds the symbols from the masks.
+                    u32 o = 0, rowb = 0, ns = 0, R = 0;                          // ns = symbols in the rows before this one
+                    bool nocode = false;
+                    for (;;) {
+                        const u32 e = s_lt[g][pk >> (32u - K7_LTBITS)];
+                        const u32 l1 = e & 15u, l2 = e >> 4;
+                        const u32 advv = l1 ? l1 + l2 : K7_UNRES;                // how far a step starting at this lane's bit goes
+                        {                                                      // the next row's bits: requested now, used after the chain
+                            const u64 need = ((P + rowb + 191u) >> 5) + 2u;
+                            while (wl < need) {
+                                s_win[((u32)wl + lane) & (K7_WIN - 1u)] = __builtin_bswap32(pf);
+                                wl += 64u;
+                                pf = br_load(r, wl >> 6);
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        const u32 pkn = win_peek32(s_win, pw, pb + rowb + 64u + lane);
+                        K7_T(1);
+                        u64 mask = 0;                                          // bit b = a step starts at bit b of the row
+#define K7_STEP { const u32 a_ = (u32)__builtin_amdgcn_readlane((int)advv, (int)o); mask |= 1ull << o; o += a_; if (o >= 64u) break; }
+                        for (;;) {
+                            for (;;) { K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP }
+                            if (o < K7_UNRES) break;
+                            const u32 off = o - K7_UNRES;                          // the code at bit `off` is longer than the table's reach,
+                            const u32 u20 = win_peek32(s_win, pw, pb + rowb + off) >> 12;   // or there is no code at all
+                            const u64 m = __ballot((int)u20 <= limLA);             // lane L = length L (:290-297)
+                            if (m == 0) { nocode = true; mask &= ~(1ull << off); o = off; break; }   // i > maxLen (:292)
+                            o = off + (u32)__builtin_ctzll(m);
+                            if (o >= 64u) break;
+                        }
+                        K7_T(2);
+                        const u64 twoM = __ballot(l2 != 0u) & mask;
+                        const u32 rc = (u32)__builtin_popcountll(mask) + (u32)__builtin_popcountll(twoM);
+                        if (lane == 0) s_gmask[gh & (K7_GRING - 1u)][R] = mask;
+                        if (nocode && ns + rc < 50u) break;
+                        nocode = false;                                        // a bit without a code behind symbol 50 is the next group's business
+                        if (ns + rc >= 50u) {
+                            // the row where symbol 50 starts = where the next group starts: the step that reaches 50 (or, taking two, 51)
+                            const u64 le = lt_mask | (1ull << lane);
+                            const u32 inc = ns + (u32)__builtin_popcountll(mask & le) + (u32)__builtin_popcountll(twoM & le);
+                            const u64 m50 = __ballot(((mask >> lane) & 1ull) && inc >= 50u);
+                            const u32 kk = (u32)__builtin_ctzll(m50);
+                            if ((u32)__builtin_amdgcn_readlane((int)inc, (int)kk) == 50u) {
+                                const u64 above = kk == 63u ? 0ull : (mask >> (kk + 1u)) << (kk + 1u);
+                                gend = rowb + (above ? (u32)__builtin_ctzll(above) : o);       // where the next step starts
+                            } else gend = rowb + kk + (u32)__builtin_amdgcn_readlane((int)l1, (int)kk);   // after the first of its two codes
+                            break;
+                        }
+                        ns += rc;
+                        R++;
+                        o -= 64u;
+                        rowb += 64u;
+                        pk = pkn;
+                    }
+                    i = R + 1u;                                                // rows in the record
+                    gexit = rowb + o;                                          // where the step after the last marked one starts
+                    if (nocode) flags = K7_G_NOCODE;
+                }
+                if (lane == 0) { s_gP[gh & (K7_GRING - 1u)] = P; s_ginfo[gh & (K7_GRING - 1u)] = i | (g << 8) | flags | (gexit << 16); }
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 0) lds_publish(&s_head, np);
-                P += (u32)__builtin_amdgcn_readlane((int)pn, (int)(cntg ? cntg - 1u : 0u));       // end of the last symbol taken
-                if (st || lds_observe(&s_abort)) break;
+                gh++;
+                if (lane == 0) lds_publish(&s_ghead, gh);
+                K7_T(3);
+                if (flags) break;
+                P += gend;
             }
-            if (lane == 0) { s_pstat = st; s_endbit = P; s_nsym = nsym; s_pwait = pwait; lds_publish(&s_done, 1u); }
+#ifdef K7_PROF
+            if (lane == 0) for (int k = 0; k < 5; k++) s_prof[k] = prof_[k];
+#endif
+            if (lane == 0) { s_pwait = pwait; lds_publish(&s_adone, 1u); }
         } else if (wave == 1) {
-            // ---- wave 1: symbols -> RLE2 -> MTF -> per row of 64 symbols a (run, literal) token pair per lane --------
-            // Only the MTF recurrence over the row's literals is serial.  RUNA/RUNB symbols never enter it: a maximal stretch
-            // of them is a bijective base-2 number (:318-335) that every lane ending a stretch takes from two ballots, and the
-            // byte a run repeats is the one the literal before it produced.
+            // ---- wave B: the symbols of a group; per row of 64 symbols the run lengths and the literals' MTF indices ----
+            // RUNA/RUNB symbols never enter the serial MTF loop of wave C: a maximal stretch of them is a bijective base-2 number
+            // (:318-335) that every lane ending a stretch takes from two ballots.
             const u32 symTotal = (u32)__builtin_amdgcn_readfirstlane((int)s_symTotal);
-            u32 l0, l1, l2, l3;            // the MTF list in the byte domain (entries are symToByte values), one per lane
-            {
-                const u8* m8 = (const u8*)s_mtf;
-                l0 = m8[lane]; l1 = m8[64u + lane]; l2 = m8[128u + lane]; l3 = m8[192u + lane];
-            }
-            u32 cnt = 0, trow = 0;
             int st = 0;
+            u32 gt = 0, np = 0, consumed = 0, rows = 0, cnt = 0;
             u32 runN = 0;                  // RUNA/RUNB symbols since the run (re)started: the reference's runPos == 1 << runN, 0 = no run pending
             u64 runT = 0;
-            u32 consumed = 0;              // always a multiple of 64 while wave 0 runs
-            u64 cwait = 0;
-            bool finished = false;
-            const u64 lt_mask = (1ull << lane) - 1ull;
-            while (!finished) {
-                const u32 b0 = consumed;
-                u32 head = lds_observe(&s_head);
-                if (head - b0 < 64u) {                                         // wait for the whole row unless wave 0 has stopped
-                    if (lds_observe(&s_done)) {
-                        head = lds_observe(&s_head);
-                        if (head == b0) break;                                 // wave 0 stopped without end-of-block
-                    } else { const u64 w0 = clock64(); __builtin_amdgcn_s_sleep(2); cwait += clock64() - w0; continue; }
+            u64 nsym = 0, endbit = 0, cwait = 0;
+            bool eob = false, finished = false;
+#ifdef K7_PROF
+            u64 prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_ = clock64();
+#endif
+            while (!eob && !st) {
+                if (lds_observe(&s_ghead) == gt) {
+                    const u64 w0 = clock64();
+                    while (lds_observe(&s_ghead) == gt && !lds_observe(&s_adone)) __builtin_amdgcn_s_sleep(1);
+                    cwait += clock64() - w0;
+                    if (lds_observe(&s_ghead) == gt) { st = DEC_DATA_ERROR; break; }   // wave A has gone (it always leaves a last record: not reached)
                 }
-                const u32 hi = head - b0 < 64u ? head - b0 : 64u;              // symbols [b0, b0+hi) are ready
-                const bool valid = lane < hi;
-                const u32 symv = valid ? s_ring[(b0 + lane) & (K7_RING - 1u)] : 0u;
-                const u32 idxv = symv - 1u;                                    // MTF index of a literal
-                const u64 mE = __ballot(valid && symv > symTotal);             // end of block (:349-350)
-                const u32 eobAt = mE ? (u32)__builtin_ctzll(mE) : 64u;
-                const bool inrow = valid && lane <= eobAt;
-                const bool isL = inrow && symv >= 2u && lane != eobAt;
-                const u64 mA = __ballot(inrow && symv == 0u), mB = __ballot(inrow && symv == 1u), mL = __ballot(isL);
-                const u64 nonrun = mL | (mE ? 1ull << eobAt : 0ull);
-                const bool isN = isL || lane == eobAt;
-                // the run symbols in front of this lane: [start, lane)
-                const u64 below = nonrun & lt_mask;
-                const u32 start = below ? 64u - (u32)__builtin_clzll(below) : 0u;
-                const u32 len = lane - start;
-                const u64 seg = (1ull << len) - 1ull;                          // len <= 63
-                RunAcc ra;
-                ra.N = below ? 0u : runN;
-                ra.T = below ? 0ull : runT;
-                run_extend(ra, (mA >> start) & seg, (mB >> start) & seg, len);
-                const bool fl = isN && ra.N != 0u;                             // :340-347: a pending run is flushed in front of this symbol
-                const u32 flc = fl ? (ra.T > (u64)DEC_CAP ? DEC_CAP + 1u : (u32)ra.T) : 0u;
-                u32 rowsum = flc + (isL ? 1u : 0u);
-                for (int off = 32; off > 0; off >>= 1) rowsum += __shfl_xor(rowsum, off);
-                rowsum = (u32)__builtin_amdgcn_readfirstlane((int)rowsum);
-                if (cnt + rowsum > DEC_CAP) { st = DEC_DATA_ERROR; if (lane == 0) lds_publish(&s_abort, 1u); break; }   // :342, :351
-                cnt += rowsum;
-                // the row's literals, compacted: lane t = MTF index of the t-th literal
-                const u32 rank = (u32)__builtin_popcountll(mL & lt_mask);
-                const u32 nlit = (u32)__builtin_popcountll(mL);
-                const bool far = __ballot(isL && idxv >= 64u) != 0ull;
-                const u32 f0 = (u32)__builtin_amdgcn_readlane((int)l0, 0);       // front of the list before the row's first literal
-                if (isL) s_cidx[rank] = idxv;
+                K7_T(5);
+                const u32 slotg = gt & (K7_GRING - 1u);
+                const u64 P = s_gP[slotg];
+                const u32 info = (u32)__builtin_amdgcn_readfirstlane((int)s_ginfo[slotg]);
+                const u32 nrows = info & 0xffu, g = (info >> 8) & 15u, gexit = info >> 16;
+                if (info & K7_G_NOSEL) { st = DEC_DATA_ERROR; break; }          // more symbols than selectors (:286-287)
+                const u32 jeob = (u32)__builtin_amdgcn_readfirstlane((int)s_jeob[g]);
+                // where the steps of wave A start, in order: step k into lane k (the first 64 are more than the group's 50 symbols need)
+                u32 K = 0;
+                for (u32 rr = 0; rr < nrows; rr++) {
+                    const u64 mk = s_gmask[slotg][rr];
+                    const u32 rk = K + (u32)__builtin_popcountll(mk & lt_mask);
+                    if (((mk >> lane) & 1ull) && rk < 64u) s_spos[rk] = (u16)(rr * 64u + lane);
+                    K += (u32)__builtin_popcountll(mk);
+                }
+                if (lane == 0 && K < 64u) s_spos[K] = (u16)gexit;
+                if (K > 63u) K = 63u;
                 __builtin_amdgcn_wave_barrier();
-                const u32 cidx = s_cidx[lane];
+                const u32 sk = s_spos[lane], sn = s_spos[(lane + 1u) & 63u];
                 __builtin_amdgcn_wave_barrier();
-                u32 outc = 0;                                                  // lane t = byte of the t-th literal
-                if (!far) {
-                    // mtf(mtfSymbol, sym - 1) :53-60 for an index below 64: one v_readlane, one DPP shift, one select; straight-line
-                    // steps, four per loop branch
-#define K7_MTF_STEP(t_) do {                                                                                       \
-                        const u32 idx_ = (u32)__builtin_amdgcn_readlane((int)cidx, (int)(t_));                     \
-                        const u32 src_ = (u32)__builtin_amdgcn_readlane((int)l0, (int)idx_);                       \
-                        const u32 sh_ = (u32)__builtin_amdgcn_update_dpp((int)src_, (int)l0, 0x138, 0xf, 0xf, false); \
-                        l0 = lane <= idx_ ? sh_ : l0;                                                              \
-                        outc = (u32)cjs_writelane((int)src_, (int)(t_), (int)outc);                                \
-                    } while (0)
-                    u32 t = 0;
-                    for (; t + 4u <= nlit; t += 4u) { K7_MTF_STEP(t); K7_MTF_STEP(t + 1u); K7_MTF_STEP(t + 2u); K7_MTF_STEP(t + 3u); }
-                    if (nlit & 2u) { K7_MTF_STEP(t); K7_MTF_STEP(t + 1u); t += 2u; }
-                    if (nlit & 1u) K7_MTF_STEP(t);
-                } else {
-                    for (u32 t = 0; t < nlit; t++) {
-                        const u32 idx = (u32)__builtin_amdgcn_readlane((int)cidx, (int)t);
-                        const u32 src = mtf_step(l0, l1, l2, l3, idx, lane);
-                        outc = (u32)cjs_writelane((int)src, (int)t, (int)outc);
+                // lane k < K = step k: one code, or two when the table knew both
+                const bool have = lane < K;
+                const u32 tot = sn - sk;
+                u32 c32 = 0, la = tot, lb = 0;
+                bool two = false;
+                if (have) {
+                    c32 = win_peek(s_win, P + sk);
+                    const u32 e = s_lt[g][c32 >> (32u - K7_LTBITS)];
+                    two = (e >> 4) != 0u;
+                    if (two) { la = e & 15u; lb = e >> 4; }
+                }
+                const u32 cntv = have ? (two ? 2u : 1u) : 0u;
+                const u32 incl = wave_incl_scan_dpp(cntv);
+                const u32 ia = incl - cntv, ib = ia + 1u;                      // the symbols' numbers in the group
+                const u32 listed = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+                u32 syma = 0, symb = 0;
+                bool bada = false, badb = false, eoba = false, eobb = false;
+                if (have) {
+                    const u32 ja = (c32 >> (32u - la)) - s_base[g][la];
+                    bada = ja >= 258u;                                         // :299-300 (base <= 2^28: no wrap)
+                    syma = s_perm[g][bada ? 0u : ja];
+                    eoba = !bada && ja == jeob;
+                    if (two) {
+                        const u32 jb = ((c32 << la) >> (32u - lb)) - s_base[g][lb];
+                        badb = jb >= 258u;
+                        symb = s_perm[g][badb ? 0u : jb];
+                        eobb = !badb && jb == jeob;
                     }
                 }
-                // back to the row's lanes: own byte for a literal, the byte of the literal before for a run
-                const u32 nb = (u32)__builtin_popcountll(mL & lt_mask);        // literals in front of this lane
-                const u32 own = __shfl(outc, (int)(rank & 63u));
-                const u32 prevb = __shfl(outc, (int)((nb - 1u) & 63u));
-                const u32 rb = nb ? prevb : f0;
-                const u32 tr = fl && ra.T ? (flc | (rb << 24)) : 0u;            // flc < 2^24
-                const u32 tl = isL ? (own | 0x100u) : 0u;
-                while (trow - lds_observe(&s_ttail) >= K7_TROWS && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1);
-                s_trun[(trow & (K7_TROWS - 1u)) * 64u + lane] = tr;
-                s_tlit[(trow & (K7_TROWS - 1u)) * 64u + lane] = tl;
+                // the first end-of-block symbol and the first symbol in error, in symbol order
+                const u64 mEa = __ballot(eoba), mEb = __ballot(eobb), mBa = __ballot(bada), mBb = __ballot(badb);
+                u32 eIdx = 64u, bIdx = 64u, eEnd = 0;
+                if (mEa | mEb) {
+                    const u32 ke = (u32)__builtin_ctzll(mEa | mEb);
+                    const bool first = (mEa >> ke) & 1ull;
+                    eIdx = (u32)__builtin_amdgcn_readlane((int)ia, (int)ke) + (first ? 0u : 1u);
+                    eEnd = first ? (u32)__builtin_amdgcn_readlane((int)(sk + la), (int)ke) : (u32)__builtin_amdgcn_readlane((int)sn, (int)ke);
+                }
+                if (mBa | mBb) {
+                    const u32 kb = (u32)__builtin_ctzll(mBa | mBb);
+                    bIdx = (u32)__builtin_amdgcn_readlane((int)ia, (int)kb) + (((mBa >> kb) & 1ull) ? 0u : 1u);
+                }
+                if ((info & K7_G_NOCODE) && listed < bIdx) bIdx = listed;       // the symbol after the listed ones has no code
+                if (eIdx > 49u) eIdx = 64u;                                    // symbols 50.. belong to the next group: wave A reads them again
+                if (bIdx > 49u) bIdx = 64u;
+                u32 cntg = 50u;
+                if (bIdx < eIdx) st = DEC_DATA_ERROR;
+                else if (eIdx < 64u) { eob = true; cntg = eIdx + 1u; endbit = P + eEnd; }
+                __builtin_amdgcn_wave_barrier();                               // the record (and the stream words under it) may go now
+                gt++;
+                if (lane == 0) { lds_publish(&s_gtail, gt); if (eob || st) lds_publish(&s_stop, 1u); }
+                if (st) break;
+                nsym += cntg;
+                if (have && ia < cntg) s_sym[(np + ia) & (K7_SYMS - 1u)] = (u16)syma;
+                if (two && ib < cntg) s_sym[(np + ib) & (K7_SYMS - 1u)] = (u16)symb;
+                np += cntg;
                 __builtin_amdgcn_wave_barrier();
-                trow++;
-                if (lane == 0) lds_publish(&s_thead, trow);
-                if (mE) { finished = true; break; }
-                // the run symbols behind the row's last literal carry over
-                {
+                K7_T(6);
+                // whole rows of 64 symbols (the last one of the block as it is)
+                while (!st && (np - consumed >= 64u || (eob && np > consumed))) {
+                    const u32 hi = np - consumed < 64u ? np - consumed : 64u;
+                    const bool valid = lane < hi;
+                    const u32 symv = valid ? s_sym[(consumed + lane) & (K7_SYMS - 1u)] : 0u;
+                    const u32 idxv = symv - 1u;                                // MTF index of a literal
+                    const u64 mE = __ballot(valid && symv > symTotal);         // end of block (:349-350)
+                    const u32 eobAt = mE ? (u32)__builtin_ctzll(mE) : 64u;
+                    const bool inrow = valid && lane <= eobAt;
+                    const bool isL = inrow && symv >= 2u && lane != eobAt;
+                    const u64 mA = __ballot(inrow && symv == 0u), mB = __ballot(inrow && symv == 1u), mL = __ballot(isL);
+                    const u64 nonrun = mL | (mE ? 1ull << eobAt : 0ull);
+                    const bool isN = isL || lane == eobAt;
+                    // the run symbols in front of this lane: [start, lane)
+                    const u64 below = nonrun & lt_mask;
+                    const u32 start = below ? 64u - (u32)__builtin_clzll(below) : 0u;
+                    const u32 len2 = lane - start;
+                    const u64 seg = (1ull << len2) - 1ull;                     // len2 <= 63
+                    RunAcc ra;
+                    ra.N = below ? 0u : runN;
+                    ra.T = below ? 0ull : runT;
+                    run_extend(ra, (mA >> start) & seg, (mB >> start) & seg, len2);
+                    const bool fl = isN && ra.N != 0u;                         // :340-347: a pending run is flushed in front of this symbol
+                    const u32 flc = fl ? (ra.T > (u64)DEC_CAP ? DEC_CAP + 1u : (u32)ra.T) : 0u;
+                    const u32 rowsum = wave_sum_dpp(flc + (isL ? 1u : 0u));
+                    if (cnt + rowsum > DEC_CAP) { st = DEC_DATA_ERROR; break; }   // :342, :351
+                    cnt += rowsum;
+                    // the row's literals, compacted: entry t = MTF index of the t-th literal
+                    const u32 rank = (u32)__builtin_popcountll(mL & lt_mask);
+                    const bool far = __ballot(isL && idxv >= 64u) != 0ull;
+                    const u32 slotr = rows & (K7_RROWS - 1u);
+                    if (rows - lds_observe(&s_dtail) >= K7_RROWS) {
+                        const u64 w0 = clock64();
+                        while (rows - lds_observe(&s_dtail) >= K7_RROWS && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1);
+                        cwait += clock64() - w0;
+                    }
+                    if (isL) s_cidx[slotr][rank] = (u16)idxv;
+                    s_rrun[slotr][lane] = flc | (isL ? 1u << 24 : 0u);          // flc < 2^24
+                    if (lane == 0) { s_rmL[slotr] = mL; s_rinfo[slotr] = far ? 1u : 0u; }
+                    __builtin_amdgcn_wave_barrier();
+                    rows++;
+                    if (lane == 0) lds_publish(&s_rhead, rows);
+                    consumed += hi;
+                    if (mE) { finished = true; break; }
+                    // the run symbols behind the row's last literal carry over
                     const u32 st0 = nonrun ? 64u - (u32)__builtin_clzll(nonrun) : 0u;
                     const u32 ln = hi - st0;
                     const u64 sg = ln == 64u ? ~0ull : ((1ull << ln) - 1ull);
@@ -511,30 +602,95 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                     runN = c.N;
                     runT = c.T;
                 }
-                consumed = b0 + hi;
-                if (lane == 0) lds_publish(&s_tail, consumed);
-                if (lds_observe(&s_abort)) break;
+                K7_T(7);
             }
-            if (!st && !finished) st = -1;                                     // wave 0 reports why it stopped
-            if (lane == 0) { s_cstat = st; s_cnt = cnt; s_cwait = cwait; if (st) lds_publish(&s_abort, 1u); lds_publish(&s_tdone, 1u); }
-        } else {
-            // ---- wave 2: token rows -> bytes of the last column ------------------------------------------
-            u8* out = D.tt + (size_t)slot * D.ttStride;
-            u32 taken = 0, opos = 0;
+            if (st == 0 && !finished) st = DEC_DATA_ERROR;                     // unreachable for st == 0 (a block ends with its end-of-block symbol)
+#ifdef K7_PROF
+            if (lane == 0) for (int k = 5; k < 10; k++) s_prof[k] = prof_[k];
+#endif
+            if (lane == 0) {
+                s_pstat = st; s_cnt = cnt; s_cwait = cwait; s_endbit = endbit; s_nsym = nsym;
+                if (st) lds_publish(&s_abort, 1u);
+                lds_publish(&s_stop, 1u);
+                lds_publish(&s_bdone, 1u);
+            }
+        } else if (wave == 2) {
+            // ---- wave C: the MTF recurrence over the literals of a row ------------------------------------
+            u32 l0, l1, l2, l3;            // the MTF list in the byte domain (entries are symToByte values), one per lane
+            {
+                const u8* m8 = (const u8*)s_mtf;
+                l0 = m8[lane]; l1 = m8[64u + lane]; l2 = m8[128u + lane]; l3 = m8[192u + lane];
+            }
+            u32 rr = 0;
             for (;;) {
-                u32 head = lds_observe(&s_thead);
-                if (head == taken) {
-                    if (lds_observe(&s_tdone)) {
-                        head = lds_observe(&s_thead);
-                        if (head == taken) break;
-                    } else { __builtin_amdgcn_s_sleep(2); continue; }
+                if (lds_observe(&s_rhead) == rr) {
+                    if (lds_observe(&s_abort)) break;
+                    if (lds_observe(&s_bdone)) { if (lds_observe(&s_rhead) == rr) break; }
+                    else { __builtin_amdgcn_s_sleep(1); continue; }
                 }
-                const u32 tr = s_trun[(taken & (K7_TROWS - 1u)) * 64u + lane], tl = s_tlit[(taken & (K7_TROWS - 1u)) * 64u + lane];
-                const u32 c = tr & 0xffffffu, rb = tr >> 24, f = (tl >> 8) & 1u;
+                const u32 slotr = rr & (K7_RROWS - 1u);
+                const u32 cidx = s_cidx[slotr][lane];
+                const u32 nlit = (u32)__builtin_popcountll(s_rmL[slotr]);
+                const bool far = __builtin_amdgcn_readfirstlane((int)s_rinfo[slotr]) != 0;
+                const u32 f0 = (u32)__builtin_amdgcn_readlane((int)l0, 0);       // front of the list before the row's first literal
+                u32 outc = 0;                                                  // lane t = byte of the t-th literal
+                if (!far) {
+                    // mtf(mtfSymbol, sym - 1) :53-60 for an index below 64: one v_readlane, one DPP shift, one select; straight-line
+                    // steps, eight per loop branch
+#define K7_MTF_STEP(t_) do {                                                                                       \
+                        const u32 idx_ = (u32)__builtin_amdgcn_readlane((int)cidx, (int)(t_));                     \
+                        const u32 src_ = (u32)__builtin_amdgcn_readlane((int)l0, (int)idx_);                       \
+                        const u32 sh_ = (u32)__builtin_amdgcn_update_dpp((int)src_, (int)l0, 0x138, 0xf, 0xf, false); \
+                        l0 = lane <= idx_ ? sh_ : l0;                                                              \
+                        outc = (u32)cjs_writelane((int)src_, (int)(t_), (int)outc);                                \
+                    } while (0)
+                    u32 t = 0;
+                    for (; t + 8u <= nlit; t += 8u) {
+                        K7_MTF_STEP(t); K7_MTF_STEP(t + 1u); K7_MTF_STEP(t + 2u); K7_MTF_STEP(t + 3u);
+                        K7_MTF_STEP(t + 4u); K7_MTF_STEP(t + 5u); K7_MTF_STEP(t + 6u); K7_MTF_STEP(t + 7u);
+                    }
+                    if (nlit & 4u) { K7_MTF_STEP(t); K7_MTF_STEP(t + 1u); K7_MTF_STEP(t + 2u); K7_MTF_STEP(t + 3u); t += 4u; }
+                    if (nlit & 2u) { K7_MTF_STEP(t); K7_MTF_STEP(t + 1u); t += 2u; }
+                    if (nlit & 1u) K7_MTF_STEP(t);
+                } else {
+                    for (u32 t = 0; t < nlit; t++) {
+                        const u32 idx = (u32)__builtin_amdgcn_readlane((int)cidx, (int)t);
+                        const u32 src = mtf_step(l0, l1, l2, l3, idx, lane);
+                        outc = (u32)cjs_writelane((int)src, (int)t, (int)outc);
+                    }
+                }
+                s_out[slotr][lane] = (u8)outc;
+                if (lane == 0) s_rf0[slotr] = f0;
+                __builtin_amdgcn_wave_barrier();
+                rr++;
+                if (lane == 0) lds_publish(&s_chead, rr);
+            }
+            if (lane == 0) lds_publish(&s_cdone, 1u);
+        } else {
+            // ---- wave D: rows -> bytes of the last column ----------------------------------------------------
+            u8* out = D.tt + (size_t)slot * D.ttStride;
+            u32 rr = 0, opos = 0;
+            for (;;) {
+                if (lds_observe(&s_chead) == rr) {
+                    if (lds_observe(&s_abort)) break;
+                    if (lds_observe(&s_cdone)) { if (lds_observe(&s_chead) == rr) break; }
+                    else { __builtin_amdgcn_s_sleep(1); continue; }
+                }
+                const u32 slotr = rr & (K7_RROWS - 1u);
+                const u32 rinfo = s_rrun[slotr][lane];
+                const u64 mL = s_rmL[slotr];
+                const u32 outc = s_out[slotr][lane];
+                const u32 f0 = s_rf0[slotr];
+                // back to the row's lanes: own byte for a literal, the byte of the literal before for a run
+                const u32 rank = (u32)__builtin_popcountll(mL & lt_mask);
+                const u32 own = __shfl(outc, (int)(rank & 63u));
+                const u32 prevb = __shfl(outc, (int)((rank - 1u) & 63u));
+                const u32 rb = rank ? prevb : f0;
+                const u32 c = rinfo & 0xffffffu, f = (rinfo >> 24) & 1u;
                 const u32 tot = c + f;
-                const u32 incl = wave_incl_scan_u32(tot);
+                const u32 incl = wave_incl_scan_dpp(tot);
                 const u32 at = opos + incl - tot;
-                if (f) out[at + c] = (u8)tl;                                   // the common case: one coalesced store per row
+                if (f) out[at + c] = (u8)own;                                  // the common case: one coalesced store per row
                 if (c && c < 64u) for (u32 i = 0; i < c; i++) out[at + i] = (u8)rb;
                 u64 big = __ballot(c >= 64u);                                  // long runs: the whole wave fills each of them
                 while (big) {
@@ -545,9 +701,9 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
                     for (u32 i = lane; i < bc; i += 64u) out[bat + i] = (u8)bb;
                 }
                 opos += (u32)__builtin_amdgcn_readlane((int)incl, 63);
-                taken++;
+                rr++;
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 0) lds_publish(&s_ttail, taken);
+                if (lane == 0) lds_publish(&s_dtail, rr);
             }
         }
     }
@@ -555,7 +711,6 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
     if (threadIdx.x == 0) {
         DecResult res;
         int st = s_pstat;
-        if (st == 0 && s_hdr) st = s_cstat == -1 ? DEC_DATA_ERROR : s_cstat;
         if (st == 0 && s_origPtr >= s_cnt) st = DEC_DATA_ERROR;               // :372
         res.endbit = s_endbit;
         res.status = st;
@@ -565,6 +720,7 @@ __global__ __launch_bounds__(192) void k7_decode(DecBuf D, u32 first, u32 count)
         res.cycles = clock64() - t_start;
         res.symbols = s_nsym;
         res.pwait = s_pwait;
+        for (int k = 0; k < 10; k++) res.prof[k] = s_prof[k];
         res.cwait = s_cwait;
         D.res[slot] = res;
     }
@@ -577,7 +733,7 @@ int k7_scan(const u8* d_in, u64 len, u64 first_bit, u64* d_cand, u32* d_ncand, u
     return CJS_OK;
 }
 int k7_run(DecBuf D, u32 first, u32 count, hipStream_t stream) {
-    hipLaunchKernelGGL(k7_decode, dim3(count), dim3(192), 0, stream, D, first, count);
+    hipLaunchKernelGGL(k7_decode, dim3(count), dim3(256), 0, stream, D, first, count);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

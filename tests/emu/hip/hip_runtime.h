@@ -234,18 +234,28 @@ static inline void __builtin_amdgcn_s_sleep(int) { emu::yield_(); }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
 template <class T> static inline void __hip_atomic_store(T* p, T v, int, int) { *(volatile T*)p = v; }
 template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *(volatile T*)p; }
-// DPP: wave_shr:1 (0x138): lane l reads lane l-1, lane 0 keeps `old`; row_shr:n (0x111..0x11f): lane l reads lane l-n of
+// DPP (lanes of rows not in row_mask keep `old`): wave_shr:1 (0x138): lane l reads lane l-1, lane 0 keeps `old`; row_shr:n (0x111..0x11f): lane l reads lane l-n of
 // its row of 16, lanes whose source falls outside the row keep `old` (bound_ctrl false) or get 0 (bound_ctrl true)
-static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool bound_ctrl) {
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int, bool bound_ctrl) {
     const int l = emu::lane();
+    const bool row_on = (row_mask >> (l >> 4)) & 1;
     if (ctrl == 0x138) {
         const int v = emu_shfl_(src, l > 0 ? l - 1 : 0);
-        return l > 0 ? v : old;
+        return l > 0 && row_on ? v : old;
     }
     if (ctrl >= 0x111 && ctrl <= 0x11f) {
         const int n = ctrl - 0x110, r = l & 15;
         const int v = emu_shfl_(src, r >= n ? l - n : l);
+        if (!row_on) return old;
         return r >= n ? v : (bound_ctrl ? 0 : old);
+    }
+    if (ctrl == 0x142) {                                   // row_bcast:15: lane 15 of every row to the next row
+        const int v = emu_shfl_(src, l >= 16 ? (l & ~15) - 1 : 0);
+        return l >= 16 && row_on ? v : old;
+    }
+    if (ctrl == 0x143) {                                   // row_bcast:31: lane 31 to rows 2 and 3
+        const int v = emu_shfl_(src, 31);
+        return l >= 32 && row_on ? v : old;
     }
     abort();
 }
