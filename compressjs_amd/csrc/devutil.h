@@ -6,6 +6,16 @@
 // intrinsic is reached by its name)
 extern "C" __device__ int cjs_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
+// m | 1 << (b & 63) in ONE scalar instruction where the compiler takes two (b is wave-uniform)
+__device__ __forceinline__ u64 bitset1_b64(u64 m, u32 b) {
+#if defined(__AMDGCN__)
+    asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(b));
+    return m;
+#else
+    return m | (1ull << (b & 63u));
+#endif
+}
+
 // mask of lanes whose low `nbits` of d equal this lane's (and are valid)
 __device__ __forceinline__ u64 match_any(u32 d, int nbits, bool valid) {
     u64 m = __ballot(valid);

@@ -145,6 +145,13 @@ __device__ __forceinline__ u32 win_peek32(const u32* win, u32 w0, u32 q) {
     return (u32)(two >> (32u - sh));
 }
 
+// the same for a lane that keeps the byte address of its word (not yet wrapped into the window) and 32 - (bit in the word)
+__device__ __forceinline__ u32 win_peek_at(const u32* win, u32 wa, u32 shc) {
+    const char* b = (const char*)win;
+    const u64 two = ((u64)*(const u32*)(b + (wa & (K7_WIN * 4u - 4u))) << 32) | *(const u32*)(b + ((wa + 4u) & (K7_WIN * 4u - 4u)));
+    return (u32)(two >> shc);
+}
+
 // one move-to-front step on the 256-entry list held one entry per lane in four registers (position p = register p >> 6,
 // lane p & 63): returns the entry at idx and moves it to the front (mtf(), lib/Bzip2.js:53-60).  idx is wave-uniform.
 __device__ __forceinline__ u32 mtf_step(u32& l0, u32& l1, u32& l2, u32& l3, u32 idx, u32 lane) {
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
         if (wave == 0) {
             // ---- wave A: where the Huffman codes of a group of 50 start -------------------------------
             u64 P = br_tell(r);            // bit where the current group starts
-            u64 wl = (P >> 11) << 6;       // stream words [wl - K7_WIN, wl) are in s_win; pf = raw words of chunk wl / 64
+            u32 wl = (u32)(P >> 11) << 6;  // stream words [wl - K7_WIN, wl) are in s_win; pf = raw words of chunk wl / 64
             u32 pf = br_load(r, wl >> 6);
             u32 selrow = 0, selnext = gsel[lane];
             u32 selector = 0, gh = 0;
@@ -347,14 +354,14 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
             u64 prof_[5] = {0, 0, 0, 0, 0}, tl_ = clock64();
 #endif
             for (;;) {
-                if (lds_observe(&s_stop) || lds_observe(&s_abort)) break;
+                if (lds_observe(&s_stop)) break;                               // wave B raises it whenever it leaves, also on an error
                 u32 i = 0, g = 0, gend = 0, gexit = 0;
                 u32 flags = 0;
                 if (gh - lds_observe(&s_gtail) >= K7_GRING) {                  // a free record for this group's row masks
                     const u64 w0 = clock64();
-                    while (gh - lds_observe(&s_gtail) >= K7_GRING && !lds_observe(&s_stop) && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1);
+                    while (gh - lds_observe(&s_gtail) >= K7_GRING && !lds_observe(&s_stop)) __builtin_amdgcn_s_sleep(1);
                     pwait += clock64() - w0;
-                    if (lds_observe(&s_stop) || lds_observe(&s_abort)) break;
+                    if (lds_observe(&s_stop)) break;
                 }
                 if (selector >= nSel) flags = K7_G_NOSEL;                      // an error only if wave B gets this far (:286-287)
                 else {
@@ -365,72 +372,87 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                     selector++;
                     const int limLA = lane < 32u ? s_limLA[g][lane] : -1;
                     K7_T(0);
-                    const u32 pw = (u32)(P >> 5) & (K7_WIN - 1u), pb = (u32)P & 31u;        // P as a word of the window and a bit in it
-                    {
-                        const u64 need = ((P + 127u) >> 5) + 2u;               // words the peeks of rows 0 and 1 touch
-                        while (wl < need) {
-                            s_win[((u32)wl + lane) & (K7_WIN - 1u)] = __builtin_bswap32(pf);
-                            wl += 64u;
-                            pf = br_load(r, wl >> 6);
-                        }
-                        __builtin_amdgcn_wave_barrier();
+                    const u32 pw = (u32)(P >> 5), pb = (u32)P & 31u;            // P as a stream word and a bit in it
+                    // this lane's bit of row r starts shc bits below the top of the word pair at byte wa + 8r of the window
+                    const u32 shc = 32u - ((pb + lane) & 31u);
+                    u32 wa = (pw + ((pb + lane) >> 5)) * 4u;
+                    u32 needw = pw + 9u;                                       // words the peeks of rows 0, 1 and 2 touch
+                    while ((int)(wl - needw) < 0) {
+                        s_win[(wl + lane) & (K7_WIN - 1u)] = __builtin_bswap32(pf);
+                        wl += 64u;
+                        pf = br_load(r, wl >> 6);
                     }
-                    u32 pk = win_peek32(s_win, pw, pb + lane);                  // the 32 bits at this lane's bit of row 0
+                    __builtin_amdgcn_wave_barrier();
+                    // Two rows ahead of the chain: the 32 bits at every bit of row r+2 and the table entries of row r+1 are requested
+                    // before row r is walked - a lone wave would otherwise sit out both LDS round trips in front of every row.
+                    u32 e = s_lt[g][win_peek_at(s_win, wa, shc) >> (32u - K7_LTBITS)];   // table entry of the step starting at this lane's bit
+                    u32 pk = win_peek_at(s_win, wa + 8u, shc);                   // the 32 bits at this lane's bit of the NEXT row
+                    wa += 16u;
                     // The chain of code starts, a row of 64 bits at a time.  One STEP takes the code at the current bit and, when
                     // the table knows it, the code after it too; all a step does is look up how far it goes (one v_readlane), mark
                     // its start in the row's mask and advance - a handful of scalar instructions.  Wave B finds the symbols from the masks.
                     u32 o = 0, rowb = 0, ns = 0, R = 0;                          // ns = symbols in the rows before this one
                     bool nocode = false;
-                    for (;;) {
-                        const u32 e = s_lt[g][pk >> (32u - K7_LTBITS)];
-                        const u32 l1 = e & 15u, l2 = e >> 4;
-                        const u32 advv = l1 ? l1 + l2 : K7_UNRES;                // how far a step starting at this lane's bit goes
-                        {                                                      // the next row's bits: requested now, used after the chain
-                            const u64 need = ((P + rowb + 191u) >> 5) + 2u;
-                            while (wl < need) {
-                                s_win[((u32)wl + lane) & (K7_WIN - 1u)] = __builtin_bswap32(pf);
-                                wl += 64u;
-                                pf = br_load(r, wl >> 6);
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                        const u32 pkn = win_peek32(s_win, pw, pb + rowb + 64u + lane);
-                        K7_T(1);
-                        u64 mask = 0;                                          // bit b = a step starts at bit b of the row
-#define K7_STEP { const u32 a_ = (u32)__builtin_amdgcn_readlane((int)advv, (int)o); mask |= 1ull << o; o += a_; if (o >= 64u) break; }
-                        for (;;) {
-                            for (;;) { K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP }
-                            if (o < K7_UNRES) break;
-                            const u32 off = o - K7_UNRES;                          // the code at bit `off` is longer than the table's reach,
-                            const u32 u20 = win_peek32(s_win, pw, pb + rowb + off) >> 12;   // or there is no code at all
-                            const u64 m = __ballot((int)u20 <= limLA);             // lane L = length L (:290-297)
-                            if (m == 0) { nocode = true; mask &= ~(1ull << off); o = off; break; }   // i > maxLen (:292)
+                    // (gotos: with structured loops and their breaks the compiler spends as many instructions on exit flags as the
+                    // walk itself takes; every instruction of a lone wave costs 5-9 clocks)
+                    u32 l1, l2, advv, en, pkn, nsn;
+                    u64 mask, twoM;
+                row_top:
+                    l1 = e & 15u;
+                    l2 = e >> 4;
+                    advv = l1 ? l1 + l2 : K7_UNRES;                            // how far a step starting at this lane's bit goes
+                    en = s_lt[g][pk >> (32u - K7_LTBITS)];                    // row r+1: requested now, used after the chain
+                    needw += 2u;
+                    while ((int)(wl - needw) < 0) {
+                        s_win[(wl + lane) & (K7_WIN - 1u)] = __builtin_bswap32(pf);
+                        wl += 64u;
+                        pf = br_load(r, wl >> 6);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    pkn = win_peek_at(s_win, wa, shc);                          // row r+2
+                    wa += 8u;
+                    K7_T(1);
+                    mask = 0;                                                  // bit b = a step starts at bit b of the row
+#define K7_STEP { const u32 a_ = (u32)__builtin_amdgcn_readlane((int)advv, (int)o); mask = bitset1_b64(mask, o); o += a_; if (o >= 64u) goto left_row; }
+                walk_row:
+                    K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP K7_STEP
+                    goto walk_row;
+                left_row:
+                    if (o >= K7_UNRES) {
+                        const u32 off = o - K7_UNRES;                          // the code at bit `off` is longer than the table's reach,
+                        const u32 u20 = win_peek32(s_win, pw, pb + rowb + off) >> 12;   // or there is no code at all
+                        const u64 m = __ballot((int)u20 <= limLA);             // lane L = length L (:290-297)
+                        if (m == 0) { nocode = true; mask &= ~(1ull << off); o = off; }   // i > maxLen (:292)
+                        else {
                             o = off + (u32)__builtin_ctzll(m);
-                            if (o >= 64u) break;
+                            if (o < 64u) goto walk_row;
                         }
-                        K7_T(2);
-                        const u64 twoM = __ballot(l2 != 0u) & mask;
-                        const u32 rc = (u32)__builtin_popcountll(mask) + (u32)__builtin_popcountll(twoM);
-                        if (lane == 0) s_gmask[gh & (K7_GRING - 1u)][R] = mask;
-                        if (nocode && ns + rc < 50u) break;
-                        nocode = false;                                        // a bit without a code behind symbol 50 is the next group's business
-                        if (ns + rc >= 50u) {
-                            // the row where symbol 50 starts = where the next group starts: the step that reaches 50 (or, taking two, 51)
-                            const u64 le = lt_mask | (1ull << lane);
-                            const u32 inc = ns + (u32)__builtin_popcountll(mask & le) + (u32)__builtin_popcountll(twoM & le);
-                            const u64 m50 = __ballot(((mask >> lane) & 1ull) && inc >= 50u);
-                            const u32 kk = (u32)__builtin_ctzll(m50);
-                            if ((u32)__builtin_amdgcn_readlane((int)inc, (int)kk) == 50u) {
-                                const u64 above = kk == 63u ? 0ull : (mask >> (kk + 1u)) << (kk + 1u);
-                                gend = rowb + (above ? (u32)__builtin_ctzll(above) : o);       // where the next step starts
-                            } else gend = rowb + kk + (u32)__builtin_amdgcn_readlane((int)l1, (int)kk);   // after the first of its two codes
-                            break;
-                        }
-                        ns += rc;
+                    }
+                    K7_T(2);
+                    twoM = __ballot(l2 != 0u) & mask;
+                    nsn = ns + (u32)__builtin_popcountll(mask) + (u32)__builtin_popcountll(twoM);
+                    if (lane == 0) s_gmask[gh & (K7_GRING - 1u)][R] = mask;
+                    if (nsn < 50u && !nocode) {
+                        ns = nsn;
                         R++;
                         o -= 64u;
                         rowb += 64u;
+                        e = en;
                         pk = pkn;
+                        goto row_top;
+                    }
+                    if (nsn >= 50u) {
+                        // the row where symbol 50 starts = where the next group starts: the step that reaches 50 (or, taking two, 51);
+                        // a bit without a code behind it is the next group's business
+                        nocode = false;
+                        const u64 le = lt_mask | (1ull << lane);
+                        const u32 inc = ns + (u32)__builtin_popcountll(mask & le) + (u32)__builtin_popcountll(twoM & le);
+                        const u64 m50 = __ballot(((mask >> lane) & 1ull) && inc >= 50u);
+                        const u32 kk = (u32)__builtin_ctzll(m50);
+                        if ((u32)__builtin_amdgcn_readlane((int)inc, (int)kk) == 50u) {
+                            const u64 above = kk == 63u ? 0ull : (mask >> (kk + 1u)) << (kk + 1u);
+                            gend = rowb + (above ? (u32)__builtin_ctzll(above) : o);       // where the next step starts
+                        } else gend = rowb + kk + (u32)__builtin_amdgcn_readlane((int)l1, (int)kk);   // after the first of its two codes
                     }
                     i = R + 1u;                                                // rows in the record
                     gexit = rowb + o;                                          // where the step after the last marked one starts

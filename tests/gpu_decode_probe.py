@@ -17,4 +17,4 @@ for it in range(3):
 assert m == n and bool((out[:n].cpu().numpy() == d).all())
 print("round trip ok")
 if n >= 100_000_000:
-    print("blocks in flight: min(%d candidates, 4096); 3 waves per block" % ((n + 899980) // 899981))
+    print("blocks in flight: min(%d candidates, 4096); 4 waves per block" % ((n + 899980) // 899981))
