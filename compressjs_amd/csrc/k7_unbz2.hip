@@ -5,17 +5,16 @@
 //                   to a candidate list.  The reference never searches - it reads the next header
 //                   where the previous block ended - so the host walks the real chain through the
 //                   candidates afterwards (decode.hip) and ignores hits that are not on it.
-//   k7_decode       two WAVES per candidate block (code boundaries | symbols, RLE2, MTF), pipelined
-//                   through an LDS ring.  The 64 lanes of a wave execute one uniform instruction
-//                   stream (the Huffman/MTF recurrences are serial) and use the vector registers as
-//                   tables indexed with v_readlane instead of going to LDS for every symbol:
-//                     - 2 x 64 stream words prefetched per lane (coalesced 256-byte loads),
-//                     - limit[] / base[] of the current coding table: lane L holds length L; the
-//                       code length is one ballot of "prefix(L) <= limit[L]" (:290-297),
-//                     - permute[] of the current table: 3 registers x 64 lanes (two u16 each),
-//                     - the 256-entry MTF list, kept in the byte domain (entries are symToByte values):
-//                       4 bytes per lane, shifted with one DPP wave_shr,
-//                     - output: one (byte, count) token per literal/run, expanded 64 tokens at a time.
+//   k7_decode       FOUR WAVES per candidate block, a software pipeline through LDS rings (details at the kernel):
+//                     A  header, then where the Huffman codes start: per row of 64 bit positions every lane looks up how
+//                        far a step (one or two codes) starting at its bit goes; the chain through the row is five scalar
+//                        instructions per step (v_readlane, s_bitset1, s_add, s_cmp, s_cbranch);
+//                     B  the symbols of a group of 50 (50 lanes at once), RLE2 run lengths from ballots, MTF indices;
+//                     C  the MTF recurrence (256-entry list one entry per lane, one DPP shift per literal);
+//                     D  expansion into the BWT last column.
+//                   At 10^8 bytes there are 112 blocks for 1024 SIMDs: every wave runs alone, an instruction costs 5-9
+//                   clocks, a v_readlane -> SGPR -> use round trip 20-30, an LDS round trip 50-60 (tests/microbench/
+//                   lone_wave.hip) - the design counts instructions on the serial chains, nothing else.
 //                   Output: the BWT last column (dbuf low bytes) of the block, its length, origPtr,
 //                   the stored CRC, the bit position where the block ends, or an Err code.
 #include "decode.h"
@@ -183,16 +182,21 @@ __device__ __forceinline__ u32 mtf_step(u32& l0, u32& l1, u32& l2, u32& l3, u32 
 #define K7_T(k_) do { } while (0)
 #endif
 
-// Three waves per block, a software pipeline through two LDS rings:
-//   wave 0  parses the block header, then decodes the Huffman symbols one GROUP of 50 at a time (one coding table per
-//           group, lib/Bzip2.js:283-300).  Where the next code starts is a serial recurrence, but how long the code
-//           starting at a given bit is, is not: every lane looks the length up for its own bit offset (64 offsets per
-//           row, a table indexed by the next 10 bits), the chain of code starts is then followed with one v_readlane
-//           per symbol, and the 50 symbols themselves (canonical index, permute[], end-of-block, the checks of
-//           :292-300) are extracted by 50 lanes at once;
-//   wave 1  undoes RLE2 and MTF and emits one (byte, count) token per literal or run (:305-366);
-//   wave 2  expands 64 tokens per step into the block's last column (prefix sum of the counts, one
-//           coalesced byte store per row in the common all-literal case).
+// Four waves per block, a software pipeline through LDS rings (a group = 50 symbols of one coding table,
+// lib/Bzip2.js:283-300; a row = 64 bit positions of the stream (wave A) or 64 symbols (waves B, C, D)):
+//   wave A  parses the block header, then finds where the codes start.  Where the next code starts is a serial recurrence, but
+//           how far a STEP - the code at a given bit and, when the 10-bit table knows it, the code after it - goes is not: every
+//           lane looks that up for its own bit of the row, and the walk through the row is one v_readlane and four scalar
+//           instructions per step.  Hands over, per group, the masks of step starts of its rows;
+//   wave B  turns the masks into the symbols (canonical index, permute[], end-of-block, the checks of :292-300: 50 lanes at
+//           once), regroups them into rows, computes the RLE2 run lengths (:318-347) and the dbufCount checks per row from
+//           ballots, and compacts the literals' MTF indices;
+//   wave C  runs the MTF recurrence (:53-60) over the compacted literals;
+//   wave D  expands rows into the block's last column (DPP prefix sum of run length + 1, one coalesced byte store per row in
+//           the common all-literal case).
+// Rings: A -> B group records (K7_GRING), B -> C, D symbol rows (K7_RROWS), C -> D output bytes in the same slots.  Waits end on
+// the producer's progress or on s_stop / s_abort / s_adone / s_bdone / s_cdone; wave B decides everything that depends on the
+// order of symbols (which error or end-of-block comes first), exactly as the sequential reference would meet them.
 __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count) {
     const u32 slot = blockIdx.x;
     if (slot >= count) return;
