@@ -5,6 +5,8 @@ are -- they keep the kernel logic and the host orchestration honest in a contain
 import ctypes as C
 import hashlib
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -299,6 +301,30 @@ def test_decoder_multi_block_and_long_runs(emu_ctx):
     for sid, s, ms in decode_cases.streams():
         if sid in want and s is not None:
             check_stream(L, h, sid, s, ms, g[sid])
+
+
+def test_decoder_code_less_bits_behind_symbol_50():
+    """A corrupted block whose Huffman data runs into bits that no code of the group's table matches only AFTER the group's 50th
+    symbol (they belong to the next group): the wave that walks the code starts must leave them to the next group and go on.
+    (It once stopped there, and the symbol wave waited for ever; found by the GPU fuzz, seed 1 case 191.)  In a subprocess with
+    a timeout: a hang must fail, not block the suite."""
+    stagelib.build_emu()
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import stagelib, oracle
+from decode_fuzz import run_gpu
+from compressjs_amd import _lib
+L = _lib.load(stagelib.EMU_SO)
+h = L.cjs_create(0, 2)
+s = bytes.fromhex("425a683131415926535910294ff7000129118040001b69b6c0200060295514f6054dfa7a850c000e2873436a1943f50ea87543ed0d50f287743286")
+want = oracle.bz2_decompress(s, False)
+got = run_gpu(L, h, s, False)
+assert want[0] == -5 and got[:2] == (want[0], want[1]), (got[:2], want[:2])
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    out = subprocess.check_output([sys.executable, "-c", code], timeout=120).decode()
+    assert out.strip().endswith("ok")
 
 
 def test_bwtc_decode_inverts_reference_streams(emu_ctx, golden):
