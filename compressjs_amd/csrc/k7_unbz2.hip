@@ -358,9 +358,10 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
             u64 prof_[5] = {0, 0, 0, 0, 0}, tl_ = clock64();
 #endif
             for (;;) {
-                if (lds_observe(&s_stop)) break;                               // wave B raises it whenever it leaves, also on an error
                 u32 i = 0, g = 0, gend = 0, gexit = 0;
                 u32 flags = 0;
+                // (wave B raises s_stop whenever it leaves, also on an error; it is looked at only when the ring is full: at most
+                // K7_GRING groups of bits behind the block's end are walked for nothing)
                 if (gh - lds_observe(&s_gtail) >= K7_GRING) {                  // a free record for this group's row masks
                     const u64 w0 = clock64();
                     while (gh - lds_observe(&s_gtail) >= K7_GRING && !lds_observe(&s_stop)) __builtin_amdgcn_s_sleep(1);
@@ -374,7 +375,6 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                     if ((selector & 511u) == 0) { selrow = selnext; selnext = gsel[(((selector >> 9) + 1u) << 6) + lane]; }
                     g = ((u32)__builtin_amdgcn_readlane((int)selrow, (int)((selector >> 3) & 63u)) >> (4u * (selector & 7u))) & 15u;
                     selector++;
-                    const int limLA = lane < 32u ? s_limLA[g][lane] : -1;
                     K7_T(0);
                     const u32 pw = (u32)(P >> 5), pb = (u32)P & 31u;            // P as a stream word and a bit in it
                     // this lane's bit of row r starts shc bits below the top of the word pair at byte wa + 8r of the window
@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                     // (gotos: with structured loops and their breaks the compiler spends as many instructions on exit flags as the
                     // walk itself takes; every instruction of a lone wave costs 5-9 clocks)
                     u32 l1, l2, advv, en, pkn, nsn;
+                    u32 mlo = 0, mhi = 0;
                     u64 mask, twoM;
                 row_top:
                     l1 = e & 15u;
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                     if (o >= K7_UNRES) {
                         const u32 off = o - K7_UNRES;                          // the code at bit `off` is longer than the table's reach,
                         const u32 u20 = win_peek32(s_win, pw, pb + rowb + off) >> 12;   // or there is no code at all
+                        const int limLA = lane < 32u ? s_limLA[g][lane] : -1;
                         const u64 m = __ballot((int)u20 <= limLA);             // lane L = length L (:290-297)
                         if (m == 0) { nocode = true; mask &= ~(1ull << off); o = off; }   // i > maxLen (:292)
                         else {
@@ -435,7 +437,8 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                     K7_T(2);
                     twoM = __ballot(l2 != 0u) & mask;
                     nsn = ns + (u32)__builtin_popcountll(mask) + (u32)__builtin_popcountll(twoM);
-                    if (lane == 0) s_gmask[gh & (K7_GRING - 1u)][R] = mask;
+                    mlo = (u32)cjs_writelane((int)(u32)mask, (int)R, (int)mlo);          // lane R of (mhi:mlo) = the mask of row R
+                    mhi = (u32)cjs_writelane((int)(u32)(mask >> 32), (int)R, (int)mhi);
                     if (nsn < 50u && !nocode) {
                         ns = nsn;
                         R++;
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                         } else gend = rowb + kk + (u32)__builtin_amdgcn_readlane((int)l1, (int)kk);   // after the first of its two codes
                     }
                     i = R + 1u;                                                // rows in the record
+                    if (lane < K7_GROWS) s_gmask[gh & (K7_GRING - 1u)][lane] = ((u64)mhi << 32) | mlo;
                     gexit = rowb + o;                                          // where the step after the last marked one starts
                     if (nocode) flags = K7_G_NOCODE;
                 }
