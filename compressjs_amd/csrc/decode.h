@@ -33,7 +33,7 @@ struct DecResult {
     u64 cycles;      // shader clocks k7_decode spent on the block (s_memtime)
     u64 symbols;     // Huffman symbols decoded
     u64 pwait, cwait; // clocks the boundary wave / the symbol wave spent waiting for each other
-    u64 prof[10];     // -DK7_PROF builds: clocks per section of waves 0 and 1 (k7_unbz2.hip)
+    u64 prof[14];     // -DK7_PROF builds: clocks per section of the four waves (k7_unbz2.hip)
 };
 
 struct DecBuf {

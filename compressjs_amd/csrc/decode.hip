@@ -277,12 +277,12 @@ static int decode_batch(DecState& S, hipStream_t st, const u64* pos, u32 count, 
         fprintf(stderr, "[k7] %u blocks: %.1f Mcycles/block, %.0f symbols/block, %.0f bytes/block, %.1f cycles/symbol (boundary wave waits %.1f, symbol wave waits %.1f)\n",
                 count, cy / 1e6 / count, (double)sy / count, (double)by / count, sy ? (double)cy / sy : 0.0,
                 sy ? (double)pw / sy : 0.0, sy ? (double)cw / sy : 0.0);
-        u64 pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        for (u32 i = 0; i < count; i++) for (int k = 0; k < 10; k++) pf[k] += res[i].prof[k];
+        u64 pf[14] = {0};
+        for (u32 i = 0; i < count; i++) for (int k = 0; k < 14; k++) pf[k] += res[i].prof[k];
         if (pf[2] && sy)                                           // a -DK7_PROF build
-            fprintf(stderr, "[k7] clocks/symbol  wave 0: group setup %.1f, row fill %.1f, chain %.1f, symbols %.1f, hand-over %.1f | wave 1: wait+load %.1f, "
-                    "row masks %.1f, MTF %.1f, tokens %.1f (ring wait+store %.1f)\n", (double)pf[0] / sy, (double)pf[1] / sy, (double)pf[2] / sy, (double)pf[3] / sy,
-                    (double)pf[4] / sy, (double)pf[5] / sy, (double)pf[6] / sy, (double)pf[7] / sy, (double)pf[8] / sy, (double)pf[9] / sy);
+            fprintf(stderr, "[k7] clocks/symbol  A: group set-up %.1f, row fill + row end %.1f, walk %.1f, group end + hand-over %.1f | B: wait %.1f, symbols %.1f, "
+                    "rows %.1f | C: MTF %.1f, wait %.1f | D: expand %.1f, wait %.1f\n", (double)pf[0] / sy, (double)pf[1] / sy, (double)pf[2] / sy, (double)pf[3] / sy,
+                    (double)pf[5] / sy, (double)pf[6] / sy, (double)pf[7] / sy, (double)pf[10] / sy, (double)pf[11] / sy, (double)pf[12] / sy, (double)pf[13] / sy);
     }
     return 0;
 }

@@ -225,11 +225,11 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
     __shared__ u32 s_ghead, s_gtail, s_stop, s_rhead, s_chead, s_dtail, s_adone, s_bdone, s_cdone, s_abort, s_symTotal, s_hdr;
     __shared__ int s_pstat;
     __shared__ u32 s_cnt, s_origPtr, s_crc;
-    __shared__ u64 s_endbit, s_nsym, s_pwait, s_cwait, s_prof[10];
+    __shared__ u64 s_endbit, s_nsym, s_pwait, s_cwait, s_prof[14];
 
     u32* gsel = D.sel + (size_t)slot * 4160u;             // [4096 + 64] words: 32768 selectors, 4 bits each, + one row of slack
     const u64 t_start = clock64();
-    if (threadIdx.x == 0) { s_ghead = 0; s_gtail = 0; s_stop = 0; s_rhead = 0; s_chead = 0; s_dtail = 0; s_adone = 0; s_bdone = 0; s_cdone = 0; s_abort = 0; s_pstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; for (int k = 0; k < 10; k++) s_prof[k] = 0; }
+    if (threadIdx.x == 0) { s_ghead = 0; s_gtail = 0; s_stop = 0; s_rhead = 0; s_chead = 0; s_dtail = 0; s_adone = 0; s_bdone = 0; s_cdone = 0; s_abort = 0; s_pstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; for (int k = 0; k < 14; k++) s_prof[k] = 0; }
     __syncthreads();
     BitRd r;
     u32 nSel = 0;
@@ -652,12 +652,16 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                 l0 = m8[lane]; l1 = m8[64u + lane]; l2 = m8[128u + lane]; l3 = m8[192u + lane];
             }
             u32 rr = 0;
+#ifdef K7_PROF
+            u64 prof_[14] = {0}, tl_ = clock64();
+#endif
             for (;;) {
                 if (lds_observe(&s_rhead) == rr) {
                     if (lds_observe(&s_abort)) break;
                     if (lds_observe(&s_bdone)) { if (lds_observe(&s_rhead) == rr) break; }
                     else { __builtin_amdgcn_s_sleep(1); continue; }
                 }
+                K7_T(11);
                 const u32 slotr = rr & (K7_RROWS - 1u);
                 const u32 cidx = s_cidx[slotr][lane];
                 const u32 nlit = (u32)__builtin_popcountll(s_rmL[slotr]);
@@ -694,18 +698,26 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                 __builtin_amdgcn_wave_barrier();
                 rr++;
                 if (lane == 0) lds_publish(&s_chead, rr);
+                K7_T(10);
             }
+#ifdef K7_PROF
+            if (lane == 0) { s_prof[10] = prof_[10]; s_prof[11] = prof_[11]; }
+#endif
             if (lane == 0) lds_publish(&s_cdone, 1u);
         } else {
             // ---- wave D: rows -> bytes of the last column ----------------------------------------------------
             u8* out = D.tt + (size_t)slot * D.ttStride;
             u32 rr = 0, opos = 0;
+#ifdef K7_PROF
+            u64 prof_[14] = {0}, tl_ = clock64();
+#endif
             for (;;) {
                 if (lds_observe(&s_chead) == rr) {
                     if (lds_observe(&s_abort)) break;
                     if (lds_observe(&s_cdone)) { if (lds_observe(&s_chead) == rr) break; }
                     else { __builtin_amdgcn_s_sleep(1); continue; }
                 }
+                K7_T(13);
                 const u32 slotr = rr & (K7_RROWS - 1u);
                 const u32 rinfo = s_rrun[slotr][lane];
                 const u64 mL = s_rmL[slotr];
@@ -734,7 +746,11 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                 rr++;
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) lds_publish(&s_dtail, rr);
+                K7_T(12);
             }
+#ifdef K7_PROF
+            if (lane == 0) { s_prof[12] = prof_[12]; s_prof[13] = prof_[13]; }
+#endif
         }
     }
     __syncthreads();
@@ -750,7 +766,7 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
         res.cycles = clock64() - t_start;
         res.symbols = s_nsym;
         res.pwait = s_pwait;
-        for (int k = 0; k < 10; k++) res.prof[k] = s_prof[k];
+        for (int k = 0; k < 14; k++) res.prof[k] = s_prof[k];
         res.cwait = s_cwait;
         D.res[slot] = res;
     }
