@@ -116,11 +116,21 @@ __global__ __launch_bounds__(256) void k8_walk(DecBuf D, u32 nvalid) {
     if (WRITE) {
         u8* pre = D.pre + (size_t)slot * DEC_STRIDE;
         u32 q = D.splOff[so];
+        // the sublist's bytes are consecutive in the output: four at a time as one aligned word (a quarter of the store
+        // transactions); the bytes in front of the first word boundary and behind the last one singly - those words are shared
+        // with the neighbouring sublists
+        u32 acc = 0, have = 0;
         do {
             const u32 e = word[x];
-            pre[q++] = (u8)e;                              // first-column byte of row x = next output byte
+            const u32 b = e & 0xffu;                       // first-column byte of row x = next output byte
             x = e >> 8;
+            if ((q & 3u) == 0u) { acc = b; have = 1u; }
+            else if (have) { acc |= b << (8u * (q & 3u)); have++; }
+            else pre[q] = (u8)b;
+            q++;
+            if (have == 4u) { *(u32*)(pre + q - 4u) = acc; have = 0u; }
         } while (!is_spl(x, p0));
+        for (u32 k = 0; k < have; k++) pre[q - have + k] = (u8)(acc >> (8u * k));
     } else {
         u32 cnt = 0;
         do { x = word[x] >> 8; cnt++; } while (!is_spl(x, p0));
