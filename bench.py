@@ -211,7 +211,7 @@ def main():
         if g is not None:
             assert hashlib.sha256(host.tobytes()).hexdigest() == g["in_sha256"], "workload generator drifted from the reference-made golden"
             vs_ref = bool(sha == g["out_sha256"] and len(comp) == g["out_len"])
-        verified, port, pcie = None, None, None
+        verified, port, pcie, decode_mb_s = None, None, None, None
         if not args.no_verify:
             import bz2
             # independent decoder (libbz2), bounded to keep the default run short
@@ -220,6 +220,11 @@ def main():
             # the whole stream through the GPU decoder (K7-K9), compared on the device
             back = torch.empty(total + 64, dtype=torch.uint8, device=dev)
             nback = ctx.decompress_device(out, back)
+            torch.cuda.synchronize()
+            a = time.perf_counter()                            # (the second call: the decoder's buffers exist now)
+            nback = ctx.decompress_device(out, back)
+            torch.cuda.synchronize()
+            decode_mb_s = round(total / (time.perf_counter() - a) / 1e6, 1)
             whole = d_in if world == 1 else torch.from_numpy(host).to(dev)
             verified = verified and nback == total and bool(torch.equal(back[:total], whole[:total]))
             del back, whole
@@ -301,6 +306,7 @@ def main():
                        "bit_exact_vs_reference_digest": vs_ref,
                        "bit_exact_vs_oracle_prefix_and_roundtrip": verified,
                        "pcie_inclusive_mb_s": pcie,
+                       "gpu_decode_mb_s": decode_mb_s,
                        "sha256": sha},
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 2),
                          "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
