@@ -97,6 +97,45 @@ __global__ void k_indep(u64* out, u32* sink) {          // independent SALU + VA
     if (threadIdx.x == 0) { out[0] = t1 - t0; sink[1] = a + b + c + d; }
     sink[64 + threadIdx.x] = v0 + v1 + v2 + v3;
 }
+
+// the walk step of k7_decode's wave A in four stages: o += adv[o] | + s_bitset1 | + compare and an untaken branch | masked, no branch
+__global__ void k_walk1(u64* out, u32* sink) {
+    u32 v = 1u + (threadIdx.x & 3u);
+    u32 o = (u32)__builtin_amdgcn_readfirstlane((int)sink[0]) & 63u, a = 0;
+    const u64 t0 = clock64();
+    for (int i = 0; i < REP / 16; i++) { R16(asm volatile("v_readlane_b32 %1, %2, %0\n\ts_add_u32 %0, %0, %1\n\ts_and_b32 %0, %0, 63" : "+s"(o), "+s"(a) : "v"(v) : "scc");) }
+    const u64 t1 = clock64();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; sink[1] = o; }
+}
+__global__ void k_walk2(u64* out, u32* sink) {
+    u32 v = 1u + (threadIdx.x & 3u);
+    u32 o = (u32)__builtin_amdgcn_readfirstlane((int)sink[0]) & 63u, a = 0; u64 m = 0;
+    const u64 t0 = clock64();
+    for (int i = 0; i < REP / 16; i++) { R16(asm volatile("v_readlane_b32 %1, %3, %0\n\ts_bitset1_b64 %2, %0\n\ts_add_u32 %0, %0, %1\n\ts_and_b32 %0, %0, 63" : "+s"(o), "+s"(a), "+s"(m) : "v"(v) : "scc");) }
+    const u64 t1 = clock64();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; sink[1] = o + (u32)m; }
+}
+__global__ void k_walk3(u64* out, u32* sink) {
+    u32 v = 1u + (threadIdx.x & 3u);
+    u32 o = (u32)__builtin_amdgcn_readfirstlane((int)sink[0]) & 63u, a = 0; u64 m = 0;
+    const u64 t0 = clock64();
+    for (int i = 0; i < REP / 16; i++) {
+        R16(asm volatile("v_readlane_b32 %1, %3, %0\n\ts_bitset1_b64 %2, %0\n\ts_add_u32 %0, %0, %1\n\ts_and_b32 %0, %0, 63\n\ts_cmp_lt_u32 %0, 64\n\ts_cbranch_scc0 9f\n9:" : "+s"(o), "+s"(a), "+s"(m) : "v"(v) : "scc");)
+    }
+    const u64 t1 = clock64();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; sink[1] = o + (u32)m; }
+}
+__global__ void k_walk4(u64* out, u32* sink) {
+    u32 v = 1u + (threadIdx.x & 3u);
+    u32 o = (u32)__builtin_amdgcn_readfirstlane((int)sink[0]) & 31u, a = 0, in = 0; u64 m = 0;
+    const u64 t0 = clock64();
+    for (int i = 0; i < REP / 16; i++) {
+        R16(asm volatile("s_sub_u32 %3, %0, 64\n\tv_readlane_b32 %1, %4, %0\n\ts_ashr_i32 %3, %3, 31\n\ts_bitset1_b64 %2, %0\n\ts_and_b32 %1, %1, %3\n\ts_add_u32 %0, %0, %1\n\ts_and_b32 %0, %0, 31"
+                         : "+s"(o), "+s"(a), "+s"(m), "+s"(in) : "v"(v) : "scc");)
+    }
+    const u64 t1 = clock64();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; sink[1] = o + (u32)m; }
+}
 #define RUN(k, n, what) do { hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d_out, d_sink); hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, d_out, d_sink); \
     hipDeviceSynchronize(); u64 c; hipMemcpy(&c, d_out, 8, hipMemcpyDeviceToHost); printf("%-34s %7.1f clocks per %s\n", #k, (double)c / (n), what); } while (0)
 int main() {
@@ -112,5 +151,9 @@ int main() {
     RUN(k_bperm, REP, "dependent ds_bpermute_b32");
     RUN(k_branch, 0x1000, "3-instruction loop iteration");
     RUN(k_indep, REP / 16 * 4 * 8, "independent instruction");
+    RUN(k_walk1, REP, "readlane + s_add (+ s_and)");
+    RUN(k_walk2, REP, "... + s_bitset1_b64");
+    RUN(k_walk3, REP, "... + s_cmp + untaken s_cbranch");
+    RUN(k_walk4, REP, "masked step without a branch");
     return 0;
 }
