@@ -145,18 +145,22 @@ def main():
     ctx = Context(local, args.batch)
     on_device = args.workload == "lcg" and world > 1           # cfg4: every GPU fills its own slice in HBM (LCG jump-ahead)
     host = None
-    if rank == 0 or not on_device:
-        host = workloads.stream(args.workload, total)          # every rank can name the bytes; only its slice goes to its GPU
     if world == 1:
+        host = workloads.stream(args.workload, total)
         d_in = torch.from_numpy(host).to(dev)
     else:
+        # the job's stream = one document of args.size bytes per rank (tests/workloads.py): a rank generates its own document and
+        # the margin in front of it, not the whole job; rank 0 names the whole stream only after the timed region, to verify it
         lo, hi = slice_bounds(total, rank, world)
         wlo = max(0, lo - margin_bytes(args.level))            # the slice + the tail of the previous rank's slice
         if on_device:
             d_in = torch.empty(hi - wlo, dtype=torch.uint8, device=dev)
             ctx.lcg_ascii_device(d_in, 7, first=wlo)
         else:
-            d_in = torch.from_numpy(host[wlo:hi]).to(dev)
+            win = workloads.window(args.workload, args.size, rank, margin_bytes(args.level))
+            assert win.size == hi - wlo
+            d_in = torch.from_numpy(win).to(dev)
+            del win
     bound = int(ctx.L.cjs_bz2_compress_bound(total))
     d_out = torch.zeros((bound + 3) & ~3, dtype=torch.uint8, device=dev)
     seg = None
@@ -169,11 +173,11 @@ def main():
             return d_out[:n]
         seg.zero_()
         def whole():                                           # only the replicated fall-back (run-heavy input) needs it
-            if host is not None:
-                return torch.from_numpy(host).to(dev)
-            t = torch.empty(total, dtype=torch.uint8, device=dev)
-            ctx.lcg_ascii_device(t, 7, first=0)
-            return t
+            if on_device:
+                t = torch.empty(total, dtype=torch.uint8, device=dev)
+                ctx.lcg_ascii_device(t, 7, first=0)
+                return t
+            return torch.from_numpy(workloads.world_stream(args.workload, args.size, world)).to(dev)
         return sharded_compress_sliced(ctx, d_in, wlo, total, args.level, seg=seg, d_all=whole)
 
     for _ in range(args.warmup):
@@ -198,6 +202,8 @@ def main():
 
     if rank == 0:
         import ctypes as C
+        if host is None:
+            host = workloads.world_stream(args.workload, args.size, world)
         comp = out.cpu().numpy().tobytes()
         sha = hashlib.sha256(comp).hexdigest()
         # ---- parity of the WHOLE stream: the digest the reference itself produced on these bytes -------------
@@ -301,7 +307,10 @@ def main():
                                    % (workloads.DESCRIPTIONS[args.workload], args.size, args.level, args.level * 100000 - 19,
                                       3 if args.workload == "lcg" else 2),
                        "input_bytes": total, "compressed_bytes": len(comp),
-                       "blocks_in_flight": args.batch, "sharding": "blocks/%d" % world,
+                       "blocks_in_flight": args.batch,
+                       "sharding": "blocks/%d" % world if world == 1 else
+                                   "one %d-byte document per GPU, one .bz2 stream of the %d documents; every rank holds its document + %d bytes of the one before"
+                                   % (args.size, world, margin_bytes(args.level)),
                        "device_ms_per_step": round(dev_ms / args.steps, 3),
                        "bit_exact_vs_reference_digest": vs_ref,
                        "bit_exact_vs_oracle_prefix_and_roundtrip": verified,

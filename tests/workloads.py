@@ -116,3 +116,40 @@ def stream(name: str, n: int) -> np.ndarray:
     if name == "e8sb":
         return e8s_b(n)
     raise KeyError(name)
+
+
+def document(name: str, n: int, r: int) -> np.ndarray:
+    """Multi-GPU runs (bench.py --gpus N): the job's stream is N documents of n bytes one after another, document r being
+    rank r's slice.  Document 0 is stream(name, n); the others differ by seed (or are the next n bytes of the tiling / of
+    the LCG sequence), so a rank can name its own bytes - and the margin in front of them - without generating the whole job."""
+    if r == 0:
+        return stream(name, n)
+    if name == "enwik":
+        return synth.enwik_like(n, 2025 + r)
+    if name == "text":
+        return synth.text_like(n, 2025 + r)
+    if name == "lcg":
+        return synth.lcg_ascii(n * (r + 1), 7)[n * r:]
+    if name == "e8sa":
+        base = _e8_base()
+        k0 = (n * r) % base.size
+        return np.tile(base, (k0 + n) // base.size + 1)[k0:k0 + n].copy()
+    if name == "e8sb":
+        return e8s_b(n, seed=0x2545F491 + 0x10001 * r)
+    raise KeyError(name)
+
+
+def world_stream(name: str, n: int, world: int) -> np.ndarray:
+    return np.concatenate([document(name, n, r) for r in range(world)]) if world > 1 else stream(name, n)
+
+
+def window(name: str, n: int, r: int, margin: int) -> np.ndarray:
+    """Bytes [r*n - margin, (r+1)*n) of world_stream (clipped at 0): rank r's slice and the tail of what precedes it."""
+    parts = [document(name, n, r)]
+    need, q = min(margin, r * n), r - 1
+    while need > 0:
+        d = document(name, n, q)
+        parts.insert(0, d[-need:] if need < d.size else d)
+        need -= min(need, d.size)
+        q -= 1
+    return np.concatenate(parts) if len(parts) > 1 else parts[0]
