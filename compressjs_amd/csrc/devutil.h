@@ -16,6 +16,13 @@ __device__ __forceinline__ u64 bitset1_b64(u64 m, u32 b) {
 #endif
 }
 
+// keeps the compiler from sinking the computation (typically a load) of v below this point
+__device__ __forceinline__ void pin_vgpr(u32& v) {
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(v));
+#endif
+}
+
 // mask of lanes whose low `nbits` of d equal this lane's (and are valid)
 __device__ __forceinline__ u64 match_any(u32 d, int nbits, bool valid) {
     u64 m = __ballot(valid);

@@ -83,19 +83,27 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
         __builtin_amdgcn_wave_barrier();
         k10_sum_tree(tree, numSyms, lane);
     };
+    // The wave runs alone on its SIMD (a launch has one wave per block and far fewer blocks than SIMDs): every instruction costs
+    // 5-9 clocks, an LDS round trip ~50, a v_readlane into an SGPR and its use 20-30 (tests/microbench/lone_wave.hip).  So the
+    // common path is kept short: no exec masking (lanes above the path read and rewrite tree[0], which is 0 and stays 0: node
+    // = leaf >> lane is 0 there, and so is the "left sibling" index of the root), outputs go into their row by v_writelane,
+    // and the next row of symbols is requested a row ahead.
+    const u32 sh = lane < 31u ? lane : 31u;                   // leaf < 1024: lanes 10.. see node 0
+    u32 nxt = lane < nsym ? sym[lane] : 0u;
     for (u32 r0 = 0; r0 < nsym; r0 += 64u) {
-        const u32 mine = r0 + lane < nsym ? sym[r0 + lane] : 0u;
+        const u32 mine = nxt;
+        nxt = r0 + 64u + lane < nsym ? sym[r0 + 64u + lane] : 0u;
         const u32 rows = nsym - r0 < 64u ? nsym - r0 : 64u;
         for (u32 t = 0; t < rows; t++) {
             const u32 s = (u32)__builtin_amdgcn_readlane((int)mine, (int)t);
-            // the common case in ONE LDS round trip: path nodes and left siblings of all levels at once, the sibling sum over
-            // the row of 16 lanes by DPP row_shr adds, leaf / root values by v_readlane, the new root from registers
+            // path nodes and left siblings of all levels in ONE LDS round trip, the sibling sum over the row of 16 lanes by DPP
+            // row_shr adds, leaf / root values by v_readlane, the new root from registers
             const u32 leaf = numSyms + s;
             const u32 L = 32u - (u32)__clz((int)leaf);
-            const u32 node = leaf >> lane;
-            const bool on = lane < L;
-            const u32 val = on ? tree[node] : 0u;
-            u32 sib = (on && node > 1u && (node & 1u)) ? tree[node - 1u] : 0u;
+            const u32 node = leaf >> sh;
+            const u32 val = tree[node];
+            u32 sib = tree[(node & 1u) ? node - 1u : 0u];     // left sibling of a right child; the root's "sibling" is tree[0] = 0
+            pin_vgpr(sib);                                    // both reads in flight before the branch below waits for the first
             const u32 leafv = (u32)__builtin_amdgcn_readlane((int)val, 0);
             if ((leafv & 0xFFFF0000u) == 0u) {                // never seen (or scaled away): the escape symbol first  :53-57
                 const u32 esc = numSyms - 1u;
@@ -115,10 +123,10 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
             const u32 lt = (u32)__builtin_amdgcn_readlane((int)sib, 15);
             const u32 to = (u32)__builtin_amdgcn_readlane((int)val, (int)(L - 1u));
             const u32 upd = increment << 16;                  // (the escape symbol itself never occurs in the data)
-            if (on) tree[node] = val + upd;
+            tree[node] = val + (lane < L ? upd : 0u);
             __builtin_amdgcn_wave_barrier();
-            const u32 sl = (leafv >> 16) | ((lt >> 16) << 16);
-            if (lane == (nout & 63u)) { my_sl = sl; my_to = to >> 16; }
+            my_sl = (u32)cjs_writelane((int)((leafv >> 16) | ((lt >> 16) << 16)), (int)(nout & 63u), (int)my_sl);
+            my_to = (u32)cjs_writelane((int)(to >> 16), (int)(nout & 63u), (int)my_to);
             nout++;
             if ((nout & 63u) == 0u) { osl[nout - 64u + lane] = my_sl; oto[nout - 64u + lane] = my_to; }
             if (((to + upd) >> 16) >= max_prob) rescale();
