@@ -1,4 +1,4 @@
-# What the numbers in DESIGN.md section 4 / profiles/r02_* were produced with (one gpurun call, ~4 GPU-minutes):
+# What the numbers in DESIGN.md section 4 / profiles/r02_* were produced with (one gpurun call, ~5 GPU-minutes):
 #   bash tests/gpu_round_end.sh      (writes under gpurun_out/r02/; copy what is to be kept into profiles/)
 cd ${GRAFT_REPO_ROOT:-.}
 R=$(pwd); O=$R/gpurun_out/r02; mkdir -p $O; export TMPDIR=/tmp
@@ -56,4 +56,11 @@ for k in ('k1f_bsort', 'k1f_scatter', 'k1f_hist'):
 PY
 # 4. other data shapes
 timeout 300 python tests/gpu_perf_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/r02_shapes.log
-ls $O | head -40
+# 5. decoder (K7-K9): kernel stats at 10^8 and 10^9 bytes, rate at 4*10^8; BWTC -9 (cfg5)
+export PYTHONPATH=$R
+cd /tmp && timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o r02_decode -- python $R/tests/gpu_decode_probe.py > $O/decode_1e8.log 2>&1; grep decompress $O/decode_1e8.log | tail -1
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o r02_decode_1e9 -- python $R/tests/gpu_decode_probe.py 1000000000 > $O/decode_1e9.log 2>&1; grep decompress $O/decode_1e9.log | tail -1
+cd $R
+timeout 100 python tests/gpu_decode_probe.py 400000000 2>&1 | grep decompress | tail -1
+timeout 300 python bench.py --codec bwtc 2>/dev/null | tail -1 > $O/r02_bench_bwtc.json; cut -c1-160 $O/r02_bench_bwtc.json
+ls $O | head -60
