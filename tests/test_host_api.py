@@ -63,3 +63,17 @@ def test_node_dropin_loads_and_fails_loudly_without_gpu():
           "try{c.Bzip2.compressFile(Buffer.from('abc'),null,0)}catch(e){console.log('E2:'+e.message)}")
     out = subprocess.check_output(["node", "-e", js], cwd=ROOT).decode()
     assert "no CPU path" in out and "E2:Invalid block size multiplier" in out and "NOTHROW" not in out
+
+
+def test_bench_documents_tile_the_job_stream():
+    """bench.py --gpus N: the job's stream is one document per rank; a rank's window (its document + the margin in front of it)
+    must be exactly those bytes of the whole stream, and document 0 the single-GPU stream."""
+    import workloads
+    n, world = 200_000, 3
+    for name in ("enwik", "text", "lcg") + (("e8sa",) if workloads.have_fixtures() else ()):
+        whole = workloads.world_stream(name, n, world)
+        assert whole.size == n * world and (whole[:n] == workloads.stream(name, n)).all()
+        for r in range(world):
+            for margin in (0, 999, n, n + 5, 2 * n + 7):
+                lo = max(0, r * n - margin)
+                assert (workloads.window(name, n, r, margin) == whole[lo:(r + 1) * n]).all(), (name, r, margin)
