@@ -103,8 +103,8 @@ def bench_bwtc(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)       # (a 13 ms step: the clocks of an idle GPU need several to come up)
     ap.add_argument("--size", type=int, default=100_000_000, help="input bytes per GPU")
     ap.add_argument("--level", type=int, default=9)
     ap.add_argument("--workload", default="enwik", choices=["enwik", "text", "lcg", "e8sa", "e8sb"])

@@ -5,7 +5,7 @@ R=$(pwd); O=$R/gpurun_out/r02; mkdir -p $O; export TMPDIR=/tmp
 # 1. the bench line (default workload) and the secondary workloads of SURVEY.md 8(d)
 timeout 300 python bench.py 2>/dev/null | tail -1 > $O/r02_bench.json; cat $O/r02_bench.json | cut -c1-400
 for w in e8sa lcg e8sb text; do
-  timeout 300 python bench.py --workload $w --steps 5 2>/dev/null | tail -1 > $O/r02_bench_$w.json
+  timeout 300 python bench.py --workload $w 2>/dev/null | tail -1 > $O/r02_bench_$w.json
   python -c "import json; j=json.load(open('$O/r02_bench_$w.json')); print('$w', j['value'], 'MB/s', j['ms_per_step'], 'ms', 'bit_exact_vs_reference', j['config']['bit_exact_vs_reference_digest'], 'pcie', j['config']['pcie_inclusive_mb_s'])"
 done
 # 2. per-kernel times, one stream (every kernel has the GPU to itself), rocprofv3 --kernel-trace --stats
