@@ -160,6 +160,15 @@ __device__ __forceinline__ u32 mtf_step(u32& l0, u32& l1, u32& l2, u32& l3, u32 
         l0 = lane <= idx ? sh : l0;
         return src;
     }
+    if (idx < 128u) {                                             // second register (byte alphabets of ~100 symbols end here)
+        const u32 r = idx - 64u;
+        const u32 c0 = (u32)__builtin_amdgcn_readlane((int)l0, 63);
+        const u32 src = (u32)__builtin_amdgcn_readlane((int)l1, (int)r);
+        const u32 s1 = (u32)__builtin_amdgcn_update_dpp((int)c0, (int)l1, 0x138, 0xf, 0xf, false);
+        l0 = (u32)__builtin_amdgcn_update_dpp((int)src, (int)l0, 0x138, 0xf, 0xf, false);
+        l1 = lane <= r ? s1 : l1;
+        return src;
+    }
     const u32 q = idx >> 6, r = idx & 63u;
     const u32 c0 = (u32)__builtin_amdgcn_readlane((int)l0, 63), c1 = (u32)__builtin_amdgcn_readlane((int)l1, 63);
     const u32 c2 = (u32)__builtin_amdgcn_readlane((int)l2, 63);
@@ -687,11 +696,14 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                     if (nlit & 2u) { K7_MTF_STEP(t); K7_MTF_STEP(t + 1u); t += 2u; }
                     if (nlit & 1u) K7_MTF_STEP(t);
                 } else {
-                    for (u32 t = 0; t < nlit; t++) {
-                        const u32 idx = (u32)__builtin_amdgcn_readlane((int)cidx, (int)t);
-                        const u32 src = mtf_step(l0, l1, l2, l3, idx, lane);
-                        outc = (u32)cjs_writelane((int)src, (int)t, (int)outc);
-                    }
+#define K7_MTF_ANY(t_) do {                                                                                        \
+                        const u32 idx_ = (u32)__builtin_amdgcn_readlane((int)cidx, (int)(t_));                     \
+                        const u32 src_ = mtf_step(l0, l1, l2, l3, idx_, lane);                                     \
+                        outc = (u32)cjs_writelane((int)src_, (int)(t_), (int)outc);                                \
+                    } while (0)
+                    u32 t = 0;
+                    for (; t + 4u <= nlit; t += 4u) { K7_MTF_ANY(t); K7_MTF_ANY(t + 1u); K7_MTF_ANY(t + 2u); K7_MTF_ANY(t + 3u); }
+                    for (; t < nlit; t++) K7_MTF_ANY(t);
                 }
                 s_out[slotr][lane] = (u8)outc;
                 if (lane == 0) s_rf0[slotr] = f0;
