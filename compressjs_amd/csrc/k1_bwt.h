@@ -10,6 +10,8 @@
 #define K1_STAT_BIGROT 116     // stats[116..123]: rotations in 8-byte groups of more than 64 members, counted by k1f_bsort (8 spread words)
 #define K1_STAT_MEDROT 112     // stats[112]: rotations in the groups k1_emit_medium listed (65..K1_MED_MAX rotations each)
 #define K1_STAT_FRONT_BIG 104  // stats[104]: buckets of the sample-sort front end that did not fit LDS
+#define K1_STAT_PUREROT 124    // stats[124]: rotations in front-end buckets of ONE 8-byte key (> 64 members) or beyond LDS, counted by k1f_scan
+#define K1_DEEP_LANE 8u        // groups up to this size go to the lane kernels (k1_deep_pairs / k1_deep_small): one lane each
 #define K1_STATS 128
 #define K1_DM_SUB 64u      // sub-lists per class of the medium rounds (one counter each: a single counter serialises millions of appends)
 #define K1_SPREAD 128
@@ -84,5 +86,7 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws);
 // enqueue the whole K1 pipeline on `stream`; max_n = largest block length in the batch
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
 // k1_front.hip: rotations of every block sorted by their first 8 bytes into B.SA, group heads into B.HN
-int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
+// it_min / it_max: in-bucket deepening iterations of k1f_bsort (0 / 0: off, the K1-deep tile kernel does that work);
+// purerot_max: its predictor threshold (see k1f_bsort)
+int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 it_min, u32 it_max, u32 purerot_max);
 size_t k1_front_tilehist_words(const BatchGeom& g);   // u32 per block the front end needs in tileHist

@@ -735,7 +735,6 @@ __global__ __launch_bounds__(256) void k1_refine(K1Buf B, BatchGeom g, u32 h, in
 // route to the order BWT.js:372-417 defines.
 // ---------------------------------------------------------------------------------------------
 #define K1_DEEP_BIG 64u
-#define K1_DEEP_LANE 8u         // groups up to this size: one lane each (phase 2)
 
 // W big-endian 64-bit words of text starting at byte p of T (any alignment), through DWORD-ALIGNED loads plus
 // v_alignbyte.  PMC (TCP_TOTAL_CACHE_ACCESSES): a byte-misaligned 16-byte load costs the vector L1 ~4 accesses,
@@ -2055,17 +2054,27 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const bool front = front_env && (u64)max_n * 16u <= (u64)K1F_NB * K1F_C * 9u;
     const u32 d0 = (B.linear || front) ? 8u : sort_bytes;
     const int p0 = front ? 8 : (int)(8u - d0);
+    // K1-deep: iterations of 8 text bytes each (0 switches it off; default 32 = ties up to 264 bytes)
+    static const u32 deep_iters = []() -> u32 { const char* e = getenv("CJS_DEEP_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 32u; return v > 4000u ? 4000u : v; }();
+    // CJS_BSORT_DEPTH = text bytes every bucket of the front end is sorted by before k1f_bsort writes it (in-bucket deepening,
+    // 12 bytes per iteration; default 64; 0: off - the K1-deep tile kernel of rounds 1/2 does that work, kept for A/B runs);
+    // beyond that a bucket goes on while it holds a group of more than 8 rotations, up to 8 + 8 * CJS_DEEP_ITERS bytes
+    static const u32 bsort_depth = []() -> u32 { const char* e = getenv("CJS_BSORT_DEPTH"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 64u; return v > 32000u ? 32000u : v; }();
+    // CJS_DEEP_BIG_DIV: text comparison is skipped when more than 1/DIV of the rotations sit in big 8-byte groups (see k1f_bsort / k1_deep)
+    static const u32 big_div = []() -> u32 { const char* e = getenv("CJS_DEEP_BIG_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();
+    const bool fused = front && !B.linear && deep_iters > 0 && bsort_depth > 8u;      // in-bucket deepening replaces the k1_deep tile kernel
     if (front) {
-        const int rc = k1_front_run(B, g, max_n, stream);
+        const u32 max_depth = fused ? 8u + 8u * deep_iters : 0u;
+        const int rc = k1_front_run(B, g, max_n, stream, fused ? (bsort_depth < max_depth ? bsort_depth : max_depth) : 0u, max_depth, (u32)(((u64)g.nb * max_n) / big_div));
         if (rc) return rc;
         if (getenv("CJS_K1_TRACE")) {
-            u32 fs[20];
+            u32 fs[K1_STATS - K1_STAT_FRONT_BIG];
             HIP_CHECK_RET(hipMemcpyAsync(fs, B.stats + K1_STAT_FRONT_BIG, sizeof fs, hipMemcpyDeviceToHost, stream));
             HIP_CHECK_RET(hipStreamSynchronize(stream));
             u64 bg = 0;
             for (u32 i = 0; i < 8u; i++) bg += fs[K1_STAT_BIGROT - K1_STAT_FRONT_BIG + i];
-            fprintf(stderr, "[k1] front end: %u oversize buckets, %llu of %llu rotations in 8-byte groups above 64; k1f_bsort stage clocks/256 (K1F_TRACE builds): load %u  sample %u  partition %u  leaves %u  flush %u\n",
-                    fs[0], (unsigned long long)bg, (unsigned long long)g.nb * max_n, fs[1], fs[2], fs[3], fs[4], fs[5]);
+            fprintf(stderr, "[k1] front end: %u oversize buckets, %llu of %llu rotations in 8-byte groups above 64, %u in one-key buckets; k1f_bsort stage clocks/256 (K1F_TRACE builds): load %u  sample %u  partition %u  leaves %u  deepen %u  flush %u\n",
+                    fs[0], (unsigned long long)bg, (unsigned long long)g.nb * max_n, fs[K1_STAT_PUREROT - K1_STAT_FRONT_BIG], fs[1], fs[2], fs[3], fs[4], fs[5], fs[6]);
         }
     }
     for (int p = p0; p < 8; p++) {
@@ -2099,19 +2108,19 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const char* e = getenv("CJS_SPARSE_MIN");
         return e ? (u64)strtoull(e, nullptr, 10) : (u64)(1u << 20);
     }();
-    // K1-deep: iterations of 8 text bytes each (0 switches it off; default 32 = ties up to 264 bytes)
-    static const u32 deep_iters = []() -> u32 { const char* e = getenv("CJS_DEEP_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 32u; return v > 4000u ? 4000u : v; }();
     static const u32 deep_tile = []() -> u32 { const char* e = getenv("CJS_DEEP_TILE"); return e ? (u32)strtoul(e, nullptr, 10) : 256u; }();
     static const u32 deep_dbg = []() -> u32 { const char* e = getenv("CJS_DEEP_DBG"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();   // timing experiments: 1 = no phase 1, 2 = no phase 2
     const bool deep = deep_iters > 0 && !B.linear;
     if (deep) {
-        HIP_CHECK_RET(hipMemcpyAsync(B.HX, B.HN, hbytes, hipMemcpyDeviceToDevice, stream));
-        // CJS_DEEP_BIG_DIV: K1-deep's tile kernel returns at once when more than 1/DIV of the rotations sit in 8-byte groups of more
-        // than 64 members (counted by k1f_bsort; with CJS_FRONT=0 the count is 0 and the stage always runs)
-        static const u32 big_div = []() -> u32 { const char* e = getenv("CJS_DEEP_BIG_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();
+        // K1-deep's tile kernel returns at once when more than 1/CJS_DEEP_BIG_DIV of the rotations sit in 8-byte groups of more
+        // than 64 members (counted by k1f_bsort; with CJS_FRONT=0 the count is 0 and the stage always runs).  With in-bucket
+        // deepening (the default) k1f_bsort has done its work already and listed the groups of 2..8 that are left.
         const u32 bigrot_max = (u32)(total_n / big_div);
-        if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters, deep_dbg, d0, bigrot_max);
-        else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg, d0, bigrot_max);
+        if (!fused) {
+            HIP_CHECK_RET(hipMemcpyAsync(B.HX, B.HN, hbytes, hipMemcpyDeviceToDevice, stream));
+            if (deep_tile == 1024u) hipLaunchKernelGGL((k1_deep<1024, 256>), gridHX, dim3(256), 0, stream, B, g, deep_iters, deep_dbg, d0, bigrot_max);
+            else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg, d0, bigrot_max);
+        }
         // medium groups (9 .. K1_MED_MAX rotations) by text, 8 bytes per round; what they shed goes to the lane kernels' lists.
         // CJS_DEEP_MED = rounds (default 8: depths d0 .. d0 + 56; 0 switches the stage off)
         static const u32 med_rounds = []() -> u32 { const char* e = getenv("CJS_DEEP_MED"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v > 64u ? 64u : v; }();

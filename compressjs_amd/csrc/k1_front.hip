@@ -152,6 +152,9 @@ __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptile
         dbase[tid] = excl;
         B.fstart[(size_t)b * (K1F_NB + 1) + tid] = excl;
         if (tid == 0) B.fstart[(size_t)b * (K1F_NB + 1) + K1F_NB] = n;
+        const u64* sp = B.fsplit + (size_t)b * K1F_NB;
+        const bool pure = tid > 0u && tid < K1F_NB - 1u && sp[tid] == sp[tid - 1u] + 1u;
+        if ((pure && tot > 64u) || tot > K1F_C) atomicAdd(&B.stats[K1_STAT_PUREROT], tot);
     }
     __syncthreads();
     u32 run = dbase[d];
@@ -192,6 +195,19 @@ __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptile
         B.fstart[(size_t)b * (K1F_NB + 1) + tid + r * 1024u] = base[r];
     }
     if (tid == 0) B.fstart[(size_t)b * (K1F_NB + 1) + K1F_NB] = n;
+    {   // rotations in buckets of one 8-byte key (or too big for LDS): k1f_bsort's predictor for in-bucket deepening
+        const u64* sp = B.fsplit + (size_t)b * K1F_NB;
+        u32 pr = 0;
+#pragma unroll
+        for (u32 r = 0; r < R; r++) {
+            const u32 d = tid + r * 1024u;
+            const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
+            if ((pure && sum[r] > 64u) || sum[r] > K1F_C) pr += sum[r];
+        }
+        u32 total;
+        (void)block_excl_scan_1024(pr, sh, &total);
+        if (tid == 0 && total) atomicAdd(&B.stats[K1_STAT_PUREROT], total);
+    }
 #pragma unroll
     for (u32 r = 0; r < R; r++) {
         const u32 d = tid + r * 1024u;
@@ -265,9 +281,12 @@ __device__ __forceinline__ void k1f_write_heads(u32* HN, u32 start, u32 end, F i
 #else
 #define K1F_STAMP(slot) do { } while (0)
 #endif
+#ifndef K1F_BT
 #define K1F_BT 256                                      // threads of a bucket-sort workgroup
-#define K1F_E (K1F_C / K1F_BT)                          // rotations per thread
-// measured (10^8-byte enwik stream, k1f_bsort ms): 32 leaves x 4 samples 3.66, 32 x 2 4.06, 64 x 4 3.86, 64 x 2 3.49
+#endif
+#define K1F_NW (K1F_BT / 64)                            // its waves
+#define K1F_E ((K1F_C + K1F_BT - 1) / K1F_BT)            // rotations per thread
+// measured (10^8-byte enwik stream, k1f_bsort ms, round 2): 32 leaves x 4 samples 3.66, 32 x 2 4.06, 64 x 4 3.86, 64 x 2 3.49
 #ifndef K1F_LK
 #define K1F_LK 64                                       // local sub-buckets (leaves) of a bucket, at most
 #endif
@@ -275,15 +294,285 @@ __device__ __forceinline__ void k1f_write_heads(u32* HN, u32 start, u32 end, F i
 #define K1F_LOVS 2                                      // local samples per leaf
 #endif
 #define K1F_LS (K1F_LOVS * K1F_LK)                      // local samples, at most
+#define K1F_HW (K1F_C / 32 + 2)                         // words of the in-LDS head bitmap (bits >= cnt are set: sentinel)
+#ifndef K1F_MINW
+#define K1F_MINW 8                                      // waves per SIMD the register allocation of k1f_bsort is held to (8 workgroups per CU)
+#endif
+#ifndef K1F_GBIG
+#define K1F_GBIG 256u                                   // in-bucket deepening ranks groups up to this size by counting (O(size^2), one wave)
+#endif
+#define K1F_STEP 12u                                    // text bytes per deepening iteration: what ONE 16-byte aligned load yields at any alignment
 
-// One workgroup per bucket.  The bucket's (key, index) pairs are brought into LDS and sorted by a second, LOCAL
-// sample sort: up to 128 of the bucket's own keys are ranked by counting, every 4th is a local splitter, the
-// rotations are partitioned into <= 32 leaves (unstable LDS counting), and every leaf is sorted by ONE WAVE by
-// rank counting with the candidates broadcast through v_readlane: rank = #smaller + #equal-with-smaller-slot.
-// A leaf of m <= 64 rotations costs m steps of ~9 instructions; there are five workgroup barriers per bucket (an
-// 8-bit LSD sort of the same bucket took seven passes of ~20 barriers each and ran 4x longer).  Equal keys stay
-// one group: its head is the member with no equal key in a smaller slot.
-__global__ __launch_bounds__(K1F_BT) void k1f_bsort(K1Buf B, BatchGeom g) {
+// 12 text bytes at T + p (any alignment) as (first 8 big-endian, next 4 big-endian): one dwordx4 load + v_alignbyte.
+// A random 8-byte gather and a random 16-byte gather cost the L2 the same line; the deepening iterations below are
+// bound by exactly those gathers, so every one of them takes as many key bytes as fit the LDS budget.
+__device__ __forceinline__ void k1f_load_be96(const u8* T, u32 p, u64& k0, u32& k1) {
+    const u32 sh = p & 3u;
+    u32 d[4];
+    __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 16);
+    const u32 w0 = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+    const u32 w1 = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+    const u32 w2 = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+    k0 = ((u64)__builtin_bswap32(w0) << 32) | (u64)__builtin_bswap32(w1);
+    k1 = __builtin_bswap32(w2);
+}
+
+// largest head position <= q / smallest head position > q in an LDS bitmap whose bit 0 and every bit >= cnt are set
+__device__ __forceinline__ u32 k1f_prev_head(const u32* hb, u32 q) {
+    u32 w = q >> 5;
+    u32 m = hb[w] & (0xFFFFFFFFu >> (31u - (q & 31u)));
+    while (!m) m = hb[--w];
+    return w * 32u + 31u - (u32)__clz((int)m);
+}
+__device__ __forceinline__ u32 k1f_next_head(const u32* hb, u32 q) {
+    u32 w = q >> 5;
+    u32 m = (q & 31u) == 31u ? 0u : (hb[w] & (0xFFFFFFFEu << (q & 31u)));
+    while (!m) m = hb[++w];
+    return w * 32u + (u32)__ffs((int)m) - 1u;
+}
+
+// LDS of a bucket-sort workgroup (views into the kernel's __shared__ arrays)
+struct K1fS {
+    u64* k0;        // [K1F_C]  key, first 8 bytes (position order)
+    u32* k1;        // [K1F_C]  key, next 4 bytes (deepening only; also the staging array of the index permutation)
+    u32* sx;        // [K1F_C]  rotation index at every position
+    u32* hb;        // [K1F_HW] group heads (bit 0 and bits >= cnt set)
+    u32* fb;        // [K1F_HW] positions of frozen groups
+    u32* h0;        // [K1F_HW] the heads the deepening started from (they cut the bucket into the waves' ranges)
+    u32* df;        // [K1F_HW] big groups (by head position) in which some key differed: frozen from then on
+    u16* nqp;       // [K1F_C]  per iteration and position: new position | head << 15, or a K1F_NQ_* marker
+    u32* wd;        // [K1F_NW] depth every wave's groups are known to share when it stopped
+    u32* misc;      // [2 * K1F_NW] workgroup-wide scratch words
+};
+#define K1F_NQ_IDLE 0xFFFEu     // not in an active group
+#define K1F_NQ_PEND 0xFFFDu     // active, key fetched
+#define K1F_NQ_HUGE 0xFFFCu     // member of a group above K1F_GBIG: stays where it is
+
+__device__ __forceinline__ void k1f_init_bitmaps(const K1fS& S, u32 cnt) {
+    for (u32 i = threadIdx.x; i < K1F_HW; i += K1F_BT) {        // head bitmap: bit 0 and the sentinel bits (>= cnt) set
+        const u32 lo = i * 32u;
+        S.hb[i] = (lo >= cnt ? 0xFFFFFFFFu : (lo + 32u > cnt ? 0xFFFFFFFFu << (cnt - lo) : 0u)) | (i == 0 ? 1u : 0u);
+        S.fb[i] = 0;
+        S.df[i] = 0;
+    }
+}
+__device__ __forceinline__ bool k1f_bit(const u32* bm, u32 q) { return (bm[q >> 5] >> (q & 31u)) & 1u; }
+__device__ __forceinline__ u32 k1f_first_head_ge(const u32* hb, u32 x) { return x == 0u ? 0u : k1f_next_head(hb, x - 1u); }
+
+// In-bucket deepening of positions [0, cnt): sx[] and hb[] describe a slice sorted by its first `depth` bytes, groups of
+// equal prefixes marked.  The groups are dealt to the WAVES (wave w takes the groups whose head lies in the 64-position
+// chunks K1F_NW * j + w: contiguous ranges, fixed before the first iteration), and every wave then iterates ON ITS OWN -
+// no workgroup barrier inside the loop, 16..32 waves per CU at different points of their chains hide each other's
+// latencies (the first version synchronised the workgroup three times per iteration and ran at a fifth of the gather
+// rate tests/microbench/gather.hip measures for L2-resident text: 250 G gathers/s at 4..16 bytes each).  An iteration
+// of a wave = five passes over the rows (64 positions) of its ranges:
+//   P1 the K1F_STEP text bytes at the current depth of every rotation that still ties (one 16-byte load each),
+//   P2 rank inside the group by counting (candidates read from LDS four at a time; lanes of one group read the same
+//      address = broadcast): new position, and "opens a sub-group" for the member with no equal key before it,
+//   P3 the indices move (staged through k1[], which P2 no longer needs), P4 the new heads.
+// A wave goes on while depth < min_depth, then only while it holds a group of more than 8 rotations, up to max_depth.
+// Groups above K1F_GBIG rotations are only tested for "all bytes equal" (then they simply get deeper) and are frozen
+// otherwise: they stay classes of equal prefixes of >= 8 bytes for the later stages.
+__device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u32 cnt, u32 depth, u32 min_depth, u32 max_depth) {
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    for (u32 i = tid; i < K1F_HW; i += K1F_BT) S.h0[i] = S.hb[i];
+    __syncthreads();
+    u32 lo[K1F_E], hi[K1F_E];                           // the wave's ranges (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < K1F_E; j++) {
+        const u32 base = ((u32)j * K1F_NW + w) * 64u;
+        lo[j] = 0; hi[j] = 0;
+        if (base < cnt) {
+            const u32 l = k1f_first_head_ge(S.h0, base);
+            if (l < base + 64u) { lo[j] = l; hi[j] = base + 64u >= cnt ? cnt : k1f_first_head_ge(S.h0, base + 64u); }
+        }
+        lo[j] = (u32)__builtin_amdgcn_readfirstlane((int)lo[j]);
+        hi[j] = (u32)__builtin_amdgcn_readfirstlane((int)hi[j]);
+    }
+    while (depth < max_depth) {
+        const u32 dm = depth % n;
+        bool any = false;
+        // P1: keys of the active rotations (two rows per step: their loads are in flight together)
+#pragma unroll
+        for (int j = 0; j < K1F_E; j++) {
+            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 128u) {
+                const u32 qa = r0 + lane, qb = r0 + 64u + lane;
+                const bool ina = qa < hi[j], inb = qb < hi[j];
+                const bool acta = ina && !(k1f_bit(S.hb, qa) && k1f_bit(S.hb, qa + 1u)) && !k1f_bit(S.fb, qa);
+                const bool actb = inb && !(k1f_bit(S.hb, qb) && k1f_bit(S.hb, qb + 1u)) && !k1f_bit(S.fb, qb);
+                u64 ka = 0, kb = 0;
+                u32 la = 0, lb = 0;
+                if (acta) { u32 p = S.sx[qa] + dm; if (p >= n) p -= n; k1f_load_be96(T, p, ka, la); }
+                if (actb) { u32 p = S.sx[qb] + dm; if (p >= n) p -= n; k1f_load_be96(T, p, kb, lb); }
+                if (ina) S.nqp[qa] = (u16)(acta ? K1F_NQ_PEND : K1F_NQ_IDLE);
+                if (inb) S.nqp[qb] = (u16)(actb ? K1F_NQ_PEND : K1F_NQ_IDLE);
+                if (acta) { S.k0[qa] = ka; S.k1[qa] = la; }
+                if (actb) { S.k0[qb] = kb; S.k1[qb] = lb; }
+                any = any || __ballot(acta || actb) != 0ull;
+            }
+        }
+        if (!any) break;                                // nothing of this wave ties any more
+        __builtin_amdgcn_wave_barrier();
+        // P2: ranks
+        bool big = false;
+#pragma unroll
+        for (int j = 0; j < K1F_E; j++) {
+            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
+                const u32 q = r0 + lane;
+                const bool act = q < hi[j] && S.nqp[q] == K1F_NQ_PEND;
+                if (__ballot(act) == 0ull) continue;
+                u32 gl = 0;
+                if (act) {
+                    const u32 gs = k1f_prev_head(S.hb, q), ge = k1f_next_head(S.hb, q);
+                    gl = ge - gs;
+                    const u64 m0 = S.k0[q];
+                    const u32 m1 = S.k1[q];
+                    if (gl > K1F_GBIG) {
+                        if (S.k0[gs] != m0 || S.k1[gs] != m1) atomicOr(&S.df[gs >> 5], 1u << (gs & 31u));
+                        S.nqp[q] = (u16)K1F_NQ_HUGE;
+                    } else {
+                        u32 less = 0, eqb = 0;
+                        for (u32 i = gs; i < ge; i += 4u) {
+                            u64 c0[4];
+                            u32 c1[4];
+#pragma unroll
+                            for (u32 u = 0; u < 4u; u++) {
+                                const u32 ii = i + u < ge ? i + u : ge - 1u;
+                                c0[u] = S.k0[ii];
+                                c1[u] = S.k1[ii];
+                            }
+#pragma unroll
+                            for (u32 u = 0; u < 4u; u++) {
+                                const bool in = i + u < ge;
+                                const bool lt = c0[u] < m0 || (c0[u] == m0 && c1[u] < m1);
+                                const bool eq = c0[u] == m0 && c1[u] == m1;
+                                less += (in && lt) ? 1u : 0u;
+                                eqb += (in && eq && i + u < q) ? 1u : 0u;
+                            }
+                        }
+                        S.nqp[q] = (u16)((gs + less + eqb) | (eqb == 0u ? 0x8000u : 0u));
+                    }
+                }
+                big = big || __ballot(gl > 8u) != 0ull;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // P3: the indices to their new positions (through k1[]: a permutation inside every group)
+#pragma unroll
+        for (int j = 0; j < K1F_E; j++)
+            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
+                const u32 q = r0 + lane;
+                const u32 v = q < hi[j] ? S.nqp[q] : K1F_NQ_IDLE;
+                if (v < K1F_NQ_HUGE) S.k1[v & 0x7FFFu] = S.sx[q];
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < K1F_E; j++)
+            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
+                const u32 q = r0 + lane;
+                const u32 v = q < hi[j] ? S.nqp[q] : K1F_NQ_IDLE;
+                if (v < K1F_NQ_HUGE) S.sx[q] = S.k1[q];
+            }
+        // P4: new heads; big groups in which something differed are frozen as they are
+#pragma unroll
+        for (int j = 0; j < K1F_E; j++)
+            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
+                const u32 q = r0 + lane;
+                const u32 v = q < hi[j] ? S.nqp[q] : K1F_NQ_IDLE;
+                if (v < K1F_NQ_HUGE) {
+                    const u32 p = v & 0x7FFFu;
+                    if (v & 0x8000u) atomicOr(&S.hb[p >> 5], 1u << (p & 31u));      // (the group's own head is set already: harmless)
+                } else if (v == K1F_NQ_HUGE) {
+                    const u32 gs = k1f_prev_head(S.hb, q);
+                    if (k1f_bit(S.df, gs)) atomicOr(&S.fb[q >> 5], 1u << (q & 31u));
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+        depth += K1F_STEP;
+        if (depth >= min_depth && !big) break;          // only groups of <= 8 left: the lane kernels' work
+    }
+    if (lane == 0) S.wd[w] = depth;
+    __syncthreads();
+}
+
+// Results of positions [0, cnt) of the slice that starts at suffix-array position `pos0` of block b: the suffix indices,
+// the head bits, and (lists) the groups of 2..K1_DEEP_LANE rotations for the lane kernels, with the depth they share (the
+// depth their wave reached, S.wd): descriptors are counted per class over the workgroup and appended with ONE atomic per
+// class (whose latency the suffix-array stores cover).  `depth`: the depth when k1f_deepen did not run.
+__device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const BatchGeom& g, u32 b, u32 d, u32 pos0, u32 cnt,
+                                          bool lists) {
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    u32* SA = B.SA + (size_t)b * g.stride + pos0;
+    u32* HN = B.HN + (size_t)b * g.hstride;
+    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB), xr = (b & 7u) * K1_DEEP_SUB + (d & (K1_DEEP_SUB - 1u));
+    const u64 lt = lanemask_lt();
+    u64 balc[2][K1F_E];
+    u32 glv[K1F_E];
+    if (lists) {
+        u32 tot0 = 0, tot1 = 0;
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 q0 = (u32)it * K1F_BT + w * 64u;
+            balc[0][it] = 0; balc[1][it] = 0; glv[it] = 0;
+            if (q0 >= cnt) continue;                    // wave-uniform
+            const u32 q = q0 + lane;
+            bool take = false;
+            u32 gl = 0;
+            if (q < cnt && k1f_bit(S.hb, q) && !k1f_bit(S.hb, q + 1u)) {
+                gl = k1f_next_head(S.hb, q) - q;
+                take = gl <= K1_DEEP_LANE;
+            }
+            // depth: that of the wave that owned the group (the owner of the chunk its original head lies in)
+            glv[it] = take ? (gl | (S.wd[(k1f_prev_head(S.h0, q) >> 6) % K1F_NW] << 8)) : 0u;
+            balc[0][it] = __ballot(take && gl == 2u);
+            balc[1][it] = __ballot(take && gl > 2u);
+            tot0 += (u32)__popcll(balc[0][it]);
+            tot1 += (u32)__popcll(balc[1][it]);
+        }
+        if (lane == 0) { S.misc[w] = tot0; S.misc[K1F_NW + w] = tot1; }
+        __syncthreads();
+        if (tid < 2) {                                  // thread c: class c - the waves' counts become offsets, one global atomic
+            u32 run = 0;
+            for (u32 i = 0; i < K1F_NW; i++) { const u32 c = S.misc[tid * K1F_NW + i]; S.misc[tid * K1F_NW + i] = run; run += c; }
+            const u32 base = run ? atomicAdd(&B.deepCnt[tid * 8u * K1_DEEP_SUB + xr], run) : 0u;
+            for (u32 i = 0; i < K1F_NW; i++) S.misc[tid * K1F_NW + i] += base;
+        }
+    }
+    for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = S.sx[i];
+    k1f_write_heads(HN, pos0, pos0 + cnt, [&](u32 p) { return k1f_bit(S.hb, p - pos0); });
+    if (lists) {
+        __syncthreads();
+        u32 gb0 = S.misc[w], gb1 = S.misc[K1F_NW + w];
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 q = (u32)it * K1F_BT + tid;
+            if (glv[it]) {
+                const u32 gl = glv[it] & 0xFFu, depth = glv[it] >> 8;
+                const int cls = gl == 2u ? 0 : 1;
+                const u32 idx = (cls ? gb1 : gb0) + (u32)__popcll(balc[cls][it] & lt);
+                if (idx < rcap)
+                    B.listT[cls][(size_t)xr * rcap + idx] = ((u64)b << 52) | ((u64)(pos0 + q) << 26) | ((u64)depth << 4) | (u64)(gl - 1u);
+            }
+            gb0 += (u32)__popcll(balc[0][it]);
+            gb1 += (u32)__popcll(balc[1][it]);
+        }
+    }
+}
+
+// One workgroup per bucket (a bucket is a KEY RANGE: everything that ties on its first 8 bytes, or deeper, is inside).
+//   1. (key, index) pairs into LDS; a second, LOCAL sample sort: up to 128 of the bucket's own keys ranked by counting,
+//      every 2nd a local splitter, the rotations moved into <= 64 leaves (leaf order, in place: every thread still
+//      holds its pairs in registers).
+//   2. Every rotation ranks itself inside its leaf by counting, ALL LANES AT ONCE (a lane per rotation, the leaf's keys
+//      read from LDS four at a time: lanes of one leaf read the same address = broadcast).  Round 2 gave a whole wave to
+//      one leaf of ~14 rotations and broadcast the candidates through v_readlane: 22 % of the lanes busy.
+//   3. In-bucket deepening (k1f_deepen; round 3, replaces the K1-deep tile kernel and most of the lane kernels' work).
+//   4. Suffix-array slice and head bits are written ONCE; the groups of 2..8 rotations that are left go to the lane
+//      kernels' lists with the depth they are known to share (k1f_flush).
+// `purerot_max`: when more rotations than this sit in buckets of ONE 8-byte key (HTML-like input, counted by k1f_scan),
+// the ties are long repeats that text comparison does not settle and step 3 / the lists are skipped (as K1-deep was).
+// min_depth / max_depth = 0: no deepening (the K1-deep tile kernel of rounds 1-2 follows; kept for A/B runs and linear mode).
+__global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 min_depth, u32 max_depth, u32 purerot_max) {
     u32 b, d;
     if (!xcd_block_tile(g.nb, b, d)) return;
     const u32 n = B.nlen[b];
@@ -300,42 +589,254 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort(K1Buf B, BatchGeom g) {
     const u64* sp = B.fsplit + (size_t)b * K1F_NB;
     // a bucket between the splitters v and v+1 holds one key only
     const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
-    if (pure || cnt == 1u) {
+    const bool deepen = max_depth > 8u && B.stats[K1_STAT_PUREROT] <= purerot_max;
+    if (cnt == 1u || (pure && (!deepen || cnt > K1F_C))) {
         for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
         k1f_write_heads(HN, start, end, [&](u32 p) { return p == start; });
         if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (see k1_run: K1-deep predictor)
         return;
     }
     __shared__ u64 key[K1F_C];
-    __shared__ u32 idx[K1F_C];
-    __shared__ u16 perm[K1F_C];                         // leaf order -> arrival slot
-    __shared__ u64 smp[K1F_LS], sp2[K1F_LK];
-    __shared__ u32 cnt2[K1F_LK], off2[K1F_LK + 1];
-    __shared__ u32 srank[K1F_LS];
-    __shared__ u32 hbits[K1F_C / 32 + 2];
-    __shared__ u32 dstart[256], sh[256];
-    __shared__ u32 single;
+    __shared__ u32 key1[K1F_C];
+    __shared__ u32 sx[K1F_C];
+    __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];
+    __shared__ u32 wdep[K1F_NW], misc[2 * K1F_NW];
+    // scratch: the local sample sort (samples, splitters, ranks) and, later, the deepening's new positions
+    __shared__ u64 scr64[256];
+    // leaf bookkeeping of the local sample sort lives in key1[], which only the deepening uses
+    u32* cnt2 = key1;                                   // [K1F_LK]
+    u32* off2 = key1 + K1F_LK;                          // [K1F_LK + 1]
+    u8* lf = (u8*)(key1 + 2 * K1F_LK + 4);              // [K1F_C]
+    static_assert((2 * K1F_LK + 4) * 4 + K1F_C <= K1F_C * 4, "leaf bookkeeping fits key1[]");
+    static_assert((K1F_LS + K1F_LK) * 8 + K1F_LS * 4 <= 256 * 8 && K1F_C * 2 <= 256 * 8 && K1F_C >= 256 && K1F_C < 0x7FF0, "scratch: samples + splitters + ranks, later K1F_C u16 new positions");
+    u64* smp = scr64;
+    u64* sp2 = scr64 + K1F_LS;
+    u32* srank = (u32*)(scr64 + K1F_LS + K1F_LK);
+    K1fS S;
+    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.wd = wdep; S.misc = misc;
     if (cnt > K1F_C) {
+        // oversize bucket (unlucky sampling or a moderately heavy key): listed for k1f_bsort_big (its code in here cost this kernel
+        // 45 VGPRs, i.e. three of its eight waves per SIMD)
+        if (tid == 0) {
+            const u32 idx = atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
+            if (idx < B.largeCap) B.large[idx] = make_uint2(b, d);
+            atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
+        }
+        return;
+    }
+    // ---- the common case: everything in LDS.  Stage 0: indices, then keys (all loads of a stage in flight together)
+#ifdef K1F_TRACE
+    long long tprev_ = clock64();
+#endif
+    if (pure) {
+        // one 8-byte key (small blocks: a quantile is a few dozen rotations): a single group at depth 8, straight to the deepening
+        for (u32 i = tid; i < cnt; i += K1F_BT) sx[i] = SB[i];
+        k1f_init_bitmaps(S, cnt);
+        if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
+        __syncthreads();
+    } else {
+        u32 v[K1F_E];
+        u64 k[K1F_E];
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 i = (u32)it * K1F_BT + tid;
+            v[it] = i < cnt ? SB[i] : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 i = (u32)it * K1F_BT + tid;
+            k[it] = i < cnt ? k1f_load_be64(T, v[it]) : 0ull;
+        }
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 i = (u32)it * K1F_BT + tid;
+            if (i < cnt) key[i] = k[it];
+        }
+        k1f_init_bitmaps(S, cnt);
+        if (tid < K1F_LK) cnt2[tid] = 0;
+        K1F_STAMP(0);
+        u32 K = 1u;
+        while (K < K1F_LK && cnt >= 48u * K) K <<= 1;   // leaves of ~24..48 rotations (K1F_LK = 32), ~12..24 (64)
+        if (K1F_LK == 64 && K > 1u && K < 64u) K <<= 1;
+        __syncthreads();
+        if (K > 1u) {
+            // stage 1: LOVS * K samples, ranked by counting; every LOVS-th is a local splitter (equal neighbours: the heavy-key rule)
+            const u32 LS = K1F_LOVS * K;
+            // (all waves: thread t ranks sample t % LS against one LS / (K1F_BT / LS)-th of the samples, partial ranks summed in LDS)
+            const u32 parts = K1F_BT / LS < 1u ? 1u : (K1F_BT / LS > LS ? LS : K1F_BT / LS), si = tid % LS, part = tid / LS;   // powers of two
+            if (tid < LS) { smp[tid] = key[(u32)((u64)tid * cnt / LS)]; srank[tid] = 0; }
+            __syncthreads();
+            if (part < parts) {
+                const u64 mine = smp[si];
+                const u32 per = LS / parts, j0 = part * per;
+                u32 r = 0;
+#pragma unroll 8
+                for (u32 j = j0; j < j0 + per; j++) {
+                    const u64 o = smp[j];
+                    r += (o < mine || (o == mine && j < si)) ? 1u : 0u;
+                }
+                atomicAdd(&srank[si], r);
+            }
+            __syncthreads();
+            u64 mine = 0;
+            if (tid < LS) mine = smp[tid];
+            __syncthreads();
+            if (tid < LS) smp[srank[tid]] = mine;
+            __syncthreads();
+            if (tid < K1F_LK) {
+                u64 vv = ~0ull;
+                if (tid + 1u < K) {
+                    const u64 q = smp[(tid + 1u) * K1F_LOVS];
+                    vv = q;
+                    if (tid >= 1u && smp[tid * K1F_LOVS] == q && q != ~0ull) vv = q + 1u;
+                }
+                sp2[tid] = vv;
+            }
+            __syncthreads();
+            K1F_STAMP(1);
+            // stage 2: leaf of every rotation, slot inside the leaf by an LDS counter
+            u32 L[K1F_E];
+#pragma unroll
+            for (int it = 0; it < K1F_E; it++) {
+                const u32 i = (u32)it * K1F_BT + tid;
+                L[it] = 0xFFFFFFFFu;
+                if (i < cnt) {
+                    u32 pos = 0;
+                    for (u32 step = K >> 1; step >= 1u; step >>= 1)
+                        if (sp2[pos + step - 1u] <= k[it]) pos += step;
+                    L[it] = (pos << 16) | atomicAdd(&cnt2[pos], 1u);
+                }
+            }
+            __syncthreads();
+            if (w == 0) {
+                const u32 c = lane < K ? cnt2[lane] : 0u;
+                const u32 inc = wave_incl_scan_u32(c);
+                if (lane < K1F_LK) off2[lane] = inc - c;
+                if (lane == 0) off2[K1F_LK] = cnt;
+            }
+            __syncthreads();
+            // the pairs move to leaf order IN PLACE: nobody reads the arrival-order arrays any more (own pairs are in registers)
+#pragma unroll
+            for (int it = 0; it < K1F_E; it++)
+                if (L[it] != 0xFFFFFFFFu) {
+                    const u32 leaf = L[it] >> 16, q = off2[leaf] + (L[it] & 0xFFFFu);
+                    key[q] = k[it];
+                    sx[q] = v[it];
+                    lf[q] = (u8)leaf;
+                }
+        } else {
+#pragma unroll
+            for (int it = 0; it < K1F_E; it++) {
+                const u32 i = (u32)it * K1F_BT + tid;
+                if (i < cnt) { sx[i] = v[it]; lf[i] = 0; }
+            }
+            if (tid == 0) { cnt2[0] = cnt; off2[0] = 0; off2[1] = cnt; }
+            if (tid < K1F_LK) sp2[tid] = ~0ull;
+        }
+        __syncthreads();
+        K1F_STAMP(2);
+        // stage 3: every rotation ranks itself inside its leaf (a lane per rotation, four candidates per LDS round trip).
+        // less = smaller keys, eqb = equal keys in earlier slots; members of one group (equal keys) end up next to each
+        // other and the one with eqb == 0 is its head.
+        u32 q[K1F_E];                                   // final position | head << 31
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 i = (u32)it * K1F_BT + tid;
+            q[it] = 0xFFFFFFFFu;
+            if (i < cnt) {
+                const u32 leaf = lf[i];
+                const u32 o = off2[leaf], e = leaf + 1u < K ? off2[leaf + 1u] : cnt;
+                const u64 mine = key[i];
+                k[it] = mine;
+                v[it] = sx[i];
+                const bool pure2 = K > 1u && leaf > 0u && leaf + 1u < K && sp2[leaf] == sp2[leaf - 1u] + 1u;   // one key only
+                if (pure2) q[it] = i | (i == o ? 0x80000000u : 0u);
+                else {
+                    u32 less = 0, eqb = 0;
+                    for (u32 j = o; j < e; j += 4u) {
+                        u64 c[4];
+#pragma unroll
+                        for (u32 u = 0; u < 4u; u++) c[u] = key[j + u < e ? j + u : e - 1u];
+#pragma unroll
+                        for (u32 u = 0; u < 4u; u++) {
+                            const bool in = j + u < e;
+                            less += (in && c[u] < mine) ? 1u : 0u;
+                            eqb += (in && c[u] == mine && j + u < i) ? 1u : 0u;
+                        }
+                    }
+                    q[it] = (o + less + eqb) | (eqb == 0 ? 0x80000000u : 0u);
+                }
+                if (i == o && e - o > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], e - o);   // a leaf this big is (mostly) one key
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++)
+            if (q[it] != 0xFFFFFFFFu) {
+                const u32 p = q[it] & 0x7FFFFFFFu;
+                sx[p] = v[it];
+                if (q[it] >> 31) atomicOr(&hbits[p >> 5], 1u << (p & 31u));
+            }
+        __syncthreads();
+    }
+    K1F_STAMP(3);
+    if (deepen) k1f_deepen(S, T, n, cnt, 8u, min_depth, max_depth);
+    K1F_STAMP(4);
+    k1f_flush(S, B, g, b, d, start, cnt, deepen);
+    K1F_STAMP(5);
+}
+
+// Oversize buckets (more than K1F_C rotations: unlucky sampling or a moderately heavy key; ~400 of 229 000 on the enwik stream),
+// listed by k1f_bsort: stable LSD passes through global memory, one digit byte gathered from the text per pass, ping-pong
+// between the bucket's slices of SB and SA (wave 0 scatters row by row: stable by construction; rare, so simple).  The sorted
+// slice is then deepened like a bucket, in windows of <= K1F_C positions that end on a group boundary.
+__global__ __launch_bounds__(K1F_BT) void k1f_bsort_big(K1Buf B, BatchGeom g, u32 min_depth, u32 max_depth, u32 purerot_max) {
+    __shared__ u64 key[K1F_C];
+    __shared__ u32 key1[K1F_C];
+    __shared__ u32 sx[K1F_C];
+    __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];
+    __shared__ u32 wdep[K1F_NW], misc[2 * K1F_NW];
+    __shared__ u64 scr64[256];
+    K1fS S;
+    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.wd = wdep; S.misc = misc;
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    u32 nbig = B.stats[K1_STAT_FRONT_BIG];
+    if (nbig > B.largeCap) nbig = B.largeCap;
+    const bool deepen = max_depth > 8u && B.stats[K1_STAT_PUREROT] <= purerot_max;
+    for (u32 li = blockIdx.x; li < nbig; li += gridDim.x) {
+        __syncthreads();
+        const u32 b = B.large[li].x, d = B.large[li].y;
+        const u32 n = B.nlen[b];
+        const u32* fs = B.fstart + (size_t)b * (K1F_NB + 1);
+        const u32 start = fs[d], end = fs[d + 1];
+        const u32 cnt = end - start;
+        const u8* T = B.T + (size_t)b * g.tstride;
+        const u32* SB = B.SB + (size_t)b * g.stride + start;
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32* HN = B.HN + (size_t)b * g.hstride;
+    {
         // ---- oversize bucket (unlucky sampling or a moderately heavy key): stable LSD passes through global memory,
         //      one digit byte gathered from the text per pass, ping-pong between the bucket's slices of SB and SA.
         //      Wave 0 scatters row by row (stable by construction); rare, so simple.
-        if (tid == 0) { atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u); atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt); }
+        u32* dstart = (u32*)key;                        // [256]
+        u32* sh = dstart + 256;                         // [256]
+        u32* single = misc;
         u32* bufs[2] = {(u32*)SB, SA};
         int cur = 0;
         for (u32 pass = 0; pass < 8u; pass++) {
             const u32* src = bufs[cur];
             u32* dst = bufs[cur ^ 1];
-            dstart[tid] = 0;
-            if (tid == 0) single = 0;
+            if (tid < 256u) dstart[tid] = 0;
+            if (tid == 0) *single = 0;
             __syncthreads();
             for (u32 i = tid; i < cnt; i += K1F_BT) atomicAdd(&dstart[T[src[i] + 7u - pass]], 1u);
             __syncthreads();
-            const u32 c = dstart[tid];
-            if (c == cnt) single = 1;
+            const u32 c = tid < 256u ? dstart[tid] : 0u;
+            if (c == cnt) *single = 1;
             __syncthreads();
-            if (single) { __syncthreads(); continue; }  // every rotation has the same byte here (uniform)
+            if (*single) { __syncthreads(); continue; }  // every rotation has the same byte here (uniform)
             const u32 ex = block_excl_scan_256(c, sh);
-            dstart[tid] = ex;
+            if (tid < 256u) dstart[tid] = ex;
             __syncthreads();
             if (w == 0) {
                 const u64 lt = lanemask_lt();
@@ -362,171 +863,69 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort(K1Buf B, BatchGeom g) {
             __threadfence_block();
             __syncthreads();
         }
-        k1f_write_heads(HN, start, end, [&](u32 p) {
-            return p == start || k1f_load_be64(T, SA[p - start]) != k1f_load_be64(T, SA[p - start - 1u]);
-        });
-        return;
-    }
-    // ---- the common case: everything in LDS.  Stage 0: indices, then keys (all loads of a stage in flight together)
-#ifdef K1F_TRACE
-    long long tprev_ = clock64();
-#endif
-    {
-        u32 v[K1F_E];
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++) {
-            const u32 i = (u32)it * K1F_BT + tid;
-            v[it] = i < cnt ? SB[i] : 0u;
-        }
-        u64 k[K1F_E];
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++) {
-            const u32 i = (u32)it * K1F_BT + tid;
-            k[it] = i < cnt ? k1f_load_be64(T, v[it]) : 0ull;
-        }
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++) {
-            const u32 i = (u32)it * K1F_BT + tid;
-            if (i < cnt) { key[i] = k[it]; idx[i] = v[it]; }
-        }
-    }
-    for (u32 i = tid; i < K1F_C / 32 + 2; i += K1F_BT) hbits[i] = 0;
-    if (tid < K1F_LK) cnt2[tid] = 0;
-    // leaves: ~24..48 rotations each
-    K1F_STAMP(0);
-    u32 K = 1u;
-    while (K < K1F_LK && cnt >= 48u * K) K <<= 1;       // leaves of ~24..48 rotations (K1F_LK = 32), ~12..24 (64)
-    if (K1F_LK == 64 && K > 1u && K < 64u) K <<= 1;
-    __syncthreads();
-    if (K > 1u) {
-        // stage 1: 4K samples, ranked by counting; every 4th is a local splitter (equal neighbours: the heavy-key rule)
-        const u32 LS = K1F_LOVS * K;
-        // (all four waves: thread t ranks sample t % LS against one LS / (256 / LS)-th of the samples, partial ranks summed in LDS)
-        const u32 parts = K1F_BT / LS < 1u ? 1u : (K1F_BT / LS > LS ? LS : K1F_BT / LS), si = tid % LS, part = tid / LS;   // powers of two
-        if (tid < LS) { smp[tid] = key[(u32)((u64)tid * cnt / LS)]; srank[tid] = 0; }
-        __syncthreads();
-        if (part < parts) {
-            const u64 mine = smp[si];
-            const u32 per = LS / parts, j0 = part * per;
-            u32 r = 0;
-#pragma unroll 8
-            for (u32 j = j0; j < j0 + per; j++) {
-                const u64 o = smp[j];
-                r += (o < mine || (o == mine && j < si)) ? 1u : 0u;
-            }
-            atomicAdd(&srank[si], r);
-        }
-        __syncthreads();
-        u64 mine = 0;
-        if (tid < LS) mine = smp[tid];
-        __syncthreads();
-        if (tid < LS) smp[srank[tid]] = mine;
-        __syncthreads();
-        if (tid < K1F_LK) {
-            u64 v = ~0ull;
-            if (tid + 1u < K) {
-                const u64 q = smp[(tid + 1u) * K1F_LOVS];
-                v = q;
-                if (tid >= 1u && smp[tid * K1F_LOVS] == q && q != ~0ull) v = q + 1u;
-            }
-            sp2[tid] = v;
-        }
-        __syncthreads();
-        K1F_STAMP(1);
-        // stage 2: leaf of every rotation, slot inside the leaf by an LDS counter
-        u32 ls[K1F_E];
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++) {
-            const u32 i = (u32)it * K1F_BT + tid;
-            ls[it] = 0xFFFFFFFFu;
-            if (i < cnt) {
-                const u64 kk = key[i];
-                u32 pos = 0;
-                for (u32 step = K >> 1; step >= 1u; step >>= 1)
-                    if (sp2[pos + step - 1u] <= kk) pos += step;
-                ls[it] = (pos << 16) | atomicAdd(&cnt2[pos], 1u);
-            }
-        }
-        __syncthreads();
-        if (w == 0) {
-            const u32 c = lane < K ? cnt2[lane] : 0u;
-            const u32 inc = wave_incl_scan_u32(c);
-            if (lane < K1F_LK) off2[lane] = inc - c;
-            if (lane == 0) off2[K1F_LK] = cnt;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++)
-            if (ls[it] != 0xFFFFFFFFu) perm[off2[ls[it] >> 16] + (ls[it] & 0xFFFFu)] = (u16)((u32)it * K1F_BT + tid);
-    } else {
-        for (u32 i = tid; i < cnt; i += K1F_BT) perm[i] = (u16)i;
-        if (tid == 0) { cnt2[0] = cnt; off2[0] = 0; off2[1] = cnt; }
-    }
-    __syncthreads();
-    K1F_STAMP(2);
-    // stage 3: one wave per leaf.  Every member ranks itself against all members, the candidates broadcast through
-    // v_readlane (no memory access in the loop): less = smaller keys, eqb = equal keys in earlier slots.
-    // (handing the leaves out through an LDS counter instead of round-robin hung on the MI355X - for (;;) around a
-    // lane-0 atomic + v_readfirstlane - although it ran on the CPU build; the static split costs < 5 %)
-    for (u32 lf = w; lf < K; lf += K1F_BT / 64) {
-        const u32 m = (u32)__builtin_amdgcn_readfirstlane((int)cnt2[lf]), o = (u32)__builtin_amdgcn_readfirstlane((int)off2[lf]);   // wave-uniform, in SGPRs
-        if (m == 0) continue;
-        const bool pure2 = K > 1u && lf > 0u && lf + 1u < K && sp2[lf] == sp2[lf - 1u] + 1u;    // one key only
-        if (m > 64u && lane == 0) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], m);            // a leaf this big is (mostly) one key
-        if (pure2 || m == 1u) {
-            for (u32 j = lane; j < m; j += 64u) SA[o + j] = idx[perm[o + j]];
-            if (lane == 0) atomicOr(&hbits[o >> 5], 1u << (o & 31u));
+        if (!deepen) {
+            k1f_write_heads(HN, start, end, [&](u32 p) {
+                return p == start || k1f_load_be64(T, SA[p - start]) != k1f_load_be64(T, SA[p - start - 1u]);
+            });
             continue;
         }
-        if (m <= 64u) {
-            // the common case, one row: count the smaller keys only (7 instructions per candidate); members with equal keys
-            // end up with equal counts (and only they do), so their order and the group head fall out of one match_any
-            const bool valid = lane < m;
-            const u32 e = valid ? perm[o + lane] : 0u;
-            const u64 ke = valid ? key[e] : 0ull;
-            const int clo = (int)(u32)ke, chi = (int)(u32)(ke >> 32);
-            u32 less = 0;
-            for (u32 t = 0; t < m; t++) {
-                const u64 kt = ((u64)(u32)__builtin_amdgcn_readlane(chi, (int)t) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, (int)t);
-                less += kt < ke ? 1u : 0u;
+        // the sorted slice in windows of <= K1F_C positions that end on a group boundary: each is deepened like a bucket.
+        // A group that alone exceeds a window stays one group of equal 8-byte prefixes (head bit only).
+        const u32* src = SA;                            // sorted by 8 bytes (this workgroup's own stores, fenced above)
+        u32 a = 0;
+        while (a < cnt) {                               // `a` is workgroup-uniform
+            u32 len = cnt - a < K1F_C ? cnt - a : K1F_C;
+            __syncthreads();
+            for (u32 i = tid; i < len; i += K1F_BT) {
+                const u32 s = src[a + i];
+                sx[i] = s;
+                key[i] = k1f_load_be64(T, s);
             }
-            const u64 same = match_any(less, 6, valid);
-            const u32 eqb = (u32)__popcll(same & lanemask_lt());
-            if (valid) {
-                const u32 q = o + less + eqb;
-                SA[q] = idx[e];
-                if (eqb == 0) atomicOr(&hbits[q >> 5], 1u << (q & 31u));
+            __syncthreads();
+            // heads inside the window
+            k1f_init_bitmaps(S, len);
+            __syncthreads();
+            for (u32 i = tid + 1u; i < len; i += K1F_BT)
+                if (key[i] != key[i - 1u]) atomicOr(&hbits[i >> 5], 1u << (i & 31u));
+            if (tid == 0) {
+                u32 cut = len;                          // the window ends where a group ends
+                if (a + len < cnt && k1f_load_be64(T, src[a + len]) == key[len - 1u]) cut = 0xFFFFFFFFu;
+                misc[1] = cut;
             }
-            continue;
-        }
-        for (u32 r0 = 0; r0 < m; r0 += 64u) {
-            const u32 j = r0 + lane;
-            const bool valid = j < m;
-            const u32 e = valid ? perm[o + j] : 0u;
-            const u64 ke = valid ? key[e] : 0ull;
-            u32 less = 0, eqb = 0;
-            for (u32 c0 = 0; c0 < m; c0 += 64u) {
-                const u32 cj = c0 + lane;
-                const u64 ck = cj < m ? (c0 == r0 ? ke : key[perm[o + cj]]) : 0ull;
-                const int clo = (int)(u32)ck, chi = (int)(u32)(ck >> 32);
-                const u32 mm = m - c0 < 64u ? m - c0 : 64u;
-                for (u32 t = 0; t < mm; t++) {
-                    const u64 kt = ((u64)(u32)__builtin_amdgcn_readlane(chi, (int)t) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, (int)t);
-                    less += kt < ke ? 1u : 0u;
-                    eqb += (kt == ke && c0 + t < j) ? 1u : 0u;
+            __syncthreads();
+            if (misc[1] == 0xFFFFFFFFu) {
+                const u32 ph = k1f_prev_head(hbits, len - 1u);
+                __syncthreads();
+                if (ph == 0u) {
+                    // one group fills the whole window: find its end, mark its head, leave it as it is
+                    const u64 k0v = key[0];
+                    u32 e = a + len;
+                    for (;;) {                          // uniform: every thread looks at the same positions
+                        if (e >= cnt) break;
+                        if (k1f_load_be64(T, src[e]) != k0v) break;
+                        e++;
+                    }
+                    if (tid == 0) {
+                        const u32 p = start + a;
+                        atomicOr(&HN[p >> 5], 1u << (p & 31u));
+                    }
+                    a = e;
+                    continue;
                 }
+                len = ph;
+                __syncthreads();
+                k1f_init_bitmaps(S, len);
+                __syncthreads();
+                for (u32 i = tid + 1u; i < len; i += K1F_BT)
+                    if (key[i] != key[i - 1u]) atomicOr(&hbits[i >> 5], 1u << (i & 31u));
+                __syncthreads();
             }
-            if (valid) {
-                const u32 q = o + less + eqb;
-                SA[q] = idx[e];
-                if (eqb == 0) atomicOr(&hbits[q >> 5], 1u << (q & 31u));
-            }
+            k1f_deepen(S, T, n, len, 8u, min_depth, max_depth);
+            k1f_flush(S, B, g, b, d, start + a, len, true);
+            a += len;
         }
     }
-    __syncthreads();
-    K1F_STAMP(3);
-    k1f_write_heads(HN, start, end, [&](u32 p) { const u32 i = p - start; return ((hbits[i >> 5] >> (i & 31u)) & 1u) != 0u; });
-    K1F_STAMP(4);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -534,7 +933,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort(K1Buf B, BatchGeom g) {
 // ---------------------------------------------------------------------------------------------
 size_t k1_front_tilehist_words(const BatchGeom& g) { return (size_t)k1f_ptiles(g) * K1F_NB; }
 
-int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
+int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 min_depth, u32 max_depth, u32 purerot_max) {
     const u32 ptiles = k1f_ptiles(g);
     const u32 nb8 = (g.nb + 7u) & ~7u;
     hipLaunchKernelGGL(k1f_sample, dim3(g.nb), dim3(1024), 0, stream, B, g);
@@ -545,7 +944,8 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const u32 slot = pr && pr->enabled ? __atomic_fetch_add(&pr->used, 1u, __ATOMIC_RELAXED) : K1_PROF_MAX;
     const bool timed = slot < K1_PROF_MAX;
     if (timed) (void)hipEventRecord(pr->ev[2 * slot], stream);
-    hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB, nb8), dim3(K1F_BT), 0, stream, B, g);
+    hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB, nb8), dim3(K1F_BT), 0, stream, B, g, min_depth, max_depth, purerot_max);
+    hipLaunchKernelGGL(k1f_bsort_big, dim3(g.nb * 8u < 256u ? g.nb * 8u : 256u), dim3(K1F_BT), 0, stream, B, g, min_depth, max_depth, purerot_max);
     if (timed) {
         (void)hipEventRecord(pr->ev[2 * slot + 1], stream);
         __atomic_fetch_add(&pr->elements, (u64)g.nb * max_n, __ATOMIC_RELAXED);
