@@ -12,7 +12,9 @@
 #define K1_STAT_FRONT_BIG 104  // stats[104]: buckets of the sample-sort front end that did not fit LDS
 #define K1_STAT_PUREROT 124    // stats[124]: rotations in front-end buckets of ONE 8-byte key (> 64 members) or beyond LDS, counted by k1f_scan
 #define K1_DEEP_LANE 8u        // groups up to this size go to the lane kernels (k1_deep_pairs / k1_deep_small): one lane each
-#define K1_STATS 128
+#define K1R_MAXR 40            // refinement rounds at most
+#define K1_STAT_RTRACE 128      // stats[128..135]: K1F_TRACE builds, stage clocks of k1r_round
+#define K1_STATS 144
 #define K1_DM_SUB 64u      // sub-lists per class of the medium rounds (one counter each: a single counter serialises millions of appends)
 #define K1_SPREAD 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS
@@ -75,6 +77,9 @@ struct K1Buf {
     u64* listM[2];    //               65..K1_MED_MAX rotations
     u64* listL[2];    //               more than K1_MED_MAX rotations
     u32 listTCap, listSCap, listMCap, listLCap;
+    u64* rlist[2];    // [nb][stride]   refinement rounds (k1r_round): entries of the rotations that still tie, in/out
+    u32* rcnt;        // [K1R_MAXR + 1][rstride]  entries per round and block
+    u32 rstride;
     u8* U;            // [nb][stride]   BWT output
     u32* pidx;        // [nb]           origPtr
 };
@@ -86,7 +91,9 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws);
 // enqueue the whole K1 pipeline on `stream`; max_n = largest block length in the batch
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
 // k1_front.hip: rotations of every block sorted by their first 8 bytes into B.SA, group heads into B.HN
-// it_min / it_max: in-bucket deepening iterations of k1f_bsort (0 / 0: off, the K1-deep tile kernel does that work);
-// purerot_max: its predictor threshold (see k1f_bsort)
-int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 it_min, u32 it_max, u32 purerot_max);
+// iters: in-bucket deepening iterations of k1f_bsort (K1F_STEP = 12 bytes each); lists: fill the round lists (0: neither - the
+// K1-deep tile kernel does that work); purerot_max: the predictor threshold (see k1f_bsort)
+int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max);
+int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth);
+#define K1F_STEP 12u           // text bytes per in-bucket iteration / refinement round: what ONE 16-byte aligned load yields at any alignment
 size_t k1_front_tilehist_words(const BatchGeom& g);   // u32 per block the front end needs in tileHist

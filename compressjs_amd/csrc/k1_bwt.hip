@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     if (b == 0) for (u32 i = gid; i < 4u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
     if (b == 0 && gid < 4u * K1_DM_SUB) B.dmCnt[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 32u * 2u * K1_SPREAD; i += gridDim.x * blockDim.x) B.spread[i] = 0;
+    if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rstride; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
         u32 w;
@@ -1981,6 +1982,8 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += 2 * al256((size_t)g.nb * (g.stride / 8) * 8);       // listS cur/next
     tot += 2 * al256((size_t)g.nb * (g.stride / 64) * 8);      // listM cur/next
     tot += 2 * al256((size_t)g.nb * (g.stride / K1_MED_MAX + 1) * 8);   // listL cur/next
+    tot += 2 * al256(e * 8);                                   // rlist in/out
+    tot += al256((size_t)(K1R_MAXR + 1) * ((g.nb + 7u) & ~7u) * 4);   // rcnt
     return tot;
 }
 
@@ -2017,7 +2020,11 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.listM[1] = (u64*)p; p += al256((size_t)B.listMCap * 8);
     B.listLCap = g.nb * (g.stride / K1_MED_MAX + 1);
     B.listL[0] = (u64*)p; p += al256((size_t)B.listLCap * 8);
-    B.listL[1] = (u64*)p;
+    B.listL[1] = (u64*)p; p += al256((size_t)B.listLCap * 8);
+    B.rlist[0] = (u64*)p; p += al256(e * 8);
+    B.rlist[1] = (u64*)p; p += al256(e * 8);
+    B.rstride = (g.nb + 7u) & ~7u;
+    B.rcnt = (u32*)p;
 }
 
 static int g_k1_last_sparse_rounds = 0, g_k1_last_rounds = 0;
@@ -2056,16 +2063,16 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const int p0 = front ? 8 : (int)(8u - d0);
     // K1-deep: iterations of 8 text bytes each (0 switches it off; default 32 = ties up to 264 bytes)
     static const u32 deep_iters = []() -> u32 { const char* e = getenv("CJS_DEEP_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 32u; return v > 4000u ? 4000u : v; }();
-    // CJS_BSORT_DEPTH = text bytes every bucket of the front end is sorted by before k1f_bsort writes it (in-bucket deepening,
-    // 12 bytes per iteration; default 64; 0: off - the K1-deep tile kernel of rounds 1/2 does that work, kept for A/B runs);
-    // beyond that a bucket goes on while it holds a group of more than 8 rotations, up to 8 + 8 * CJS_DEEP_ITERS bytes
-    static const u32 bsort_depth = []() -> u32 { const char* e = getenv("CJS_BSORT_DEPTH"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 64u; return v > 32000u ? 32000u : v; }();
+    // CJS_BSORT_ITERS = in-bucket deepening iterations of k1f_bsort (12 bytes each; default 2: the groups it lists share 32 bytes);
+    // CJS_ROUNDS=0: no lists and no refinement rounds - the K1-deep tile kernel and the lane kernels of rounds 1/2 do that work
+    // (kept for A/B runs).  The rounds go on up to 8 + 8 * CJS_DEEP_ITERS bytes (264), what still ties there is left to prefix doubling.
+    static const u32 bsort_iters = []() -> u32 { const char* e = getenv("CJS_BSORT_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 2u; return v > 64u ? 64u : v; }();
+    static const bool rounds_env = []() { const char* e = getenv("CJS_ROUNDS"); return !e || atoi(e) != 0; }();
     // CJS_DEEP_BIG_DIV: text comparison is skipped when more than 1/DIV of the rotations sit in big 8-byte groups (see k1f_bsort / k1_deep)
     static const u32 big_div = []() -> u32 { const char* e = getenv("CJS_DEEP_BIG_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();
-    const bool fused = front && !B.linear && deep_iters > 0 && bsort_depth > 8u;      // in-bucket deepening replaces the k1_deep tile kernel
+    const bool fused = front && !B.linear && deep_iters > 0 && rounds_env && max_n <= (1u << 20);      // (list entries hold 20-bit indices)
     if (front) {
-        const u32 max_depth = fused ? 8u + 8u * deep_iters : 0u;
-        const int rc = k1_front_run(B, g, max_n, stream, fused ? (bsort_depth < max_depth ? bsort_depth : max_depth) : 0u, max_depth, (u32)(((u64)g.nb * max_n) / big_div));
+        const int rc = k1_front_run(B, g, max_n, stream, fused ? bsort_iters : 0u, fused ? 1u : 0u, (u32)(((u64)g.nb * max_n) / big_div));
         if (rc) return rc;
         if (getenv("CJS_K1_TRACE")) {
             u32 fs[K1_STATS - K1_STAT_FRONT_BIG];
@@ -2138,6 +2145,24 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             }
             hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0);   // k1_emit_medium's counters; groups the last round listed stay marked in the bitmap
             hipLaunchKernelGGL(k1_dm_reset, dim3(1), dim3(128), 0, stream, B, (int)(med_rounds & 1u));
+        }
+        // the refinement rounds over what k1f_bsort listed (after the medium stage: its rounds use listS[] as scratch, and the
+        // last refinement round appends what outlasts it to the lane kernels' second-pass lists in there)
+        if (fused) {
+            const int rc = k1_rounds_run(B, g, stream, 8u + K1F_STEP * bsort_iters, 8u + 8u * deep_iters);
+            if (rc) return rc;
+            if (k1_trace) {
+                u32 rc2[K1R_MAXR + 1], rt[8];
+                u64 tot[K1R_MAXR + 1] = {0};
+                for (u32 r = 0; r <= K1R_MAXR; r++) {
+                    for (u32 bb = 0; bb < g.nb; bb += 1) { HIP_CHECK_RET(hipMemcpyAsync(&rc2[r], B.rcnt + (size_t)r * B.rstride + bb, 4, hipMemcpyDeviceToHost, stream)); HIP_CHECK_RET(hipStreamSynchronize(stream)); tot[r] += rc2[r]; }
+                }
+                HIP_CHECK_RET(hipMemcpyAsync(rt, B.stats + K1_STAT_RTRACE, sizeof rt, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK_RET(hipStreamSynchronize(stream));
+                fprintf(stderr, "[k1] refinement rounds, entries per round:");
+                for (u32 r = 0; r <= K1R_MAXR && tot[r]; r++) fprintf(stderr, " %llu", (unsigned long long)tot[r]);
+                fprintf(stderr, "\n[k1] k1r_round stage clocks/256 (K1F_TRACE builds): load %u  keys %u  rank %u  classify %u  reserve %u  write %u\n", rt[0], rt[1], rt[2], rt[3], rt[4], rt[5]);
+            }
         }
         // lane kernels: CJS_DEEP_LANE_CAP = bytes a pair / small group is walked before it is left to the rank rounds
         // (default 4096: boilerplate passages of the text streams tie for up to ~3 KB; 0 = no second pass)

@@ -281,6 +281,11 @@ __device__ __forceinline__ void k1f_write_heads(u32* HN, u32 start, u32 end, F i
 #else
 #define K1F_STAMP(slot) do { } while (0)
 #endif
+#ifdef K1F_TRACE
+#define K1R_STAMP(slot) do { if (tid == 0) { const long long now_ = clock64(); atomicAdd(&B.stats[K1_STAT_RTRACE + (slot)], (u32)((now_ - tprev_) >> 8)); tprev_ = now_; } } while (0)
+#else
+#define K1R_STAMP(slot) do { } while (0)
+#endif
 #ifndef K1F_BT
 #define K1F_BT 256                                      // threads of a bucket-sort workgroup
 #endif
@@ -301,7 +306,6 @@ __device__ __forceinline__ void k1f_write_heads(u32* HN, u32 start, u32 end, F i
 #ifndef K1F_GBIG
 #define K1F_GBIG 256u                                   // in-bucket deepening ranks groups up to this size by counting (O(size^2), one wave)
 #endif
-#define K1F_STEP 12u                                    // text bytes per deepening iteration: what ONE 16-byte aligned load yields at any alignment
 
 // 12 text bytes at T + p (any alignment) as (first 8 big-endian, next 4 big-endian): one dwordx4 load + v_alignbyte.
 // A random 8-byte gather and a random 16-byte gather cost the L2 the same line; the deepening iterations below are
@@ -341,8 +345,7 @@ struct K1fS {
     u32* h0;        // [K1F_HW] the heads the deepening started from (they cut the bucket into the waves' ranges)
     u32* df;        // [K1F_HW] big groups (by head position) in which some key differed: frozen from then on
     u16* nqp;       // [K1F_C]  per iteration and position: new position | head << 15, or a K1F_NQ_* marker
-    u32* wd;        // [K1F_NW] depth every wave's groups are known to share when it stopped
-    u32* misc;      // [2 * K1F_NW] workgroup-wide scratch words
+    u32* misc;      // [K1F_E * K1F_NW] workgroup-wide scratch words
 };
 #define K1F_NQ_IDLE 0xFFFEu     // not in an active group
 #define K1F_NQ_PEND 0xFFFDu     // active, key fetched
@@ -362,18 +365,18 @@ __device__ __forceinline__ u32 k1f_first_head_ge(const u32* hb, u32 x) { return 
 // In-bucket deepening of positions [0, cnt): sx[] and hb[] describe a slice sorted by its first `depth` bytes, groups of
 // equal prefixes marked.  The groups are dealt to the WAVES (wave w takes the groups whose head lies in the 64-position
 // chunks K1F_NW * j + w: contiguous ranges, fixed before the first iteration), and every wave then iterates ON ITS OWN -
-// no workgroup barrier inside the loop, 16..32 waves per CU at different points of their chains hide each other's
-// latencies (the first version synchronised the workgroup three times per iteration and ran at a fifth of the gather
-// rate tests/microbench/gather.hip measures for L2-resident text: 250 G gathers/s at 4..16 bytes each).  An iteration
-// of a wave = five passes over the rows (64 positions) of its ranges:
+// no workgroup barrier inside the loop.  An iteration of a wave = passes over the rows (64 positions) of its ranges:
 //   P1 the K1F_STEP text bytes at the current depth of every rotation that still ties (one 16-byte load each),
 //   P2 rank inside the group by counting (candidates read from LDS four at a time; lanes of one group read the same
 //      address = broadcast): new position, and "opens a sub-group" for the member with no equal key before it,
 //   P3 the indices move (staged through k1[], which P2 no longer needs), P4 the new heads.
-// A wave goes on while depth < min_depth, then only while it holds a group of more than 8 rotations, up to max_depth.
-// Groups above K1F_GBIG rotations are only tested for "all bytes equal" (then they simply get deeper) and are frozen
-// otherwise: they stay classes of equal prefixes of >= 8 bytes for the later stages.
-__device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u32 cnt, u32 depth, u32 min_depth, u32 max_depth) {
+// Exactly `iters` iterations (a wave with nothing left stops earlier): every group that is left shares depth + K1F_STEP *
+// iters bytes, which is what the list-driven rounds (k1r_round) start from.  While most rotations still tie (the first one
+// or two iterations) this is the cheapest place to take bytes off them - the bucket is in LDS anyway; later the rows of
+// a bucket are mostly idle lanes (PMC: 550 VALU instructions per wave and iteration whatever is left), which is why the
+// rest is done on compacted lists.  Groups above K1F_GBIG rotations are only tested for "all bytes equal" (then they
+// simply get deeper) and are frozen otherwise: they stay classes of equal prefixes of >= 8 bytes for the later stages.
+__device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u32 cnt, u32 depth, u32 iters) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     for (u32 i = tid; i < K1F_HW; i += K1F_BT) S.h0[i] = S.hb[i];
     __syncthreads();
@@ -389,7 +392,7 @@ __device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u3
         lo[j] = (u32)__builtin_amdgcn_readfirstlane((int)lo[j]);
         hi[j] = (u32)__builtin_amdgcn_readfirstlane((int)hi[j]);
     }
-    while (depth < max_depth) {
+    for (u32 it = 0; it < iters; it++, depth += K1F_STEP) {
         const u32 dm = depth % n;
         bool any = false;
         // P1: keys of the active rotations (two rows per step: their loads are in flight together)
@@ -414,20 +417,17 @@ __device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u3
         if (!any) break;                                // nothing of this wave ties any more
         __builtin_amdgcn_wave_barrier();
         // P2: ranks
-        bool big = false;
 #pragma unroll
         for (int j = 0; j < K1F_E; j++) {
             for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
                 const u32 q = r0 + lane;
                 const bool act = q < hi[j] && S.nqp[q] == K1F_NQ_PEND;
                 if (__ballot(act) == 0ull) continue;
-                u32 gl = 0;
                 if (act) {
                     const u32 gs = k1f_prev_head(S.hb, q), ge = k1f_next_head(S.hb, q);
-                    gl = ge - gs;
                     const u64 m0 = S.k0[q];
                     const u32 m1 = S.k1[q];
-                    if (gl > K1F_GBIG) {
+                    if (ge - gs > K1F_GBIG) {
                         if (S.k0[gs] != m0 || S.k1[gs] != m1) atomicOr(&S.df[gs >> 5], 1u << (gs & 31u));
                         S.nqp[q] = (u16)K1F_NQ_HUGE;
                     } else {
@@ -453,7 +453,6 @@ __device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u3
                         S.nqp[q] = (u16)((gs + less + eqb) | (eqb == 0u ? 0x8000u : 0u));
                     }
                 }
-                big = big || __ballot(gl > 8u) != 0ull;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -488,74 +487,65 @@ __device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u3
                 }
             }
         __builtin_amdgcn_wave_barrier();
-        depth += K1F_STEP;
-        if (depth >= min_depth && !big) break;          // only groups of <= 8 left: the lane kernels' work
     }
-    if (lane == 0) S.wd[w] = depth;
     __syncthreads();
 }
 
-// Results of positions [0, cnt) of the slice that starts at suffix-array position `pos0` of block b: the suffix indices,
-// the head bits, and (lists) the groups of 2..K1_DEEP_LANE rotations for the lane kernels, with the depth they share (the
-// depth their wave reached, S.wd): descriptors are counted per class over the workgroup and appended with ONE atomic per
-// class (whose latency the suffix-array stores cover).  `depth`: the depth when k1f_deepen did not run.
-__device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const BatchGeom& g, u32 b, u32 d, u32 pos0, u32 cnt,
-                                          bool lists) {
+// Results of positions [0, cnt) of the slice that starts at suffix-array position `pos0` of block b: the suffix indices and the
+// head bits; with `lists`, every unfrozen group of 2..K1F_GBIG rotations goes, member by member, to the block's list of
+// the first refinement round (k1r_round), and its positions are marked as heads right away: the rounds resolve them or,
+// where a tie outlasts the last round, clear the bits again.  One atomic per workgroup reserves the list slots.
+__device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const BatchGeom& g, u32 b, u32 pos0, u32 cnt, bool lists) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     u32* SA = B.SA + (size_t)b * g.stride + pos0;
     u32* HN = B.HN + (size_t)b * g.hstride;
-    const u32 rcap = B.listTCap / (8u * K1_DEEP_SUB), xr = (b & 7u) * K1_DEEP_SUB + (d & (K1_DEEP_SUB - 1u));
+    u32* lb = S.h0;                                     // listed positions (the deepening's copy of the heads is no longer needed)
     const u64 lt = lanemask_lt();
-    u64 balc[2][K1F_E];
-    u32 glv[K1F_E];
+    u64 bal[K1F_E];
+    u32 gsv[K1F_E];
     if (lists) {
-        u32 tot0 = 0, tot1 = 0;
 #pragma unroll
         for (int it = 0; it < K1F_E; it++) {
             const u32 q0 = (u32)it * K1F_BT + w * 64u;
-            balc[0][it] = 0; balc[1][it] = 0; glv[it] = 0;
-            if (q0 >= cnt) continue;                    // wave-uniform
-            const u32 q = q0 + lane;
-            bool take = false;
-            u32 gl = 0;
-            if (q < cnt && k1f_bit(S.hb, q) && !k1f_bit(S.hb, q + 1u)) {
-                gl = k1f_next_head(S.hb, q) - q;
-                take = gl <= K1_DEEP_LANE;
+            bal[it] = 0; gsv[it] = 0;
+            if (q0 >= cnt) {                            // wave-uniform
+                if (lane < 2u && (q0 >> 5) + lane < K1F_HW) lb[(q0 >> 5) + lane] = 0;
+                if (lane == 0) S.misc[(u32)it * K1F_NW + w] = 0;
+                continue;
             }
-            // depth: that of the wave that owned the group (the owner of the chunk its original head lies in)
-            glv[it] = take ? (gl | (S.wd[(k1f_prev_head(S.h0, q) >> 6) % K1F_NW] << 8)) : 0u;
-            balc[0][it] = __ballot(take && gl == 2u);
-            balc[1][it] = __ballot(take && gl > 2u);
-            tot0 += (u32)__popcll(balc[0][it]);
-            tot1 += (u32)__popcll(balc[1][it]);
+            const u32 q = q0 + lane;
+            bool listed = false;
+            if (q < cnt && !(k1f_bit(S.hb, q) && k1f_bit(S.hb, q + 1u)) && !k1f_bit(S.fb, q)) {
+                gsv[it] = k1f_prev_head(S.hb, q);
+                listed = k1f_next_head(S.hb, q) - gsv[it] <= K1F_GBIG;
+            }
+            bal[it] = __ballot(listed);
+            if (lane == 0) { lb[q0 >> 5] = (u32)bal[it]; lb[(q0 >> 5) + 1u] = (u32)(bal[it] >> 32); }
+            if (lane == 0) S.misc[(u32)it * K1F_NW + w] = (u32)__popcll(bal[it]);     // rows in position order: it-major, wave-minor
         }
-        if (lane == 0) { S.misc[w] = tot0; S.misc[K1F_NW + w] = tot1; }
         __syncthreads();
-        if (tid < 2) {                                  // thread c: class c - the waves' counts become offsets, one global atomic
+        if (tid == 0) {                                 // the rows' counts become list offsets: one global atomic reserves the slots
             u32 run = 0;
-            for (u32 i = 0; i < K1F_NW; i++) { const u32 c = S.misc[tid * K1F_NW + i]; S.misc[tid * K1F_NW + i] = run; run += c; }
-            const u32 base = run ? atomicAdd(&B.deepCnt[tid * 8u * K1_DEEP_SUB + xr], run) : 0u;
-            for (u32 i = 0; i < K1F_NW; i++) S.misc[tid * K1F_NW + i] += base;
+            for (u32 i = 0; i < K1F_E * K1F_NW; i++) { const u32 c = S.misc[i]; S.misc[i] = run; run += c; }
+            const u32 base = run ? atomicAdd(&B.rcnt[b], run) : 0u;
+            for (u32 i = 0; i < K1F_E * K1F_NW; i++) S.misc[i] += base;
         }
     }
     for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = S.sx[i];
-    k1f_write_heads(HN, pos0, pos0 + cnt, [&](u32 p) { return k1f_bit(S.hb, p - pos0); });
+    __syncthreads();
     if (lists) {
-        __syncthreads();
-        u32 gb0 = S.misc[w], gb1 = S.misc[K1F_NW + w];
+        k1f_write_heads(HN, pos0, pos0 + cnt, [&](u32 p) { return k1f_bit(S.hb, p - pos0) || k1f_bit(lb, p - pos0); });
+        u64* L = B.rlist[0] + (size_t)b * g.stride;
 #pragma unroll
         for (int it = 0; it < K1F_E; it++) {
             const u32 q = (u32)it * K1F_BT + tid;
-            if (glv[it]) {
-                const u32 gl = glv[it] & 0xFFu, depth = glv[it] >> 8;
-                const int cls = gl == 2u ? 0 : 1;
-                const u32 idx = (cls ? gb1 : gb0) + (u32)__popcll(balc[cls][it] & lt);
-                if (idx < rcap)
-                    B.listT[cls][(size_t)xr * rcap + idx] = ((u64)b << 52) | ((u64)(pos0 + q) << 26) | ((u64)depth << 4) | (u64)(gl - 1u);
+            if ((bal[it] >> lane) & 1ull) {
+                const u32 idx = S.misc[(u32)it * K1F_NW + w] + (u32)__popcll(bal[it] & lt);
+                if (idx < g.stride) L[idx] = ((u64)(q == gsv[it] ? 1u : 0u) << 63) | ((u64)S.sx[q] << 20) | (u64)(pos0 + q);
             }
-            gb0 += (u32)__popcll(balc[0][it]);
-            gb1 += (u32)__popcll(balc[1][it]);
         }
+    } else {
+        k1f_write_heads(HN, pos0, pos0 + cnt, [&](u32 p) { return k1f_bit(S.hb, p - pos0); });
     }
 }
 
@@ -571,8 +561,8 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
 //      kernels' lists with the depth they are known to share (k1f_flush).
 // `purerot_max`: when more rotations than this sit in buckets of ONE 8-byte key (HTML-like input, counted by k1f_scan),
 // the ties are long repeats that text comparison does not settle and step 3 / the lists are skipped (as K1-deep was).
-// min_depth / max_depth = 0: no deepening (the K1-deep tile kernel of rounds 1-2 follows; kept for A/B runs and linear mode).
-__global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 min_depth, u32 max_depth, u32 purerot_max) {
+// lists = 0: no deepening and no lists (the K1-deep tile kernel of rounds 1-2 follows; kept for A/B runs, and linear mode).
+__global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
     u32 b, d;
     if (!xcd_block_tile(g.nb, b, d)) return;
     const u32 n = B.nlen[b];
@@ -589,7 +579,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     const u64* sp = B.fsplit + (size_t)b * K1F_NB;
     // a bucket between the splitters v and v+1 holds one key only
     const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
-    const bool deepen = max_depth > 8u && B.stats[K1_STAT_PUREROT] <= purerot_max;
+    const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
     if (cnt == 1u || (pure && (!deepen || cnt > K1F_C))) {
         for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
         k1f_write_heads(HN, start, end, [&](u32 p) { return p == start; });
@@ -600,7 +590,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     __shared__ u32 key1[K1F_C];
     __shared__ u32 sx[K1F_C];
     __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];
-    __shared__ u32 wdep[K1F_NW], misc[2 * K1F_NW];
+    __shared__ u32 misc[K1F_E * K1F_NW];
     // scratch: the local sample sort (samples, splitters, ranks) and, later, the deepening's new positions
     __shared__ u64 scr64[256];
     // leaf bookkeeping of the local sample sort lives in key1[], which only the deepening uses
@@ -613,7 +603,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     u64* sp2 = scr64 + K1F_LS;
     u32* srank = (u32*)(scr64 + K1F_LS + K1F_LK);
     K1fS S;
-    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.wd = wdep; S.misc = misc;
+    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.misc = misc;
     if (cnt > K1F_C) {
         // oversize bucket (unlucky sampling or a moderately heavy key): listed for k1f_bsort_big (its code in here cost this kernel
         // 45 VGPRs, i.e. three of its eight waves per SIMD)
@@ -780,9 +770,9 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
         __syncthreads();
     }
     K1F_STAMP(3);
-    if (deepen) k1f_deepen(S, T, n, cnt, 8u, min_depth, max_depth);
+    if (deepen) k1f_deepen(S, T, n, cnt, 8u, iters);
     K1F_STAMP(4);
-    k1f_flush(S, B, g, b, d, start, cnt, deepen);
+    k1f_flush(S, B, g, b, start, cnt, deepen);
     K1F_STAMP(5);
 }
 
@@ -790,19 +780,19 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
 // listed by k1f_bsort: stable LSD passes through global memory, one digit byte gathered from the text per pass, ping-pong
 // between the bucket's slices of SB and SA (wave 0 scatters row by row: stable by construction; rare, so simple).  The sorted
 // slice is then deepened like a bucket, in windows of <= K1F_C positions that end on a group boundary.
-__global__ __launch_bounds__(K1F_BT) void k1f_bsort_big(K1Buf B, BatchGeom g, u32 min_depth, u32 max_depth, u32 purerot_max) {
+__global__ __launch_bounds__(K1F_BT) void k1f_bsort_big(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
     __shared__ u64 key[K1F_C];
     __shared__ u32 key1[K1F_C];
     __shared__ u32 sx[K1F_C];
     __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];
-    __shared__ u32 wdep[K1F_NW], misc[2 * K1F_NW];
+    __shared__ u32 misc[K1F_E * K1F_NW];
     __shared__ u64 scr64[256];
     K1fS S;
-    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.wd = wdep; S.misc = misc;
+    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.misc = misc;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     u32 nbig = B.stats[K1_STAT_FRONT_BIG];
     if (nbig > B.largeCap) nbig = B.largeCap;
-    const bool deepen = max_depth > 8u && B.stats[K1_STAT_PUREROT] <= purerot_max;
+    const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
     for (u32 li = blockIdx.x; li < nbig; li += gridDim.x) {
         __syncthreads();
         const u32 b = B.large[li].x, d = B.large[li].y;
@@ -920,11 +910,225 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort_big(K1Buf B, BatchGeom g, u3
                     if (key[i] != key[i - 1u]) atomicOr(&hbits[i >> 5], 1u << (i & 31u));
                 __syncthreads();
             }
-            k1f_deepen(S, T, n, len, 8u, min_depth, max_depth);
-            k1f_flush(S, B, g, b, d, start + a, len, true);
+            k1f_deepen(S, T, n, len, 8u, iters);
+            k1f_flush(S, B, g, b, start + a, len, true);
             a += len;
         }
     }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// list-driven refinement rounds
+// ---------------------------------------------------------------------------------------------
+// What k1f_bsort leaves tied (groups of 2..K1F_GBIG rotations, sharing `depth` bytes) sits in per-block lists, one 8-byte
+// entry per rotation: head << 63 | rotation index << 20 | suffix-array position; a group = consecutive entries, the first
+// one flagged.  A round takes K1R_STEP = 24 more text bytes off every listed rotation: a workgroup owns the groups that START
+// in its K1R_T entries (it reads K1R_W = K1F_GBIG entries ahead for the tail of the last one), fetches the keys (two
+// 16-byte loads per rotation, all loads of a thread in flight together; all tiles of a block run on one XCD: the text is in
+// that L2), ranks every rotation inside its group by counting, and then
+//   - a rotation that ends up alone is FINAL: its index goes to the suffix array (its position was marked a head by
+//     k1f_bsort already),
+//   - the others are written, compacted and in their new order, to the next round's list (one atomic per workgroup).
+// Every lane of every round works on a rotation that still ties - which the in-bucket iterations of k1f_bsort (rows of
+// mostly idle lanes after the second iteration) and the lane kernels (one lane per group, serial) could not offer.  The
+// kernel is bound by the latency of its three dependent memory round trips (list, text, list-slot atomic): PMC shows its
+// waves parked 78 % of their cycles, so it keeps the entries in registers (LDS holds keys only: 8 workgroups per CU) and
+// takes 24 bytes per round (half the rounds, twice the loads in flight).
+// The LAST round (`final`) writes what still ties (long repeats, identical rotations) to the suffix array, clears the
+// head bits of its non-heads, and hands groups of 2..8 to the second pass of the lane kernels (k1_deep_pairs<true> /
+// k1_deep_small<true>: up to CJS_DEEP_LANE_CAP bytes); what they leave, and bigger groups, the doubling rounds of k1_run take.
+#define K1R_STEP 24u
+#define K1R_T 512u
+#define K1R_W K1F_GBIG
+#define K1R_N (K1R_T + K1R_W)
+#define K1R_ROWS (K1R_N / 64u)
+#define K1R_RPW (K1R_ROWS / 4u)                         // rows per wave
+#define K1R_HW (K1R_N / 32u + 2u)
+static_assert(K1R_ROWS % 4u == 0, "rows are dealt to four waves");
+
+// 24 text bytes at T + p (any alignment) as three big-endian 64-bit words: a dwordx4 + a dwordx3 load, six v_alignbyte
+__device__ __forceinline__ void k1r_load_be192(const u8* T, u32 p, u64& a, u64& b, u64& c) {
+    const u32 sh = p & 3u;
+    u32 d[7];
+    __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 28);
+    u32 x[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[j] = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[j + 1], d[j], sh));
+    a = ((u64)x[0] << 32) | x[1];
+    b = ((u64)x[2] << 32) | x[3];
+    c = ((u64)x[4] << 32) | x[5];
+}
+
+#ifndef K1R_MINW
+#define K1R_MINW 6                                      // waves per SIMD the register allocation is held to (80 VGPRs: no spill; 8 spills 16)
+#endif
+__global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g, u32 round, u32 depth, u32 final) {
+    u32 b, t0;
+    if (!xcd_block_tile(g.nb, b, t0)) return;
+    u32 cnt = B.rcnt[(size_t)round * B.rstride + b];
+    if (cnt > g.stride) cnt = g.stride;
+    if (t0 * K1R_T >= cnt) return;
+    const u32 n = B.nlen[b];
+    const u8* T = B.T + (size_t)b * g.tstride;
+    const u64* Lin = B.rlist[round & 1u] + (size_t)b * g.stride;
+    u64* Lout = B.rlist[(round & 1u) ^ 1u] + (size_t)b * g.stride;
+    u32* ocnt = B.rcnt + (size_t)(round + 1u) * B.rstride + b;
+    u32* SA = B.SA + (size_t)b * g.stride;
+    u32* HN = B.HN + (size_t)b * g.hstride;
+    __shared__ u64 kA[K1R_N], kB[K1R_N], kC[K1R_N];
+    __shared__ u32 hb[K1R_HW], nh[K1R_HW];
+    __shared__ u32 rowcnt[K1R_ROWS];
+    __shared__ u32 obase;
+    u32* sn = (u32*)kC;                                 // indices in their new order (kC is free once the ranks are known)
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32 dm = depth % n;
+    const u64 lt = lanemask_lt();
+    for (u32 t = t0; t * K1R_T < cnt; t += gridDim.x) {
+        const u32 e0 = t * K1R_T;
+        const u32 m = cnt - e0 < K1R_N ? cnt - e0 : K1R_N;
+        __syncthreads();
+#ifdef K1F_TRACE
+        long long tprev_ = clock64();
+#endif
+        // entries (kept in registers) and their head bits (rows of 64 are aligned to the bitmap words; beyond m: heads = sentinel)
+        u64 e[K1R_RPW];
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++) {
+            const u32 i = (it * 4u + w) * 64u + lane;
+            e[it] = i < m ? Lin[e0 + i] : (1ull << 63);
+        }
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++) {
+            const u32 row = it * 4u + w;
+            const u64 bal = __ballot((e[it] >> 63) != 0ull);
+            if (lane == 0) { hb[row * 2u] = (u32)bal; hb[row * 2u + 1u] = (u32)(bal >> 32); nh[row * 2u] = 0; nh[row * 2u + 1u] = 0; }
+        }
+        if (tid < 2) { hb[K1R_N / 32u + tid] = 0xFFFFFFFFu; nh[K1R_N / 32u + tid] = 0xFFFFFFFFu; }
+        __syncthreads();
+        K1R_STAMP(0);
+        // owned: the groups that start in [0, K1R_T)
+        const u32 lo = (hb[0] & 1u) ? 0u : k1f_next_head(hb, 0u);
+        const u32 hi = m <= K1R_T ? m : k1f_first_head_ge(hb, K1R_T);
+        if (lo >= hi || lo >= K1R_T) continue;          // (uniform) cannot happen: groups are shorter than a tile
+        // keys: all loads of the thread in flight together
+        {
+            u64 ka[K1R_RPW], kb[K1R_RPW], kc[K1R_RPW];
+#pragma unroll
+            for (u32 it = 0; it < K1R_RPW; it++) {
+                const u32 i = (it * 4u + w) * 64u + lane;
+                ka[it] = 0; kb[it] = 0; kc[it] = 0;
+                if (i >= lo && i < hi) {
+                    u32 p = ((u32)(e[it] >> 20) & 0xFFFFFu) + dm;
+                    if (p >= n) p -= n;
+                    k1r_load_be192(T, p, ka[it], kb[it], kc[it]);
+                }
+            }
+#pragma unroll
+            for (u32 it = 0; it < K1R_RPW; it++) {
+                const u32 i = (it * 4u + w) * 64u + lane;
+                if (i >= lo && i < hi) { kA[i] = ka[it]; kB[i] = kb[it]; kC[i] = kc[it]; }
+            }
+        }
+        if (tid == 0) atomicOr(&nh[hi >> 5], 1u << (hi & 31u));
+        __syncthreads();
+        K1R_STAMP(1);
+        // rank inside the group: new position, sub-group heads
+        u32 qn[K1R_RPW];
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++) {
+            const u32 i = (it * 4u + w) * 64u + lane;
+            qn[it] = 0xFFFFFFFFu;
+            if (i >= lo && i < hi) {
+                const u32 gs = k1f_prev_head(hb, i), ge = k1f_next_head(hb, i);
+                const u64 m0 = kA[i], m1 = kB[i], m2 = kC[i];
+                u32 less = 0, eqb = 0;
+                for (u32 j = gs; j < ge; j += 2u) {
+                    u64 c0[2], c1[2], c2[2];
+#pragma unroll
+                    for (u32 u = 0; u < 2u; u++) {
+                        const u32 jj = j + u < ge ? j + u : ge - 1u;
+                        c0[u] = kA[jj];
+                        c1[u] = kB[jj];
+                        c2[u] = kC[jj];
+                    }
+#pragma unroll
+                    for (u32 u = 0; u < 2u; u++) {
+                        const bool in = j + u < ge;
+                        const bool eq01 = c0[u] == m0 && c1[u] == m1;
+                        const bool ltk = c0[u] < m0 || (c0[u] == m0 && c1[u] < m1) || (eq01 && c2[u] < m2);
+                        const bool eq = eq01 && c2[u] == m2;
+                        less += (in && ltk) ? 1u : 0u;
+                        eqb += (in && eq && j + u < i) ? 1u : 0u;
+                    }
+                }
+                qn[it] = (gs + less + eqb) | (eqb == 0u ? 0x80000000u : 0u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++)
+            if (qn[it] != 0xFFFFFFFFu) {
+                const u32 q = qn[it] & 0x7FFFFFFFu, i = (it * 4u + w) * 64u + lane;
+                // the index, and its suffix-array position in the new order (positions inside a group are consecutive)
+                sn[2u * q] = (u32)(e[it] >> 20) & 0xFFFFFu;
+                sn[2u * q + 1u] = ((u32)e[it] & 0xFFFFFu) + q - i;
+                if (qn[it] >> 31) atomicOr(&nh[q >> 5], 1u << (q & 31u));
+            }
+        __syncthreads();
+        K1R_STAMP(2);
+        // new order: singles are final, the others go on
+        u64 sbal[K1R_RPW];
+        u32 spos[K1R_RPW], sv[K1R_RPW];
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++) {
+            const u32 row = it * 4u + w, i = row * 64u + lane;
+            bool surv = false;
+            spos[it] = 0; sv[it] = 0;
+            if (i >= lo && i < hi) {
+                const bool h = k1f_bit(nh, i), h1 = k1f_bit(nh, i + 1u);
+                const u32 s = sn[2u * i], pos = sn[2u * i + 1u];
+                surv = !(h && h1);
+                if (!surv || final) SA[pos] = s;
+                if (final && surv) {
+                    if (!h) atomicAnd(&HN[pos >> 5], ~(1u << (pos & 31u)));
+                    else {
+                        // a group that outlasted the rounds: 2..8 rotations go to the lane kernels' second pass
+                        const u32 gl = k1f_next_head(nh, i) - i;
+                        if (gl <= K1_DEEP_LANE) {
+                            const u32 cls = gl == 2u ? 0u : 1u;
+                            const u32 xr = (b & 7u) * K1_DEEP_SUB + ((pos >> 10) & (K1_DEEP_SUB - 1u)), rcap2 = B.listSCap / (8u * K1_DEEP_SUB);
+                            const u32 idx = atomicAdd(&B.deepCnt[(2u + cls) * 8u * K1_DEEP_SUB + xr], 1u);
+                            const u32 dd = depth + K1R_STEP < 0xFFFFu ? depth + K1R_STEP : 0xFFFFu;
+                            if (idx < rcap2) B.listS[cls][(size_t)xr * rcap2 + idx] = ((u64)b << 52) | ((u64)pos << 26) | ((u64)dd << 4) | (u64)(gl - 1u);
+                        }
+                    }
+                }
+                spos[it] = pos | (h ? 0x80000000u : 0u);
+                sv[it] = s;
+            }
+            sbal[it] = __ballot(surv && !final);
+            if (lane == 0) rowcnt[row] = (u32)__popcll(sbal[it]);
+        }
+        if (final) continue;                            // (uniform)
+        __syncthreads();
+        K1R_STAMP(3);
+        if (tid == 0) {
+            u32 run = 0;
+            for (u32 r = 0; r < K1R_ROWS; r++) { const u32 c = rowcnt[r]; rowcnt[r] = run; run += c; }
+            obase = run ? atomicAdd(ocnt, run) : 0u;
+        }
+        __syncthreads();
+        K1R_STAMP(4);
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++) {
+            const u32 row = it * 4u + w;
+            if ((sbal[it] >> lane) & 1ull) {
+                const u32 idx = obase + rowcnt[row] + (u32)__popcll(sbal[it] & lt);
+                if (idx < g.stride) Lout[idx] = ((u64)(spos[it] >> 31) << 63) | ((u64)sv[it] << 20) | (u64)(spos[it] & 0xFFFFFu);
+            }
+        }
+        K1R_STAMP(5);
     }
 }
 
@@ -933,7 +1137,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort_big(K1Buf B, BatchGeom g, u3
 // ---------------------------------------------------------------------------------------------
 size_t k1_front_tilehist_words(const BatchGeom& g) { return (size_t)k1f_ptiles(g) * K1F_NB; }
 
-int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 min_depth, u32 max_depth, u32 purerot_max) {
+int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max) {
     const u32 ptiles = k1f_ptiles(g);
     const u32 nb8 = (g.nb + 7u) & ~7u;
     hipLaunchKernelGGL(k1f_sample, dim3(g.nb), dim3(1024), 0, stream, B, g);
@@ -944,11 +1148,28 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
     const u32 slot = pr && pr->enabled ? __atomic_fetch_add(&pr->used, 1u, __ATOMIC_RELAXED) : K1_PROF_MAX;
     const bool timed = slot < K1_PROF_MAX;
     if (timed) (void)hipEventRecord(pr->ev[2 * slot], stream);
-    hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB, nb8), dim3(K1F_BT), 0, stream, B, g, min_depth, max_depth, purerot_max);
-    hipLaunchKernelGGL(k1f_bsort_big, dim3(g.nb * 8u < 256u ? g.nb * 8u : 256u), dim3(K1F_BT), 0, stream, B, g, min_depth, max_depth, purerot_max);
+    hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max);
     if (timed) {
         (void)hipEventRecord(pr->ev[2 * slot + 1], stream);
         __atomic_fetch_add(&pr->elements, (u64)g.nb * max_n, __ATOMIC_RELAXED);
+    }
+    hipLaunchKernelGGL(k1f_bsort_big, dim3(g.nb * 8u < 256u ? g.nb * 8u : 256u), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
+// the refinement rounds over the lists k1f_bsort filled: depth0 = what the listed groups share, up to max_depth
+int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth) {
+    const u32 nb8 = (g.nb + 7u) & ~7u;
+    const u32 full = (g.stride + K1R_T - 1u) / K1R_T;
+    u32 rounds = max_depth > depth0 ? (max_depth - depth0 + K1R_STEP - 1u) / K1R_STEP : 1u;
+    if (rounds > K1R_MAXR) rounds = K1R_MAXR;
+    for (u32 r = 0; r < rounds; r++) {
+        // the lists shrink from round to round (text: by a quarter to a third): later rounds launch fewer workgroups, each walks
+        // its share of the tiles (an empty workgroup still costs its dispatch)
+        u32 tiles = full >> r;
+        if (tiles < 16u) tiles = 16u;
+        hipLaunchKernelGGL(k1r_round, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
     }
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
