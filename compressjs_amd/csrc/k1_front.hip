@@ -961,8 +961,14 @@ __device__ __forceinline__ void k1r_load_be192(const u8* T, u32 p, u64& a, u64& 
 }
 
 #ifndef K1R_MINW
-#define K1R_MINW 6                                      // waves per SIMD the register allocation is held to (80 VGPRs: no spill; 8 spills 16)
+#define K1R_MINW 4                                      // waves per SIMD the register allocation is held to
 #endif
+// The kernel is a software pipeline over the tiles a workgroup walks (t0, t0 + gridDim.x, ...): its first version ran one
+// tile per workgroup with four DEPENDENT memory round trips (list entries -> text gather -> ... -> list-slot atomic ->
+// stores) and its waves were parked 78 % of their cycles (PMC SQ_WAIT_ANY; stage clocks: list load 16 %, gather 45 %,
+// atomic 20 %).  Now, while tile k is ranked in LDS, the entries of tile k+2 and the text of tile k+1 are on their way
+// (they live in registers until their turn), and the slot reservation of tile k-1 returns: the survivors of a tile are
+// written one iteration late.  Four barriers per tile, no memory latency on the critical path.
 __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g, u32 round, u32 depth, u32 final) {
     u32 b, t0;
     if (!xcd_block_tile(g.nb, b, t0)) return;
@@ -977,69 +983,129 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     u32* SA = B.SA + (size_t)b * g.stride;
     u32* HN = B.HN + (size_t)b * g.hstride;
     __shared__ u64 kA[K1R_N], kB[K1R_N], kC[K1R_N];
-    __shared__ u32 hb[K1R_HW], nh[K1R_HW];
-    __shared__ u32 rowcnt[K1R_ROWS];
+    __shared__ u32 hb[K1R_HW], nh[K1R_HW], hb2[K1R_HW];
+    __shared__ u32 rowcnt[2][K1R_ROWS];
     __shared__ u32 obase;
-    u32* sn = (u32*)kC;                                 // indices in their new order (kC is free once the ranks are known)
+    u32* sn = (u32*)kC;                                 // (index, position) in the new order (kC is free once the ranks are known)
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32 dm = depth % n;
     const u64 lt = lanemask_lt();
-    for (u32 t = t0; t * K1R_T < cnt; t += gridDim.x) {
-        const u32 e0 = t * K1R_T;
-        const u32 m = cnt - e0 < K1R_N ? cnt - e0 : K1R_N;
-        __syncthreads();
-#ifdef K1F_TRACE
-        long long tprev_ = clock64();
-#endif
-        // entries (kept in registers) and their head bits (rows of 64 are aligned to the bitmap words; beyond m: heads = sentinel)
-        u64 e[K1R_RPW];
+    const u32 G = gridDim.x;
+    const u64 SENT = 1ull << 63;
+    auto load_tile = [&](u32 t, u64 (&e)[K1R_RPW]) {
+        const u32 e0 = t * K1R_T;                       // (t * K1R_T cannot overflow: t < 2^22)
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
-            e[it] = i < m ? Lin[e0 + i] : (1ull << 63);
+            e[it] = (e0 < cnt && i < cnt - e0) ? Lin[e0 + i] : SENT;
         }
+    };
+    auto heads_to = [&](u32* bm, const u64 (&e)[K1R_RPW], bool clear_nh) {
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 row = it * 4u + w;
             const u64 bal = __ballot((e[it] >> 63) != 0ull);
-            if (lane == 0) { hb[row * 2u] = (u32)bal; hb[row * 2u + 1u] = (u32)(bal >> 32); nh[row * 2u] = 0; nh[row * 2u + 1u] = 0; }
+            if (lane == 0) {
+                bm[row * 2u] = (u32)bal; bm[row * 2u + 1u] = (u32)(bal >> 32);
+                if (clear_nh) { nh[row * 2u] = 0; nh[row * 2u + 1u] = 0; }
+            }
         }
-        if (tid < 2) { hb[K1R_N / 32u + tid] = 0xFFFFFFFFu; nh[K1R_N / 32u + tid] = 0xFFFFFFFFu; }
+        if (tid < 2) { bm[K1R_N / 32u + tid] = 0xFFFFFFFFu; if (clear_nh) nh[K1R_N / 32u + tid] = 0xFFFFFFFFu; }
+    };
+    // owned range of a tile whose head bits are in bm: the groups that start in [0, K1R_T)
+    auto owned = [&](const u32* bm, u32 t, u32& lo, u32& hi) {
+        const u32 e0 = t * K1R_T;
+        lo = 0; hi = 0;
+        if (e0 >= cnt) return;
+        const u32 m = cnt - e0 < K1R_N ? cnt - e0 : K1R_N;
+        lo = (bm[0] & 1u) ? 0u : k1f_next_head(bm, 0u);
+        hi = m <= K1R_T ? m : k1f_first_head_ge(bm, K1R_T);
+        if (lo >= K1R_T || lo >= hi) { lo = 0; hi = 0; }           // cannot happen: groups are shorter than a tile
+    };
+    // raw text of the owned entries of a tile (7 dwords each, decoded when the tile's turn comes)
+    auto gather = [&](const u64 (&e)[K1R_RPW], u32 lo, u32 hi, u32 (&d)[K1R_RPW][7]) {
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++) {
+            const u32 i = (it * 4u + w) * 64u + lane;
+#pragma unroll
+            for (int j = 0; j < 7; j++) d[it][j] = 0;
+            if (i >= lo && i < hi) {
+                u32 p = ((u32)(e[it] >> 20) & 0xFFFFFu) + dm;
+                if (p >= n) p -= n;
+                __builtin_memcpy(d[it], __builtin_assume_aligned(T + (p & ~3u), 4), 28);
+            }
+        }
+    };
+    u64 eC[K1R_RPW], eN[K1R_RPW], eNN[K1R_RPW];
+    u32 dC[K1R_RPW][7];
+    u32 pv_s[K1R_RPW], pv_p[K1R_RPW];
+    u64 pv_bal[K1R_RPW];
+    u32 abase = 0, par = 0;
+    bool pv_valid = false;
+    u32 tc = t0;
+    // prologue: entries of the first two tiles, text of the first
+    load_tile(tc, eC);
+    load_tile(tc + G, eN);
+    heads_to(hb, eC, false);
+    __syncthreads();
+    u32 loC, hiC;
+    owned(hb, tc, loC, hiC);
+#pragma unroll
+    for (u32 it = 0; it < K1R_RPW; it++) { pv_s[it] = 0; pv_p[it] = 0; pv_bal[it] = 0; }
+    gather(eC, loC, hiC, dC);
+    __syncthreads();
+    for (; tc * K1R_T < cnt; tc += G) {
+#ifdef K1F_TRACE
+        long long tprev_ = clock64();
+#endif
+        // 1. entries of the tile after next
+        load_tile(tc + 2u * G, eNN);
+        // 2. head bits of this tile and the next; keys of this tile (gathered during the previous iteration) into LDS
+        heads_to(hb, eC, true);
+        heads_to(hb2, eN, false);
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++) {
+            const u32 i = (it * 4u + w) * 64u + lane;
+            if (i >= loC && i < hiC) {
+                u32 p = ((u32)(eC[it] >> 20) & 0xFFFFFu) + dm;
+                if (p >= n) p -= n;
+                const u32 sh = p & 3u;
+                u32 x[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) x[j] = __builtin_bswap32(__builtin_amdgcn_alignbyte(dC[it][j + 1], dC[it][j], sh));
+                kA[i] = ((u64)x[0] << 32) | x[1];
+                kB[i] = ((u64)x[2] << 32) | x[3];
+                kC[i] = ((u64)x[4] << 32) | x[5];
+            }
+        }
+        if (tid == 0 && pv_valid) obase = abase;
         __syncthreads();
         K1R_STAMP(0);
-        // owned: the groups that start in [0, K1R_T)
-        const u32 lo = (hb[0] & 1u) ? 0u : k1f_next_head(hb, 0u);
-        const u32 hi = m <= K1R_T ? m : k1f_first_head_ge(hb, K1R_T);
-        if (lo >= hi || lo >= K1R_T) continue;          // (uniform) cannot happen: groups are shorter than a tile
-        // keys: all loads of the thread in flight together
-        {
-            u64 ka[K1R_RPW], kb[K1R_RPW], kc[K1R_RPW];
+        // 3. the previous tile's survivors to the next round's list
+        if (pv_valid && !final) {
 #pragma unroll
             for (u32 it = 0; it < K1R_RPW; it++) {
-                const u32 i = (it * 4u + w) * 64u + lane;
-                ka[it] = 0; kb[it] = 0; kc[it] = 0;
-                if (i >= lo && i < hi) {
-                    u32 p = ((u32)(e[it] >> 20) & 0xFFFFFu) + dm;
-                    if (p >= n) p -= n;
-                    k1r_load_be192(T, p, ka[it], kb[it], kc[it]);
+                const u32 row = it * 4u + w;
+                if ((pv_bal[it] >> lane) & 1ull) {
+                    const u32 idx = obase + rowcnt[par ^ 1u][row] + (u32)__popcll(pv_bal[it] & lt);
+                    if (idx < g.stride) Lout[idx] = ((u64)(pv_p[it] >> 31) << 63) | ((u64)pv_s[it] << 20) | (u64)(pv_p[it] & 0xFFFFFu);
                 }
             }
-#pragma unroll
-            for (u32 it = 0; it < K1R_RPW; it++) {
-                const u32 i = (it * 4u + w) * 64u + lane;
-                if (i >= lo && i < hi) { kA[i] = ka[it]; kB[i] = kb[it]; kC[i] = kc[it]; }
-            }
         }
-        if (tid == 0) atomicOr(&nh[hi >> 5], 1u << (hi & 31u));
-        __syncthreads();
+        // 4. text of the next tile's owned entries: in flight while this tile is ranked
+        u32 loN, hiN;
+        owned(hb2, tc + G, loN, hiN);
+        u32 dN[K1R_RPW][7];
+        gather(eN, loN, hiN, dN);
+        if (tid == 0) atomicOr(&nh[hiC >> 5], 1u << (hiC & 31u));
         K1R_STAMP(1);
-        // rank inside the group: new position, sub-group heads
+        // 5. rank inside the group: new position, sub-group heads
         u32 qn[K1R_RPW];
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
             qn[it] = 0xFFFFFFFFu;
-            if (i >= lo && i < hi) {
+            if (i >= loC && i < hiC) {
                 const u32 gs = k1f_prev_head(hb, i), ge = k1f_next_head(hb, i);
                 const u64 m0 = kA[i], m1 = kB[i], m2 = kC[i];
                 u32 less = 0, eqb = 0;
@@ -1071,21 +1137,19 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
             if (qn[it] != 0xFFFFFFFFu) {
                 const u32 q = qn[it] & 0x7FFFFFFFu, i = (it * 4u + w) * 64u + lane;
                 // the index, and its suffix-array position in the new order (positions inside a group are consecutive)
-                sn[2u * q] = (u32)(e[it] >> 20) & 0xFFFFFu;
-                sn[2u * q + 1u] = ((u32)e[it] & 0xFFFFFu) + q - i;
+                sn[2u * q] = (u32)(eC[it] >> 20) & 0xFFFFFu;
+                sn[2u * q + 1u] = ((u32)eC[it] & 0xFFFFFu) + q - i;
                 if (qn[it] >> 31) atomicOr(&nh[q >> 5], 1u << (q & 31u));
             }
         __syncthreads();
         K1R_STAMP(2);
-        // new order: singles are final, the others go on
-        u64 sbal[K1R_RPW];
-        u32 spos[K1R_RPW], sv[K1R_RPW];
+        // 6. new order: singles are final, the others go on (written during the next iteration)
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 row = it * 4u + w, i = row * 64u + lane;
             bool surv = false;
-            spos[it] = 0; sv[it] = 0;
-            if (i >= lo && i < hi) {
+            pv_p[it] = 0; pv_s[it] = 0;
+            if (i >= loC && i < hiC) {
                 const bool h = k1f_bit(nh, i), h1 = k1f_bit(nh, i + 1u);
                 const u32 s = sn[2u * i], pos = sn[2u * i + 1u];
                 surv = !(h && h1);
@@ -1104,31 +1168,44 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
                         }
                     }
                 }
-                spos[it] = pos | (h ? 0x80000000u : 0u);
-                sv[it] = s;
+                pv_p[it] = pos | (h ? 0x80000000u : 0u);
+                pv_s[it] = s;
             }
-            sbal[it] = __ballot(surv && !final);
-            if (lane == 0) rowcnt[row] = (u32)__popcll(sbal[it]);
+            pv_bal[it] = __ballot(surv && !final);
+            if (lane == 0) rowcnt[par][row] = (u32)__popcll(pv_bal[it]);
         }
-        if (final) continue;                            // (uniform)
         __syncthreads();
         K1R_STAMP(3);
-        if (tid == 0) {
+        // 7. slots for the survivors (the result is used one iteration later)
+        if (tid == 0 && !final) {
             u32 run = 0;
-            for (u32 r = 0; r < K1R_ROWS; r++) { const u32 c = rowcnt[r]; rowcnt[r] = run; run += c; }
-            obase = run ? atomicAdd(ocnt, run) : 0u;
+            for (u32 r = 0; r < K1R_ROWS; r++) { const u32 c = rowcnt[par][r]; rowcnt[par][r] = run; run += c; }
+            abase = run ? atomicAdd(ocnt, run) : 0u;
         }
-        __syncthreads();
         K1R_STAMP(4);
+        // 8. rotate
+#pragma unroll
+        for (u32 it = 0; it < K1R_RPW; it++) {
+            eC[it] = eN[it]; eN[it] = eNN[it];
+#pragma unroll
+            for (int j = 0; j < 7; j++) dC[it][j] = dN[it][j];
+        }
+        loC = loN; hiC = hiN;
+        par ^= 1u;
+        pv_valid = true;
+    }
+    // drain: the last tile's survivors
+    if (pv_valid && !final) {
+        if (tid == 0) obase = abase;
+        __syncthreads();
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 row = it * 4u + w;
-            if ((sbal[it] >> lane) & 1ull) {
-                const u32 idx = obase + rowcnt[row] + (u32)__popcll(sbal[it] & lt);
-                if (idx < g.stride) Lout[idx] = ((u64)(spos[it] >> 31) << 63) | ((u64)sv[it] << 20) | (u64)(spos[it] & 0xFFFFFu);
+            if ((pv_bal[it] >> lane) & 1ull) {
+                const u32 idx = obase + rowcnt[par ^ 1u][row] + (u32)__popcll(pv_bal[it] & lt);
+                if (idx < g.stride) Lout[idx] = ((u64)(pv_p[it] >> 31) << 63) | ((u64)pv_s[it] << 20) | (u64)(pv_p[it] & 0xFFFFFu);
             }
         }
-        K1R_STAMP(5);
     }
 }
 
@@ -1167,7 +1244,7 @@ int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u
     for (u32 r = 0; r < rounds; r++) {
         // the lists shrink from round to round (text: by a quarter to a third): later rounds launch fewer workgroups, each walks
         // its share of the tiles (an empty workgroup still costs its dispatch)
-        u32 tiles = full >> r;
+        u32 tiles = (full >> r) / 8u;                 // a workgroup walks ~8 tiles (software pipeline), later rounds fewer
         if (tiles < 16u) tiles = 16u;
         hipLaunchKernelGGL(k1r_round, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
     }
