@@ -23,6 +23,17 @@ __device__ __forceinline__ void pin_vgpr(u32& v) {
 #endif
 }
 
+// Workgroup barrier that orders LDS only: __syncthreads() also fences global memory, i.e. the compiler puts s_waitcnt vmcnt(0)
+// in front of s_barrier and every load a software pipeline keeps in flight across the barrier is drained right there.
+// (The hardware does not need that: barriers do not drain VMEM.)  Data exchanged through GLOBAL memory needs __syncthreads().
+__device__ __forceinline__ void lds_barrier() {
+#if defined(__AMDGCN__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 // mask of lanes whose low `nbits` of d equal this lane's (and are valid)
 __device__ __forceinline__ u64 match_any(u32 d, int nbits, bool valid) {
     u64 m = __ballot(valid);

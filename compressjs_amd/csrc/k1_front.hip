@@ -502,7 +502,7 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
     u32* lb = S.h0;                                     // listed positions (the deepening's copy of the heads is no longer needed)
     const u64 lt = lanemask_lt();
     u64 bal[K1F_E];
-    u32 gsv[K1F_E];
+    u32 gsv[K1F_E];                                     // listed: index in the group | (length - 1) << 8
     if (lists) {
 #pragma unroll
         for (int it = 0; it < K1F_E; it++) {
@@ -516,8 +516,9 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
             const u32 q = q0 + lane;
             bool listed = false;
             if (q < cnt && !(k1f_bit(S.hb, q) && k1f_bit(S.hb, q + 1u)) && !k1f_bit(S.fb, q)) {
-                gsv[it] = k1f_prev_head(S.hb, q);
-                listed = k1f_next_head(S.hb, q) - gsv[it] <= K1F_GBIG;
+                const u32 gs = k1f_prev_head(S.hb, q), gl = k1f_next_head(S.hb, q) - gs;
+                listed = gl <= K1F_GBIG;
+                gsv[it] = (q - gs) | ((gl - 1u) << 8);
             }
             bal[it] = __ballot(listed);
             if (lane == 0) { lb[q0 >> 5] = (u32)bal[it]; lb[(q0 >> 5) + 1u] = (u32)(bal[it] >> 32); }
@@ -541,7 +542,7 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
             const u32 q = (u32)it * K1F_BT + tid;
             if ((bal[it] >> lane) & 1ull) {
                 const u32 idx = S.misc[(u32)it * K1F_NW + w] + (u32)__popcll(bal[it] & lt);
-                if (idx < g.stride) L[idx] = ((u64)(q == gsv[it] ? 1u : 0u) << 63) | ((u64)S.sx[q] << 20) | (u64)(pos0 + q);
+                if (idx < g.stride) L[idx] = ((u64)gsv[it] << 40) | ((u64)S.sx[q] << 20) | (u64)(pos0 + q);
             }
         }
     } else {
@@ -921,20 +922,24 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort_big(K1Buf B, BatchGeom g, u3
 // ---------------------------------------------------------------------------------------------
 // list-driven refinement rounds
 // ---------------------------------------------------------------------------------------------
-// What k1f_bsort leaves tied (groups of 2..K1F_GBIG rotations, sharing `depth` bytes) sits in per-block lists, one 8-byte
-// entry per rotation: head << 63 | rotation index << 20 | suffix-array position; a group = consecutive entries, the first
-// one flagged.  A round takes K1R_STEP = 24 more text bytes off every listed rotation: a workgroup owns the groups that START
-// in its K1R_T entries (it reads K1R_W = K1F_GBIG entries ahead for the tail of the last one), fetches the keys (two
-// 16-byte loads per rotation, all loads of a thread in flight together; all tiles of a block run on one XCD: the text is in
-// that L2), ranks every rotation inside its group by counting, and then
+// What k1f_bsort leaves tied (groups of 2..K1F_GBIG = 256 rotations, sharing `depth` bytes) sits in per-block lists, one
+// 8-byte entry per rotation:  (group length - 1) << 48 | index in the group << 40 | rotation index << 20 | suffix-array
+// position;  a group = consecutive entries.  A round takes K1R_STEP = 24 more text bytes off every listed rotation: a
+// workgroup owns the groups that START in its K1R_T entries (it reads K1R_W = 256 entries ahead for the tail of the last
+// one; an entry knows where its group starts, so there is no bitmap), fetches the keys (a dwordx4 + a dwordx3 load per
+// rotation; all tiles of a block run on one XCD: the text is in that L2), ranks every rotation inside its group by counting
+// (smaller keys, equal keys before it, equal keys in all), and then
 //   - a rotation that ends up alone is FINAL: its index goes to the suffix array (its position was marked a head by
 //     k1f_bsort already),
-//   - the others are written, compacted and in their new order, to the next round's list (one atomic per workgroup).
+//   - the others go, compacted and in their new order, to the next round's list (their slot: the survivors before them in
+//     the tile, from a bitmap by new position + one atomic per workgroup).
 // Every lane of every round works on a rotation that still ties - which the in-bucket iterations of k1f_bsort (rows of
-// mostly idle lanes after the second iteration) and the lane kernels (one lane per group, serial) could not offer.  The
-// kernel is bound by the latency of its three dependent memory round trips (list, text, list-slot atomic): PMC shows its
-// waves parked 78 % of their cycles, so it keeps the entries in registers (LDS holds keys only: 8 workgroups per CU) and
-// takes 24 bytes per round (half the rounds, twice the loads in flight).
+// mostly idle lanes after the second iteration) and the lane kernels (one lane per group, serial) could not offer.
+// The kernel is a software pipeline over the tiles a workgroup walks (t0, t0 + gridDim.x, ...): its first version ran one
+// tile per workgroup with four DEPENDENT memory round trips (list -> text -> list-slot atomic -> stores), its waves parked
+// 78 % of their cycles (PMC SQ_WAIT_ANY).  Now, while tile k is ranked in LDS, the entries of tile k+2 and the text of tile
+// k+1 are on their way (they live in registers until their turn), and the slot reservation of tile k-1 returns: the
+// survivors of a tile are written one iteration late.  Three barriers per tile.
 // The LAST round (`final`) writes what still ties (long repeats, identical rotations) to the suffix array, clears the
 // head bits of its non-heads, and hands groups of 2..8 to the second pass of the lane kernels (k1_deep_pairs<true> /
 // k1_deep_small<true>: up to CJS_DEEP_LANE_CAP bytes); what they leave, and bigger groups, the doubling rounds of k1_run take.
@@ -944,31 +949,16 @@ __global__ __launch_bounds__(K1F_BT) void k1f_bsort_big(K1Buf B, BatchGeom g, u3
 #define K1R_N (K1R_T + K1R_W)
 #define K1R_ROWS (K1R_N / 64u)
 #define K1R_RPW (K1R_ROWS / 4u)                         // rows per wave
-#define K1R_HW (K1R_N / 32u + 2u)
-static_assert(K1R_ROWS % 4u == 0, "rows are dealt to four waves");
-
-// 24 text bytes at T + p (any alignment) as three big-endian 64-bit words: a dwordx4 + a dwordx3 load, six v_alignbyte
-__device__ __forceinline__ void k1r_load_be192(const u8* T, u32 p, u64& a, u64& b, u64& c) {
-    const u32 sh = p & 3u;
-    u32 d[7];
-    __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 28);
-    u32 x[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) x[j] = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[j + 1], d[j], sh));
-    a = ((u64)x[0] << 32) | x[1];
-    b = ((u64)x[2] << 32) | x[3];
-    c = ((u64)x[4] << 32) | x[5];
-}
-
+#define K1R_SW (K1R_N / 32u)                            // words of the survivor bitmap
+static_assert(K1R_ROWS % 4u == 0 && K1R_SW <= 64u && K1F_GBIG <= 256u, "rows are dealt to four waves; one wave scans the bitmap; 8-bit group fields");
+#define K1R_POS(e) ((u32)(e) & 0xFFFFFu)
+#define K1R_S(e) ((u32)((e) >> 20) & 0xFFFFFu)
+#define K1R_IDX(e) ((u32)((e) >> 40) & 0xFFu)
+#define K1R_LEN(e) (((u32)((e) >> 48) & 0xFFu) + 1u)
 #ifndef K1R_MINW
 #define K1R_MINW 4                                      // waves per SIMD the register allocation is held to
 #endif
-// The kernel is a software pipeline over the tiles a workgroup walks (t0, t0 + gridDim.x, ...): its first version ran one
-// tile per workgroup with four DEPENDENT memory round trips (list entries -> text gather -> ... -> list-slot atomic ->
-// stores) and its waves were parked 78 % of their cycles (PMC SQ_WAIT_ANY; stage clocks: list load 16 %, gather 45 %,
-// atomic 20 %).  Now, while tile k is ranked in LDS, the entries of tile k+2 and the text of tile k+1 are on their way
-// (they live in registers until their turn), and the slot reservation of tile k-1 returns: the survivors of a tile are
-// written one iteration late.  Four barriers per tile, no memory latency on the critical path.
+
 __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g, u32 round, u32 depth, u32 final) {
     u32 b, t0;
     if (!xcd_block_tile(g.nb, b, t0)) return;
@@ -983,54 +973,30 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     u32* SA = B.SA + (size_t)b * g.stride;
     u32* HN = B.HN + (size_t)b * g.hstride;
     __shared__ u64 kA[K1R_N], kB[K1R_N], kC[K1R_N];
-    __shared__ u32 hb[K1R_HW], nh[K1R_HW], hb2[K1R_HW];
-    __shared__ u32 rowcnt[2][K1R_ROWS];
+    __shared__ u32 sb[2][K1R_SW], pre[2][K1R_SW + 1];
     __shared__ u32 obase;
-    u32* sn = (u32*)kC;                                 // (index, position) in the new order (kC is free once the ranks are known)
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32 dm = depth % n;
-    const u64 lt = lanemask_lt();
     const u32 G = gridDim.x;
-    const u64 SENT = 1ull << 63;
     auto load_tile = [&](u32 t, u64 (&e)[K1R_RPW]) {
-        const u32 e0 = t * K1R_T;                       // (t * K1R_T cannot overflow: t < 2^22)
+        const u32 e0 = t * K1R_T;
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
-            e[it] = (e0 < cnt && i < cnt - e0) ? Lin[e0 + i] : SENT;
+            e[it] = (e0 < cnt && i < cnt - e0) ? Lin[e0 + i] : 0ull;          // beyond the list: a group of one, never owned
         }
     };
-    auto heads_to = [&](u32* bm, const u64 (&e)[K1R_RPW], bool clear_nh) {
-#pragma unroll
-        for (u32 it = 0; it < K1R_RPW; it++) {
-            const u32 row = it * 4u + w;
-            const u64 bal = __ballot((e[it] >> 63) != 0ull);
-            if (lane == 0) {
-                bm[row * 2u] = (u32)bal; bm[row * 2u + 1u] = (u32)(bal >> 32);
-                if (clear_nh) { nh[row * 2u] = 0; nh[row * 2u + 1u] = 0; }
-            }
-        }
-        if (tid < 2) { bm[K1R_N / 32u + tid] = 0xFFFFFFFFu; if (clear_nh) nh[K1R_N / 32u + tid] = 0xFFFFFFFFu; }
-    };
-    // owned range of a tile whose head bits are in bm: the groups that start in [0, K1R_T)
-    auto owned = [&](const u32* bm, u32 t, u32& lo, u32& hi) {
-        const u32 e0 = t * K1R_T;
-        lo = 0; hi = 0;
-        if (e0 >= cnt) return;
-        const u32 m = cnt - e0 < K1R_N ? cnt - e0 : K1R_N;
-        lo = (bm[0] & 1u) ? 0u : k1f_next_head(bm, 0u);
-        hi = m <= K1R_T ? m : k1f_first_head_ge(bm, K1R_T);
-        if (lo >= K1R_T || lo >= hi) { lo = 0; hi = 0; }           // cannot happen: groups are shorter than a tile
-    };
+    // owned: the group starts inside the tile's first K1R_T entries
+    auto own = [&](u64 e, u32 i) { const u32 gs = i - K1R_IDX(e); return K1R_LEN(e) >= 2u && gs < K1R_T; };     // (i < idx wraps to a huge gs)
     // raw text of the owned entries of a tile (7 dwords each, decoded when the tile's turn comes)
-    auto gather = [&](const u64 (&e)[K1R_RPW], u32 lo, u32 hi, u32 (&d)[K1R_RPW][7]) {
+    auto gather = [&](const u64 (&e)[K1R_RPW], u32 (&d)[K1R_RPW][7]) {
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
 #pragma unroll
             for (int j = 0; j < 7; j++) d[it][j] = 0;
-            if (i >= lo && i < hi) {
-                u32 p = ((u32)(e[it] >> 20) & 0xFFFFFu) + dm;
+            if (own(e[it], i)) {
+                u32 p = K1R_S(e[it]) + dm;
                 if (p >= n) p -= n;
                 __builtin_memcpy(d[it], __builtin_assume_aligned(T + (p & ~3u), 4), 28);
             }
@@ -1038,36 +1004,29 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     };
     u64 eC[K1R_RPW], eN[K1R_RPW], eNN[K1R_RPW];
     u32 dC[K1R_RPW][7];
-    u32 pv_s[K1R_RPW], pv_p[K1R_RPW];
-    u64 pv_bal[K1R_RPW];
+    u64 pv_e[K1R_RPW];                                  // survivors of the previous tile: their new entries ...
+    u32 pv_i[K1R_RPW];                                  // ... and slots relative to the tile's reservation (~0: none)
     u32 abase = 0, par = 0;
     bool pv_valid = false;
     u32 tc = t0;
     // prologue: entries of the first two tiles, text of the first
     load_tile(tc, eC);
     load_tile(tc + G, eN);
-    heads_to(hb, eC, false);
-    __syncthreads();
-    u32 loC, hiC;
-    owned(hb, tc, loC, hiC);
 #pragma unroll
-    for (u32 it = 0; it < K1R_RPW; it++) { pv_s[it] = 0; pv_p[it] = 0; pv_bal[it] = 0; }
-    gather(eC, loC, hiC, dC);
-    __syncthreads();
+    for (u32 it = 0; it < K1R_RPW; it++) { pv_e[it] = 0; pv_i[it] = 0xFFFFFFFFu; }
+    gather(eC, dC);
     for (; tc * K1R_T < cnt; tc += G) {
 #ifdef K1F_TRACE
         long long tprev_ = clock64();
 #endif
         // 1. entries of the tile after next
         load_tile(tc + 2u * G, eNN);
-        // 2. head bits of this tile and the next; keys of this tile (gathered during the previous iteration) into LDS
-        heads_to(hb, eC, true);
-        heads_to(hb2, eN, false);
+        // 2. keys of this tile (gathered during the previous iteration) into LDS
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
-            if (i >= loC && i < hiC) {
-                u32 p = ((u32)(eC[it] >> 20) & 0xFFFFFu) + dm;
+            if (own(eC[it], i)) {
+                u32 p = K1R_S(eC[it]) + dm;
                 if (p >= n) p -= n;
                 const u32 sh = p & 3u;
                 u32 x[6];
@@ -1078,37 +1037,34 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
                 kC[i] = ((u64)x[4] << 32) | x[5];
             }
         }
+        if (tid < K1R_SW) sb[par][tid] = 0;
         if (tid == 0 && pv_valid) obase = abase;
-        __syncthreads();
+        lds_barrier();
         K1R_STAMP(0);
         // 3. the previous tile's survivors to the next round's list
         if (pv_valid && !final) {
 #pragma unroll
-            for (u32 it = 0; it < K1R_RPW; it++) {
-                const u32 row = it * 4u + w;
-                if ((pv_bal[it] >> lane) & 1ull) {
-                    const u32 idx = obase + rowcnt[par ^ 1u][row] + (u32)__popcll(pv_bal[it] & lt);
-                    if (idx < g.stride) Lout[idx] = ((u64)(pv_p[it] >> 31) << 63) | ((u64)pv_s[it] << 20) | (u64)(pv_p[it] & 0xFFFFFu);
+            for (u32 it = 0; it < K1R_RPW; it++)
+                if (pv_i[it] != 0xFFFFFFFFu) {
+                    const u32 idx = obase + pv_i[it];
+                    if (idx < g.stride) Lout[idx] = pv_e[it];
                 }
-            }
         }
         // 4. text of the next tile's owned entries: in flight while this tile is ranked
-        u32 loN, hiN;
-        owned(hb2, tc + G, loN, hiN);
         u32 dN[K1R_RPW][7];
-        gather(eN, loN, hiN, dN);
-        if (tid == 0) atomicOr(&nh[hiC >> 5], 1u << (hiC & 31u));
+        gather(eN, dN);
         K1R_STAMP(1);
-        // 5. rank inside the group: new position, sub-group heads
+        // 5. rank inside the group: smaller keys, equal keys before, equal keys in all
         u32 qn[K1R_RPW];
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
             qn[it] = 0xFFFFFFFFu;
-            if (i >= loC && i < hiC) {
-                const u32 gs = k1f_prev_head(hb, i), ge = k1f_next_head(hb, i);
+            pv_i[it] = 0xFFFFFFFFu;
+            if (own(eC[it], i)) {
+                const u32 gs = i - K1R_IDX(eC[it]), ge = gs + K1R_LEN(eC[it]);
                 const u64 m0 = kA[i], m1 = kB[i], m2 = kC[i];
-                u32 less = 0, eqb = 0;
+                u32 less = 0, eqb = 0, eqt = 0;
                 for (u32 j = gs; j < ge; j += 2u) {
                     u64 c0[2], c1[2], c2[2];
 #pragma unroll
@@ -1126,86 +1082,70 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
                         const bool eq = eq01 && c2[u] == m2;
                         less += (in && ltk) ? 1u : 0u;
                         eqb += (in && eq && j + u < i) ? 1u : 0u;
+                        eqt += (in && eq) ? 1u : 0u;
                     }
                 }
-                qn[it] = (gs + less + eqb) | (eqb == 0u ? 0x80000000u : 0u);
+                const u32 q = gs + less + eqb;
+                const u32 s = K1R_S(eC[it]), pos = K1R_POS(eC[it]) + q - i;     // positions inside a group are consecutive
+                const bool surv = eqt > 1u;
+                if (!surv || final) SA[pos] = s;
+                if (surv) {
+                    if (!final) {
+                        qn[it] = q;
+                        atomicOr(&sb[par][q >> 5], 1u << (q & 31u));
+                        pv_e[it] = ((u64)(eqt - 1u) << 48) | ((u64)eqb << 40) | ((u64)s << 20) | (u64)pos;
+                    } else if (eqb) {
+                        atomicAnd(&HN[pos >> 5], ~(1u << (pos & 31u)));
+                    } else if (eqt <= K1_DEEP_LANE) {
+                        // a group that outlasted the rounds: 2..8 rotations go to the lane kernels' second pass
+                        const u32 cls = eqt == 2u ? 0u : 1u;
+                        const u32 xr = (b & 7u) * K1_DEEP_SUB + ((pos >> 10) & (K1_DEEP_SUB - 1u)), rcap2 = B.listSCap / (8u * K1_DEEP_SUB);
+                        const u32 idx = atomicAdd(&B.deepCnt[(2u + cls) * 8u * K1_DEEP_SUB + xr], 1u);
+                        const u32 dd = depth + K1R_STEP < 0xFFFFu ? depth + K1R_STEP : 0xFFFFu;
+                        if (idx < rcap2) B.listS[cls][(size_t)xr * rcap2 + idx] = ((u64)b << 52) | ((u64)pos << 26) | ((u64)dd << 4) | (u64)(eqt - 1u);
+                    }
+                }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        K1R_STAMP(2);
+        // 6. survivors before every bitmap word (one wave), slots for all of them (the result is used one iteration later)
+        if (w == 0 && !final) {
+            const u32 c = lane < K1R_SW ? (u32)__popc(sb[par][lane]) : 0u;
+            const u32 inc = wave_incl_scan_u32(c);
+            if (lane < K1R_SW) pre[par][lane] = inc - c;
+            const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            if (lane == 0) abase = total ? atomicAdd(ocnt, total) : 0u;
+        }
+        lds_barrier();
+        K1R_STAMP(3);
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++)
             if (qn[it] != 0xFFFFFFFFu) {
-                const u32 q = qn[it] & 0x7FFFFFFFu, i = (it * 4u + w) * 64u + lane;
-                // the index, and its suffix-array position in the new order (positions inside a group are consecutive)
-                sn[2u * q] = (u32)(eC[it] >> 20) & 0xFFFFFu;
-                sn[2u * q + 1u] = ((u32)eC[it] & 0xFFFFFu) + q - i;
-                if (qn[it] >> 31) atomicOr(&nh[q >> 5], 1u << (q & 31u));
+                const u32 q = qn[it];
+                pv_i[it] = pre[par][q >> 5] + (u32)__popc(sb[par][q >> 5] & ((1u << (q & 31u)) - 1u));
             }
-        __syncthreads();
-        K1R_STAMP(2);
-        // 6. new order: singles are final, the others go on (written during the next iteration)
-#pragma unroll
-        for (u32 it = 0; it < K1R_RPW; it++) {
-            const u32 row = it * 4u + w, i = row * 64u + lane;
-            bool surv = false;
-            pv_p[it] = 0; pv_s[it] = 0;
-            if (i >= loC && i < hiC) {
-                const bool h = k1f_bit(nh, i), h1 = k1f_bit(nh, i + 1u);
-                const u32 s = sn[2u * i], pos = sn[2u * i + 1u];
-                surv = !(h && h1);
-                if (!surv || final) SA[pos] = s;
-                if (final && surv) {
-                    if (!h) atomicAnd(&HN[pos >> 5], ~(1u << (pos & 31u)));
-                    else {
-                        // a group that outlasted the rounds: 2..8 rotations go to the lane kernels' second pass
-                        const u32 gl = k1f_next_head(nh, i) - i;
-                        if (gl <= K1_DEEP_LANE) {
-                            const u32 cls = gl == 2u ? 0u : 1u;
-                            const u32 xr = (b & 7u) * K1_DEEP_SUB + ((pos >> 10) & (K1_DEEP_SUB - 1u)), rcap2 = B.listSCap / (8u * K1_DEEP_SUB);
-                            const u32 idx = atomicAdd(&B.deepCnt[(2u + cls) * 8u * K1_DEEP_SUB + xr], 1u);
-                            const u32 dd = depth + K1R_STEP < 0xFFFFu ? depth + K1R_STEP : 0xFFFFu;
-                            if (idx < rcap2) B.listS[cls][(size_t)xr * rcap2 + idx] = ((u64)b << 52) | ((u64)pos << 26) | ((u64)dd << 4) | (u64)(gl - 1u);
-                        }
-                    }
-                }
-                pv_p[it] = pos | (h ? 0x80000000u : 0u);
-                pv_s[it] = s;
-            }
-            pv_bal[it] = __ballot(surv && !final);
-            if (lane == 0) rowcnt[par][row] = (u32)__popcll(pv_bal[it]);
-        }
-        __syncthreads();
-        K1R_STAMP(3);
-        // 7. slots for the survivors (the result is used one iteration later)
-        if (tid == 0 && !final) {
-            u32 run = 0;
-            for (u32 r = 0; r < K1R_ROWS; r++) { const u32 c = rowcnt[par][r]; rowcnt[par][r] = run; run += c; }
-            abase = run ? atomicAdd(ocnt, run) : 0u;
-        }
         K1R_STAMP(4);
-        // 8. rotate
+        // 7. rotate
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             eC[it] = eN[it]; eN[it] = eNN[it];
 #pragma unroll
             for (int j = 0; j < 7; j++) dC[it][j] = dN[it][j];
         }
-        loC = loN; hiC = hiN;
         par ^= 1u;
         pv_valid = true;
     }
     // drain: the last tile's survivors
     if (pv_valid && !final) {
         if (tid == 0) obase = abase;
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
-        for (u32 it = 0; it < K1R_RPW; it++) {
-            const u32 row = it * 4u + w;
-            if ((pv_bal[it] >> lane) & 1ull) {
-                const u32 idx = obase + rowcnt[par ^ 1u][row] + (u32)__popcll(pv_bal[it] & lt);
-                if (idx < g.stride) Lout[idx] = ((u64)(pv_p[it] >> 31) << 63) | ((u64)pv_s[it] << 20) | (u64)(pv_p[it] & 0xFFFFFu);
+        for (u32 it = 0; it < K1R_RPW; it++)
+            if (pv_i[it] != 0xFFFFFFFFu) {
+                const u32 idx = obase + pv_i[it];
+                if (idx < g.stride) Lout[idx] = pv_e[it];
             }
-        }
     }
 }
 
