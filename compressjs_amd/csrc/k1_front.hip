@@ -1096,8 +1096,9 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
                         pv_e[it] = ((u64)(eqt - 1u) << 48) | ((u64)eqb << 40) | ((u64)s << 20) | (u64)pos;
                     } else if (eqb) {
                         atomicAnd(&HN[pos >> 5], ~(1u << (pos & 31u)));
-                    } else if (eqt <= K1_DEEP_LANE) {
-                        // a group that outlasted the rounds: 2..8 rotations go to the lane kernels' second pass
+                    } else if (eqt <= K1_DEEP_LANE && n >= 64u) {
+                        // a group that outlasted the rounds: 2..8 rotations go to the lane kernels' second pass (their walk wraps
+                        // around the block at most once per step: not for blocks shorter than a step)
                         const u32 cls = eqt == 2u ? 0u : 1u;
                         const u32 xr = (b & 7u) * K1_DEEP_SUB + ((pos >> 10) & (K1_DEEP_SUB - 1u)), rcap2 = B.listSCap / (8u * K1_DEEP_SUB);
                         const u32 idx = atomicAdd(&B.deepCnt[(2u + cls) * 8u * K1_DEEP_SUB + xr], 1u);
