@@ -7,6 +7,7 @@
 #include "decode_host.h"
 #include <vector>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <functional>
 #include <mutex>
@@ -287,8 +288,25 @@ done:
 
 // BWTC: what the coder thread needs of one group of sub-batches (kept in the context: fresh 100 MB vectors per call would
 // be page-faulted in by the D2H copies)
-struct BwtcBlockJob { u32 len, pidx, nsym, ntri; u32 used[8]; size_t off; };
-struct BwtcGroupJob { std::vector<BwtcBlockJob> blocks; std::vector<u32> a, t; std::vector<u16> sym; bool busy = false; };
+struct BwtcBlockJob { u32 len, pidx, nsym, ntri; u32 used[8]; size_t off; bool host; size_t soff; };   // host: K10 gave up (triples beyond its rows): model on the host
+// triples of a group of blocks on the host: PINNED (hipHostMalloc, grow-only): the 350 MB of a 10^8-byte input took ~100 ms to
+// arrive in pageable vectors, more than K1 + K2 together
+struct PinnedU32 {
+    u32* p = nullptr; size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return CJS_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        n += n / 8 + 1024;
+        const hipError_t e = hipHostMalloc((void**)&p, n * sizeof(u32), hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return CJS_E_HIP - (int)e; }
+        cap = n;
+        return CJS_OK;
+    }
+    u32* data() { return p; }
+    ~PinnedU32() { if (p) (void)hipHostFree(p); }
+};
+struct BwtcGroupJob { std::vector<BwtcBlockJob> blocks; PinnedU32 a, t; std::vector<u16> sym; bool busy = false; size_t nready = 0; };   // nready: leading blocks whose data has landed
 
 struct cjs_ctx {
     int device;
@@ -690,7 +708,7 @@ extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_l
     if (rc) return rc;
     // one batch of blocks per segment; CJS_SEG_BYTES (tests) overrides.  Inputs of up to a batch and a half go in one
     // piece: half-size batches cost more (16.9 vs 14.2 ms per 10^8 bytes) than overlapping their copies would save.
-    static const uint64_t seg_env = []() -> uint64_t { const char* ev = getenv("CJS_SEG_BYTES"); return ev ? strtoull(ev, nullptr, 10) : 0; }();
+    const uint64_t seg_env = []() -> uint64_t { const char* ev = getenv("CJS_SEG_BYTES"); return ev ? strtoull(ev, nullptr, 10) : 0; }();   // (read per call)
     const uint64_t seg_bytes = seg_env ? seg_env : (uint64_t)c->batch_blocks * ((u32)level * 100000u - 19u);
     if (in_len > seg_bytes + seg_bytes / 2) return compress_segmented(c, in, in_len, level, out, out_cap, seg_bytes);
     if (in_len) TRYR(hipMemcpyAsync(c->din, in, in_len, hipMemcpyHostToDevice, c->stream));
@@ -732,7 +750,7 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
     if (level < 1 || level > 9) return CJS_E_LEVEL;
     for (u32 i = 0; i < n; i++) if (!ctxs[i]) return CJS_E_ARG;
     const u32 cap = (u32)level * 100000u - 19u;
-    static const uint64_t seg_env = []() -> uint64_t { const char* ev = getenv("CJS_SEG_BYTES"); return ev ? strtoull(ev, nullptr, 10) : 0; }();
+    const uint64_t seg_env = []() -> uint64_t { const char* ev = getenv("CJS_SEG_BYTES"); return ev ? strtoull(ev, nullptr, 10) : 0; }();   // (read per call)
     const uint64_t seg_bytes = seg_env ? seg_env : (uint64_t)ctxs[0]->batch_blocks * cap;
     const uint64_t nseg = (in_len + seg_bytes - 1) / seg_bytes;
     if (n == 1 || nseg <= 1) return cjs_bz2_compress(ctxs[0], in, in_len, level, out, out_cap);
@@ -746,8 +764,9 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
     S[0].s = 0; S[0].s_known = true;
     std::mutex mu;
     std::condition_variable cv;
-    int err = 0;                    // first error; 1 = fall back to one device
-    auto fail = [&](int code) { std::lock_guard<std::mutex> g(mu); if (!err) err = code; cv.notify_all(); };
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::atomic<int> err{0};        // first error; 1 = fall back to one device (the workers read it without the lock)
+    auto fail = [&](int code) { std::lock_guard<std::mutex> g(mu); if (!err.load()) err.store(code); cv.notify_all(); };
     // phase 1 of one segment on its context
     auto encode_seg = [&](uint64_t k) {
         cjs_ctx* c = ctxs[k % n];
@@ -851,6 +870,8 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
     u32 blocks = 0;
     for (uint64_t k = 0; k < nseg; k++) blocks += S[k].count;
     ctxs[0]->last_blocks = blocks;
+    // (cjs_last_device_ms: this path has no single device interval; it reports the wall time of the call)
+    ctxs[0]->last_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return result;
 }
 
@@ -955,7 +976,11 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
     // levels 6..9: the adaptive FenwickModel of every block runs on the GPU too (K10, one wave per block: a serial
     // recurrence, ~170 ms per launch whatever the number of blocks), the host keeps the range coder.
     // CJS_BWTC_GPU_MODEL=0: model on the host as in round 1 (A/B runs).
-    static const bool gpu_model = []() { const char* ev = getenv("CJS_BWTC_GPU_MODEL"); return !ev || atoi(ev) != 0; }();
+    const bool gpu_model = []() { const char* ev = getenv("CJS_BWTC_GPU_MODEL"); return !ev || atoi(ev) != 0; }();          // (read per call)
+    // rows of K10's triples: 2 x stride per block in the round lists of K1 (free in linear mode); CJS_K10_CAP (tests) shrinks them
+    const u32 k10_ostride = 2u * make_geom(c->sub_blocks, (u32)level * 100000u).stride;
+    const u32 k10_cap = []() -> u32 { const char* ev = getenv("CJS_K10_CAP"); return ev ? (u32)strtoul(ev, nullptr, 10) : 0xFFFFFFFFu; }() < k10_ostride
+                            ? (u32)strtoul(getenv("CJS_K10_CAP"), nullptr, 10) : k10_ostride;
     const bool tri = gpu_model && level >= 6;
     // Sub-batches are processed in GROUPS of one per stream: their GPU stages are issued back to back on different
     // streams (the K10 launches of a group overlap), then everything the coder needs is copied to host vectors and
@@ -967,6 +992,10 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
     std::condition_variable cv;
     std::vector<GroupJob*> queue;
     bool done_issuing = false;
+    const bool btrace = getenv("CJS_BWTC_TRACE") != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
+    auto msnow = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
+    double coder_busy = 0, coder_first = 0;
     std::thread coder_thread([&]() {
         for (;;) {
             GroupJob* job = nullptr;
@@ -977,10 +1006,19 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
                 job = queue.front();
                 queue.erase(queue.begin());
             }
-            for (const BlockJob& bj : job->blocks) {
-                if (tri) bwtc_block_triples(coder, bj.len, bj.pidx, bj.used, job->a.data() + bj.off, job->t.data() + bj.off, bj.ntri);
-                else bwtc_block(coder, bj.len, bj.pidx, bj.used, job->sym.data() + bj.off, bj.nsym);
+            const double tj0 = msnow();
+            if (coder_first == 0) coder_first = tj0;
+            for (size_t bi = 0; bi < job->blocks.size(); bi++) {
+                {   // the copies of a group land stream by stream: start on what is there
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&]() { return bi < job->nready || done_issuing; });
+                    if (bi >= job->nready) return;                     // (error path: the issuer gave up)
+                }
+                const BlockJob& bj = job->blocks[bi];
+                if (tri && !bj.host) bwtc_block_triples(coder, bj.len, bj.pidx, bj.used, job->a.data() + bj.off, job->t.data() + bj.off, bj.ntri);
+                else bwtc_block(coder, bj.len, bj.pidx, bj.used, job->sym.data() + (tri ? bj.soff : bj.off), bj.nsym);
             }
+            coder_busy += msnow() - tj0;
             { std::lock_guard<std::mutex> lk(mu); job->busy = false; cv.notify_all(); }
         }
     });
@@ -996,6 +1034,7 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
     TRYR(hipStreamSynchronize(st));                                // the input is resident
     TRYR(hipEventRecord(c->ev0, st));
     float gpu_ms = 0.f;
+    try {
     for (u64 first = 0; first < nblocks; first += (u64)c->sub_blocks * ns) {
         Pipe Ps[CJS_NSTREAMS];
         u32 nbs[CJS_NSTREAMS] = {0, 0, 0, 0};
@@ -1025,8 +1064,16 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
             TRYR(hipMemcpyAsync(P.nlen, nls, nb * 4, hipMemcpyHostToDevice, ss));
             rc = k1_run(P.k1, P.g, max_n, ss);
             if (!rc) rc = k2_run(P, max_n, ss);
-            if (!rc && tri) rc = k10_model_run(P, P.k1.SB, P.k1.KA, P.ngroups, ss);
+            if (!rc && tri) rc = k10_model_run(P, (u32*)P.k1.rlist[0], (u32*)P.k1.rlist[1], P.ngroups, k10_ostride, k10_cap, ss);
             if (rc) { stop_coder(); (void)bwtc_end(coder); return rc; }
+        }
+        // the per-block results, only now: a device-to-host copy into pageable memory blocks the HOST until the stream has
+        // drained, i.e. for the 132 ms of that stream's K10 - issued inside the loop above it kept the next stream's K1 / K2 /
+        // K10 from even being launched (kernel trace of round 2: the two K10 launches ran back to back, 264 ms)
+        for (u32 si = 0; si < ns && nbs[si]; si++) {
+            hipStream_t ss = c->sub[si];
+            Pipe& P = Ps[si];
+            const u32 nb = nbs[si];
             const size_t o = (size_t)si * c->sub_blocks;
             if (tri) TRYR(hipMemcpyAsync(hntri.data() + o, P.ngroups, nb * 4, hipMemcpyDeviceToHost, ss));
             TRYR(hipMemcpyAsync(hpos.data() + o, P.pos, nb * 4, hipMemcpyDeviceToHost, ss));
@@ -1040,8 +1087,9 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
             job = !c->bwtc_jobs[0]->busy ? c->bwtc_jobs[0] : c->bwtc_jobs[1];
             job->busy = true;
         }
+        if (btrace) fprintf(stderr, "[bwtc] group issued at %.1f ms\n", msnow());
         job->blocks.clear();
-        size_t total = 0;
+        size_t total = 0, stotal = 0;
         for (u32 si = 0; si < ns && nbs[si]; si++) {
             TRYR(hipStreamSynchronize(c->sub[si]));
             const size_t o = (size_t)si * c->sub_blocks;
@@ -1050,29 +1098,53 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
                 bj.len = nl[o + b]; bj.pidx = hpidx[o + b];
                 bj.nsym = hpos[o + b] - 1;                         // K2 appends bzip2's EOB; BWTC has none
                 bj.ntri = tri ? hntri[o + b] : 0;
+                bj.host = tri && bj.ntri > k10_cap;                 // K10_OVERFLOW (or anything beyond the row: never copied)
+                bj.soff = 0;
+                if (bj.host) { bj.ntri = 0; bj.soff = stotal; stotal += (size_t)bj.nsym + 1; }
                 memcpy(bj.used, hused.data() + (o + b) * 8, 32);
                 bj.off = total;
                 total += (tri ? bj.ntri : bj.nsym) + 1;
                 job->blocks.push_back(bj);
             }
         }
-        if (tri) { if (job->a.size() < total) { job->a.resize(total); job->t.resize(total); } } else if (job->sym.size() < total) job->sym.resize(total);
+        if (btrace) fprintf(stderr, "[bwtc] K1 + K2 + K10 of the group done at %.1f ms\n", msnow());
+        if (tri) {
+            rc = job->a.reserve(total);
+            if (!rc) rc = job->t.reserve(total);
+            if (rc) { stop_coder(); (void)bwtc_end(coder); return rc; }
+            if (job->sym.size() < stotal) job->sym.resize(stotal);
+        }
+        else if (job->sym.size() < total) job->sym.resize(total);
         size_t k = 0;
         for (u32 si = 0; si < ns && nbs[si]; si++)
             for (u32 b = 0; b < nbs[si]; b++, k++) {
                 const BlockJob& bj = job->blocks[k];
                 Pipe& P = Ps[si];
-                if (tri && bj.ntri) {
-                    TRYR(hipMemcpyAsync(job->a.data() + bj.off, P.k1.SB + (size_t)b * g.stride, (size_t)bj.ntri * 4, hipMemcpyDeviceToHost, c->sub[si]));
-                    TRYR(hipMemcpyAsync(job->t.data() + bj.off, P.k1.KA + (size_t)b * g.stride, (size_t)bj.ntri * 4, hipMemcpyDeviceToHost, c->sub[si]));
+                if (tri && bj.host) {
+                    if (bj.nsym) TRYR(hipMemcpyAsync(job->sym.data() + bj.soff, P.A + (size_t)b * g.stride, (size_t)bj.nsym * 2, hipMemcpyDeviceToHost, c->sub[si]));
+                } else if (tri && bj.ntri) {
+                    TRYR(hipMemcpyAsync(job->a.data() + bj.off, (u32*)P.k1.rlist[0] + (size_t)b * k10_ostride, (size_t)bj.ntri * 4, hipMemcpyDeviceToHost, c->sub[si]));
+                    TRYR(hipMemcpyAsync(job->t.data() + bj.off, (u32*)P.k1.rlist[1] + (size_t)b * k10_ostride, (size_t)bj.ntri * 4, hipMemcpyDeviceToHost, c->sub[si]));
                 } else if (!tri && bj.nsym) {
                     TRYR(hipMemcpyAsync(job->sym.data() + bj.off, P.A + (size_t)b * g.stride, (size_t)bj.nsym * 2, hipMemcpyDeviceToHost, c->sub[si]));
                 }
             }
-        for (u32 si = 0; si < ns && nbs[si]; si++) TRYR(hipStreamSynchronize(c->sub[si]));
-        { std::lock_guard<std::mutex> lk(mu); queue.push_back(job); cv.notify_all(); }
+        if (btrace) fprintf(stderr, "[bwtc] copies issued at %.1f ms\n", msnow());
+        { std::lock_guard<std::mutex> lk(mu); job->nready = 0; queue.push_back(job); cv.notify_all(); }
+        for (u32 si = 0; si < ns && nbs[si]; si++) {
+            TRYR(hipStreamSynchronize(c->sub[si]));
+            { std::lock_guard<std::mutex> lk(mu); job->nready += nbs[si]; cv.notify_all(); }
+        }
     }
+    } catch (const std::exception&) {                              // e.g. std::bad_alloc while sizing a job: the coder thread must be joined
+        stop_coder();
+        (void)bwtc_end(coder);
+        return CJS_E_NOSPACE;
+    }
+    const double t_issued = msnow();
     stop_coder();
+    if (btrace) fprintf(stderr, "[bwtc] %llu blocks: GPU stages + copies issued and done at %.1f ms, coder started at %.1f ms, busy %.1f ms, all done at %.1f ms\n",
+                        (unsigned long long)nblocks, t_issued, coder_first, coder_busy, msnow());
     TRYR(hipEventRecord(c->ev1, st));
     TRYR(hipStreamSynchronize(st));
     TRYR(hipEventElapsedTime(&gpu_ms, c->ev0, c->ev1));

@@ -87,7 +87,7 @@ static int dec_alloc(DecState& S, u32 slots) {
 // a quarter of the HBM that is free right now (a 400 MB level-1 stream, or a small stream stuffed with fake
 // block magics, has thousands of candidates: 4096 slots would pin 23 GB).  Fewer slots only mean more batches.
 static u32 dec_slot_limit(u32 min_slots) {
-    static const u32 env_cap = []() -> u32 { const char* e = getenv("CJS_DEC_MAX_SLOTS"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();
+    const u32 env_cap = []() -> u32 { const char* e = getenv("CJS_DEC_MAX_SLOTS"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();   // (read per call)
     u32 lim = DEC_MAX_SLOTS;
     if (env_cap) lim = env_cap;
     else {

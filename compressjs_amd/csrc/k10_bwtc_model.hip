@@ -16,6 +16,7 @@
 #include "pipeline.h"
 
 #define K10_MAXSYM 260
+#define K10_OVERFLOW 0xFFFFFFFFu
 
 __device__ __forceinline__ void k10_sum_tree(u32* tree, u32 numSyms, u32 lane) {      // lib/FenwickModel.js:167-172
     // tree[i] = tree[2i] + tree[2i+1] for i = numSyms-1 .. 1: children have a longer bit length, so go level by level
@@ -26,17 +27,21 @@ __device__ __forceinline__ void k10_sum_tree(u32* tree, u32 numSyms, u32 lane) {
     }
 }
 
-// out: sylt[b][k] = sy_f | lt_f << 16, tot[b][k] = tot_f for the k-th encodeFreq call of block b; ntri[b] = their number
+// out: sylt[b][k] = sy_f | lt_f << 16, tot[b][k] = tot_f for the k-th encodeFreq call of block b; ntri[b] = their number.
+// A block emits one triple per symbol PLUS one per escape (a first occurrence, or a symbol whose frequency was scaled down to 0:
+// ~1.3 % of the symbols on random bytes, up to ~18 % on adversarial input), so the rows hold `ocap` = 2 x stride triples (the
+// round-2 rows of `stride` overflowed into the next block on incompressible input); a block that would not fit even there
+// stops, reports K10_OVERFLOW and is modelled on the host (bwtc_block).
 __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const u32* pos, const u32* alpha, u32* sylt, u32* tot,
-                                                u32* ntri) {
+                                                u32* ntri, u32 ostride, u32 ocap) {
     __shared__ u32 tree[2 * K10_MAXSYM + 8];
     const u32 b = blockIdx.x, lane = threadIdx.x;
     const u32 nsym = pos[b] ? pos[b] - 1u : 0u;               // K2 appended bzip2's end-of-block symbol; BWTC has none
     const u32 size = alpha[b] + 1u;                           // FenwickModel(coder, alphabetSize + 1, ...)  lib/BWTC.js:105
     const u32 numSyms = size + 1u, increment = 0x0100u, max_prob = 0xFF00u;
     const u16* sym = A + (size_t)b * stride;
-    u32* osl = sylt + (size_t)b * stride;
-    u32* oto = tot + (size_t)b * stride;
+    u32* osl = sylt + (size_t)b * ostride;
+    u32* oto = tot + (size_t)b * ostride;
     // init :13-32
     for (u32 i = lane; i < 2u * numSyms; i += 64u) tree[i] = i >= numSyms ? (i == numSyms + size ? increment << 16 : 1u) : 0u;
     __builtin_amdgcn_wave_barrier();
@@ -91,6 +96,10 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
     const u32 sh = lane < 31u ? lane : 31u;                   // leaf < 1024: lanes 10.. see node 0
     u32 nxt = lane < nsym ? sym[lane] : 0u;
     for (u32 r0 = 0; r0 < nsym; r0 += 64u) {
+        if (nout + 192u > ocap) {                             // a row adds at most 128 triples (wave-uniform)
+            if (lane == 0) ntri[b] = K10_OVERFLOW;
+            return;
+        }
         const u32 mine = nxt;
         nxt = r0 + 64u + lane < nsym ? sym[r0 + 64u + lane] : 0u;
         const u32 rows = nsym - r0 < 64u ? nsym - r0 : 64u;
@@ -136,8 +145,8 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
     if (lane == 0) ntri[b] = nout;
 }
 
-int k10_model_run(Pipe P, u32* sylt, u32* tot, u32* ntri, hipStream_t stream) {
-    hipLaunchKernelGGL(k10_model, dim3(P.g.nb), dim3(64), 0, stream, (const u16*)P.A, P.g.stride, (const u32*)P.pos, (const u32*)P.alpha, sylt, tot, ntri);
+int k10_model_run(Pipe P, u32* sylt, u32* tot, u32* ntri, u32 ostride, u32 ocap, hipStream_t stream) {
+    hipLaunchKernelGGL(k10_model, dim3(P.g.nb), dim3(64), 0, stream, (const u16*)P.A, P.g.stride, (const u32*)P.pos, (const u32*)P.alpha, sylt, tot, ntri, ostride, ocap);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

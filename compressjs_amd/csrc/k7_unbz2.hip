@@ -97,6 +97,10 @@ __device__ __forceinline__ void tab_set(u32& reg, u32 idx, u32 val) {
     if (lane_id() == (idx >> 2)) reg = (reg & ~(0xffu << (8u * (idx & 3u)))) | (val << (8u * (idx & 3u)));
 }
 
+// every cross-wave wait loop gives up after this many s_sleep(1) rounds (~64 clocks each: ~0.2 s) and reports a data error
+#ifndef K7_SPIN_CAP
+#define K7_SPIN_CAP (1u << 23)
+#endif
 #define K7_GRING 4u          // groups in flight between waves A and B
 #define K7_RROWS 8u          // rows of 64 symbols in flight between waves B, C and D
 #define K7_SYMS 512u
@@ -232,13 +236,14 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
     __shared__ u8 s_out[K7_RROWS][64];     // C -> D: byte of the t-th literal of the row
     __shared__ u32 s_rf0[K7_RROWS];        // C -> D: front of the MTF list before the row
     __shared__ u32 s_ghead, s_gtail, s_stop, s_rhead, s_chead, s_dtail, s_adone, s_bdone, s_cdone, s_abort, s_symTotal, s_hdr;
+    __shared__ u32 s_hung;             // a wait loop ran into K7_SPIN_CAP: the block is reported as a data error instead of hanging the queue
     __shared__ int s_pstat;
     __shared__ u32 s_cnt, s_origPtr, s_crc;
     __shared__ u64 s_endbit, s_nsym, s_pwait, s_cwait, s_prof[14];
 
     u32* gsel = D.sel + (size_t)slot * 4160u;             // [4096 + 64] words: 32768 selectors, 4 bits each, + one row of slack
     const u64 t_start = clock64();
-    if (threadIdx.x == 0) { s_ghead = 0; s_gtail = 0; s_stop = 0; s_rhead = 0; s_chead = 0; s_dtail = 0; s_adone = 0; s_bdone = 0; s_cdone = 0; s_abort = 0; s_pstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; for (int k = 0; k < 14; k++) s_prof[k] = 0; }
+    if (threadIdx.x == 0) { s_ghead = 0; s_gtail = 0; s_stop = 0; s_rhead = 0; s_chead = 0; s_dtail = 0; s_adone = 0; s_bdone = 0; s_cdone = 0; s_abort = 0; s_hung = 0; s_pstat = 0; s_cnt = 0; s_hdr = 0; s_nsym = 0; s_endbit = 0; s_pwait = 0; s_cwait = 0; for (int k = 0; k < 14; k++) s_prof[k] = 0; }
     __syncthreads();
     BitRd r;
     u32 nSel = 0;
@@ -373,7 +378,11 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                 // K7_GRING groups of bits behind the block's end are walked for nothing)
                 if (gh - lds_observe(&s_gtail) >= K7_GRING) {                  // a free record for this group's row masks
                     const u64 w0 = clock64();
-                    while (gh - lds_observe(&s_gtail) >= K7_GRING && !lds_observe(&s_stop)) __builtin_amdgcn_s_sleep(1);
+                    u32 spins = 0;
+                    while (gh - lds_observe(&s_gtail) >= K7_GRING && !lds_observe(&s_stop)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > K7_SPIN_CAP) { lds_publish(&s_hung, 1u); lds_publish(&s_abort, 1u); lds_publish(&s_stop, 1u); }
+                    }
                     pwait += clock64() - w0;
                     if (lds_observe(&s_stop)) break;
                 }
@@ -504,7 +513,11 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
             while (!eob && !st) {
                 if (lds_observe(&s_ghead) == gt) {
                     const u64 w0 = clock64();
-                    while (lds_observe(&s_ghead) == gt && !lds_observe(&s_adone)) __builtin_amdgcn_s_sleep(1);
+                    u32 spins = 0;
+                    while (lds_observe(&s_ghead) == gt && !lds_observe(&s_adone)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > K7_SPIN_CAP) { lds_publish(&s_hung, 1u); break; }      // falls into the data error below
+                    }
                     cwait += clock64() - w0;
                     if (lds_observe(&s_ghead) == gt) { st = DEC_DATA_ERROR; break; }   // wave A has gone (it always leaves a last record: not reached)
                 }
@@ -619,7 +632,11 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                     const u32 slotr = rows & (K7_RROWS - 1u);
                     if (rows - lds_observe(&s_dtail) >= K7_RROWS) {
                         const u64 w0 = clock64();
-                        while (rows - lds_observe(&s_dtail) >= K7_RROWS && !lds_observe(&s_abort)) __builtin_amdgcn_s_sleep(1);
+                        u32 spins = 0;
+                        while (rows - lds_observe(&s_dtail) >= K7_RROWS && !lds_observe(&s_abort)) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > K7_SPIN_CAP) { lds_publish(&s_hung, 1u); lds_publish(&s_abort, 1u); }
+                        }
                         cwait += clock64() - w0;
                     }
                     if (isL) s_cidx[slotr][rank] = (u16)idxv;
@@ -660,7 +677,7 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                 const u8* m8 = (const u8*)s_mtf;
                 l0 = m8[lane]; l1 = m8[64u + lane]; l2 = m8[128u + lane]; l3 = m8[192u + lane];
             }
-            u32 rr = 0;
+            u32 rr = 0, spins = 0;
 #ifdef K7_PROF
             u64 prof_[14] = {0}, tl_ = clock64();
 #endif
@@ -668,8 +685,13 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                 if (lds_observe(&s_rhead) == rr) {
                     if (lds_observe(&s_abort)) break;
                     if (lds_observe(&s_bdone)) { if (lds_observe(&s_rhead) == rr) break; }
-                    else { __builtin_amdgcn_s_sleep(1); continue; }
+                    else {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > K7_SPIN_CAP) { lds_publish(&s_hung, 1u); lds_publish(&s_abort, 1u); }
+                        continue;
+                    }
                 }
+                spins = 0;
                 K7_T(11);
                 const u32 slotr = rr & (K7_RROWS - 1u);
                 const u32 cidx = s_cidx[slotr][lane];
@@ -719,7 +741,7 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
         } else {
             // ---- wave D: rows -> bytes of the last column ----------------------------------------------------
             u8* out = D.tt + (size_t)slot * D.ttStride;
-            u32 rr = 0, opos = 0;
+            u32 rr = 0, opos = 0, spins = 0;
 #ifdef K7_PROF
             u64 prof_[14] = {0}, tl_ = clock64();
 #endif
@@ -727,8 +749,13 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
                 if (lds_observe(&s_chead) == rr) {
                     if (lds_observe(&s_abort)) break;
                     if (lds_observe(&s_cdone)) { if (lds_observe(&s_chead) == rr) break; }
-                    else { __builtin_amdgcn_s_sleep(1); continue; }
+                    else {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > K7_SPIN_CAP) { lds_publish(&s_hung, 1u); lds_publish(&s_abort, 1u); }
+                        continue;
+                    }
                 }
+                spins = 0;
                 K7_T(13);
                 const u32 slotr = rr & (K7_RROWS - 1u);
                 const u32 rinfo = s_rrun[slotr][lane];
@@ -769,6 +796,7 @@ __global__ __launch_bounds__(256) void k7_decode(DecBuf D, u32 first, u32 count)
     if (threadIdx.x == 0) {
         DecResult res;
         int st = s_pstat;
+        if (s_hung && st == 0) st = DEC_DATA_ERROR;                              // a bounded wait gave up (never seen; a guard against hanging the GPU queue)
         if (st == 0 && s_origPtr >= s_cnt) st = DEC_DATA_ERROR;               // :372
         res.endbit = s_endbit;
         res.status = st;

@@ -92,7 +92,7 @@ int k0_prepass(K0Buf K, u32 cap, hipStream_t stream);
 int k6_unbwt_linear(const u8* dT, u8* dU, u32 n, u32 pidx, void* ws, hipStream_t stream);
 int k2_run(Pipe P, u32 max_n, hipStream_t stream);
 // BWTC levels 6..9: FenwickModel of every block on the GPU -> (sy_f | lt_f << 16, tot_f) per encodeFreq call, [nb][stride] each
-int k10_model_run(Pipe P, u32* sylt, u32* tot, u32* ntri, hipStream_t stream);
+int k10_model_run(Pipe P, u32* sylt, u32* tot, u32* ntri, u32 ostride, u32 ocap, hipStream_t stream);
 int k34_run(Pipe P, hipStream_t stream);
 int k3_alloc_lengths_run(long long* d_arr, const u32* d_off, u32 count, int maxlen, hipStream_t stream);
 int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after = nullptr, hipEvent_t done = nullptr);

@@ -262,6 +262,40 @@ def test_bwtc_streams_vs_reference_digest(emu_ctx, golden):
     assert n >= 9                                         # incl. levels 1-5 (DefSumModel, lib/BWTC.js:107)
 
 
+def test_bwtc_fuzz_vs_reference_and_k10_overflow_fallback(emu_ctx):
+    """A slice of the reference-made BWTC fuzz vectors (tests/golden/golden_bwtc.json; all 308 run on the GPU) through the CPU
+    debug build, and the same inputs with K10's rows shrunk to nothing (CJS_K10_CAP: every block overflows and is modelled on
+    the host instead): the bytes must not change."""
+    import json
+    import bwtc_cases
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_bwtc.json")))["vectors"]
+    L, h = emu_ctx
+
+    def run(d, lv):
+        cap = int(L.cjs_bwtc_compress_bound(d.size))
+        out = np.zeros(cap, np.uint8)
+        m = L.cjs_bwtc_compress(h, d.ctypes.data, d.size, lv, out.ctypes.data, cap, d.size)
+        assert m > 0
+        return out[:m].tobytes()
+
+    n = 0
+    for i in range(0, bwtc_cases.N_SMALL, 3):
+        d, lv = bwtc_cases.case(i)
+        if d.size > 6000:
+            continue
+        v = g["fuzz%d" % i]
+        o = run(d, lv)
+        assert len(o) == v["out_len"] and hashlib.sha256(o).hexdigest() == v["out_sha256"], (i, lv, d.size)
+        if lv >= 6 and n % 4 == 0:
+            os.environ["CJS_K10_CAP"] = "64"
+            try:
+                assert run(d, lv) == o, (i, lv)
+            finally:
+                del os.environ["CJS_K10_CAP"]
+        n += 1
+    assert n >= 60
+
+
 def test_decoder_vs_reference_vectors(emu_ctx):
     """GPU decoder (K7 entropy decode, K8 inverse BWT by splitter ranking, K9 un-RLE1 + CRC) through the
     C ABI on the CPU debug build: every small stream of the decode catalogue - valid, truncated,

@@ -367,6 +367,59 @@ def test_bwtc_round_trip_fuzz(ctx):
         assert ctx.bwtc_decompress(np.frombuffer(z, dtype=np.uint8)) == d.tobytes(), (case, level, n, k)
 
 
+def test_bwtc_differential_fuzz_vs_reference(ctx):
+    """308 reference-made BWTC streams (tests/golden/golden_bwtc.json, make_golden_bwtc.py): 300 small fuzz inputs over all levels
+    (escape-heavy and rescale-heavy alphabets for FenwickModel, DefSumModel for 1-5), five multi-block inputs (two of them random
+    bytes at levels 6 and 9: K10 emits ~1.3 % more triples than symbols there - the round-2 rows overflowed into the next block),
+    and SURVEY.md 8(c)'s BWTC -9 digests of sample2/4/5."""
+    import json
+    import bwtc_cases
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_bwtc.json")))["vectors"]
+    n = 0
+    for i in range(bwtc_cases.N_SMALL):
+        d, lv = bwtc_cases.case(i)
+        v = g["fuzz%d" % i]
+        assert v["level"] == lv and v["in_len"] == d.size and _sha(d.tobytes()) == v["in_sha256"], i
+        o = ctx.bwtc_compress(d, lv)
+        assert len(o) == v["out_len"] and _sha(o) == v["out_sha256"], ("fuzz", i, lv, d.size)
+        n += 1
+    for cid, d, lv in bwtc_cases.big_cases():
+        v = g[cid]
+        o = ctx.bwtc_compress(d, lv)
+        assert len(o) == v["out_len"] and _sha(o) == v["out_sha256"], cid
+        assert ctx.bwtc_decompress(np.frombuffer(o, dtype=np.uint8)) == d.tobytes(), cid
+        n += 1
+    for cid in ("sample2", "sample4", "sample5"):
+        d = cases.case_input(cid)
+        assert d is not None, "reference fixtures not staged"
+        v = g[cid + ":bwtc:9"]
+        o = ctx.bwtc_compress(d, 9)
+        assert len(o) == v["out_len"] and _sha(o) == v["out_sha256"], cid
+        n += 1
+    assert n == 308
+
+
+def test_bwtc_model_on_gpu_equals_model_on_host(ctx):
+    """K10 (FenwickModel on the GPU) against the host model of bwtc_host.hip on incompressible multi-block input at every
+    level 6..9, and with K10's rows shrunk (CJS_K10_CAP) so that its overflow fall-back to the host model runs."""
+    rng = np.random.RandomState(5)
+    for lv in (6, 7, 8, 9):
+        d = rng.randint(0, 256, size=2 * lv * 100000 + 12345).astype(np.uint8)
+        a = ctx.bwtc_compress(d, lv)
+        os.environ["CJS_BWTC_GPU_MODEL"] = "0"
+        try:
+            b = ctx.bwtc_compress(d, lv)
+        finally:
+            del os.environ["CJS_BWTC_GPU_MODEL"]
+        os.environ["CJS_K10_CAP"] = "300000"
+        try:
+            c = ctx.bwtc_compress(d, lv)
+        finally:
+            del os.environ["CJS_K10_CAP"]
+        assert a == b == c, lv
+        assert ctx.bwtc_decompress(np.frombuffer(a, dtype=np.uint8)) == d.tobytes(), lv
+
+
 def test_two_streams_with_host_threads_same_bytes():
     """CJS_STREAMS=2 (one host thread per stream, balanced sub-batches) must give the single-stream bytes."""
     import subprocess

@@ -77,3 +77,30 @@ def test_bench_documents_tile_the_job_stream():
             for margin in (0, 999, n, n + 5, 2 * n + 7):
                 lo = max(0, r * n - margin)
                 assert (workloads.window(name, n, r, margin) == whole[lo:(r + 1) * n]).all(), (name, r, margin)
+
+
+def test_range_coder_division_by_reciprocal_is_exact():
+    """bwtc_host.hip replaces RangeCoder.encodeFreq's `range / tot` (lib/RangeCoder.js:81) by a multiplication with
+    ceil(2^48 / tot): exact for tot <= 0xFFFF, range < 2^32.  Every tot against the ranges where a wrong floor would show:
+    multiples of tot and their neighbours around every power of two, the ends of the range, and random ranges."""
+    import numpy as np
+    import stagelib
+    L = C.CDLL(stagelib.build_emu())
+    L.cjs_dbg_rc_div.restype = C.c_uint32
+    L.cjs_dbg_rc_div.argtypes = [C.c_uint32, C.c_uint32]
+    rng = np.random.RandomState(3)
+    tots = list(range(1, 300)) + [int(x) for x in rng.randint(300, 65536, size=1500)] + [65535, 65534, 0xFF00, 0xFEFF, 32768, 32767, 32769]
+    for tot in tots:
+        cand = {0, 1, tot - 1, tot, tot + 1, 0xFFFFFFFF, 0xFFFFFFFE, 0x80000000, 0x7FFFFFFF, 0x00800000, 0x007FFFFF}
+        for k in range(8, 33):
+            q = (1 << k) // tot
+            for m in (q - 1, q, q + 1):
+                for d in (-1, 0, 1):
+                    cand.add(m * tot + d)
+        top = (0xFFFFFFFF // tot) * tot
+        cand.update((top - 1, top, top + 1))
+        cand.update(int(x) for x in rng.randint(0, 1 << 32, size=8, dtype=np.uint64))
+        for r in cand:
+            if 0 <= r <= 0xFFFFFFFF:
+                assert L.cjs_dbg_rc_div(r, tot) == r // tot, (r, tot)
+    assert L.cjs_dbg_rc_div(0xFFFFFFFF, 70000) == 0xFFFFFFFF // 70000      # beyond the table: plain division
