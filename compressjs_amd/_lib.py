@@ -13,7 +13,7 @@ _lib = None
 
 # every symbol include/compressjs_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_lcg_ascii_device", "cjs_bz2_compress_bound", "cjs_bz2_compress",
-           "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_plan_block_start", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
+           "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_plan_block_start", "cjs_bz2_plan_scan", "cjs_bz2_plan_cost", "cjs_bz2_plan_phase", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
            "cjs_bwtc_compress_bound",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
            "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
@@ -69,6 +69,12 @@ def load(path: str | None = None):
     L.cjs_bz2_plan.argtypes = [vp, vp, C.c_uint64, C.c_int]
     L.cjs_bz2_plan_block_start.restype = C.c_int64
     L.cjs_bz2_plan_block_start.argtypes = [vp, C.c_uint32]
+    L.cjs_bz2_plan_scan.restype = C.c_int64
+    L.cjs_bz2_plan_scan.argtypes = [vp, vp, C.c_uint64, C.c_int]
+    L.cjs_bz2_plan_cost.restype = C.c_int64
+    L.cjs_bz2_plan_cost.argtypes = [vp, C.c_uint64]
+    L.cjs_bz2_plan_phase.restype = C.c_int64
+    L.cjs_bz2_plan_phase.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int]
     L.cjs_bz2_encode_blocks.restype = C.c_int64
     L.cjs_bz2_encode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint64,
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

@@ -146,6 +146,21 @@ class Context:
         return _lib.check(self.L.cjs_lcg_ascii_device(self.h, d_out.data_ptr(), d_out.numel(), int(seed) & 0xFFFFFFFF, int(first)),
                           "cjs_lcg_ascii_device")
 
+    # parallel plan of a slice (compressjs_amd/dist.py: sharded_compress_parallel; include/compressjs_amd.h)
+    def plan_scan(self, d_in, level: int = 9) -> int:
+        """K0's scans over d_in (slice + following margin); returns the input's own RLE1 cost total."""
+        return _lib.check(self.L.cjs_bz2_plan_scan(self.h, d_in.data_ptr(), d_in.numel(), int(level)), "cjs_bz2_plan_scan")
+
+    def plan_cost(self, pos: int) -> int:
+        return _lib.check(self.L.cjs_bz2_plan_cost(self.h, int(pos)), "cjs_bz2_plan_cost")
+
+    def plan_phase(self, own_len: int, phase: int, last: bool) -> int:
+        """Blocks that start in [0, own_len): their number, or -1 when the slice cannot be planned on its own (CJS_E_SPEC)."""
+        n = self.L.cjs_bz2_plan_phase(self.h, int(own_len), int(phase), 1 if last else 0)
+        if n == -25:
+            return -1
+        return _lib.check(n, "cjs_bz2_plan_phase")
+
     def plan_block_start(self, k: int) -> int:
         """First input byte (relative to the planned input) of block k of the current plan."""
         return _lib.check(self.L.cjs_bz2_plan_block_start(self.h, int(k)), "cjs_bz2_plan_block_start")

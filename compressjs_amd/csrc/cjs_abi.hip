@@ -336,6 +336,8 @@ struct cjs_ctx {
     K0Buf plan;
     int plan_level;
     u32 plan_blocks;
+    int scan_level;            // cjs_bz2_plan_scan ran for this level (0: no scan)
+    uint64_t scan_total;
     // decoder state (allocated by the first decompress call)
     DecState* dec;
     float dec_ms;
@@ -900,6 +902,76 @@ extern "C" int64_t cjs_bz2_plan(cjs_ctx* c, const void* d_in, uint64_t in_len, i
     TRYR(hipStreamSynchronize(c->stream));
     c->plan_blocks = nblocks;
     c->plan_level = level;
+    return (int64_t)nblocks;
+#undef TRYR
+}
+
+// ---- parallel plan of a slice (multi-GPU): see k0_rle1.hip "the blocks of a SLICE of a longer stream" and compressjs_amd/dist.py ----
+// cjs_bz2_plan_scan: K0's tile scans over d_in (the rank's slice followed by the margin it holds of what comes after); returns
+// the input's own RLE1 cost total.  cjs_bz2_plan_cost: that cost prefix at byte `pos`.  cjs_bz2_plan_phase: the blocks that
+// START in [0, own_len), given that boundaries lie where the prefix reaches phase + m * cap; returns their number (they are
+// then blocks 0 .. n-1 for cjs_bz2_encode_blocks), or CJS_E_SPEC when the slice cannot be planned on its own (a boundary
+// inside a long run, a block longer than the margin): the caller falls back to the chained / replicated plan.
+extern "C" int64_t cjs_bz2_plan_scan(cjs_ctx* c, const void* d_in, uint64_t in_len, int level) {
+    if (!c || (!d_in && in_len)) return CJS_E_ARG;
+    if (level < 1 || level > 9) return CJS_E_LEVEL;
+    hipError_t e;
+#define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
+    TRYR(hipSetDevice(c->device));
+    const u32 cap = (u32)level * 100000u - 19u;
+    c->plan_level = 0;
+    c->plan_blocks = 0;
+    c->scan_level = 0;
+    int rc = grow(&c->planws, &c->planws_bytes, k0_bytes(in_len, cap));
+    if (rc) return rc;
+    k0_carve(c->plan, (const u8*)d_in, in_len, cap, c->planws);
+    uint64_t total = 0;
+    if (in_len) {
+        rc = k0_scans(c->plan, c->stream);
+        if (rc) return rc;
+        TRYR(hipMemcpyAsync(&total, c->plan.tileC + c->plan.ntiles, 8, hipMemcpyDeviceToHost, c->stream));
+        TRYR(hipStreamSynchronize(c->stream));
+    }
+    c->scan_level = level;
+    c->scan_total = total;
+    return (int64_t)total;
+#undef TRYR
+}
+
+extern "C" int64_t cjs_bz2_plan_cost(cjs_ctx* c, uint64_t pos) {
+    if (!c || !c->scan_level) return CJS_E_ARG;
+    if (pos >= c->plan.in_len) return (int64_t)c->scan_total;
+    if (pos == 0) return 0;
+    hipError_t e;
+#define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
+    TRYR(hipSetDevice(c->device));
+    const int rc = k0_eval(c->plan, pos, c->stream);
+    if (rc) return rc;
+    uint64_t v = 0;
+    TRYR(hipMemcpyAsync(&v, c->plan.specC, 8, hipMemcpyDeviceToHost, c->stream));
+    TRYR(hipStreamSynchronize(c->stream));
+    return (int64_t)v;
+#undef TRYR
+}
+
+extern "C" int64_t cjs_bz2_plan_phase(cjs_ctx* c, uint64_t own_len, uint64_t phase, int last) {
+    if (!c || !c->scan_level || own_len > c->plan.in_len) return CJS_E_ARG;
+    hipError_t e;
+#define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
+    TRYR(hipSetDevice(c->device));
+    const u32 cap = (u32)c->scan_level * 100000u - 19u;
+    if (phase >= cap) return CJS_E_ARG;
+    c->plan_level = 0;
+    c->plan_blocks = 0;
+    if (c->plan.in_len == 0) { c->plan_level = c->scan_level; return 0; }
+    const int rc = k0_phase_plan(c->plan, cap, phase, own_len, last ? 1u : 0u, c->scan_total, c->stream);
+    if (rc) return rc;
+    u32 nblocks = 0;
+    TRYR(hipMemcpyAsync(&nblocks, c->plan.nBlocks, 4, hipMemcpyDeviceToHost, c->stream));
+    TRYR(hipStreamSynchronize(c->stream));
+    if (nblocks == K0_PHASE_FAIL) return CJS_E_SPEC;
+    c->plan_blocks = nblocks;
+    c->plan_level = c->scan_level;
     return (int64_t)nblocks;
 #undef TRYR
 }

@@ -15,6 +15,7 @@ typedef unsigned long long u64;
 #define CJS_E_ARG (-22)
 #define CJS_E_NOGPU (-23)      // no HIP device: the product has no CPU path
 #define CJS_E_UNSUPPORTED (-24)  // input outside what this build handles (e.g. a stream with more magic patterns than bytes / 4)
+#define CJS_E_SPEC (-25)       // cjs_bz2_plan_phase: the slice cannot be planned on its own (the caller falls back)
 #define CJS_E_HIP (-100)       // -100 - hipError_t
 
 #define CJS_WAVE 64

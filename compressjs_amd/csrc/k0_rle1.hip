@@ -582,12 +582,8 @@ void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws) {
     K.specBad = (u64*)p;
 }
 
-// whole-input pre-pass: tile scans + block chain.  After it *K.nBlocks and blk* are valid.
-int k0_prepass(K0Buf K, u32 cap, hipStream_t stream) {
-    if (K.in_len == 0) {
-        HIP_CHECK_RET(hipMemsetAsync(K.nBlocks, 0, 4, stream));
-        return CJS_OK;
-    }
+// tile scans only: run starts (tileA / tileB) and the cost prefix C at every tile (tileC; tileC[ntiles] = the total)
+int k0_scans(K0Buf K, hipStream_t stream) {
     const u32 nt = (u32)K.ntiles, nc = (u32)K.nchunks;
     hipLaunchKernelGGL(k0_tile_last, dim3(nt), dim3(256), 0, stream, K);
     HIP_CHECK_RET(hipMemcpyAsync(K.tileB, K.tileA, K.ntiles * 8, hipMemcpyDeviceToDevice, stream));
@@ -599,10 +595,109 @@ int k0_prepass(K0Buf K, u32 cap, hipStream_t stream) {
     hipLaunchKernelGGL(k0_scan_chunks<false>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, K.tileC + K.ntiles);
     hipLaunchKernelGGL(k0_scan_apply<false>, dim3(nc), dim3(256), 0, stream, K.tileC, (const u64*)K.chunk, K.ntiles);
     HIP_CHECK_RET(hipMemsetAsync(K.specBad, 0xFF, 8, stream));
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
+// whole-input pre-pass: tile scans + block chain.  After it *K.nBlocks and blk* are valid.
+int k0_prepass(K0Buf K, u32 cap, hipStream_t stream) {
+    if (K.in_len == 0) {
+        HIP_CHECK_RET(hipMemsetAsync(K.nBlocks, 0, 4, stream));
+        return CJS_OK;
+    }
+    const int rc = k0_scans(K, stream);
+    if (rc) return rc;
     const u32 nspec = (u32)(K.in_len * 5 / 4 / cap + 2 < K.maxBlocks ? K.in_len * 5 / 4 / cap + 2 : K.maxBlocks);
     hipLaunchKernelGGL(k0_chain_spec, dim3(nspec), dim3(256), 0, stream, K, cap);
     hipLaunchKernelGGL(k0_chain_accept, dim3((nspec + 255) / 256), dim3(256), 0, stream, K, cap);
     hipLaunchKernelGGL(k0_chain, dim3(1), dim3(256), 0, stream, K, cap);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
+// ---- the blocks of a SLICE of a longer stream (multi-GPU: every rank plans its own slice at once) --------------
+// With G(i) the cost prefix of the WHOLE stream, block k of the stream starts at min{ i : G(i) >= k cap } wherever the
+// speculation of k0_chain_spec holds.  A rank that holds bytes [lo, lo + in_len) knows G(lo) from one all_gather of per-slice
+// totals and boundary runs (compressjs_amd/dist.py), and G(lo + i) = G(lo) + delta + C(i) with this input's own prefix C
+// beyond its first run: its boundaries are the positions where C reaches phase + m cap, phase = (-(G(lo) + delta)) mod cap.
+//   k0_phase_spec    boundary m = min{ i : C(i) >= phase + m cap }, one workgroup each; flags what k0_chain_spec flags
+//   k0_phase_accept  the blocks that START before own_len (the rest of the input is the margin that completes the last of
+//                    them); *nBlocks = their number, or K0_PHASE_FAIL when a boundary is flagged or the margin too short
+//                    (the caller falls back to the chained / replicated drivers).  `last`: the input ends where the stream
+//                    ends - the final block may be short (lib/Bzip2.js:922) or absent (:916).
+__global__ __launch_bounds__(256) void k0_phase_spec(K0Buf K, u32 cap, u64 phase) {
+    __shared__ u64 sh[256];
+    __shared__ u32 sh32[4];
+    const u64 total = K.tileC[K.ntiles];
+    const u64 m = blockIdx.x;
+    const u64 t = phase + m * (u64)cap;
+    if (t > total) { if (threadIdx.x == 0) { K.specEnd[m] = K.in_len + 1; K.specC[m] = 0; } return; }
+    u64 ce = 0, e = 0;
+    if (t) e = k0_searchC(K, t, 0, sh, sh32, &ce);
+    if (threadIdx.x == 0) {
+        bool bad = e > K.in_len || ce != t;
+        if (!bad && e < K.in_len && e > 0 && K.in[e - 1] == K.in[e]) {
+            const u8 c = K.in[e];
+            u32 len = 2;
+            for (u64 q = e + 1; q < K.in_len && len < 4 && K.in[q] == c; q++) len++;
+            for (u64 q = e - 1; q > 0 && len < 4 && K.in[q - 1] == c; q--) len++;
+            bad = len >= 4;
+        }
+        K.specEnd[m] = e;
+        K.specC[m] = ce;
+        if (bad) atomicMin((unsigned long long*)K.specBad, (unsigned long long)m);
+    }
+}
+
+__global__ __launch_bounds__(256) void k0_phase_accept(K0Buf K, u32 cap, u64 phase, u64 own_len, u32 last, u32 nbound) {
+    __shared__ u32 nb, fail;
+    if (threadIdx.x == 0) { nb = 0; fail = 0; }
+    __syncthreads();
+    const u64 total = K.tileC[K.ntiles];
+    const u64 bad = *K.specBad;
+    for (u32 m = threadIdx.x; m < nbound; m += 256u) {
+        const u64 t = phase + (u64)m * cap;
+        if (t > total) continue;
+        const u64 s = K.specEnd[m];
+        if (s >= own_len) continue;                               // starts in the margin (or at the very end): the next rank's
+        if (m >= K.maxBlocks) { atomicOr(&fail, 1u); continue; }
+        u64 e, n = cap;
+        u64 used = m;                                             // highest boundary this block relies on
+        if (t + cap <= total && m + 1u < nbound) { e = K.specEnd[m + 1u]; used = m + 1u; }
+        else if (last) { e = K.in_len; n = total - t; }           // the stream ends inside this block
+        else { atomicOr(&fail, 1u); continue; }                   // the margin does not reach the end of the block
+        if (bad <= used) { atomicOr(&fail, 1u); continue; }
+        if (n == 0) continue;                                     // (last) nothing after the boundary: no block (lib/Bzip2.js:916)
+        K.blkStart[m] = s;
+        K.blkEnd[m] = e;
+        K.blkN[m] = (u32)n;
+        K.blkAdj[m] = t;                                          // = C(s)
+        K.blkRe[m] = s;
+        atomicMax(&nb, m + 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *K.nBlocks = fail ? K0_PHASE_FAIL : nb;
+}
+
+__global__ __launch_bounds__(256) void k0_eval_at(K0Buf K, u64 pos) {
+    __shared__ u64 sh[256];
+    __shared__ u32 sh32[4];
+    const u64 c = k0_evalC(K, pos, sh, sh32);
+    if (threadIdx.x == 0) K.specC[0] = c;
+}
+
+int k0_eval(K0Buf K, u64 pos, hipStream_t stream) {
+    hipLaunchKernelGGL(k0_eval_at, dim3(1), dim3(256), 0, stream, K, pos);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
+int k0_phase_plan(K0Buf K, u32 cap, u64 phase, u64 own_len, u32 last, u64 total, hipStream_t stream) {
+    u64 nb = total >= phase ? (total - phase) / cap + 2 : 1;
+    if (nb > (u64)K.maxBlocks + 1) nb = (u64)K.maxBlocks + 1;
+    HIP_CHECK_RET(hipMemsetAsync(K.specBad, 0xFF, 8, stream));
+    hipLaunchKernelGGL(k0_phase_spec, dim3((u32)nb), dim3(256), 0, stream, K, cap, phase);
+    hipLaunchKernelGGL(k0_phase_accept, dim3(1), dim3(256), 0, stream, K, cap, phase, own_len, last, (u32)nb);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

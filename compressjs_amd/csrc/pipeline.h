@@ -88,6 +88,11 @@ struct K0Buf {
 size_t k0_bytes(u64 in_len, u32 cap);
 void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws);
 int k0_prepass(K0Buf K, u32 cap, hipStream_t stream);
+// multi-GPU parallel plan (see k0_rle1.hip): scans only; C at a position (-> K.specC[0]); the blocks that start in [0, own_len)
+#define K0_PHASE_FAIL 0xFFFFFFFFu
+int k0_scans(K0Buf K, hipStream_t stream);
+int k0_eval(K0Buf K, u64 pos, hipStream_t stream);
+int k0_phase_plan(K0Buf K, u32 cap, u64 phase, u64 own_len, u32 last, u64 total, hipStream_t stream);
 
 int k6_unbwt_linear(const u8* dT, u8* dU, u32 n, u32 pidx, void* ws, hipStream_t stream);
 int k2_run(Pipe P, u32 max_n, hipStream_t stream);

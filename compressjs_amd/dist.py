@@ -228,3 +228,134 @@ def sharded_compress_sliced(ctx, d_win: torch.Tensor, win_lo: int, total: int, l
     if trace is not None:
         print("[dist] " + ", ".join("%s %.2f ms" % (n, (t - trace[i][1]) * 1e3) for i, (n, t) in enumerate(trace[1:])), flush=True)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# parallel plan (round 3): no rank waits for another rank's plan
+# ---------------------------------------------------------------------------------------------
+def _g(k: int) -> int:
+    """RLE1 output bytes of the first k bytes of a fresh run (k0_g in csrc/k0_rle1.hip)."""
+    q, r = divmod(k, 255)
+    return 5 * q + (r if r < 4 else 5)
+
+
+_EDGE = 4096          # bytes of each end of a slice that are looked at for its boundary runs; a longer run -> fall back
+
+
+def _edge_runs(d_own: torch.Tensor):
+    """(head byte, head run length, tail byte, tail run length, long) of a slice, from its first / last _EDGE bytes."""
+    n = d_own.numel()
+    if n == 0:
+        return 0, 0, 0, 0, False
+    head = d_own[:min(n, _EDGE)].cpu().numpy()
+    tail = d_own[max(0, n - _EDGE):].cpu().numpy()
+    hb, tb = int(head[0]), int(tail[-1])
+    ne = (head != hb).nonzero()[0]
+    lh = int(ne[0]) if ne.size else int(head.size)
+    ne = (tail != tb).nonzero()[0]
+    lt = int(tail.size - 1 - ne[-1]) if ne.size else int(tail.size)
+    long_run = (lh == head.size and n > head.size) or (lt == tail.size and n > tail.size)
+    return hb, lh, tb, lt, long_run
+
+
+def plan_bases(meta, level: int):
+    """From the gathered per-slice summaries [(own_len, cost, head byte, head run, tail byte, tail run, long)] to, per rank,
+    (phase, ok): the RLE1 cost prefix G of the whole stream at the slice's first byte, corrected for a run that straddles
+    the slice start, taken modulo the block capacity.  Pure integer arithmetic, identical on every rank."""
+    cap = level * 100000 - 19
+    out = []
+    G = 0                       # cost prefix of the stream at the current slice start
+    inb, ink = -1, 0            # the run that reaches the slice start from the left: byte, length so far
+    for n, cost, hb, lh, tb, lt, long_run in meta:
+        ok = not long_run
+        delta = 0
+        if n and inb == hb and ink > 0:
+            delta = _g(ink + lh) - _g(ink) - _g(lh)          # the head run costs what the tail of a longer run costs
+            if ink + lh >= 4:
+                # a run of four or more bytes straddles the slice start: this rank's own prefix is wrong inside it, so no
+                # block boundary may fall into its cost span
+                c0, c1 = G, G + _g(ink + lh) - _g(ink)
+                if c0 // cap != c1 // cap or c0 % cap == 0 or c1 % cap == 0:
+                    ok = False
+        base = G + delta                                     # G(lo + i) = base + C_own(i) beyond the head run
+        out.append(((-base) % cap, ok))
+        true_cost = cost + delta
+        if n:
+            if lh == n and inb == hb and ink > 0:
+                ink += n                                     # the whole slice continues the incoming run
+            elif lh == n:
+                inb, ink = hb, n
+            else:
+                inb, ink = tb, lt
+        G += true_cost
+    return out
+
+
+def sharded_compress_parallel(ctx, d_win: torch.Tensor, own_len: int, lo: int, total: int, level: int, group=None,
+                              seg: torch.Tensor = None, fallback=None):
+    """The stream of sharded_compress with every rank holding its slice and a margin of what FOLLOWS it - d_win = stream
+    bytes [lo, min(total, lo + own_len + margin_bytes(level))) - and no chain between the ranks' plans (the reference's
+    `do { readBlock } while`, lib/Bzip2.js:913-922, is serial; the round-2 driver kept it serial across ranks):
+
+      1. every rank scans its own window (K0's cost prefix) and summarises its slice: cost total, first and last run;
+      2. ONE all_gather (7 integers per rank) gives every rank the stream's cost prefix at its slice start, hence the phase
+         of the block boundaries inside its slice: it plans the blocks that START in its slice (cjs_bz2_plan_phase) and
+         encodes them, the margin completing the last one;
+      3. a second all_gather (bits, CRC fold, block count: the one the other drivers have too) carries the flag "could not
+         plan on my own" (a boundary inside a run of four or more equal bytes, a block longer than the margin, a boundary
+         run longer than 4 KB): if any rank raises it, all fall back to `fallback()` (a callable that runs one of the other
+         drivers), else segments are shifted, sent and assembled as before.
+    Returns the stream on rank 0, None elsewhere."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    dev = d_win.device
+    trace = [] if os.environ.get("CJS_DIST_TRACE") else None
+
+    def mark(name):
+        if trace is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            trace.append((name, time.perf_counter()))
+
+    mark("start")
+    cdev = dev if (world == 1 or dist.get_backend(group) != "gloo") else torch.device("cpu")
+    ctx.plan_scan(d_win, level)
+    cost = ctx.plan_cost(own_len)
+    hb, lh, tb, lt, long_run = _edge_runs(d_win[:own_len])
+    mark("scan")
+    mine = torch.tensor([own_len, cost, hb, lh, tb, lt, 1 if long_run else 0], dtype=torch.int64, device=cdev)
+    if world > 1:
+        allv = [torch.zeros(7, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(allv, mine, group=group)
+        meta = [tuple(int(x) for x in v.cpu().tolist()) for v in allv]
+    else:
+        meta = [tuple(int(x) for x in mine.cpu().tolist())]
+    mark("all_gather summaries")
+    phase, ok = plan_bases([(m[0], m[1], m[2], m[3], m[4], m[5], bool(m[6])) for m in meta], level)[rank]
+    nb = -1
+    if ok:
+        nb = ctx.plan_phase(own_len, phase, lo + own_len >= total)
+    mark("plan")
+    bad = nb < 0
+    bits, fold, cnt = 0, 0, 0
+    if not bad and nb:
+        if seg is None:
+            seg = torch.zeros((own_len + margin_bytes(level)) * 3 // 2 + (1 << 20), dtype=torch.uint8, device=dev)
+        bits, fold, cnt = ctx.encode_blocks(0, nb, seg)
+    elif seg is None:
+        seg = torch.zeros(1 << 12, dtype=torch.uint8, device=dev)
+    mark("encode")
+    # the flag travels with the (bits, fold, count) all_gather of the assembly: bits = -1
+    flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=cdev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        if fallback is None:
+            raise RuntimeError("this input cannot be planned slice by slice (a block boundary inside a long run, or a block longer "
+                               "than the margin); use sharded_compress_sliced / sharded_compress")
+        return fallback()
+    mark("flag")
+    out = _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark)
+    if trace is not None:
+        print("[dist r%d] " % rank + ", ".join("%s %.2f ms" % (n, (t - trace[i][1]) * 1e3) for i, (n, t) in enumerate(trace[1:])), flush=True)
+    return out

@@ -52,6 +52,22 @@ int64_t cjs_bz2_plan(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level)
  * driver that holds only a slice of the stream plans from a block start, drops the last, incomplete block and tells the
  * next slice where that block started (compressjs_amd/dist.py, cjs_bz2_compress_multi). */
 int64_t cjs_bz2_plan_block_start(cjs_ctx* ctx, uint32_t k);
+/* Parallel plan of one slice of a longer stream (round 3; replaces the rank-to-rank chain of lib/Bzip2.js:913-922's serial
+ * `do { readBlock } while` across GPUs).  With G(i) the RLE1 output length of stream bytes [0, i) under uncut runs, block k of
+ * the stream starts where G reaches k * cap (cap = level * 100000 - 19, lib/Bzip2.js:636-667) unless that boundary falls
+ * into a run of four or more equal bytes.  A rank that holds stream bytes [lo, lo + in_len) - its own slice [lo, lo + own_len)
+ * and a margin of what follows - learns G(lo) from one all_gather of per-slice totals and boundary runs (compressjs_amd/dist.py):
+ *   cjs_bz2_plan_scan   K0's scans over d_in; returns the input's own cost total;
+ *   cjs_bz2_plan_cost   the input's own cost prefix at byte pos (pos = own_len: the slice's total);
+ *   cjs_bz2_plan_phase  plans the blocks that START in [0, own_len), boundaries where the own prefix reaches phase + m * cap
+ *                       (phase = (-(G(lo) + head-run correction)) mod cap; last != 0: d_in ends where the stream ends, the final
+ *                       block may be short or absent, lib/Bzip2.js:916,922).  Returns their number - they are blocks 0 .. n-1
+ *                       for cjs_bz2_encode_blocks - or CJS_E_SPEC when the slice cannot be planned on its own (a boundary in a
+ *                       long run, a block longer than the margin): the caller falls back to cjs_bz2_plan on more of the stream. */
+#define CJS_E_SPEC (-25)
+int64_t cjs_bz2_plan_scan(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level);
+int64_t cjs_bz2_plan_cost(cjs_ctx* ctx, uint64_t pos);
+int64_t cjs_bz2_plan_phase(cjs_ctx* ctx, uint64_t own_len, uint64_t phase, int last);
 int64_t cjs_bz2_encode_blocks(cjs_ctx* ctx, uint32_t first, uint32_t count, void* d_seg,
                               uint64_t seg_cap, uint32_t* crc_fold, uint32_t* n_done);
 /* Device time (HIP events on the context's stream) and block count of the last compress call. */

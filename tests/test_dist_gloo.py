@@ -1,4 +1,4 @@
-"""world_size-2 test of the multi-GPU sharding logic (compressjs_amd/dist.py) on CPU: gloo
+"""world_size-4 test of the multi-GPU sharding logic (compressjs_amd/dist.py) on CPU: gloo
 backend, kernels through the CPU logic-debug build.  The assembled stream must equal the
 single-process stream bit for bit."""
 import os
@@ -36,8 +36,22 @@ def _worker(rank, world, port, q):
         wlo = max(0, lo - margin_bytes(1))
         o2 = sharded_compress_sliced(ctx, torch.from_numpy(dd[wlo:hi].copy()), wlo, dd.size, 1, d_all=lambda: torch.from_numpy(dd.copy()))
         outs.append(o2.numpy().tobytes() if rank == 0 else None)
+    # the parallel plan (round 3): slice + FOLLOWING margin, one all_gather of summaries, no chain; inputs: text (clean
+    # boundaries), a run that straddles a slice boundary, a boundary inside a long run (falls back to the sliced driver)
+    from compressjs_amd.dist import sharded_compress_parallel
+    par = []
+    straddle = np.concatenate([synth.text_like(270000 // world - 2, 5), np.full(9, 65, np.uint8), synth.text_like(270000, 6)])[:270000]
+    for dd in (data, straddle, np.concatenate([synth.lcg_ascii(150000, 4), np.zeros(900000, np.uint8)])):
+        lo, hi = slice_bounds(dd.size, rank, world)
+        whi = min(dd.size, hi + margin_bytes(1))
+
+        def fb(dd=dd, lo=lo, hi=hi):
+            wlo = max(0, lo - margin_bytes(1))
+            return sharded_compress_sliced(ctx, torch.from_numpy(dd[wlo:hi].copy()), wlo, dd.size, 1, d_all=lambda: torch.from_numpy(dd.copy()))
+        o3 = sharded_compress_parallel(ctx, torch.from_numpy(dd[lo:whi].copy()), hi - lo, lo, dd.size, 1, fallback=fb)
+        par.append(o3.numpy().tobytes() if rank == 0 else None)
     if rank == 0:
-        q.put((out.numpy().tobytes(), outs))
+        q.put((out.numpy().tobytes(), outs, par))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,18 +65,24 @@ def test_sharded_stream_equals_reference_stream():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
+    world = 4
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, sliced = q.get(timeout=900)
+    got, sliced, par = q.get(timeout=1800)
     for p in procs:
-        p.join(timeout=900)
+        p.join(timeout=1800)
         assert p.exitcode == 0
     data = np.concatenate([synth.text_like(230000, 21), synth.runs_mixed(40000, 2)])
     assert got == oracle.bz2_compress(data, 1)
     assert sliced[0] == oracle.bz2_compress(data, 1)                                   # chained planning over three slices
     runs = np.concatenate([synth.lcg_ascii(150000, 4), np.zeros(900000, np.uint8)])
     assert sliced[1] == oracle.bz2_compress(runs, 1)                                   # a block swallows a slice: replicated fallback
+    # parallel plan over four slices: text, a 9-byte run across a slice boundary, and the run-heavy input (falls back)
+    assert par[0] == oracle.bz2_compress(data, 1)
+    straddle = np.concatenate([synth.text_like(270000 // world - 2, 5), np.full(9, 65, np.uint8), synth.text_like(270000, 6)])[:270000]
+    assert par[1] == oracle.bz2_compress(straddle, 1)
+    assert par[2] == oracle.bz2_compress(runs, 1)
 
 
 def test_shift_and_trailer_helpers():
@@ -94,6 +114,64 @@ def test_shift_kernel_equals_spec():
                 out = torch.full((n + 1,), 0xAA, dtype=torch.uint8)
                 ctx.shift_bits(seg, n, s, out)
                 assert torch.equal(out, shift_bits(seg, n, s)), (n, s)
+        ctx.close()
+    finally:
+        _lib._lib = saved
+
+
+def test_parallel_plan_equals_serial_plan():
+    """The parallel plan of compressjs_amd/dist.py (plan_bases + cjs_bz2_plan_phase) against the serial chain (cjs_bz2_plan) on
+    one process: random inputs with runs placed on and around the cuts, random cuts.  Wherever every slice accepts, the union of
+    the slices' block starts must be exactly the serial plan's; a slice may only refuse (fall back), never disagree."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stagelib
+    from compressjs_amd import _lib, synth
+    from compressjs_amd.bzip2 import Context
+    from compressjs_amd.dist import _edge_runs, margin_bytes, plan_bases
+    stagelib.build_emu()
+    saved = _lib._lib
+    _lib._lib = _lib.load(stagelib.EMU_SO)
+    try:
+        ctx = Context(0, 2)
+        rng = np.random.RandomState(11)
+        level, accepted, refused = 1, 0, 0
+        for case in range(14):
+            n = int(rng.randint(250_000, 420_000))
+            d = synth.text_like(n, 100 + case) if case % 3 else synth.lcg_ascii(n, case + 1)
+            d = d.copy()
+            world = int(rng.choice([2, 3, 4, 5]))
+            cuts = sorted(int(x) for x in rng.choice(np.arange(20_000, n - 20_000), size=world - 1, replace=False))
+            for c in cuts:                                             # runs of 1..9 equal bytes ending before / on / after the cut
+                L, sh = int(rng.randint(1, 10)), int(rng.randint(-9, 10))
+                a = max(0, c + sh - L // 2)
+                d[a:a + L] = 66
+            if case % 5 == 4:
+                d[cuts[0] - 700:cuts[0] + 900] = 0                     # a long run across a cut: must refuse
+            t = torch.from_numpy(d)
+            nser = ctx.plan(t, level)
+            serial = [ctx.plan_block_start(k) for k in range(nser)]
+            lo_hi = list(zip([0] + cuts, cuts + [n]))
+            meta = []
+            for lo, hi in lo_hi:
+                w = t[lo:min(n, hi + margin_bytes(level))]
+                ctx.plan_scan(w, level)
+                meta.append((hi - lo, ctx.plan_cost(hi - lo)) + _edge_runs(w[:hi - lo]))
+            bases = plan_bases(meta, level)
+            got, ok_all = [], True
+            for (lo, hi), (phase, ok) in zip(lo_hi, bases):
+                w = t[lo:min(n, hi + margin_bytes(level))]
+                ctx.plan_scan(w, level)
+                nb = ctx.plan_phase(hi - lo, phase, hi == n) if ok else -1
+                if nb < 0:
+                    ok_all = False
+                    break
+                got += [lo + ctx.plan_block_start(k) for k in range(nb)]
+            if ok_all:
+                assert got == serial, (case, world, cuts)
+                accepted += 1
+            else:
+                refused += 1
+        assert accepted >= 8 and refused >= 1, (accepted, refused)
         ctx.close()
     finally:
         _lib._lib = saved

@@ -153,3 +153,16 @@ def window(name: str, n: int, r: int, margin: int) -> np.ndarray:
         need -= min(need, d.size)
         q -= 1
     return np.concatenate(parts) if len(parts) > 1 else parts[0]
+
+
+def window_after(name: str, n: int, r: int, margin: int, world: int) -> np.ndarray:
+    """Bytes [r*n, min(world*n, (r+1)*n + margin)) of world_stream: rank r's slice and the head of what follows it (the parallel plan
+    of compressjs_amd/dist.py: a rank owns the blocks that START in its slice, the margin completes the last of them)."""
+    parts = [document(name, n, r)]
+    need, q = (min(margin, (world - 1 - r) * n), r + 1)
+    while need > 0 and q < world:
+        d = document(name, n, q)
+        parts.append(d[:need] if need < d.size else d)
+        need -= min(need, d.size)
+        q += 1
+    return np.concatenate(parts) if len(parts) > 1 else parts[0]
