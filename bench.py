@@ -87,6 +87,22 @@ def bench_bwtc(args):
     back = None
     if not args.no_verify and args.size <= 30_000_000:
         back = bool(ctx.bwtc_decompress(np.frombuffer(out, dtype=np.uint8)) == host.tobytes())
+    # the dominant GPU kernel of this path is k10_model (the adaptive FenwickModel: one wave per block, a serial recurrence): its
+    # algorithmic bytes are 2 (symbol read) + 8 (triple written) per encodeFreq call - measured live with HIP events around the launch
+    import ctypes as C
+    tms = (C.c_float * 5)()
+    ctx.L.cjs_bwtc_last_times(ctx.h, tms)
+    k10_ms, landed_ms, coder_ms, total_ms, ncalls = [float(x) for x in tms]
+    roof = None
+    if k10_ms > 0:
+        ach = 10.0 * ncalls / (k10_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k10_model", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 6),
+                "avg_launch_ms": round(k10_ms, 2), "alg_bytes_per_launch": 10.0 * ncalls, "traffic": None,
+                "note": "not bandwidth-bound: one wave per block walks a serial recurrence, ~%d clocks per symbol (tests/microbench/lone_wave.hip: "
+                        "5-9 clocks per dependent instruction, ~50 per LDS round trip for a wave alone on its SIMD); the line's value is bound by the "
+                        "serial host range coder: %.1f ns per encodeFreq call over %.1f M calls = %.0f ms of the %.0f ms step, after %.0f ms of GPU stages"
+                        % (round(k10_ms * 1e-3 * 2.4e9 / max(ncalls / max(1, (args.size + args.level * 100000 - 1) // (args.level * 100000)), 1)),
+                           coder_ms * 1e6 / max(ncalls, 1), ncalls / 1e6, coder_ms, total_ms, landed_ms)}
     print(json.dumps({
         "metric": "BWTC -9 compress MB/s (BASELINE.json configs[4])", "value": round(args.size / dt / 1e6, 2), "unit": "MB/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True,
@@ -95,7 +111,7 @@ def bench_bwtc(args):
         "config": {"workload": "%s, %d bytes, BWTC -%d, %d-byte blocks, host buffers in and out" % (workloads.DESCRIPTIONS[wl], args.size, args.level, args.level * 100000),
                    "compressed_bytes": len(out), "sha256": sha, "bit_exact_vs_reference_digest": vs_ref, "roundtrip": back,
                    "gpu_stages": "BWT.bwtransform (K1 linear), MTF/RLE2 (K2), FenwickModel (K10); host: RangeCoder.encodeFreq, serial"},
-        "roofline": None,
+        "roofline": roof,
         "cpu_baseline": None if g is None else {"value": g["mb_per_s"], "unit": "MB/s", "cores": 1, "kind": "reference",
                                                 "sample": "BWTC.compressFile(buf, null, %d) of cscott/compressjs under node 12 on the same %d bytes, %.1f s, build container" % (args.level, g["in_len"], g["seconds"])}}))
 

@@ -13,7 +13,7 @@ _lib = None
 
 # every symbol include/compressjs_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_lcg_ascii_device", "cjs_bz2_compress_bound", "cjs_bz2_compress",
-           "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_plan_block_start", "cjs_bz2_plan_scan", "cjs_bz2_plan_cost", "cjs_bz2_plan_phase", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
+           "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_plan_block_start", "cjs_bwtc_last_times", "cjs_bz2_plan_scan", "cjs_bz2_plan_cost", "cjs_bz2_plan_phase", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
            "cjs_bwtc_compress_bound",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
            "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",

@@ -336,6 +336,8 @@ struct cjs_ctx {
     K0Buf plan;
     int plan_level;
     u32 plan_blocks;
+    float bwtc_times[5];       // last cjs_bwtc_compress: K10 launch ms (first stream), ms until all triples were on the host, coder busy ms, total ms, encodeFreq calls
+    hipEvent_t evK10[2];
     int scan_level;            // cjs_bz2_plan_scan ran for this level (0: no scan)
     uint64_t scan_total;
     // decoder state (allocated by the first decompress call)
@@ -405,6 +407,7 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
     if (c->evReady) (void)hipEventDestroy(c->evReady);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < 2; i++) if (c->evK10[i]) (void)hipEventDestroy(c->evK10[i]);
     k1_prof_destroy(c->prof);
     dec_free(c->dec);
     delete c->bwtc_out;
@@ -906,6 +909,14 @@ extern "C" int64_t cjs_bz2_plan(cjs_ctx* c, const void* d_in, uint64_t in_len, i
 #undef TRYR
 }
 
+// (bench.py) phases of the last cjs_bwtc_compress: out[0] = ms of the first K10 launch, [1] = ms until every triple was on the host,
+// [2] = ms the range coder was busy, [3] = ms of the whole call, [4] = encodeFreq calls (model symbols + escapes)
+extern "C" int cjs_bwtc_last_times(cjs_ctx* c, float* out5) {
+    if (!c || !out5) return CJS_E_ARG;
+    for (int i = 0; i < 5; i++) out5[i] = c->bwtc_times[i];
+    return CJS_OK;
+}
+
 // ---- parallel plan of a slice (multi-GPU): see k0_rle1.hip "the blocks of a SLICE of a longer stream" and compressjs_amd/dist.py ----
 // cjs_bz2_plan_scan: K0's tile scans over d_in (the rank's slice followed by the margin it holds of what comes after); returns
 // the input's own RLE1 cost total.  cjs_bz2_plan_cost: that cost prefix at byte `pos`.  cjs_bz2_plan_phase: the blocks that
@@ -1067,7 +1078,7 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
     const bool btrace = getenv("CJS_BWTC_TRACE") != nullptr;
     const auto tb0 = std::chrono::steady_clock::now();
     auto msnow = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count(); };
-    double coder_busy = 0, coder_first = 0;
+    double coder_busy = 0, coder_first = 0, ncalls_total = 0;
     std::thread coder_thread([&]() {
         for (;;) {
             GroupJob* job = nullptr;
@@ -1136,7 +1147,11 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
             TRYR(hipMemcpyAsync(P.nlen, nls, nb * 4, hipMemcpyHostToDevice, ss));
             rc = k1_run(P.k1, P.g, max_n, ss);
             if (!rc) rc = k2_run(P, max_n, ss);
-            if (!rc && tri) rc = k10_model_run(P, (u32*)P.k1.rlist[0], (u32*)P.k1.rlist[1], P.ngroups, k10_ostride, k10_cap, ss);
+            if (!rc && tri) {
+                if (si == 0 && first == 0) { if (!c->evK10[0]) { TRYR(hipEventCreate(&c->evK10[0])); TRYR(hipEventCreate(&c->evK10[1])); } TRYR(hipEventRecord(c->evK10[0], ss)); }
+                rc = k10_model_run(P, (u32*)P.k1.rlist[0], (u32*)P.k1.rlist[1], P.ngroups, k10_ostride, k10_cap, ss);
+                if (si == 0 && first == 0) TRYR(hipEventRecord(c->evK10[1], ss));
+            }
             if (rc) { stop_coder(); (void)bwtc_end(coder); return rc; }
         }
         // the per-block results, only now: a device-to-host copy into pageable memory blocks the HOST until the stream has
@@ -1176,6 +1191,7 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
                 memcpy(bj.used, hused.data() + (o + b) * 8, 32);
                 bj.off = total;
                 total += (tri ? bj.ntri : bj.nsym) + 1;
+                ncalls_total += tri ? bj.ntri : bj.nsym;
                 job->blocks.push_back(bj);
             }
         }
@@ -1215,6 +1231,12 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
     }
     const double t_issued = msnow();
     stop_coder();
+    {
+        float k10ms = 0.f;
+        if (tri && nblocks && c->evK10[0]) (void)hipEventElapsedTime(&k10ms, c->evK10[0], c->evK10[1]);
+        c->bwtc_times[0] = k10ms; c->bwtc_times[1] = (float)t_issued; c->bwtc_times[2] = (float)coder_busy; c->bwtc_times[3] = (float)msnow();
+        c->bwtc_times[4] = (float)ncalls_total;
+    }
     if (btrace) fprintf(stderr, "[bwtc] %llu blocks: GPU stages + copies issued and done at %.1f ms, coder started at %.1f ms, busy %.1f ms, all done at %.1f ms\n",
                         (unsigned long long)nblocks, t_issued, coder_first, coder_busy, msnow());
     TRYR(hipEventRecord(c->ev1, st));

@@ -13,6 +13,7 @@
 #define K1_STAT_PUREROT 124    // stats[124]: rotations in front-end buckets of ONE 8-byte key (> 64 members) or beyond LDS, counted by k1f_scan
 #define K1_DEEP_LANE 8u        // groups up to this size go to the lane kernels (k1_deep_pairs / k1_deep_small): one lane each
 #define K1R_MAXR 40            // refinement rounds at most
+#define K1F_LEVELS 14u          // task levels of the front end (two per 8 bytes of depth: partition, then sort)
 #define K1_STAT_RTRACE 128      // stats[128..135]: K1F_TRACE builds, stage clocks of k1r_round
 #define K1_STATS 144
 #define K1_DM_SUB 64u      // sub-lists per class of the medium rounds (one counter each: a single counter serialises millions of appends)
@@ -80,6 +81,9 @@ struct K1Buf {
     u64* rlist[2];    // [nb][stride]   refinement rounds (k1r_round): entries of the rotations that still tie, in/out
     u32* rcnt;        // [K1R_MAXR + 1][rstride]  entries per round and block
     u32 rstride;
+    uint4* btask;     // [K1F_LEVELS][btaskCap]  task levels of the front end (k1f_task): (block, position, length, depth | flag)
+    u32* bcnt;        // [K1F_LEVELS]            tasks per level
+    u32 btaskCap;
     u8* U;            // [nb][stride]   BWT output
     u32* pidx;        // [nb]           origPtr
 };

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     if (b == 0 && gid < 4u * K1_DM_SUB) B.dmCnt[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 32u * 2u * K1_SPREAD; i += gridDim.x * blockDim.x) B.spread[i] = 0;
     if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rstride; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
+    if (b == 0 && gid < K1F_LEVELS) B.bcnt[gid] = 0;
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
         u32 w;
@@ -1984,6 +1985,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += 2 * al256((size_t)g.nb * (g.stride / K1_MED_MAX + 1) * 8);   // listL cur/next
     tot += 2 * al256(e * 8);                                   // rlist in/out
     tot += al256((size_t)(K1R_MAXR + 1) * ((g.nb + 7u) & ~7u) * 4);   // rcnt
+    tot += al256((size_t)K1F_LEVELS * g.nb * (g.stride / 256) * sizeof(uint4)) + 256;   // btask, bcnt
     return tot;
 }
 
@@ -2024,7 +2026,10 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.rlist[0] = (u64*)p; p += al256(e * 8);
     B.rlist[1] = (u64*)p; p += al256(e * 8);
     B.rstride = (g.nb + 7u) & ~7u;
-    B.rcnt = (u32*)p;
+    B.rcnt = (u32*)p; p += al256((size_t)(K1R_MAXR + 1) * B.rstride * 4);
+    B.btaskCap = g.nb * (g.stride / 256);
+    B.btask = (uint4*)p; p += al256((size_t)K1F_LEVELS * B.btaskCap * sizeof(uint4));
+    B.bcnt = (u32*)p;
 }
 
 static int g_k1_last_sparse_rounds = 0, g_k1_last_rounds = 0;
@@ -2069,6 +2074,8 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     static const u32 bsort_iters = []() -> u32 { const char* e = getenv("CJS_BSORT_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 2u; return v > 64u ? 64u : v; }();
     static const bool rounds_env = []() { const char* e = getenv("CJS_ROUNDS"); return !e || atoi(e) != 0; }();
     // CJS_DEEP_BIG_DIV: text comparison is skipped when more than 1/DIV of the rotations sit in big 8-byte groups (see k1f_bsort / k1_deep)
+    // (measured with the round-3 flow on E8S-A, where a third of the rotations sit in such groups: text stages + task levels 32.2 ms
+    // against 20.7 ms with this predictor - its ties are hundreds of bytes long, which prefix doubling settles in log steps)
     static const u32 big_div = []() -> u32 { const char* e = getenv("CJS_DEEP_BIG_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();
     const bool fused = front && !B.linear && deep_iters > 0 && rounds_env && max_n <= (1u << 20);      // (list entries hold 20-bit indices)
     if (front) {

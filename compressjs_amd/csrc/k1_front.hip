@@ -491,11 +491,26 @@ __device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u3
     __syncthreads();
 }
 
+// A slice that a bucket-sort workgroup cannot finish in LDS becomes a TASK of the next level of k1f_task (below):
+// x = block, y = suffix-array position of the slice, z = its length, w = depth (bytes all its rotations share) | K1F_TASK_SB
+// when the indices sit in the slice of SB (not SA).  One atomic per task (they are rare).
+#define K1F_TASK_SB 0x80000000u
+#define K1F_PS (K1F_C / 2)          // samples a task partition sorts in LDS
+#define K1F_PB (K1F_C / 4)          // sub-buckets of a task partition, at most (<= 256: one byte per id)
+static_assert(K1F_PB <= 256 && K1F_PB >= 64 && (K1F_PB & (K1F_PB - 1)) == 0 && K1F_PS % 4 == 0, "task partition geometry");
+__device__ __forceinline__ void k1f_push_task(const K1Buf& B, u32 level, u32 b, u32 pos, u32 len, u32 depth_flag) {
+    if (level >= K1F_LEVELS) return;
+    const u32 idx = atomicAdd(&B.bcnt[level], 1u);
+    if (idx < B.btaskCap) B.btask[(size_t)level * B.btaskCap + idx] = make_uint4(b, pos, len, depth_flag);
+}
+
 // Results of positions [0, cnt) of the slice that starts at suffix-array position `pos0` of block b: the suffix indices and the
 // head bits; with `lists`, every unfrozen group of 2..K1F_GBIG rotations goes, member by member, to the block's list of
 // the first refinement round (k1r_round), and its positions are marked as heads right away: the rounds resolve them or,
-// where a tie outlasts the last round, clear the bits again.  One atomic per workgroup reserves the list slots.
-__device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const BatchGeom& g, u32 b, u32 pos0, u32 cnt, bool lists) {
+// where a tie outlasts the last round, clear the bits again.  One atomic per workgroup reserves the list slots.  The other
+// groups (above K1F_GBIG rotations, frozen) stay marked as groups and become tasks of level `task_level`, `task_depth` deep.
+__device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const BatchGeom& g, u32 b, u32 pos0, u32 cnt, bool lists,
+                                          u32 task_level, u32 task_depth) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     u32* SA = B.SA + (size_t)b * g.stride + pos0;
     u32* HN = B.HN + (size_t)b * g.hstride;
@@ -515,10 +530,12 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
             }
             const u32 q = q0 + lane;
             bool listed = false;
-            if (q < cnt && !(k1f_bit(S.hb, q) && k1f_bit(S.hb, q + 1u)) && !k1f_bit(S.fb, q)) {
+            if (q < cnt && !(k1f_bit(S.hb, q) && k1f_bit(S.hb, q + 1u))) {
                 const u32 gs = k1f_prev_head(S.hb, q), gl = k1f_next_head(S.hb, q) - gs;
-                listed = gl <= K1F_GBIG;
+                listed = gl <= K1F_GBIG && !k1f_bit(S.fb, q);
                 gsv[it] = (q - gs) | ((gl - 1u) << 8);
+                // a group this workgroup could not split (above K1F_GBIG rotations, or frozen): a task of the next level
+                if (!listed && q == gs) k1f_push_task(B, task_level, b, pos0 + gs, gl, task_depth);
             }
             bal[it] = __ballot(listed);
             if (lane == 0) { lb[q0 >> 5] = (u32)bal[it]; lb[(q0 >> 5) + 1u] = (u32)(bal[it] >> 32); }
@@ -550,19 +567,200 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
     }
 }
 
+// LDS of the local sample sort (stages 1-3); aliases what only the deepening uses afterwards
+struct K1fSort {
+    u64* smp;       // [K1F_LS] samples
+    u64* sp2;       // [K1F_LK] local splitters
+    u32* srank;     // [K1F_LS]
+    u32* cnt2;      // [K1F_LK]
+    u32* off2;      // [K1F_LK + 1]
+    u8* lf;         // [K1F_C] leaf of every slot
+};
+
+// `cnt` <= K1F_C rotation indices from src[] sorted in LDS by the 8 text bytes at depth `dm` (= depth mod n): on return
+// S.sx[] holds them in order and S.hb[] the heads of the groups of equal keys (bit 0 and the sentinel bits included).
+//   stage 0  indices, then keys (all loads of a stage in flight together)
+//   stage 1  a LOCAL sample sort: up to 128 of the slice's own keys ranked by counting, every 2nd a local splitter
+//   stage 2  the pairs move into <= 64 leaves (leaf order, in place: every thread still holds its pairs in registers)
+//   stage 3  every rotation ranks itself inside its leaf by counting, ALL LANES AT ONCE (a lane per rotation, the leaf's keys
+//            read from LDS four at a time: lanes of one leaf read the same address = broadcast).  Round 2 gave a whole wave
+//            to one leaf of ~14 rotations and broadcast the candidates through v_readlane: 22 % of the lanes busy.
+// bigstat: where leaves of more than 64 rotations (mostly one key) are counted (the K1-deep predictor of k1_run), or null.
+__device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, const u8* T, u32 n, const u32* src, u32 cnt, u32 dm, u32* bigstat) {
+    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    u64* key = S.k0;
+    u32* sx = S.sx;
+    u32 v[K1F_E];
+    u64 k[K1F_E];
+#pragma unroll
+    for (int it = 0; it < K1F_E; it++) {
+        const u32 i = (u32)it * K1F_BT + tid;
+        v[it] = i < cnt ? src[i] : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < K1F_E; it++) {
+        const u32 i = (u32)it * K1F_BT + tid;
+        u32 p = v[it] + dm;
+        if (p >= n) p -= n;
+        k[it] = i < cnt ? k1f_load_be64(T, p) : 0ull;
+    }
+#pragma unroll
+    for (int it = 0; it < K1F_E; it++) {
+        const u32 i = (u32)it * K1F_BT + tid;
+        if (i < cnt) key[i] = k[it];
+    }
+    k1f_init_bitmaps(S, cnt);
+    if (tid < K1F_LK) Q.cnt2[tid] = 0;
+    u32 K = 1u;
+    while (K < K1F_LK && cnt >= 48u * K) K <<= 1;       // leaves of ~24..48 rotations (K1F_LK = 32), ~12..24 (64)
+    if (K1F_LK == 64 && K > 1u && K < 64u) K <<= 1;
+    __syncthreads();
+    if (K > 1u) {
+        // stage 1: LOVS * K samples, ranked by counting; every LOVS-th is a local splitter (equal neighbours: the heavy-key rule)
+        const u32 LS = K1F_LOVS * K;
+        // (all waves: thread t ranks sample t % LS against one LS / (K1F_BT / LS)-th of the samples, partial ranks summed in LDS)
+        const u32 parts = K1F_BT / LS < 1u ? 1u : (K1F_BT / LS > LS ? LS : K1F_BT / LS), si = tid % LS, part = tid / LS;   // powers of two
+        if (tid < LS) { Q.smp[tid] = key[(u32)((u64)tid * cnt / LS)]; Q.srank[tid] = 0; }
+        __syncthreads();
+        if (part < parts) {
+            const u64 mine = Q.smp[si];
+            const u32 per = LS / parts, j0 = part * per;
+            u32 r = 0;
+#pragma unroll 8
+            for (u32 j = j0; j < j0 + per; j++) {
+                const u64 o = Q.smp[j];
+                r += (o < mine || (o == mine && j < si)) ? 1u : 0u;
+            }
+            atomicAdd(&Q.srank[si], r);
+        }
+        __syncthreads();
+        u64 mine = 0;
+        if (tid < LS) mine = Q.smp[tid];
+        __syncthreads();
+        if (tid < LS) Q.smp[Q.srank[tid]] = mine;
+        __syncthreads();
+        if (tid < K1F_LK) {
+            u64 vv = ~0ull;
+            if (tid + 1u < K) {
+                const u64 q = Q.smp[(tid + 1u) * K1F_LOVS];
+                vv = q;
+                if (tid >= 1u && Q.smp[tid * K1F_LOVS] == q && q != ~0ull) vv = q + 1u;
+            }
+            Q.sp2[tid] = vv;
+        }
+        __syncthreads();
+        // stage 2: leaf of every rotation, slot inside the leaf by an LDS counter
+        u32 L[K1F_E];
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 i = (u32)it * K1F_BT + tid;
+            L[it] = 0xFFFFFFFFu;
+            if (i < cnt) {
+                u32 pos = 0;
+                for (u32 step = K >> 1; step >= 1u; step >>= 1)
+                    if (Q.sp2[pos + step - 1u] <= k[it]) pos += step;
+                L[it] = (pos << 16) | atomicAdd(&Q.cnt2[pos], 1u);
+            }
+        }
+        __syncthreads();
+        if (w == 0) {
+            const u32 c = lane < K ? Q.cnt2[lane] : 0u;
+            const u32 inc = wave_incl_scan_u32(c);
+            if (lane < K1F_LK) Q.off2[lane] = inc - c;
+            if (lane == 0) Q.off2[K1F_LK] = cnt;
+        }
+        __syncthreads();
+        // the pairs move to leaf order IN PLACE: nobody reads the arrival-order arrays any more (own pairs are in registers)
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++)
+            if (L[it] != 0xFFFFFFFFu) {
+                const u32 leaf = L[it] >> 16, q = Q.off2[leaf] + (L[it] & 0xFFFFu);
+                key[q] = k[it];
+                sx[q] = v[it];
+                Q.lf[q] = (u8)leaf;
+            }
+    } else {
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 i = (u32)it * K1F_BT + tid;
+            if (i < cnt) { sx[i] = v[it]; Q.lf[i] = 0; }
+        }
+        if (tid == 0) { Q.cnt2[0] = cnt; Q.off2[0] = 0; Q.off2[1] = cnt; }
+        if (tid < K1F_LK) Q.sp2[tid] = ~0ull;
+    }
+    __syncthreads();
+    // stage 3: less = smaller keys, eqb = equal keys in earlier slots; members of one group (equal keys) end up next to each
+    // other and the one with eqb == 0 is its head.
+    u32 q[K1F_E];                                       // final position | head << 31
+#pragma unroll
+    for (int it = 0; it < K1F_E; it++) {
+        const u32 i = (u32)it * K1F_BT + tid;
+        q[it] = 0xFFFFFFFFu;
+        if (i < cnt) {
+            const u32 leaf = Q.lf[i];
+            const u32 o = Q.off2[leaf], e = leaf + 1u < K ? Q.off2[leaf + 1u] : cnt;
+            const u64 mine = key[i];
+            v[it] = sx[i];
+            const bool pure2 = K > 1u && leaf > 0u && leaf + 1u < K && Q.sp2[leaf] == Q.sp2[leaf - 1u] + 1u;   // one key only
+            if (pure2) q[it] = i | (i == o ? 0x80000000u : 0u);
+            else {
+                u32 less = 0, eqb = 0;
+                for (u32 j = o; j < e; j += 4u) {
+                    u64 c[4];
+#pragma unroll
+                    for (u32 u = 0; u < 4u; u++) c[u] = key[j + u < e ? j + u : e - 1u];
+#pragma unroll
+                    for (u32 u = 0; u < 4u; u++) {
+                        const bool in = j + u < e;
+                        less += (in && c[u] < mine) ? 1u : 0u;
+                        eqb += (in && c[u] == mine && j + u < i) ? 1u : 0u;
+                    }
+                }
+                q[it] = (o + less + eqb) | (eqb == 0 ? 0x80000000u : 0u);
+            }
+            if (bigstat && i == o && e - o > 64u) atomicAdd(bigstat, e - o);      // a leaf this big is (mostly) one key
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < K1F_E; it++)
+        if (q[it] != 0xFFFFFFFFu) {
+            const u32 p = q[it] & 0x7FFFFFFFu;
+            sx[p] = v[it];
+            if (q[it] >> 31) atomicOr(&S.hb[p >> 5], 1u << (p & 31u));
+        }
+    __syncthreads();
+}
+
+// The __shared__ arrays of a bucket-sort workgroup and their views (macro: __shared__ must be declared in the kernel)
+#define K1F_DECLARE_LDS(S, Q)                                                                                                        \
+    __shared__ u64 key[K1F_C];                                                                                                       \
+    __shared__ u32 key1[K1F_C];                                                                                                      \
+    __shared__ u32 sx[K1F_C];                                                                                                        \
+    __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];                                                     \
+    __shared__ u32 misc[K1F_E * K1F_NW + 8];                                                                                         \
+    /* scratch: the local sample sort (samples, splitters, ranks) and, later, the deepening's new positions */                     \
+    __shared__ u64 scr64[256];                                                                                                       \
+    static_assert((2 * K1F_LK + 4) * 4 + K1F_C <= K1F_C * 4, "leaf bookkeeping fits key1[]");                                        \
+    static_assert((K1F_LS + K1F_LK) * 8 + K1F_LS * 4 <= 256 * 8 && K1F_C * 2 <= 256 * 8 && K1F_C >= 256 && K1F_C < 0x7FF0,            \
+                  "scratch: samples + splitters + ranks, later K1F_C u16 new positions");                                            \
+    K1fS S;                                                                                                                          \
+    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.misc = misc; \
+    K1fSort Q;                                                                                                                       \
+    Q.smp = scr64; Q.sp2 = scr64 + K1F_LS; Q.srank = (u32*)(scr64 + K1F_LS + K1F_LK);                                                \
+    /* leaf bookkeeping of the local sample sort lives in key1[], which only the deepening uses */                                  \
+    Q.cnt2 = key1; Q.off2 = key1 + K1F_LK; Q.lf = (u8*)(key1 + 2 * K1F_LK + 4);
+
 // One workgroup per bucket (a bucket is a KEY RANGE: everything that ties on its first 8 bytes, or deeper, is inside).
-//   1. (key, index) pairs into LDS; a second, LOCAL sample sort: up to 128 of the bucket's own keys ranked by counting,
-//      every 2nd a local splitter, the rotations moved into <= 64 leaves (leaf order, in place: every thread still
-//      holds its pairs in registers).
-//   2. Every rotation ranks itself inside its leaf by counting, ALL LANES AT ONCE (a lane per rotation, the leaf's keys
-//      read from LDS four at a time: lanes of one leaf read the same address = broadcast).  Round 2 gave a whole wave to
-//      one leaf of ~14 rotations and broadcast the candidates through v_readlane: 22 % of the lanes busy.
-//   3. In-bucket deepening (k1f_deepen; round 3, replaces the K1-deep tile kernel and most of the lane kernels' work).
-//   4. Suffix-array slice and head bits are written ONCE; the groups of 2..8 rotations that are left go to the lane
-//      kernels' lists with the depth they are known to share (k1f_flush).
-// `purerot_max`: when more rotations than this sit in buckets of ONE 8-byte key (HTML-like input, counted by k1f_scan),
-// the ties are long repeats that text comparison does not settle and step 3 / the lists are skipped (as K1-deep was).
-// lists = 0: no deepening and no lists (the K1-deep tile kernel of rounds 1-2 follows; kept for A/B runs, and linear mode).
+//   1. k1f_sort_lds: the bucket sorted by its first 8 bytes in LDS, groups of equal keys marked;
+//   2. k1f_deepen: `iters` in-bucket iterations of K1F_STEP more bytes (round 3);
+//   3. k1f_flush: suffix-array slice and head bits written ONCE; what still ties goes to the refinement rounds' lists, and
+//      what could not be handled here (groups above K1F_GBIG rotations) to the task levels.
+// Buckets beyond LDS (cnt > K1F_C: an unlucky sample, a moderately heavy key) and buckets of ONE 8-byte key beyond LDS
+// (HTML-like input: a quarter of all rotations) are level-0 tasks.  `lists` = 0: no deepening, no lists, no tasks but the
+// oversize buckets (the K1-deep tile kernel of rounds 1-2 follows; kept for A/B runs, and linear mode).
+// `purerot_max`: with more rotations than this in one-key buckets (counted by k1f_scan) the text stages are skipped
+// altogether (CJS_DEEP_BIG_DIV = 8: HTML-like input, whose ties of hundreds of bytes prefix doubling settles faster).
 __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
     u32 b, d;
     if (!xcd_block_tile(g.nb, b, d)) return;
@@ -572,7 +770,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     const u32 start = fs[d], end = fs[d + 1];
     if (end <= start) return;
     const u32 cnt = end - start;
-    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+    const u32 tid = threadIdx.x;
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32* SB = B.SB + (size_t)b * g.stride + start;
     u32* SA = B.SA + (size_t)b * g.stride + start;
@@ -581,41 +779,22 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     // a bucket between the splitters v and v+1 holds one key only
     const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
-    if (cnt == 1u || (pure && (!deepen || cnt > K1F_C))) {
+    if (cnt > K1F_C && (deepen || !pure)) {
+        // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB
+        if (tid == 0) {
+            k1f_push_task(B, 0u, b, start, cnt, (pure ? 8u : 0u) | K1F_TASK_SB);
+            if (!pure) atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
+            atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
+        }
+        return;
+    }
+    if (cnt == 1u || (pure && !deepen)) {
         for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
         k1f_write_heads(HN, start, end, [&](u32 p) { return p == start; });
         if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (see k1_run: K1-deep predictor)
         return;
     }
-    __shared__ u64 key[K1F_C];
-    __shared__ u32 key1[K1F_C];
-    __shared__ u32 sx[K1F_C];
-    __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];
-    __shared__ u32 misc[K1F_E * K1F_NW];
-    // scratch: the local sample sort (samples, splitters, ranks) and, later, the deepening's new positions
-    __shared__ u64 scr64[256];
-    // leaf bookkeeping of the local sample sort lives in key1[], which only the deepening uses
-    u32* cnt2 = key1;                                   // [K1F_LK]
-    u32* off2 = key1 + K1F_LK;                          // [K1F_LK + 1]
-    u8* lf = (u8*)(key1 + 2 * K1F_LK + 4);              // [K1F_C]
-    static_assert((2 * K1F_LK + 4) * 4 + K1F_C <= K1F_C * 4, "leaf bookkeeping fits key1[]");
-    static_assert((K1F_LS + K1F_LK) * 8 + K1F_LS * 4 <= 256 * 8 && K1F_C * 2 <= 256 * 8 && K1F_C >= 256 && K1F_C < 0x7FF0, "scratch: samples + splitters + ranks, later K1F_C u16 new positions");
-    u64* smp = scr64;
-    u64* sp2 = scr64 + K1F_LS;
-    u32* srank = (u32*)(scr64 + K1F_LS + K1F_LK);
-    K1fS S;
-    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.misc = misc;
-    if (cnt > K1F_C) {
-        // oversize bucket (unlucky sampling or a moderately heavy key): listed for k1f_bsort_big (its code in here cost this kernel
-        // 45 VGPRs, i.e. three of its eight waves per SIMD)
-        if (tid == 0) {
-            const u32 idx = atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
-            if (idx < B.largeCap) B.large[idx] = make_uint2(b, d);
-            atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
-        }
-        return;
-    }
-    // ---- the common case: everything in LDS.  Stage 0: indices, then keys (all loads of a stage in flight together)
+    K1F_DECLARE_LDS(S, Q)
 #ifdef K1F_TRACE
     long long tprev_ = clock64();
 #endif
@@ -626,296 +805,206 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
         if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
         __syncthreads();
     } else {
-        u32 v[K1F_E];
-        u64 k[K1F_E];
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++) {
-            const u32 i = (u32)it * K1F_BT + tid;
-            v[it] = i < cnt ? SB[i] : 0u;
-        }
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++) {
-            const u32 i = (u32)it * K1F_BT + tid;
-            k[it] = i < cnt ? k1f_load_be64(T, v[it]) : 0ull;
-        }
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++) {
-            const u32 i = (u32)it * K1F_BT + tid;
-            if (i < cnt) key[i] = k[it];
-        }
-        k1f_init_bitmaps(S, cnt);
-        if (tid < K1F_LK) cnt2[tid] = 0;
-        K1F_STAMP(0);
-        u32 K = 1u;
-        while (K < K1F_LK && cnt >= 48u * K) K <<= 1;   // leaves of ~24..48 rotations (K1F_LK = 32), ~12..24 (64)
-        if (K1F_LK == 64 && K > 1u && K < 64u) K <<= 1;
-        __syncthreads();
-        if (K > 1u) {
-            // stage 1: LOVS * K samples, ranked by counting; every LOVS-th is a local splitter (equal neighbours: the heavy-key rule)
-            const u32 LS = K1F_LOVS * K;
-            // (all waves: thread t ranks sample t % LS against one LS / (K1F_BT / LS)-th of the samples, partial ranks summed in LDS)
-            const u32 parts = K1F_BT / LS < 1u ? 1u : (K1F_BT / LS > LS ? LS : K1F_BT / LS), si = tid % LS, part = tid / LS;   // powers of two
-            if (tid < LS) { smp[tid] = key[(u32)((u64)tid * cnt / LS)]; srank[tid] = 0; }
-            __syncthreads();
-            if (part < parts) {
-                const u64 mine = smp[si];
-                const u32 per = LS / parts, j0 = part * per;
-                u32 r = 0;
-#pragma unroll 8
-                for (u32 j = j0; j < j0 + per; j++) {
-                    const u64 o = smp[j];
-                    r += (o < mine || (o == mine && j < si)) ? 1u : 0u;
-                }
-                atomicAdd(&srank[si], r);
-            }
-            __syncthreads();
-            u64 mine = 0;
-            if (tid < LS) mine = smp[tid];
-            __syncthreads();
-            if (tid < LS) smp[srank[tid]] = mine;
-            __syncthreads();
-            if (tid < K1F_LK) {
-                u64 vv = ~0ull;
-                if (tid + 1u < K) {
-                    const u64 q = smp[(tid + 1u) * K1F_LOVS];
-                    vv = q;
-                    if (tid >= 1u && smp[tid * K1F_LOVS] == q && q != ~0ull) vv = q + 1u;
-                }
-                sp2[tid] = vv;
-            }
-            __syncthreads();
-            K1F_STAMP(1);
-            // stage 2: leaf of every rotation, slot inside the leaf by an LDS counter
-            u32 L[K1F_E];
-#pragma unroll
-            for (int it = 0; it < K1F_E; it++) {
-                const u32 i = (u32)it * K1F_BT + tid;
-                L[it] = 0xFFFFFFFFu;
-                if (i < cnt) {
-                    u32 pos = 0;
-                    for (u32 step = K >> 1; step >= 1u; step >>= 1)
-                        if (sp2[pos + step - 1u] <= k[it]) pos += step;
-                    L[it] = (pos << 16) | atomicAdd(&cnt2[pos], 1u);
-                }
-            }
-            __syncthreads();
-            if (w == 0) {
-                const u32 c = lane < K ? cnt2[lane] : 0u;
-                const u32 inc = wave_incl_scan_u32(c);
-                if (lane < K1F_LK) off2[lane] = inc - c;
-                if (lane == 0) off2[K1F_LK] = cnt;
-            }
-            __syncthreads();
-            // the pairs move to leaf order IN PLACE: nobody reads the arrival-order arrays any more (own pairs are in registers)
-#pragma unroll
-            for (int it = 0; it < K1F_E; it++)
-                if (L[it] != 0xFFFFFFFFu) {
-                    const u32 leaf = L[it] >> 16, q = off2[leaf] + (L[it] & 0xFFFFu);
-                    key[q] = k[it];
-                    sx[q] = v[it];
-                    lf[q] = (u8)leaf;
-                }
-        } else {
-#pragma unroll
-            for (int it = 0; it < K1F_E; it++) {
-                const u32 i = (u32)it * K1F_BT + tid;
-                if (i < cnt) { sx[i] = v[it]; lf[i] = 0; }
-            }
-            if (tid == 0) { cnt2[0] = cnt; off2[0] = 0; off2[1] = cnt; }
-            if (tid < K1F_LK) sp2[tid] = ~0ull;
-        }
-        __syncthreads();
-        K1F_STAMP(2);
-        // stage 3: every rotation ranks itself inside its leaf (a lane per rotation, four candidates per LDS round trip).
-        // less = smaller keys, eqb = equal keys in earlier slots; members of one group (equal keys) end up next to each
-        // other and the one with eqb == 0 is its head.
-        u32 q[K1F_E];                                   // final position | head << 31
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++) {
-            const u32 i = (u32)it * K1F_BT + tid;
-            q[it] = 0xFFFFFFFFu;
-            if (i < cnt) {
-                const u32 leaf = lf[i];
-                const u32 o = off2[leaf], e = leaf + 1u < K ? off2[leaf + 1u] : cnt;
-                const u64 mine = key[i];
-                k[it] = mine;
-                v[it] = sx[i];
-                const bool pure2 = K > 1u && leaf > 0u && leaf + 1u < K && sp2[leaf] == sp2[leaf - 1u] + 1u;   // one key only
-                if (pure2) q[it] = i | (i == o ? 0x80000000u : 0u);
-                else {
-                    u32 less = 0, eqb = 0;
-                    for (u32 j = o; j < e; j += 4u) {
-                        u64 c[4];
-#pragma unroll
-                        for (u32 u = 0; u < 4u; u++) c[u] = key[j + u < e ? j + u : e - 1u];
-#pragma unroll
-                        for (u32 u = 0; u < 4u; u++) {
-                            const bool in = j + u < e;
-                            less += (in && c[u] < mine) ? 1u : 0u;
-                            eqb += (in && c[u] == mine && j + u < i) ? 1u : 0u;
-                        }
-                    }
-                    q[it] = (o + less + eqb) | (eqb == 0 ? 0x80000000u : 0u);
-                }
-                if (i == o && e - o > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], e - o);   // a leaf this big is (mostly) one key
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < K1F_E; it++)
-            if (q[it] != 0xFFFFFFFFu) {
-                const u32 p = q[it] & 0x7FFFFFFFu;
-                sx[p] = v[it];
-                if (q[it] >> 31) atomicOr(&hbits[p >> 5], 1u << (p & 31u));
-            }
-        __syncthreads();
+        k1f_sort_lds(S, Q, T, n, SB, cnt, 0u, &B.stats[K1_STAT_BIGROT + (d & 7u)]);
     }
     K1F_STAMP(3);
     if (deepen) k1f_deepen(S, T, n, cnt, 8u, iters);
     K1F_STAMP(4);
-    k1f_flush(S, B, g, b, start, cnt, deepen);
+    k1f_flush(S, B, g, b, start, cnt, deepen, 0u, 8u);
     K1F_STAMP(5);
 }
 
-// Oversize buckets (more than K1F_C rotations: unlucky sampling or a moderately heavy key; ~400 of 229 000 on the enwik stream),
-// listed by k1f_bsort: stable LSD passes through global memory, one digit byte gathered from the text per pass, ping-pong
-// between the bucket's slices of SB and SA (wave 0 scatters row by row: stable by construction; rare, so simple).  The sorted
-// slice is then deepened like a bucket, in windows of <= K1F_C positions that end on a group boundary.
-__global__ __launch_bounds__(K1F_BT) void k1f_bsort_big(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
-    __shared__ u64 key[K1F_C];
-    __shared__ u32 key1[K1F_C];
-    __shared__ u32 sx[K1F_C];
-    __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];
-    __shared__ u32 misc[K1F_E * K1F_NW];
-    __shared__ u64 scr64[256];
-    K1fS S;
-    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.misc = misc;
+// The task levels: slices that a bucket-sort workgroup could not finish in LDS.  Level L reads the tasks level L - 1 (or
+// k1f_bsort) pushed; one workgroup per task:
+//   * a slice of up to K1F_C rotations (sharing `depth` bytes) is sorted in LDS by the 8 bytes at `depth` (k1f_sort_lds),
+//     deepened and flushed like a bucket: what still ties goes to the refinement rounds' lists, groups above K1F_GBIG
+//     rotations become tasks of the next level, 8 bytes deeper;
+//   * a longer slice is PARTITIONED like a block by the front end: K1F_PS = 512 of its own keys at `depth` sorted in LDS, every
+//     k-th a splitter (a key that fills more than one quantile gets a sub-bucket of its own, 8 bytes deeper), bucket ids
+//     (one byte per rotation, in the slice of KA), an LDS histogram, the indices scattered into the other of the two index
+//     arrays (SB <-> SA); every sub-bucket is a task of the next level.
+// HTML-like input (E8S-A) has a quarter of its rotations in 8-byte groups of more than 1024 members and another 10-15 % in
+// groups of 257..1024: rounds 1-2 left all of them to prefix doubling from h = 8 (13 of 22 ms).  `last` (the last level
+// launched): whatever arrives is sorted by 8 bytes at its depth and left at that (the doubling rounds take it from there):
+// in LDS if it fits, else by stable LSD passes through global memory (one digit byte gathered per pass; slow, never seen).
+__global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 level, u32 iters, u32 lists, u32 purerot_max, u32 last) {
+    K1F_DECLARE_LDS(S, Q)
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    u32 nbig = B.stats[K1_STAT_FRONT_BIG];
-    if (nbig > B.largeCap) nbig = B.largeCap;
+    u32 ntask = B.bcnt[level];
+    if (ntask > B.btaskCap) ntask = B.btaskCap;
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
-    for (u32 li = blockIdx.x; li < nbig; li += gridDim.x) {
+    for (u32 li = blockIdx.x; li < ntask; li += gridDim.x) {
         __syncthreads();
-        const u32 b = B.large[li].x, d = B.large[li].y;
+        const uint4 tk = B.btask[(size_t)level * B.btaskCap + li];
+        const u32 b = tk.x, pos = tk.y, len = tk.z, depth = tk.w & ~K1F_TASK_SB;
+        const bool inSB = (tk.w & K1F_TASK_SB) != 0u;
         const u32 n = B.nlen[b];
-        const u32* fs = B.fstart + (size_t)b * (K1F_NB + 1);
-        const u32 start = fs[d], end = fs[d + 1];
-        const u32 cnt = end - start;
         const u8* T = B.T + (size_t)b * g.tstride;
-        const u32* SB = B.SB + (size_t)b * g.stride + start;
-        u32* SA = B.SA + (size_t)b * g.stride + start;
+        u32* SBs = B.SB + (size_t)b * g.stride + pos;
+        u32* SAs = B.SA + (size_t)b * g.stride + pos;
         u32* HN = B.HN + (size_t)b * g.hstride;
-    {
-        // ---- oversize bucket (unlucky sampling or a moderately heavy key): stable LSD passes through global memory,
-        //      one digit byte gathered from the text per pass, ping-pong between the bucket's slices of SB and SA.
-        //      Wave 0 scatters row by row (stable by construction); rare, so simple.
-        u32* dstart = (u32*)key;                        // [256]
-        u32* sh = dstart + 256;                         // [256]
-        u32* single = misc;
-        u32* bufs[2] = {(u32*)SB, SA};
-        int cur = 0;
-        for (u32 pass = 0; pass < 8u; pass++) {
-            const u32* src = bufs[cur];
-            u32* dst = bufs[cur ^ 1];
-            if (tid < 256u) dstart[tid] = 0;
-            if (tid == 0) *single = 0;
-            __syncthreads();
-            for (u32 i = tid; i < cnt; i += K1F_BT) atomicAdd(&dstart[T[src[i] + 7u - pass]], 1u);
-            __syncthreads();
-            const u32 c = tid < 256u ? dstart[tid] : 0u;
-            if (c == cnt) *single = 1;
-            __syncthreads();
-            if (*single) { __syncthreads(); continue; }  // every rotation has the same byte here (uniform)
-            const u32 ex = block_excl_scan_256(c, sh);
-            if (tid < 256u) dstart[tid] = ex;
-            __syncthreads();
-            if (w == 0) {
-                const u64 lt = lanemask_lt();
-                for (u32 r0 = 0; r0 < cnt; r0 += 64u) {
-                    const u32 i = r0 + lane;
-                    const bool valid = i < cnt;
-                    const u32 v = valid ? src[i] : 0u;
-                    const u32 dg = valid ? T[v + 7u - pass] : 0u;
-                    const u64 m = match_any(dg, 8, valid);
-                    const u32 rank = (u32)__popcll(m & lt), c2 = (u32)__popcll(m);
-                    const u32 bs = valid ? dstart[dg] : 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    if (valid) dst[bs + rank] = v;
-                    if (valid && rank == 0) dstart[dg] = bs + c2;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            __threadfence_block();
-            __syncthreads();
-            cur ^= 1;
-        }
-        if (cur == 0) {
-            for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
-            __threadfence_block();
-            __syncthreads();
-        }
-        if (!deepen) {
-            k1f_write_heads(HN, start, end, [&](u32 p) {
-                return p == start || k1f_load_be64(T, SA[p - start]) != k1f_load_be64(T, SA[p - start - 1u]);
-            });
+        const u32* src = inSB ? SBs : SAs;
+        const u32 dm = depth % n;
+        if (B.linear && depth) {
+            // linear mode (BWT.bwtransform / suffixsort: suffixes, zero padding instead of wrap-around) sorts by the first 8 bytes
+            // only: a sub-bucket of one key is one group, as the one-key buckets of k1f_bsort are
+            for (u32 i = tid; i < len; i += K1F_BT) SAs[i] = src[i];
+            if (tid == 0) atomicOr(&HN[pos >> 5], 1u << (pos & 31u));
             continue;
         }
-        // the sorted slice in windows of <= K1F_C positions that end on a group boundary: each is deepened like a bucket.
-        // A group that alone exceeds a window stays one group of equal 8-byte prefixes (head bit only).
-        const u32* src = SA;                            // sorted by 8 bytes (this workgroup's own stores, fenced above)
-        u32 a = 0;
-        while (a < cnt) {                               // `a` is workgroup-uniform
-            u32 len = cnt - a < K1F_C ? cnt - a : K1F_C;
-            __syncthreads();
-            for (u32 i = tid; i < len; i += K1F_BT) {
-                const u32 s = src[a + i];
-                sx[i] = s;
-                key[i] = k1f_load_be64(T, s);
+        if (len <= K1F_C) {
+            if (len == 1u) {
+                if (tid == 0) { SAs[0] = src[0]; atomicOr(&HN[pos >> 5], 1u << (pos & 31u)); }
+                continue;
             }
-            __syncthreads();
-            // heads inside the window
-            k1f_init_bitmaps(S, len);
-            __syncthreads();
-            for (u32 i = tid + 1u; i < len; i += K1F_BT)
-                if (key[i] != key[i - 1u]) atomicOr(&hbits[i >> 5], 1u << (i & 31u));
-            if (tid == 0) {
-                u32 cut = len;                          // the window ends where a group ends
-                if (a + len < cnt && k1f_load_be64(T, src[a + len]) == key[len - 1u]) cut = 0xFFFFFFFFu;
-                misc[1] = cut;
-            }
-            __syncthreads();
-            if (misc[1] == 0xFFFFFFFFu) {
-                const u32 ph = k1f_prev_head(hbits, len - 1u);
-                __syncthreads();
-                if (ph == 0u) {
-                    // one group fills the whole window: find its end, mark its head, leave it as it is
-                    const u64 k0v = key[0];
-                    u32 e = a + len;
-                    for (;;) {                          // uniform: every thread looks at the same positions
-                        if (e >= cnt) break;
-                        if (k1f_load_be64(T, src[e]) != k0v) break;
-                        e++;
-                    }
-                    if (tid == 0) {
-                        const u32 p = start + a;
-                        atomicOr(&HN[p >> 5], 1u << (p & 31u));
-                    }
-                    a = e;
-                    continue;
-                }
-                len = ph;
-                __syncthreads();
-                k1f_init_bitmaps(S, len);
-                __syncthreads();
-                for (u32 i = tid + 1u; i < len; i += K1F_BT)
-                    if (key[i] != key[i - 1u]) atomicOr(&hbits[i >> 5], 1u << (i & 31u));
-                __syncthreads();
-            }
-            k1f_deepen(S, T, n, len, 8u, iters);
-            k1f_flush(S, B, g, b, start + a, len, true);
-            a += len;
+            k1f_sort_lds(S, Q, T, n, src, len, dm, nullptr);
+            const bool go = deepen && !last;
+            if (go) k1f_deepen(S, T, n, len, depth + 8u, iters);
+            k1f_flush(S, B, g, b, pos, len, go, level + 1u, depth + 8u);
+            continue;
         }
-    }
+        if (!last) {
+            // ---- partition.  K1F_PS samples of the slice's keys at `depth`, ranked by counting; splitters
+            u64* smp = key;                                 // [K1F_PS]
+            u64* spl = key + K1F_PS;                        // [K1F_PB] sub-bucket j holds the keys in [spl[j-1], spl[j])
+            u32* rk = key1;                                 // [K1F_PS] ranks; then [K1F_PB] histogram, [K1F_PB] cursors
+            u32 nbk = (len + 319u) / 320u;
+            if (nbk > K1F_PB - 1u) nbk = K1F_PB - 1u;
+            for (u32 i = tid; i < K1F_PS; i += K1F_BT) {
+                const u32 at = (u32)(((u64)i * len + (k1f_hash(i, pos) % len)) / K1F_PS) % len;      // stratified, hashed
+                u32 p = src[at] + dm;
+                if (p >= n) p -= n;
+                smp[i] = k1f_load_be64(T, p);
+            }
+            __syncthreads();
+            for (u32 i = tid; i < K1F_PS; i += K1F_BT) {
+                const u64 mine = smp[i];
+                u32 r = 0;
+                for (u32 j = 0; j < K1F_PS; j += 4u) {
+                    u64 c[4];
+#pragma unroll
+                    for (u32 u = 0; u < 4u; u++) c[u] = smp[j + u];
+#pragma unroll
+                    for (u32 u = 0; u < 4u; u++) r += (c[u] < mine || (c[u] == mine && j + u < i)) ? 1u : 0u;
+                }
+                rk[i] = r;
+            }
+            __syncthreads();
+            u64 mine2[(K1F_PS + K1F_BT - 1) / K1F_BT];
+            for (u32 i = tid, k = 0; i < K1F_PS; i += K1F_BT, k++) mine2[k] = smp[i];
+            __syncthreads();
+            for (u32 i = tid, k = 0; i < K1F_PS; i += K1F_BT, k++) smp[rk[i]] = mine2[k];
+            __syncthreads();
+            for (u32 j = tid; j < K1F_PB; j += K1F_BT) {
+                u64 v = ~0ull;
+                if (j + 1u < nbk) {
+                    const u64 q = smp[(u32)(((u64)(j + 1u) * K1F_PS) / nbk)];
+                    v = q;
+                    if (j >= 1u && smp[(u32)(((u64)j * K1F_PS) / nbk)] == q && q != ~0ull) v = q + 1u;     // heavy key: [q, q+1) is a sub-bucket of its own
+                }
+                spl[j] = v;
+            }
+            __syncthreads();
+            u32* hist = key1;                               // [K1F_PB]
+            u32* cur = key1 + K1F_PB;                       // [K1F_PB]
+            for (u32 j = tid; j < K1F_PB; j += K1F_BT) hist[j] = 0;
+            __syncthreads();
+            u8* ids = (u8*)(B.KA + (size_t)b * g.stride + pos);       // one byte per rotation of the slice (KA is free after k1f_scatter)
+            for (u32 i = tid; i < len; i += K1F_BT) {
+                u32 p = src[i] + dm;
+                if (p >= n) p -= n;
+                const u64 kk = k1f_load_be64(T, p);
+                u32 id = 0;
+#pragma unroll
+                for (u32 step = K1F_PB / 2u; step >= 1u; step >>= 1)
+                    if (id + step - 1u < K1F_PB - 1u && spl[id + step - 1u] <= kk) id += step;      // spl[K1F_PB - 1] is never read
+                ids[i] = (u8)id;
+                atomicAdd(&hist[id], 1u);
+            }
+            __syncthreads();
+            {
+                const u32 c = tid < K1F_PB ? hist[tid] : 0u;
+                const u32 ex = block_excl_scan_256(c, (u32*)sx);
+                if (tid < K1F_PB) cur[tid] = ex;
+            }
+            __syncthreads();
+            u32* dst = inSB ? SAs : SBs;
+            __threadfence_block();
+            for (u32 i = tid; i < len; i += K1F_BT) {
+                const u32 id = ids[i];
+                const u32 at = atomicAdd(&cur[id], 1u);
+                dst[at] = src[i];
+            }
+            __threadfence_block();
+            __syncthreads();
+            // sub-buckets -> tasks of the next level (cur[j] is now the END of sub-bucket j)
+            for (u32 j = tid; j < K1F_PB; j += K1F_BT) {
+                const u32 c = hist[j];
+                if (!c) continue;
+                const u32 e = cur[j];
+                const bool heavy = j > 0u && j < K1F_PB - 1u && spl[j] == spl[j - 1u] + 1u;     // one key: 8 bytes deeper
+                k1f_push_task(B, level + 1u, b, pos + e - c, c, (heavy ? depth + 8u : depth) | (inSB ? 0u : K1F_TASK_SB));
+            }
+            continue;
+        }
+        // ---- last level, beyond LDS: stable LSD passes on the 8 bytes at `depth`, heads by comparing them
+        {
+            u32* dstart = (u32*)key;                        // [256]
+            u32* sh = dstart + 256;                         // [256]
+            u32* single = misc;
+            u32* bufs[2] = {inSB ? SBs : SAs, inSB ? SAs : SBs};
+            int cur = 0;
+            for (u32 pass = 0; pass < 8u; pass++) {
+                const u32* sp = bufs[cur];
+                u32* dp = bufs[cur ^ 1];
+                const u32 dmp = (depth + 7u - pass) % n;
+                if (tid < 256u) dstart[tid] = 0;
+                if (tid == 0) *single = 0;
+                __syncthreads();
+                for (u32 i = tid; i < len; i += K1F_BT) { u32 p = sp[i] + dmp; if (p >= n) p -= n; atomicAdd(&dstart[T[p]], 1u); }
+                __syncthreads();
+                const u32 c = tid < 256u ? dstart[tid] : 0u;
+                if (c == len) *single = 1;
+                __syncthreads();
+                if (*single) { __syncthreads(); continue; }  // every rotation has the same byte here (uniform)
+                const u32 ex = block_excl_scan_256(c, sh);
+                if (tid < 256u) dstart[tid] = ex;
+                __syncthreads();
+                if (w == 0) {
+                    const u64 lt = lanemask_lt();
+                    for (u32 r0 = 0; r0 < len; r0 += 64u) {
+                        const u32 i = r0 + lane;
+                        const bool valid = i < len;
+                        const u32 v = valid ? sp[i] : 0u;
+                        u32 p = v + dmp;
+                        if (p >= n) p -= n;
+                        const u32 dg = valid ? T[p] : 0u;
+                        const u64 m = match_any(dg, 8, valid);
+                        const u32 rank = (u32)__popcll(m & lt), c2 = (u32)__popcll(m);
+                        const u32 bs = valid ? dstart[dg] : 0u;
+                        __builtin_amdgcn_wave_barrier();
+                        if (valid) dp[bs + rank] = v;
+                        if (valid && rank == 0) dstart[dg] = bs + c2;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+                cur ^= 1;
+            }
+            if (bufs[cur] != SAs) {
+                for (u32 i = tid; i < len; i += K1F_BT) SAs[i] = bufs[cur][i];
+                __threadfence_block();
+                __syncthreads();
+            }
+            k1f_write_heads(HN, pos, pos + len, [&](u32 p) {
+                if (p == pos) return true;
+                u32 a = SAs[p - pos] + dm, c = SAs[p - pos - 1u] + dm;
+                if (a >= n) a -= n;
+                if (c >= n) c -= n;
+                return k1f_load_be64(T, a) != k1f_load_be64(T, c);
+            });
+        }
     }
 }
 
@@ -1171,7 +1260,11 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
         (void)hipEventRecord(pr->ev[2 * slot + 1], stream);
         __atomic_fetch_add(&pr->elements, (u64)g.nb * max_n, __ATOMIC_RELAXED);
     }
-    hipLaunchKernelGGL(k1f_bsort_big, dim3(g.nb * 8u < 256u ? g.nb * 8u : 256u), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max);
+    // the task levels: what k1f_bsort could not finish in LDS (slices beyond K1F_C, big groups), level after level; an empty
+    // level costs its launch (~2 us: the workgroups read one counter and leave)
+    for (u32 lv = 0; lv < K1F_LEVELS; lv++)
+        hipLaunchKernelGGL(k1f_task, dim3(g.nb * 16u < 2048u ? g.nb * 16u : 2048u), dim3(K1F_BT), 0, stream, B, g, lv, iters, lists, purerot_max,
+                           lv + 1u == K1F_LEVELS ? 1u : 0u);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -36,6 +36,10 @@ int64_t cjs_bwtc_compress_bound(uint64_t in_len);
 int64_t cjs_bwtc_compress(cjs_ctx* ctx, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
                           uint64_t out_cap, int64_t declared_size);
 #define CJS_E_UNSUPPORTED (-24)
+/* Phases of the last cjs_bwtc_compress (bench.py's BWTC line): out5[0] = ms of the first K10 launch (FenwickModel on the GPU),
+ * [1] = ms until every (sy_f, lt_f, tot_f) triple was on the host, [2] = ms the serial range coder (lib/RangeCoder.js:79-89) was busy,
+ * [3] = ms of the whole call, [4] = encodeFreq calls. */
+int cjs_bwtc_last_times(cjs_ctx* ctx, float* out5);
 
 /* Sharded encoding for multi-GPU runs (blocks are independent once the RLE1 split is known):
  * cjs_bz2_plan   = the readBlock chain of lib/Bzip2.js:913-922 over the whole (device) input;

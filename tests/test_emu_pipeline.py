@@ -465,7 +465,15 @@ def _front_blocks():
     heavy = synth.text_like(60000, 9).copy()                 # one 8-byte key in ~1 % of the positions, not enough quantiles
     for p in rng.randint(0, heavy.size - 8, size=500):
         heavy[p:p + 8] = np.frombuffer(b"QQQQZZZZ", np.uint8)
-    return [synth.text_like(50000, 11), synth.enwik_like(40000, 12), synth.lcg_ascii(30000, 3),
+    # heavy keys at several depths (the task levels of k1_front.hip: one-key buckets beyond LDS, groups above 256 rotations):
+    # a 40-byte phrase at 3000 places, and 2500 "table rows" that share 60 bytes before and 30 bytes after a varying field
+    deep = synth.text_like(400000, 13).copy()
+    phrase = np.frombuffer(b"<td class=\"cell numeric\" align=\"right\">", np.uint8)
+    for p in rng.randint(0, deep.size - 64, size=3000):
+        deep[p:p + phrase.size] = phrase
+    rows = np.concatenate([np.frombuffer(b"<tr><td class=\"c1\">row</td><td class=\"c2\" style=\"width:10px\">" + (b"%05d" % int(v)) +
+                                         b"</td><td>fixed tail of the row</td></tr>\n", np.uint8) for v in rng.randint(0, 100000, size=2500)])
+    return [deep, rows, synth.text_like(50000, 11), synth.enwik_like(40000, 12), synth.lcg_ascii(30000, 3),
             synth.periodic(25001, b"ab"), synth.periodic(20011, b"the quick brown fox jumps over the lazy dog\n"),
             np.zeros(12000, np.uint8), synth.runs_mixed(40000, 4), heavy,
             rng.randint(0, 256, size=23000).astype(np.uint8), rng.randint(97, 99, size=15000).astype(np.uint8),
@@ -502,6 +510,15 @@ def _front_check(variant):
     for (u, p), b in zip(_bwt_batch(L, blocks), blocks):
         uo, po = oracle.bwt_cyclic(b)
         assert p == po and np.array_equal(u, uo), (variant, b.size, bytes(b[:16]))
+    # linear mode (BWT.bwtransform: suffixes, no wrap-around) through the same front end: heavy keys must not be keyed deeper
+    L.cjs_bwt_linear.restype = C.c_int32
+    L.cjs_bwt_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    for b in blocks[:2] + blocks[4:6]:
+        u = np.zeros(b.size, np.uint8)
+        pi = C.c_uint32(0)
+        assert L.cjs_bwt_linear(b.ctypes.data, u.ctypes.data, b.size, C.byref(pi)) == 0
+        uo, po = oracle.bwt_linear(b)
+        assert pi.value == po and np.array_equal(u, uo), (variant, "linear", b.size)
 
 
 def test_segmented_host_pipeline():
