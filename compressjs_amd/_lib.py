@@ -69,6 +69,8 @@ def load(path: str | None = None):
     L.cjs_bz2_plan.argtypes = [vp, vp, C.c_uint64, C.c_int]
     L.cjs_bz2_plan_block_start.restype = C.c_int64
     L.cjs_bz2_plan_block_start.argtypes = [vp, C.c_uint32]
+    L.cjs_bwtc_last_times.restype = C.c_int
+    L.cjs_bwtc_last_times.argtypes = [vp, C.POINTER(C.c_float)]
     L.cjs_bz2_plan_scan.restype = C.c_int64
     L.cjs_bz2_plan_scan.argtypes = [vp, vp, C.c_uint64, C.c_int]
     L.cjs_bz2_plan_cost.restype = C.c_int64

@@ -2068,10 +2068,10 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const int p0 = front ? 8 : (int)(8u - d0);
     // K1-deep: iterations of 8 text bytes each (0 switches it off; default 32 = ties up to 264 bytes)
     static const u32 deep_iters = []() -> u32 { const char* e = getenv("CJS_DEEP_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 32u; return v > 4000u ? 4000u : v; }();
-    // CJS_BSORT_ITERS = in-bucket deepening iterations of k1f_bsort (12 bytes each; default 2: the groups it lists share 32 bytes);
+    // CJS_BSORT_ITERS = in-bucket deepening iterations of k1f_bsort (12 bytes each; default 1: the groups it lists share 20 bytes; measured 10^8-byte enwik ms per step with 0 / 1 / 2 / 3: 11.08 / 10.99 / 11.45 / 11.7);
     // CJS_ROUNDS=0: no lists and no refinement rounds - the K1-deep tile kernel and the lane kernels of rounds 1/2 do that work
     // (kept for A/B runs).  The rounds go on up to 8 + 8 * CJS_DEEP_ITERS bytes (264), what still ties there is left to prefix doubling.
-    static const u32 bsort_iters = []() -> u32 { const char* e = getenv("CJS_BSORT_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 2u; return v > 64u ? 64u : v; }();
+    static const u32 bsort_iters = []() -> u32 { const char* e = getenv("CJS_BSORT_ITERS"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 1u; return v > 64u ? 64u : v; }();
     static const bool rounds_env = []() { const char* e = getenv("CJS_ROUNDS"); return !e || atoi(e) != 0; }();
     // CJS_DEEP_BIG_DIV: text comparison is skipped when more than 1/DIV of the rotations sit in big 8-byte groups (see k1f_bsort / k1_deep)
     // (measured with the round-3 flow on E8S-A, where a third of the rotations sit in such groups: text stages + task levels 32.2 ms

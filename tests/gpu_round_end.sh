@@ -42,7 +42,7 @@ for w in ('enwik', 'e8sa'):
     ent = {}
     for k in sorted(set(f) | set(wr)):
         if not k.startswith('k1'): continue
-        steps = 3                                           # 1 warm-up + 2 repetitions per pass
+        steps = 2                                           # --reps 2: two compress calls per pass
         # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE x 2 on gfx950 (MI355X_MICROARCH.md, HBM section: calibrated for wide
         # streaming reads only - gathers of a few bytes and Infinity-Cache hits are counted too)
         fb = f.get(k, {}).get('FETCH_SIZE', 0) * 1024 * 2 / steps
