@@ -5,7 +5,7 @@
 // Replaces steps 1 of k1_bwt.hip (k1_hist/k1_scan/k1_scatter x 7 + k1_init_heads), i.e. the first part of the
 // work SA-IS does in BWT.bwtransform2 (lib/BWT.js:372-417, :197-300).  Nothing of the reference is ported: any
 // algorithm that delivers "rotations ordered by their first 8 bytes, groups of equal prefixes marked" feeds the
-// refinement stages (K1-deep, prefix doubling) unchanged, and the final order is the reference's.
+// refinement stages (the rounds below, K1-deep, prefix doubling) unchanged, and the final order is the reference's.
 //
 //   k1f_sample   per block: K1F_S keys (8 text bytes each) at stratified, hashed positions, bitonic-sorted in
 //                LDS; every K1F_OVS-th is a splitter.  A key that fills more than one quantile gets a bucket of
@@ -15,11 +15,17 @@
 //   k1f_scan     per block: bucket starts and per-(tile, bucket) write offsets.
 //   k1f_scatter  rotation indices to their bucket (4 bytes per rotation; order inside a bucket is irrelevant).
 //   k1f_bsort    one workgroup per bucket: gathers the 8-byte keys from the block's text (L2-resident, all tiles
-//                of a block run on one XCD), sorts (key, index) in LDS with stable 8-bit LSD passes over the
-//                bytes that actually vary inside the bucket, writes the suffix array slice and the group heads.
+//                of a block run on one XCD), sorts (key, index) in LDS by a local sample sort into <= 64 leaves and
+//                lane-parallel rank counting inside the leaves, takes K1F_STEP more bytes off what still ties
+//                (in-bucket deepening, round 3), writes the suffix array slice and the group heads once, and one
+//                list entry per rotation that still ties.
+//   k1f_task     (round 3) slices beyond LDS and groups above K1F_GBIG rotations, level after level: partitioned
+//                like a block, or sorted in LDS 8 bytes deeper.
+//   k1r_round    (round 3) list-driven refinement: 24 more text bytes per round off every listed rotation, ranked
+//                inside its group; resolved rotations are final, the others go to the next round's list.
 //
-// HBM traffic per rotation: text 1 + ids 2+2 + indices 4+4 + suffix array 4 + keys gathered from L2 = ~17 bytes
-// (the LSD design moved 7 x 20 = 140).  All integer work.
+// HBM traffic per rotation of the 8-byte sort: text 1 + ids 2+2 + indices 4+4 + suffix array 4 + keys gathered from
+// L2 = ~17 bytes (the LSD design moved 7 x 20 = 140).  All integer work.
 #include "k1_bwt.h"
 #include "devutil.h"
 

@@ -1,5 +1,5 @@
 /* compressjs_amd.h -- C ABI of libcompressjs_amd.so (MI355X-native bzip2 block pipeline).
- * (round-1 work in progress; the full entry-point list is in INTEGRATION.md)
+ * (state: round 3; the full entry-point list with the reference binding of each is in INTEGRATION.md)
  */
 #ifndef COMPRESSJS_AMD_H
 #define COMPRESSJS_AMD_H
