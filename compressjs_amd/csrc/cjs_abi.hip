@@ -317,7 +317,8 @@ struct cjs_ctx {
     hipEvent_t evDone[CJS_NSTREAMS];   // everything issued on that stream
     u32 nstreams;              // streams in use (<= CJS_NSTREAMS; env CJS_STREAMS overrides)
     u32 batch_blocks;          // blocks in flight over all streams
-    u32 sub_blocks;            // blocks per sub-batch
+    u32 sub_blocks;            // blocks per sub-batch, at most (what every stream's workspace is sized for)
+    u32 share[CJS_NSTREAMS];   // per mille of a batch that stream i's sub-batch takes (sums to 1000)
     void* ws[CJS_NSTREAMS];    // block-pipeline workspaces (level-9 geometry)
     size_t ws_bytes;
     StreamState* d_ss;         // stream cursor + combined CRC, shared by all sub-batches
@@ -376,7 +377,24 @@ extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
 #ifdef CJS_CPU_DEBUG_BUILD
     c->nstreams = 1;                             // the CPU logic-debug build runs kernels as fibers of one thread
 #endif
-    c->sub_blocks = (c->batch_blocks + c->nstreams - 1) / c->nstreams;
+    for (u32 i = 0; i < c->nstreams; i++) c->share[i] = 1000u / c->nstreams + (i < 1000u % c->nstreams ? 1u : 0u);
+    if (const char* ev = getenv("CJS_SHARES")) {        // "300,700": unequal sub-batches (the streams then leave K1 at different times)
+        u32 v[CJS_NSTREAMS], n = 0, sum = 0;
+        for (const char* q = ev; *q && n < CJS_NSTREAMS; ) {
+            v[n] = (u32)strtoul(q, (char**)&q, 10); sum += v[n++];
+            if (*q == ',' || *q == ':') q++;
+        }
+        bool good = n >= 1 && sum == 1000u;
+        for (u32 i = 0; i < n; i++) good = good && v[i] >= 50u;
+#ifndef CJS_CPU_DEBUG_BUILD
+        if (good) { c->nstreams = n; for (u32 i = 0; i < n; i++) c->share[i] = v[i]; }
+#endif
+    }
+    {
+        u32 mx = 0;
+        for (u32 i = 0; i < c->nstreams; i++) mx = c->share[i] > mx ? c->share[i] : mx;
+        c->sub_blocks = (u32)(((u64)c->batch_blocks * mx + 999u) / 1000u);
+    }
     bool ok = hipStreamCreate(&c->stream) == hipSuccess;
     BatchGeom g = make_geom(c->sub_blocks, 9u * 100000u - 19u);
     c->ws_bytes = pipe_bytes(g);
@@ -455,10 +473,27 @@ static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap
 
 static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 count, void* d_out, uint64_t out_cap) {
     BatchGeom g = make_geom(c->sub_blocks, cap);
-    // sub-batches of equal size, at least one per stream when there are enough blocks to share
-    u32 nsub = (count + c->sub_blocks - 1) / c->sub_blocks;
-    if (nsub < c->nstreams && count >= 16 * c->nstreams) nsub = c->nstreams;
-    const u32 per = nsub ? (count + nsub - 1) / nsub : 0;
+    // The blocks go out in batches of batch_blocks; a batch is cut into one sub-batch per stream by the streams' shares
+    // (when it has at least 16 blocks per stream: below that one stream takes it whole, or sub_blocks at a time).
+    std::vector<u32> sfirst, scount;
+    for (u32 f = 0; f < count; ) {
+        const u32 wave = count - f < c->batch_blocks ? count - f : c->batch_blocks;
+        if (c->nstreams > 1 && wave >= 16 * c->nstreams) {
+            u32 acc = 0, done = 0;
+            for (u32 i = 0; i < c->nstreams; i++) {
+                acc += c->share[i];
+                const u32 upto = i + 1 == c->nstreams ? wave : (u32)(((u64)wave * acc + 500u) / 1000u);
+                if (upto > done) { sfirst.push_back(first + f + done); scount.push_back(upto - done); }
+                done = upto;
+            }
+            f += wave;
+        } else {
+            const u32 take = wave < c->sub_blocks ? wave : c->sub_blocks;
+            sfirst.push_back(first + f); scount.push_back(take);
+            f += take;
+        }
+    }
+    const u32 nsub = (u32)sfirst.size();
     const u32 ns = c->nstreams < nsub ? c->nstreams : nsub;
     for (u32 i = 0; i < ns; i++) HIP_CHECK_RET(hipStreamWaitEvent(c->sub[i], c->evReady, 0));
     // K1 steers itself with small read-backs (stream syncs), so every stream gets its own host thread:
@@ -469,8 +504,7 @@ static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 coun
     auto worker = [&](u32 si) {
         if (hipSetDevice(c->device) != hipSuccess) { err = CJS_E_NOGPU; return; }
         for (u32 j = si; j < nsub; j += ns) {
-            const u32 f = first + j * per;
-            const u32 nb = first + count - f < per ? first + count - f : per;
+            const u32 f = sfirst[j], nb = scount[j];
             Pipe P;
             int rc = err.load() ? err.load() : run_sub_batch(c, K, g, cap, f, nb, si, d_out, out_cap, P);
             while (recorded.load(std::memory_order_acquire) != j) std::this_thread::yield();

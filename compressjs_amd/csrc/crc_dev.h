@@ -1,5 +1,5 @@
-// CRC-32 (poly 0x04c11db7, MSB first; lib/CRC32.js:37-103) of a byte range by one 256-thread workgroup:
-// 256 independent table-driven slices, combined with x^(8m) mod P.  Shared by K0 (encoder: CRC of
+// CRC-32 (poly 0x04c11db7, MSB first; lib/CRC32.js:37-103) of a byte range by one workgroup of 256 threads or more:
+// one independent table-driven slice per thread, combined with x^(8m) mod P.  Shared by K0 (encoder: CRC of
 // the input bytes a block consumed) and K9 (decoder: CRC of the bytes a block decodes to).
 #pragma once
 #include "cjs_common.h"
@@ -19,7 +19,25 @@ __device__ __forceinline__ u32 gf_shift(u32 v, u64 m, const u32* pw) {
     return v;
 }
 
-// All 256 threads of the block call this; tab[256], pw[40] and *acc are LDS scratch.  The CRC of
+// x^(8 * 2^k) mod P for k < 40, made by the compiler (one lane squaring forty times was 11 us at the head of every call)
+struct CrcPw { u32 v[40]; };
+constexpr u32 gf_mul_c(u32 a, u32 b) {
+    u32 r = 0;
+    for (int i = 31; i >= 0; i--) {
+        r = (r << 1) ^ ((r & 0x80000000u) ? CRC_POLY : 0u);
+        if ((b >> i) & 1u) r ^= a;
+    }
+    return r;
+}
+constexpr CrcPw crc_pw_make() {
+    CrcPw t{};
+    u32 p = 0x100u;                                       // x^8
+    for (int k = 0; k < 40; k++) { t.v[k] = p; p = gf_mul_c(p, p); }
+    return t;
+}
+static __device__ const CrcPw CRC_PW = crc_pw_make();
+
+// All threads of the block (>= 256) call this; tab[256], pw[40] and *acc are LDS scratch.  The CRC of
 // in[s, e) (init 0xffffffff, final complement) is returned to every thread.
 __device__ __forceinline__ u32 crc_range_block(const u8* in, u64 s, u64 e, u32* tab, u32* pw, u32* acc) {
     const u32 tid = threadIdx.x;
@@ -28,14 +46,12 @@ __device__ __forceinline__ u32 crc_range_block(const u8* in, u64 s, u64 e, u32* 
         for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : (c << 1);
         tab[tid] = c;
     }
-    if (tid == 0) {
-        *acc = 0;
-        u32 p = 0x100u;                                   // x^8
-        for (int k = 0; k < 40; k++) { pw[k] = p; p = gf_mul(p, p); }
-    }
+    if (tid >= 64 && tid < 104) pw[tid - 64] = CRC_PW.v[tid - 64];
+    if (tid == 0) *acc = 0;
     __syncthreads();
     const u64 len = e - s;
-    const u64 per = (((len + 255) / 256) + 15) & ~(u64)15;    // multiple of 16: aligned 16-byte loads inside
+    const u64 nt = blockDim.x;
+    const u64 per = (((len + nt - 1) / nt) + 15) & ~(u64)15;  // multiple of 16: aligned 16-byte loads inside
     const u64 lo = s + (u64)tid * per < e ? s + (u64)tid * per : e;
     const u64 hi = lo + per < e ? lo + per : e;
     u32 crc = 0;                                          // raw remainder (init 0)

@@ -535,7 +535,9 @@ __global__ __launch_bounds__(64) void k0_pad(Pipe P) {
 }
 
 // ---- CRC -----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
+// 1024 slices per block: a slice is a serial chain of dependent LDS look-ups (one per byte), and one workgroup per block is
+// all the parallelism there is (256 slices: 200 us on the critical path of every sub-batch)
+__global__ __launch_bounds__(1024) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
     const u32 b = blockIdx.x, kb = first_block + b;
     if (kb >= *K.nBlocks) return;
     __shared__ u32 tab[256];
@@ -707,7 +709,7 @@ int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream) {
     const u32 gx = cap / K0_TILE + 2;
     hipLaunchKernelGGL(k0_materialize, dim3(gx, P.g.nb), dim3(256), 0, stream, K, P, first_block, cap);
     hipLaunchKernelGGL(k0_pad, dim3(P.g.nb), dim3(64), 0, stream, P);
-    hipLaunchKernelGGL(k0_crc, dim3(P.g.nb), dim3(256), 0, stream, K, P, first_block);
+    hipLaunchKernelGGL(k0_crc, dim3(P.g.nb), dim3(1024), 0, stream, K, P, first_block);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -11,7 +11,7 @@
 //                                 new table; recount; rebuild every table)
 //   group-count rule              lib/Bzip2.js:826-830
 //
-// One 1024-thread workgroup per bzip2 block; the whole optimiser loop runs inside one launch.
+// K34_SPLIT 1024-thread workgroups per bzip2 block, two kernels per optimiser iteration (see k34_assign below).
 // Per-symbol code lengths of all (<= 6) tables are packed into one 64-bit LDS word (10 bits per
 // table) so the cost of a 50-symbol group under every table is 50 LDS reads + 50 adds.
 // The "stable sort + take upper half" is done without sorting: a cost histogram finds the
@@ -19,40 +19,66 @@
 #include "pipeline.h"
 
 #define HB_PITCH 264
+#ifdef K34_TRACE
+#define K34_NOW() wall_clock64()
+#else
+#define K34_NOW() 0ll
+#endif
+static_assert(HB_PITCH == CJS_LEN_PITCH, "fr2's rows (pipeline.hip) have the pitch of the LDS rows");
 
 // ---- allocator (serial, one lane) ------------------------------------------------------------
+// x % len: the cells these loops look at hold extended parent pointers (tail or tail + len, :86-100), i.e. values below
+// 2 len, for which the division (about forty instructions on one lane, three hundred times per table) is one subtraction;
+// anything else still divides.
+template <typename I>
+__device__ __forceinline__ int ha_mod(I x, int len) {
+    return x < (I)len ? (int)x : x < (I)(2 * len) ? (int)x - len : (int)(x % len);
+}
+
 template <typename I>
 __device__ int ha_first(const I* a, int len, int i, int nodes_to_move) {             // :52-73
     const int limit = i;
     int k = len - 2;
-    while (i >= nodes_to_move && (int)(a[i] % len) > limit) { k = i; i -= (limit - i + 1); }
+    while (i >= nodes_to_move && ha_mod(a[i], len) > limit) { k = i; i -= (limit - i + 1); }
     if (i < nodes_to_move - 1) i = nodes_to_move - 1;
     while (k > i + 1) {
         const int t = (i + k) >> 1;
-        if ((int)(a[t] % len) > limit) k = t; else i = t;
+        if (ha_mod(a[t], len) > limit) k = t; else i = t;
     }
     return k;
 }
 
 template <typename I>
-__device__ void ha_allocate(I* a, int len, int maxlen) {
+__device__ void ha_parents(I* a, int len) {
     // setExtendedParentPointers :79-105
+    // The fronts of the two queues (vh = a[head]: the oldest unconsumed internal node, vt = a[top]: the next leaf) are
+    // carried in registers: a step costs the refill of whichever front it consumed instead of four dependent reads.
+    // At the first selection of a step head < tail always holds (a step consumes at most the nodes made before it).
     a[0] += a[1];
     {
+        const I none = (I)(~(unsigned long long)0 >> (65 - 8 * sizeof(I)));          // larger than any weight
         int head = 0, top = 2;
+        I vh = a[0];
+        I vt = top < len ? a[top] : none;
         for (int tail = 1; tail < len - 1; tail++) {
             I t;
-            if (top >= len || a[head] < a[top]) { t = a[head]; a[head++] = tail; }
-            else t = a[top++];
-            if (top >= len || (head < tail && a[head] < a[top])) { t += a[head]; a[head++] = tail + len; }
-            else t += a[top++];
+            if (top >= len || vh < vt) { t = vh; a[head++] = tail; vh = head < tail ? a[head] : none; }
+            else { t = vt; top++; vt = top < len ? a[top] : none; }
+            if (top >= len || (head < tail && vh < vt)) { t += vh; a[head++] = tail + len; vh = head < tail ? a[head] : none; }
+            else { t += vt; top++; vt = top < len ? a[top] : none; }
             a[tail] = t;
+            if (head == tail) vh = t;                     // the node just made is the only one waiting
         }
     }
+}
+
+// The rest of the allocator on one lane: findNodesToRelocate, then allocateNodeLengths or allocateNodeLengthsWithRelocation
+template <typename I>
+__device__ void ha_depths_serial(I* a, int len, int maxlen) {
     // findNodesToRelocate :114-124
     int reloc = len - 2;
     for (int d = 1; d < maxlen - 1 && reloc > 1; d++) reloc = ha_first(a, len, reloc - 1, 0);
-    if ((int)(a[0] % len) >= reloc) {
+    if (ha_mod(a[0], len) >= reloc) {
         // allocateNodeLengths :131-148
         int first = len - 2, next = len - 1;
         for (int depth = 1, avail = 2; avail > 0; depth++) {
@@ -88,24 +114,104 @@ __device__ void ha_allocate(I* a, int len, int maxlen) {
     }
 }
 
-// One wave builds one table: freq[0..S) -> lens[0..S).  keys/arr are per-wave LDS scratch.
-__device__ void huff_build_wave(const u32* freq, int S, u8* lens, int* keys, int* arr) {
+template <typename I>
+__device__ void ha_allocate(I* a, int len, int maxlen) {
+    ha_parents(a, len);
+    ha_depths_serial(a, len, maxlen);
+}
+
+// The same depths by the whole wave (round 3: the serial loops above - a binary search per level, one store per leaf, every
+// step a dependent LDS round trip on one lane - were 27 of the 49 us a table took, five times per block on the critical path).
+// After ha_parents, cells 0 .. len-3 hold parent pointers and the nodes of a level are contiguous, deeper levels first.
+//   1. depth of every internal node by pointer jumping (anc / dist; log2(depth) rounds),
+//   2. nodes per depth (cnt), first node of every level = nodes deeper than it (an inclusive scan),
+//   3. the reference's relocation test, literally: reloc = first node of level maxlen - 2 (or of the level where that
+//      index falls to <= 1), no relocation iff parent(node 0) >= reloc (:114-124, :207-212),
+//   4. leaves per depth = 2 * nodes(depth - 1) - nodes(depth) (allocateNodeLengths :131-148: `avail` slots, minus the
+//      internal nodes, are leaves), handed out from the END of the sorted array, smallest depth first.
+// Returns false, with `a` untouched, when the tree is too deep: the caller runs the serial relocation path.
+// anc, dist: len ints each; cnt: 128 ints; all lanes of the wave call this.
+#define HA_DCAP 63
+template <typename I>
+__device__ bool ha_depths_wave(I* a, int len, int maxlen, int* anc, int* dist, int* cnt) {
     const int lane = (int)(threadIdx.x & 63u);
+    const int root = len - 2;
+    for (int i = lane; i <= root; i += 64) { anc[i] = i < root ? ha_mod(a[i], len) : root; dist[i] = i < root ? 1 : 0; }
+    cnt[lane] = 0;
+    const int par0 = ha_mod(a[0], len);                    // read before any lane can be past the verdict (lane 0 then rewrites a)
+    __builtin_amdgcn_wave_barrier();
+    for (;;) {
+        bool more = false;
+        for (int i = lane; i < root; i += 64) {
+            const int p = anc[i];
+            if (p != root) {                              // (anc[p], dist[p]) is a consistent pair whichever lane wrote it last
+                const int pa = anc[p], pd = dist[p];
+                anc[i] = pa; dist[i] += pd;
+                more = more || pa != root;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!__any(more ? 1 : 0)) break;
+    }
+    for (int i = lane; i <= root; i += 64) atomicAdd(&cnt[dist[i] < HA_DCAP ? dist[i] : HA_DCAP], 1);
+    __builtin_amdgcn_wave_barrier();
+    const int c = cnt[lane];
+    const int start = (len - 1) - (int)wave_incl_scan_u32((u32)c);          // first node of level `lane`
+    int reloc = root;
+    if (root > 1 && maxlen > 2) {
+        const u64 low = __ballot(lane >= 1 && start <= 1);
+        const int dstar = low ? (int)__ffsll((long long)low) - 1 : 64;
+        reloc = __shfl(start, dstar < maxlen - 2 ? dstar : maxlen - 2);
+    }
+    const int deep = dist[0];                              // the first node made is the deepest; leaves reach deep + 1 <= maxlen
+    if (par0 < reloc) return false;
+    const int above = __shfl_up(c, 1);
+    const int nl = lane >= 1 ? 2 * above - c : 0;
+    cnt[64 + lane] = (int)wave_incl_scan_u32((u32)nl);     // leaves of depth <= lane
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < len; j += 64) {
+        const int r = len - j;                             // j-th smallest weight = r-th leaf from the end
+        int dep = 1;
+        for (int D = 1; D <= deep; D++) dep += cnt[64 + D] < r ? 1 : 0;
+        a[j] = (I)dep;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+// One wave builds one table: freq[0..S) -> lens[0..S).  keys/arr and anc/dist/cnt are per-wave LDS scratch.
+__device__ void huff_build_wave(const u32* freq, int S, u8* lens, int* keys, int* arr, int* anc, int* dist, int* cnt, u32* tr = nullptr) {
+    const int lane = (int)(threadIdx.x & 63u);
+    long long t0_ = tr ? K34_NOW() : 0;
     for (int i = lane; i < S; i += 64) keys[i] = (int)((freq[i] << 9) | (u32)i);      // :566-568
     __builtin_amdgcn_wave_barrier();
     // ascending sort by rank counting (keys are distinct)
-    for (int i = lane; i < S; i += 64) {
-        const int k = keys[i];
-        int r = 0;
-        for (int j = 0; j < S; j++) r += keys[j] < k ? 1 : 0;
-        arr[r] = k;
+    {
+        constexpr int M = (CJS_MAX_SYMS + 63) / 64;       // keys per lane, at most
+        int k[M], r[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) { const int i = lane + 64 * m; k[m] = i < S ? keys[i] : 0; r[m] = 0; }
+        for (int j = 0; j < S; j++) {
+            const int kj = keys[j];                       // one broadcast read serves all of the lane's keys
+#pragma unroll
+            for (int m = 0; m < M; m++) r[m] += kj < k[m] ? 1 : 0;
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) if (lane + 64 * m < S) arr[r[m]] = k[m];
     }
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < S; i += 64) keys[i] = arr[i];                              // sorted keys
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < S; i += 64) arr[i] = (int)((u32)keys[i] >> 9);            // :570
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) ha_allocate(arr, S, CJS_MAX_BITS);                                 // :572
+    if (tr && lane == 0) { const long long t1_ = K34_NOW(); atomicAdd(tr, (u32)(t1_ - t0_)); t0_ = t1_; }
+    if (lane == 0) ha_parents(arr, S);                                                // :572
+    __builtin_amdgcn_wave_barrier();
+    if (tr && lane == 0) { const long long t1_ = K34_NOW(); atomicAdd(tr + 1, (u32)(t1_ - t0_)); t0_ = t1_; }
+    if (!ha_depths_wave(arr, S, CJS_MAX_BITS, anc, dist, cnt)) {
+        if (lane == 0) ha_depths_serial(arr, S, CJS_MAX_BITS);
+    }
+    if (tr && lane == 0) atomicAdd(tr + 2, (u32)(K34_NOW() - t0_));
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < S; i += 64) lens[keys[i] & 0x1FF] = (u8)arr[i];            // :575-578
     __builtin_amdgcn_wave_barrier();
@@ -118,15 +224,15 @@ __device__ void huff_build_wave(const u32* freq, int S, u8* lens, int* keys, int
 #define K34_GROUPS_PER_CHUNK 64
 #define K34_PRE ((K34_STAGE_WORDS + 63) / 64)
 
-// Walk every 50-symbol group of A: each wave stages 64 groups (3200 symbols) with coalesced
-// 4-byte loads, then every lane reads its own group back (stride 25 words: conflict free per half-wave).
-// `body(gi, sym)` is called for every symbol of group gi by the lane that owns it.
+// Walk the 50-symbol groups of A in chunks of 64 groups: the wave takes chunks c0, c0 + cstep, ..., stages each (3200
+// symbols) with coalesced 4-byte loads, then every lane reads its own group back (stride 25 words: conflict free per
+// half-wave).  `body(gi, sym)` is called for every symbol of group gi by the lane that owns it.
 template <class Body, class Done>
-__device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32* stage_w, Body body, Done done) {
-    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+__device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32* stage_w, u32 c0, u32 cstep, Body body, Done done) {
+    const u32 lane = threadIdx.x & 63u;
     const u32* Aw = (const u32*)A;
     const u32 nchunks = (nSel + K34_GROUPS_PER_CHUNK - 1) / K34_GROUPS_PER_CHUNK;
-    // software pipeline: the words of chunk c+16 are in flight while chunk c is consumed from LDS
+    // software pipeline: the words of the wave's next chunk are in flight while this one is consumed from LDS
     u32 pre[K34_PRE];
     auto fetch = [&](u32 c) {
         const u32 sym0 = c * K34_GROUPS_PER_CHUNK * CJS_GROUP;
@@ -138,8 +244,8 @@ __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32
             pre[k] = j < nwords ? Aw[(sym0 >> 1) + j] : 0u;
         }
     };
-    if (w < nchunks) fetch(w);
-    for (u32 c = w; c < nchunks; c += 16) {
+    if (c0 < nchunks) fetch(c0);
+    for (u32 c = c0; c < nchunks; c += cstep) {
         const u32 g0 = c * K34_GROUPS_PER_CHUNK;
 #pragma unroll
         for (int k = 0; k < K34_PRE; k++) {
@@ -147,7 +253,7 @@ __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32
             if (j < K34_STAGE_WORDS) stage_w[j] = pre[k];
         }
         __builtin_amdgcn_wave_barrier();
-        if (c + 16 < nchunks) fetch(c + 16);
+        if (c + cstep < nchunks) fetch(c + cstep);
         const u32 gi = g0 + lane;
         if (lane < K34_GROUPS_PER_CHUNK && gi < nSel) {
             const u32 cnt = pos - gi * CJS_GROUP < CJS_GROUP ? pos - gi * CJS_GROUP : CJS_GROUP;
@@ -163,16 +269,50 @@ __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32
     }
 }
 
-__global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
+// The optimiser loop of lib/Bzip2.js:685-733 as K34_SPLIT workgroups per block and two kernels per iteration (round 3; rounds
+// 1-2 ran the whole loop in ONE workgroup per block: 56 workgroups on 256 CUs for 1.1 ms, all of it latency):
+//   k34_assign(it)  G = 2 + it tables: every workgroup of the block builds the tables from the block's frequency rows (the same
+//                   serial allocator run K34_SPLIT times: latency, not work), then costs and assigns ITS chunks of groups
+//                   (chunk c belongs to workgroup (c / 16) % K34_SPLIT).  G == target: workgroup 0 writes the canonical codes.
+//   k34_split(it)   G < target: every workgroup finds the most-used table and the median cost over ALL groups (18 000 at most),
+//                   moves the upper half to table G (in its LDS copy of the selectors), recounts its chunks into
+//                   LDS rows and adds them to the block's next frequency rows (fr2, two sets used alternately).
+// The kernel boundary is the barrier between the walks; nothing waits inside a kernel.
+#ifndef K34_SPLIT
+#define K34_SPLIT 4
+#endif
+#define K34_MAX_SEL 18432        // selectors of a block, at most ((900000 + 19) / 50 rounded up; k34_run checks selPitch)
+// -DK34_TRACE builds: 100 MHz stamps between the phases of block 0 / workgroup 0, summed over the iterations into
+// k1.stats[K1_STAT_RTRACE ..]; k34_run prints them (ticks of 10 ns).  Not in product builds.
+#ifdef K34_TRACE
+#define K34_T0 long long tprev_ = wall_clock64();
+#define K34_STAMP(slot) do { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now_ = wall_clock64(); atomicAdd(&P.k1.stats[K1_STAT_RTRACE + (slot)], (u32)(now_ - tprev_)); tprev_ = now_; } } while (0)
+#else
+#define K34_T0
+#define K34_STAMP(slot) do { } while (0)
+#endif
+
+struct K34Blk {
+    u32 pos, nSel;
+    int S, target;
+};
+__device__ __forceinline__ K34Blk k34_blk(const Pipe& P, u32 b) {
+    K34Blk k;
+    k.pos = P.pos[b];
+    k.S = (int)P.alpha[b] + 2;
+    k.nSel = (k.pos + CJS_GROUP - 1) / CJS_GROUP;                                     // :841
+    k.target = k.pos >= 2400 ? 6 : k.pos >= 1200 ? 5 : k.pos >= 600 ? 4 : k.pos >= 200 ? 3 : 2;   // :826-830
+    return k;
+}
+
+__global__ __launch_bounds__(1024) void k34_assign(Pipe P, u32 it) {
     const BatchGeom g = P.g;
-    const u32 b = blockIdx.x;
-    const u32 n = P.nlen[b];
-    if (n == 0) return;
+    const u32 b = blockIdx.x / K34_SPLIT, k = blockIdx.x % K34_SPLIT;
+    if (P.nlen[b] == 0) return;
+    const K34Blk q = k34_blk(P, b);
+    const int G = 2 + (int)it, S = q.S;
+    if (G > q.target) return;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    const u32 pos = P.pos[b];
-    const int S = (int)P.alpha[b] + 2;
-    const u32 nSel = (pos + CJS_GROUP - 1) / CJS_GROUP;                               // :841
-    const int target = pos >= 2400 ? 6 : pos >= 1200 ? 5 : pos >= 600 ? 4 : pos >= 200 ? 3 : 2;
     const u16* A = P.A + (size_t)b * g.stride;
     u8* sel = P.sel + (size_t)b * P.selPitch;
     u16* cost = P.selCost + (size_t)b * P.selPitch;
@@ -181,138 +321,240 @@ __global__ __launch_bounds__(1024) void k34_tables(Pipe P) {
     __shared__ u8 lens[CJS_MAX_GROUPS][HB_PITCH];
     __shared__ u32 fr[CJS_MAX_GROUPS][HB_PITCH];
     __shared__ u64 lens64[HB_PITCH];
-    __shared__ u32 cnt[8];
-    __shared__ u32 scan_sh[20];
-    __shared__ u32 s_which, s_cstar, s_keep;
     u32* stage_w = pool + w * K34_STAGE_WORDS;
-    int (*keys)[HB_PITCH] = (int (*)[HB_PITCH])pool;                                   // [6][264]
+    int (*keys)[HB_PITCH] = (int (*)[HB_PITCH])pool;                                   // [6][264]   (before the walk)
     int (*arr)[HB_PITCH] = (int (*)[HB_PITCH])(pool + CJS_MAX_GROUPS * HB_PITCH);      // [6][264]
-    u32* chist = pool + 2 * CJS_MAX_GROUPS * HB_PITCH;                                 // [1024]
+    int (*anc)[HB_PITCH] = (int (*)[HB_PITCH])(pool + 2 * CJS_MAX_GROUPS * HB_PITCH);  // [6][264]
+    int (*dst)[HB_PITCH] = (int (*)[HB_PITCH])(pool + 3 * CJS_MAX_GROUPS * HB_PITCH);  // [6][264]
+    int (*dcn)[128] = (int (*)[128])(pool + 4 * CJS_MAX_GROUPS * HB_PITCH);            // [6][128]
 
-    const u32* gfreq = P.freq + (size_t)b * K2_FREQ_PITCH;
-    for (u32 i = tid; i < (u32)S; i += 1024) { fr[0][i] = gfreq[i]; fr[1][i] = 1; }   // :835-837
+    u32* rows = P.fr2 + ((size_t)b * 2 + (it & 1u)) * CJS_MAX_GROUPS * HB_PITCH;       // written by k34_split(it - 1)
+    u32* next = P.fr2 + ((size_t)b * 2 + ((it + 1u) & 1u)) * CJS_MAX_GROUPS * HB_PITCH;
+    K34_T0
+    if (it == 0) {
+        const u32* gfreq = P.freq + (size_t)b * K2_FREQ_PITCH;
+        for (u32 i = tid; i < (u32)S; i += 1024) { fr[0][i] = gfreq[i]; fr[1][i] = 1; }   // :835-837
+    } else {
+        for (u32 i = tid; i < (u32)G * HB_PITCH; i += 1024) (&fr[0][0])[i] = rows[i];
+    }
+    if (k == 0 && G < q.target)
+        for (u32 i = tid; i < (u32)(CJS_MAX_GROUPS * HB_PITCH); i += 1024) next[i] = 0;
     __syncthreads();
-    int G = 2;
-    for (;;) {
-        // (re)build tables 0..G-1, one wave each
-        if (w < (u32)G) huff_build_wave(fr[w], S, lens[w], keys[w], arr[w]);
-        __syncthreads();
-        for (u32 i = tid; i < (u32)S; i += 1024) {
-            u64 v = 0;
-            for (int t = 0; t < G; t++) v |= (u64)lens[t][i] << (10 * t);
-            lens64[i] = v;
-        }
-        __syncthreads();
-        // assignSelectors :671-684
-        {
-            u64 acc = 0;
-            walk_groups(A, pos, nSel, stage_w,
-                [&](u32, u32 sym) { acc += lens64[sym]; },
-                [&](u32 gi) {
-                    u32 best = 0, bc = (u32)(acc & 1023u);
-                    for (int t = 1; t < G; t++) {
-                        const u32 c = (u32)((acc >> (10 * t)) & 1023u);
-                        if (c < bc) { best = (u32)t; bc = c; }
-                    }
-                    sel[gi] = (u8)best;
-                    cost[gi] = (u16)bc;
-                    acc = 0;
-                });
-        }
-        if (G >= target) break;
-        __syncthreads();                                  // staging area is reused as chist below
-        if (tid < 8) cnt[tid] = 0;
-        chist[tid] = 0;
-        __syncthreads();
-        for (u32 gi = tid; gi < nSel; gi += 1024) atomicAdd(&cnt[sel[gi]], 1u);
-        __syncthreads();
-        if (tid == 0) {                                   // first most-used table :699
-            u32 wh = 0;
-            for (int t = 1; t < G; t++) if (cnt[t] > cnt[wh]) wh = (u32)t;
-            s_which = wh;
-        }
-        __syncthreads();
-        const u32 which = s_which;
-        for (u32 gi = tid; gi < nSel; gi += 1024)
-            if (sel[gi] == which) atomicAdd(&chist[cost[gi]], 1u);
-        __syncthreads();
-        {
-            // smallest c with (#groups of cost < c) + chist[c] > half: elements of stable rank >= half move
-            const u32 half = cnt[which] >> 1;             // :712
-            u32 tot;
-            const u32 mine = chist[tid];
-            const u32 lower = block_excl_scan_1024(mine, scan_sh, &tot);
-            if (lower <= half && half < lower + mine) { s_cstar = tid; s_keep = half - lower; }
-        }
-        __syncthreads();
-        {
-            const u32 cstar = s_cstar, keep = s_keep;
-            const u32 chunk = (nSel + 1023u) / 1024u;
-            const u32 lo = tid * chunk < nSel ? tid * chunk : nSel;
-            const u32 hi = lo + chunk < nSel ? lo + chunk : nSel;
-            u32 eq = 0;
-            for (u32 gi = lo; gi < hi; gi++) eq += (sel[gi] == which && cost[gi] == cstar) ? 1u : 0u;
-            u32 total;
-            u32 rank = block_excl_scan_1024(eq, scan_sh, &total);
-            for (u32 gi = lo; gi < hi; gi++) {
-                if (sel[gi] != which) continue;
-                const u32 c = cost[gi];
-                if (c > cstar) sel[gi] = (u8)G;
-                else if (c == cstar) { if (rank >= keep) sel[gi] = (u8)G; rank++; }
-            }
-        }
-        G++;
-        for (u32 i = tid; i < (u32)(CJS_MAX_GROUPS * HB_PITCH); i += 1024) (&fr[0][0])[i] = 0;
-        __syncthreads();
-        walk_groups(A, pos, nSel, stage_w,                 // recount :717-727
-            [&](u32 gi, u32 sym) { atomicAdd(&fr[sel[gi]][sym], 1u); },
-            [&](u32) {});
-        __syncthreads();
+    K34_STAMP(0);
+#ifdef K34_TRACE
+    if (w < (u32)G) huff_build_wave(fr[w], S, lens[w], keys[w], arr[w], anc[w], dst[w], dcn[w], blockIdx.x == 0 && w == 0 ? P.k1.stats + K1_STAT_RTRACE + 7 : nullptr);
+#else
+    if (w < (u32)G) huff_build_wave(fr[w], S, lens[w], keys[w], arr[w], anc[w], dst[w], dcn[w]);
+#endif
+    __syncthreads();
+    K34_STAMP(1);
+    for (u32 i = tid; i < (u32)S; i += 1024) {
+        u64 v = 0;
+        for (int t = 0; t < G; t++) v |= (u64)lens[t][i] << (10 * t);
+        lens64[i] = v;
     }
     __syncthreads();
-    // canonical codes :581-600, one wave per table (lane 0 serial over <= 258 symbols)
-    if (w < (u32)G && lane == 0) {
-        u32 count[CJS_MAX_BITS + 2], next[CJS_MAX_BITS + 2];
-        for (int l = 0; l <= CJS_MAX_BITS + 1; l++) count[l] = 0;
-        for (int i = 0; i < S; i++) count[lens[w][i]]++;
-        u32 c = 0; int prev = 0;
-        for (int l = 1; l <= CJS_MAX_BITS; l++) {
-            if (!count[l]) continue;
-            c <<= (l - prev);
-            next[l] = c;
-            c += count[l];
-            prev = l;
+    {   // assignSelectors :671-684
+        u64 acc = 0;
+        walk_groups(A, q.pos, q.nSel, stage_w, k * 16u + w, 16u * K34_SPLIT,
+            [&](u32, u32 sym) { acc += lens64[sym]; },
+            [&](u32 gi) {
+                u32 best = 0, bc = (u32)(acc & 1023u);
+                for (int t = 1; t < G; t++) {
+                    const u32 c = (u32)((acc >> (10 * t)) & 1023u);
+                    if (c < bc) { best = (u32)t; bc = c; }
+                }
+                sel[gi] = (u8)best;
+                cost[gi] = (u16)bc;
+                acc = 0;
+            });
+    }
+    K34_STAMP(2);
+    if (G < q.target || k != 0) return;
+    // canonical codes :581-600, one wave per table: lane l owns code length l - it counts the symbols of that length, the
+    // first codes of the lengths in use chain through the wave (c <<= l - prev; next[l] = c; c += count[l]), then the lane
+    // hands out its codes in symbol order.
+    if (w < (u32)G) {
+        const int l = (int)lane;
+        const bool mine = l >= 1 && l <= CJS_MAX_BITS;
+        u32 count = 0;
+        if (mine) for (int i = 0; i < S; i++) count += lens[w][i] == l ? 1u : 0u;
+        u32 c = 0, first = 0; int prev = 0;
+        for (int ll = 1; ll <= CJS_MAX_BITS; ll++) {
+            const u32 cl = (u32)__shfl((int)count, ll);
+            if (!cl) continue;
+            c <<= (ll - prev);
+            if (ll == l) first = c;
+            c += cl;
+            prev = ll;
         }
         u32* codes = P.codes + ((size_t)b * CJS_MAX_GROUPS + w) * CJS_LEN_PITCH;
         u8* lout = P.lens + ((size_t)b * CJS_MAX_GROUPS + w) * CJS_LEN_PITCH;
-        for (int i = 0; i < S; i++) { const int l = lens[w][i]; codes[i] = next[l]++; lout[i] = (u8)l; }
+        if (mine && count) for (int i = 0; i < S; i++) if (lens[w][i] == l) codes[i] = first++;
+        for (int i = l; i < S; i += 64) lout[i] = lens[w][i];
     }
-    if (tid == 0) { P.ngroups[b] = (u32)G; P.nsel[b] = nSel; }
+    if (tid == 0) { P.ngroups[b] = (u32)G; P.nsel[b] = q.nSel; }
+    K34_STAMP(3);
+}
+
+__global__ __launch_bounds__(1024) void k34_split(Pipe P, u32 it) {
+    const BatchGeom g = P.g;
+    const u32 b = blockIdx.x / K34_SPLIT, k = blockIdx.x % K34_SPLIT;
+    if (P.nlen[b] == 0) return;
+    const K34Blk q = k34_blk(P, b);
+    const int G = 2 + (int)it;
+    if (G >= q.target) return;
+    const u32 tid = threadIdx.x, w = tid >> 6;
+    const u32 nSel = q.nSel;
+    const u16* A = P.A + (size_t)b * g.stride;
+    const u8* sel = P.sel + (size_t)b * P.selPitch;
+    const u16* cost = P.selCost + (size_t)b * P.selPitch;
+
+    HIP_DYNAMIC_SHARED(u32, pool)
+    __shared__ u32 fr[CJS_MAX_GROUPS][HB_PITCH];
+    __shared__ u32 chist[1024];
+    __shared__ u32 cnt[8];
+    __shared__ u32 scan_sh[20];
+    __shared__ u32 s_which, s_cstar, s_keep;
+    __shared__ __attribute__((aligned(16))) u8 selL[K34_MAX_SEL];
+    u32* stage_w = pool + w * K34_STAGE_WORDS;
+    K34_T0
+    // selectors and costs of ALL groups of the block into LDS (costs in the pool, which is free until the walk): the passes
+    // below touch them four times, the last one in per-thread runs; the selectors after the move stay in LDS for the recount
+    u16* costL = (u16*)pool;                               // [selPitch]
+    for (u32 i = tid; i < (nSel + 3u) >> 2; i += 1024) ((u32*)selL)[i] = ((const u32*)sel)[i];
+    for (u32 i = tid; i < (nSel + 1u) >> 1; i += 1024) ((u32*)costL)[i] = ((const u32*)cost)[i];
+    if (tid < 8) cnt[tid] = 0;
+    chist[tid] = 0;
+    for (u32 i = tid; i < (u32)(CJS_MAX_GROUPS * HB_PITCH); i += 1024) (&fr[0][0])[i] = 0;
+    __syncthreads();
+    for (u32 g0 = 0; g0 < nSel; g0 += 1024) {              // groups per table: one ballot per table and wave, one atomic per wave
+        const u32 gi = g0 + tid;
+        const u32 v = gi < nSel ? selL[gi] : 0xFFu;
+        for (int t = 0; t < G; t++) {
+            const u64 m = __ballot(v == (u32)t);
+            if ((tid & 63u) == 0 && m) atomicAdd(&cnt[t], (u32)__popcll(m));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {                                   // first most-used table :699
+        u32 wh = 0;
+        for (int t = 1; t < G; t++) if (cnt[t] > cnt[wh]) wh = (u32)t;
+        s_which = wh;
+    }
+    __syncthreads();
+    const u32 which = s_which;
+    for (u32 gi = tid; gi < nSel; gi += 1024)
+        if (selL[gi] == which) atomicAdd(&chist[costL[gi]], 1u);
+    __syncthreads();
+    {
+        // smallest c with (#groups of cost < c) + chist[c] > half: elements of stable rank >= half move (:705-716: a STABLE
+        // sort by cost, the upper half [len >>> 1, len) goes to the new table)
+        const u32 half = cnt[which] >> 1;             // :712
+        u32 tot;
+        const u32 mine = chist[tid];
+        const u32 lower = block_excl_scan_1024(mine, scan_sh, &tot);
+        if (lower <= half && half < lower + mine) { s_cstar = tid; s_keep = half - lower; }
+    }
+    __syncthreads();
+    {
+        const u32 cstar = s_cstar, keep = s_keep;
+        const u32 chunk = (nSel + 1023u) / 1024u;
+        const u32 lo = tid * chunk < nSel ? tid * chunk : nSel;
+        const u32 hi = lo + chunk < nSel ? lo + chunk : nSel;
+        u32 eq = 0;
+        for (u32 gi = lo; gi < hi; gi++) eq += (selL[gi] == which && costL[gi] == cstar) ? 1u : 0u;
+        u32 total;
+        u32 rank = block_excl_scan_1024(eq, scan_sh, &total);
+        for (u32 gi = lo; gi < hi; gi++) {
+            u32 v = selL[gi];
+            if (v == which) {
+                const u32 c = costL[gi];
+                if (c > cstar) v = (u32)G;
+                else if (c == cstar) { if (rank >= keep) v = (u32)G; rank++; }
+            }
+            selL[gi] = (u8)v;
+        }
+    }
+    __syncthreads();
+    K34_STAMP(4);
+    // recount :717-727.  A lane owns a group, i.e. one table row; the symbols below 8 (RUNA, RUNB and the first move-to-front
+    // ranks: most of what follows a BWT) are counted in eight byte lanes of a register and added once per group - 64 lanes
+    // adding 1 to the same three LDS words 50 times over was what this walk waited for.
+    {
+        u64 hot = 0;
+        walk_groups(A, q.pos, nSel, stage_w, k * 16u + w, 16u * K34_SPLIT,
+            [&](u32 gi, u32 sym) {
+                if (sym < 8u) hot += 1ull << (8u * sym);
+                else atomicAdd(&fr[selL[gi]][sym], 1u);
+            },
+            [&](u32 gi) {
+                u32* row = fr[selL[gi]];
+#pragma unroll
+                for (u32 sy = 0; sy < 8u; sy++) {
+                    const u32 c = (u32)(hot >> (8u * sy)) & 255u;
+                    if (c) atomicAdd(&row[sy], c);
+                }
+                hot = 0;
+            });
+    }
+    __syncthreads();
+    K34_STAMP(5);
+    u32* next = P.fr2 + ((size_t)b * 2 + ((it + 1u) & 1u)) * CJS_MAX_GROUPS * HB_PITCH;   // zeroed by k34_assign(it)
+    for (u32 i = tid; i < (u32)(CJS_MAX_GROUPS * HB_PITCH); i += 1024) {
+        const u32 v = (&fr[0][0])[i];
+        if (v) atomicAdd(&next[i], v);
+    }
+    K34_STAMP(6);
 }
 
 int k34_run(Pipe P, hipStream_t stream) {
     const size_t dyn = (size_t)16 * K34_STAGE_WORDS * 4;
-    static const bool lds_ok = hipFuncSetAttribute((const void*)k34_tables, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * K34_STAGE_WORDS * 4)) == hipSuccess;
-    if (!lds_ok) return CJS_E_HIP;
-    hipLaunchKernelGGL(k34_tables, dim3(P.g.nb), dim3(1024), dyn, stream, P);
+    static const bool lds_ok = hipFuncSetAttribute((const void*)k34_assign, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * K34_STAGE_WORDS * 4)) == hipSuccess
+                            && hipFuncSetAttribute((const void*)k34_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * K34_STAGE_WORDS * 4)) == hipSuccess;
+    if (!lds_ok || P.selPitch > K34_MAX_SEL) return CJS_E_HIP;
+    for (u32 it = 0; it + 2u <= CJS_MAX_GROUPS; it++) {
+        hipLaunchKernelGGL(k34_assign, dim3(P.g.nb * K34_SPLIT), dim3(1024), dyn, stream, P, it);
+        if (it + 3u <= CJS_MAX_GROUPS) hipLaunchKernelGGL(k34_split, dim3(P.g.nb * K34_SPLIT), dim3(1024), dyn, stream, P, it);
+    }
     HIP_CHECK_RET(hipGetLastError());
+#ifdef K34_TRACE
+    {
+        u32 h[10];
+        HIP_CHECK_RET(hipMemcpyAsync(h, P.k1.stats + K1_STAT_RTRACE, sizeof h, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK_RET(hipStreamSynchronize(stream));
+        fprintf(stderr, "k34 trace (us, block 0 / workgroup 0, summed over iterations): assign load %.1f build %.1f lens64+walk %.1f codes %.1f | split count/median/move %.1f recount %.1f flush %.1f | table 0: sort %.1f parents %.1f depths %.1f\n",
+                h[0] / 100.0, h[1] / 100.0, h[2] / 100.0, h[3] / 100.0, h[4] / 100.0, h[5] / 100.0, h[6] / 100.0, h[7] / 100.0, h[8] / 100.0, h[9] / 100.0);
+    }
+#endif
     return CJS_OK;
 }
 
 // ---- standalone allocator entry (HuffmanAllocator.allocateHuffmanCodeLengths, :199-222) ------
-// One lane per array; 64-bit cells because callers of the JS function may pass weights whose sum
-// exceeds 2^31 (the block pipeline above never does).
+// One wave per array (the same two steps as the tables of a block: parents on one lane, depths by the wave; arrays beyond
+// K3_WAVE_MAX cells stay on one lane); 64-bit cells because callers of the JS function may pass weights whose sum exceeds
+// 2^31 (the block pipeline above never does).
+#define K3_WAVE_MAX 2048
 __global__ __launch_bounds__(64) void k3_alloc_lengths(long long* arr, const u32* off, u32 count, int maxlen) {
-    const u32 t = blockIdx.x * 64u + threadIdx.x;
+    const u32 t = blockIdx.x;
     if (t >= count) return;
+    __shared__ int anc[K3_WAVE_MAX], dist[K3_WAVE_MAX], cnt[128];
     long long* a = arr + off[t];
     const int len = (int)(off[t + 1] - off[t]);
-    if (len == 2) { a[0] = 1; a[1] = 1; }                                   // :201-205
-    else if (len == 1) a[0] = 1;
-    else if (len > 2) ha_allocate<long long>(a, len, maxlen);
+    const bool one = threadIdx.x == 0;
+    if (len == 2) { if (one) { a[0] = 1; a[1] = 1; } }                       // :201-205
+    else if (len == 1) { if (one) a[0] = 1; }
+    else if (len > K3_WAVE_MAX || maxlen > HA_DCAP - 1) { if (one) ha_allocate<long long>(a, len, maxlen); }
+    else if (len > 2) {
+        if (one) ha_parents<long long>(a, len);
+        __syncthreads();
+        if (!ha_depths_wave<long long>(a, len, maxlen, anc, dist, cnt)) {
+            if (one) ha_depths_serial<long long>(a, len, maxlen);
+        }
+    }
 }
 int k3_alloc_lengths_run(long long* d_arr, const u32* d_off, u32 count, int maxlen, hipStream_t stream) {
-    hipLaunchKernelGGL(k3_alloc_lengths, dim3((count + 63) / 64), dim3(64), 0, stream, d_arr, d_off, count, maxlen);
+    hipLaunchKernelGGL(k3_alloc_lengths, dim3(count), dim3(64), 0, stream, d_arr, d_off, count, maxlen);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

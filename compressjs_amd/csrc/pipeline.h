@@ -53,6 +53,7 @@ struct Pipe {
     u32* ngroups;      // [nb]
     u32* nsel;         // [nb]
     u16* selCost;      // [nb][selPitch] best cost of every 50-symbol group (optimiser scratch)
+    u32* fr2;          // [nb][2][6][CJS_LEN_PITCH] frequency rows of the optimiser's tables, two sets used alternately
     // ---- K5
     u32* hdr;          // [nb][K5_HDR_WORDS] block header bits (magic .. code-length tables)
     u32* hbits;        // [nb]           header length in bits
