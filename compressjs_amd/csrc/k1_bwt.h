@@ -25,6 +25,8 @@
 #define K1F_NB 2048         // buckets per block (power of two; k1f_bsort / k1f_hist ms per 10^8 rotations: 512 buckets x 4096-rotation slots 8.5 / 0.36,
                             // 1024 x 2048 3.40 / 0.49, 2048 x 1024 2.72 / 0.64: smaller LDS footprint = more workgroups per CU for a latency-bound kernel)
 #endif
+#define K1F_LOG_NB (K1F_NB == 512 ? 9u : K1F_NB == 1024 ? 10u : K1F_NB == 2048 ? 11u : K1F_NB == 4096 ? 12u : 0u)
+static_assert(K1F_LOG_NB != 0u, "K1F_NB: 512, 1024, 2048 or 4096");
 #ifndef K1F_OVS
 #define K1F_OVS 8           // samples per bucket (K1F_NB * K1F_OVS u64 keys are sorted in LDS by one workgroup: 128 KB)
 #endif

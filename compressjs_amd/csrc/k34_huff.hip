@@ -258,10 +258,20 @@ __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32
         if (lane < K34_GROUPS_PER_CHUNK && gi < nSel) {
             const u32 cnt = pos - gi * CJS_GROUP < CJS_GROUP ? pos - gi * CJS_GROUP : CJS_GROUP;
             const u32* gw = stage_w + lane * 25u;
-            for (u32 k = 0; k < cnt; k += 2) {
-                const u32 wd = gw[k >> 1];
-                body(gi, wd & 0xFFFFu);
-                if (k + 1 < cnt) body(gi, wd >> 16);
+            if (cnt == CJS_GROUP) {
+                // a full group (all but the last of a block): the 25 staged words first, then 50 independent bodies - as a
+                // loop this was one dependent LDS round trip per pair of symbols (6 us per chunk)
+                u32 wd[CJS_GROUP / 2];
+#pragma unroll
+                for (int k = 0; k < CJS_GROUP / 2; k++) wd[k] = gw[k];
+#pragma unroll
+                for (int k = 0; k < CJS_GROUP / 2; k++) { body(gi, wd[k] & 0xFFFFu); body(gi, wd[k] >> 16); }
+            } else {
+                for (u32 k = 0; k < cnt; k += 2) {
+                    const u32 wd = gw[k >> 1];
+                    body(gi, wd & 0xFFFFu);
+                    if (k + 1 < cnt) body(gi, wd >> 16);
+                }
             }
             done(gi);
         }
