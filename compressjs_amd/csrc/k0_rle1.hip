@@ -53,26 +53,48 @@ __device__ __forceinline__ void load16(const K0Buf& K, u64 j0, u8* b) {
     }
 }
 
+// K0_TPW tiles per workgroup, all loads issued before anything is looked at (one tile per workgroup was 24 415 workgroups of
+// one HBM round trip each, 256 lanes then queueing on ONE LDS atomicMax: 99 us for 10^8 bytes at the head of every call).
+// A later thread's boundary is a later position, so the tile's last boundary is the answer of its highest lane that has one.
+#define K0_TPW 4u
 __global__ __launch_bounds__(256) void k0_tile_last(K0Buf K) {
-    const u64 t = blockIdx.x;
-    const u64 j0 = t * K0_TILE + threadIdx.x * 16u;
-    __shared__ unsigned long long last;
-    if (threadIdx.x == 0) last = K0_NONE;
-    __syncthreads();
-    u64 mine = K0_NONE;
-    if (j0 < K.in_len) {
-        u8 b[16];
-        load16(K, j0, b);
-        const u8 prev = j0 ? K.in[j0 - 1] : 0;
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    __shared__ u64 wl[K0_TPW][4];
+    u8 b[K0_TPW][16];
+    u8 prev[K0_TPW];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u64 j = j0 + k;
-            if (j < K.in_len && (j == 0 || b[k] != (k ? b[k - 1] : prev))) mine = j + 1;
+    for (u32 q = 0; q < K0_TPW; q++) {
+        const u64 j0 = ((u64)blockIdx.x * K0_TPW + q) * K0_TILE + tid * 16u;
+        prev[q] = 0;
+        if (j0 < K.in_len) {
+            load16(K, j0, b[q]);
+            if (j0) prev[q] = K.in[j0 - 1];
         }
     }
-    if (mine != K0_NONE) atomicMax(&last, (unsigned long long)mine);
+#pragma unroll
+    for (u32 q = 0; q < K0_TPW; q++) {
+        const u64 j0 = ((u64)blockIdx.x * K0_TPW + q) * K0_TILE + tid * 16u;
+        u64 mine = K0_NONE;
+        if (j0 < K.in_len) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const u64 j = j0 + k;
+                if (j < K.in_len && (j == 0 || b[q][k] != (k ? b[q][k - 1] : prev[q]))) mine = j + 1;
+            }
+        }
+        const u64 has = __ballot(mine != K0_NONE);
+        const u64 top = __shfl(mine, has ? 63 - __clzll((long long)has) : 0);
+        if (lane == 0) wl[q][w] = has ? top : K0_NONE;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) K.tileA[t] = last;
+    if (tid < K0_TPW) {
+        const u64 t = (u64)blockIdx.x * K0_TPW + tid;
+        if (t < K.ntiles) {
+            u64 last = K0_NONE;
+            for (u32 ww = 0; ww < 4u; ww++) if (wl[tid][ww] != K0_NONE) last = wl[tid][ww];
+            K.tileA[t] = last;
+        }
+    }
 }
 
 // ---- generic 3-phase exclusive scan over u64 (sum or max), chunk = 1024 elements ------------------
@@ -200,7 +222,8 @@ __global__ __launch_bounds__(256) void k0_tile_cost(K0Buf K) {
         else sub = sub == 254u ? 0u : sub + 1u;
         c += sub < 3u ? 1u : (sub == 3u ? 2u : 0u);
     }
-    atomicAdd(&tot, c);
+    const u32 wsum = wave_incl_scan_dpp(c);               // lane 63: the wave's sum (256 lanes on one LDS atomic queued)
+    if ((threadIdx.x & 63u) == 63u) atomicAdd(&tot, wsum);
     __syncthreads();
     if (threadIdx.x == 0) K.tileC[t] = tot;
 }
@@ -540,7 +563,7 @@ __global__ __launch_bounds__(64) void k0_pad(Pipe P) {
 __global__ __launch_bounds__(1024) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
     const u32 b = blockIdx.x, kb = first_block + b;
     if (kb >= *K.nBlocks) return;
-    __shared__ u32 tab[256];
+    __shared__ u32 tab[CRC_TAB_WORDS];
     __shared__ u32 pw[40];
     __shared__ u32 acc;
     const u32 c = crc_range_block(K.in, K.blkStart[kb], K.blkEnd[kb], tab, pw, &acc);
@@ -587,7 +610,7 @@ void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws) {
 // tile scans only: run starts (tileA / tileB) and the cost prefix C at every tile (tileC; tileC[ntiles] = the total)
 int k0_scans(K0Buf K, hipStream_t stream) {
     const u32 nt = (u32)K.ntiles, nc = (u32)K.nchunks;
-    hipLaunchKernelGGL(k0_tile_last, dim3(nt), dim3(256), 0, stream, K);
+    hipLaunchKernelGGL(k0_tile_last, dim3((nt + K0_TPW - 1u) / K0_TPW), dim3(256), 0, stream, K);
     HIP_CHECK_RET(hipMemcpyAsync(K.tileB, K.tileA, K.ntiles * 8, hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(k0_scan_local<true>, dim3(nc), dim3(256), 0, stream, K.tileA, K.chunk, K.ntiles);
     hipLaunchKernelGGL(k0_scan_chunks<true>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, (u64*)nullptr);

@@ -47,6 +47,19 @@ __device__ __forceinline__ u32 k1f_hash(u32 k, u32 b) {
 // ---------------------------------------------------------------------------------------------
 // splitters
 // ---------------------------------------------------------------------------------------------
+// The K1F_S samples are sorted by a bitonic network in LDS (1024 threads).  Round 3: every thread owns K1F_SE
+// consecutive cells, so the stages with j < K1F_SE run in registers (one load + one store per cell for log2(K1F_SE) stages),
+// and the stages above them go two at a time (four cells per step: j and j/2 in one LDS round trip); 105 LDS stages
+// with a barrier each became 11 register passes + 30 four-cell passes (165 -> 70 us, on every sub-batch's critical path).
+// Cells are padded by one per 16 so that the register passes (a thread's cells are 128 bytes apart) spread over the banks.
+#define K1F_SE (K1F_S / 1024u)                           // cells per thread
+#define K1F_SPAD(i) ((i) + ((i) >> 4))
+static_assert(K1F_SE == 4u || K1F_SE == 8u || K1F_SE == 16u, "k1f_sample: 4, 8 or 16 samples per thread");
+
+__device__ __forceinline__ void k1f_cmpx(u64& a, u64& c, bool up) {
+    if ((a > c) == up) { const u64 t = a; a = c; c = t; }
+}
+
 __global__ __launch_bounds__(1024) void k1f_sample(K1Buf B, BatchGeom g) {
     const u32 b = blockIdx.x;
     const u32 n = B.nlen[b];
@@ -56,31 +69,77 @@ __global__ __launch_bounds__(1024) void k1f_sample(K1Buf B, BatchGeom g) {
         for (u32 j = tid; j < K1F_NB; j += 1024) sp[j] = ~0ull;
         return;
     }
-    __shared__ u64 s[K1F_S];
+    __shared__ u64 s[K1F_S + K1F_S / 16u];
     const u8* T = B.T + (size_t)b * g.tstride;
     for (u32 k = tid; k < K1F_S; k += 1024) {
         const u32 lo = (u32)((u64)k * n / K1F_S), hi = (u32)((u64)(k + 1u) * n / K1F_S);
         const u32 p = hi > lo + 1u ? lo + k1f_hash(k, b) % (hi - lo) : lo;
-        s[k] = k1f_load_be64(T, p);
+        s[K1F_SPAD(k)] = k1f_load_be64(T, p);
     }
     __syncthreads();
-    for (u32 kk = 2; kk <= K1F_S; kk <<= 1) {
-        for (u32 j = kk >> 1; j > 0; j >>= 1) {
+    const u32 base = tid * K1F_SE;
+    u64 r[K1F_SE];
+    {   // phases kk = 2 .. K1F_SE entirely in registers
+#pragma unroll
+        for (u32 m = 0; m < K1F_SE; m++) r[m] = s[K1F_SPAD(base + m)];
+#pragma unroll
+        for (u32 kk = 2; kk <= K1F_SE; kk <<= 1)
+#pragma unroll
+            for (u32 j = kk >> 1; j >= 1u; j >>= 1)
+#pragma unroll
+                for (u32 m = 0; m < K1F_SE; m++)
+                    if ((m & j) == 0u) k1f_cmpx(r[m], r[m | j], ((base + m) & kk) == 0u);
+#pragma unroll
+        for (u32 m = 0; m < K1F_SE; m++) s[K1F_SPAD(base + m)] = r[m];
+    }
+    __syncthreads();
+    for (u32 kk = 2u * K1F_SE; kk <= K1F_S; kk <<= 1) {
+        u32 j = kk >> 1;
+        u32 nst = 0;                                      // LDS stages of this phase: j = kk/2 .. K1F_SE
+        for (u32 t = j; t >= K1F_SE; t >>= 1) nst++;
+        if (nst & 1u) {                                   // an odd one first, two cells per step
             for (u32 i = tid; i < K1F_S / 2; i += 1024) {
                 const u32 lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u)), hi = lo | j;
-                const bool up = (lo & kk) == 0;
-                const u64 a = s[lo], c = s[hi];
-                if ((a > c) == up) { s[lo] = c; s[hi] = a; }
+                u64 a = s[K1F_SPAD(lo)], c = s[K1F_SPAD(hi)];
+                const u64 a0 = a;
+                k1f_cmpx(a, c, (lo & kk) == 0u);
+                if (a != a0) { s[K1F_SPAD(lo)] = a; s[K1F_SPAD(hi)] = c; }
+            }
+            __syncthreads();
+            j >>= 1;
+        }
+        for (; j >= 2u * K1F_SE; j >>= 2) {               // stages j and j/2, four cells per step
+            const u32 h = j >> 1;
+            for (u32 qd = tid; qd < K1F_S / 4; qd += 1024) {
+                const u32 i0 = ((qd & ~(h - 1u)) << 2) | (qd & (h - 1u));
+                const bool up = (i0 & kk) == 0u;
+                u64 a = s[K1F_SPAD(i0)], c = s[K1F_SPAD(i0 | h)], d = s[K1F_SPAD(i0 | j)], e = s[K1F_SPAD(i0 | j | h)];
+                k1f_cmpx(a, d, up); k1f_cmpx(c, e, up);   // stage j
+                k1f_cmpx(a, c, up); k1f_cmpx(d, e, up);   // stage j / 2
+                s[K1F_SPAD(i0)] = a; s[K1F_SPAD(i0 | h)] = c; s[K1F_SPAD(i0 | j)] = d; s[K1F_SPAD(i0 | j | h)] = e;
             }
             __syncthreads();
         }
+        {   // stages K1F_SE / 2 .. 1 in registers (one direction per thread: kk > K1F_SE)
+            const bool up = (base & kk) == 0u;
+#pragma unroll
+            for (u32 m = 0; m < K1F_SE; m++) r[m] = s[K1F_SPAD(base + m)];
+#pragma unroll
+            for (u32 jj = K1F_SE >> 1; jj >= 1u; jj >>= 1)
+#pragma unroll
+                for (u32 m = 0; m < K1F_SE; m++)
+                    if ((m & jj) == 0u) k1f_cmpx(r[m], r[m | jj], up);
+#pragma unroll
+            for (u32 m = 0; m < K1F_SE; m++) s[K1F_SPAD(base + m)] = r[m];
+        }
+        __syncthreads();
     }
     for (u32 j = tid; j < K1F_NB; j += 1024) {
         u64 v = ~0ull;                                  // sp[K1F_NB-1] is padding (never compared)
         if (j + 1u < K1F_NB) {
-            const u64 q = s[(j + 1u) * K1F_OVS];
+            const u64 q = s[K1F_SPAD((j + 1u) * K1F_OVS)];
             v = q;
-            if (j >= 1u && s[j * K1F_OVS] == q && q != ~0ull) v = q + 1u;   // heavy key: [q, q+1) becomes a bucket of its own
+            if (j >= 1u && s[K1F_SPAD(j * K1F_OVS)] == q && q != ~0ull) v = q + 1u;   // heavy key: [q, q+1) becomes a bucket of its own
         }
         sp[j] = v;
     }

@@ -13,7 +13,7 @@
 //   k9_block_len   per block: exclusive tile offsets and the block's decoded size
 //   k9_expand      output-driven expansion: every output byte finds its source byte by binary
 //                  search over the tile's offsets in LDS (coalesced stores, any expansion ratio)
-//   k9_crc         CRC of the decoded bytes of every block (256 slices combined with x^(8m) mod P)
+//   k9_crc         CRC of the decoded bytes of every block (1024 slices combined with x^(8m) mod P)
 #include "decode.h"
 #include "crc_dev.h"
 
@@ -177,10 +177,10 @@ __global__ __launch_bounds__(256) void k9_expand_k(DecBuf D) {
     }
 }
 
-__global__ __launch_bounds__(256) void k9_crc(DecBuf D) {
+__global__ __launch_bounds__(1024) void k9_crc(DecBuf D) {
     const u32 kb = blockIdx.x;
     const u32 slot = D.slotOf[kb];
-    __shared__ u32 tab[256];
+    __shared__ u32 tab[CRC_TAB_WORDS];
     __shared__ u32 pw[40];
     __shared__ u32 acc;
     const u64 s = D.outOff[kb], e = s + D.blkOut[slot];
@@ -200,7 +200,7 @@ int k9_sizes(DecBuf D, u32 nvalid, hipStream_t stream) {
 int k9_expand(DecBuf D, u32 nvalid, hipStream_t stream) {
     if (!nvalid) return CJS_OK;
     hipLaunchKernelGGL(k9_expand_k, dim3(DEC_TILES, nvalid), dim3(256), 0, stream, D);
-    hipLaunchKernelGGL(k9_crc, dim3(nvalid), dim3(256), 0, stream, D);
+    hipLaunchKernelGGL(k9_crc, dim3(nvalid), dim3(1024), 0, stream, D);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
