@@ -2136,8 +2136,11 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             else hipLaunchKernelGGL((k1_deep<256, 64>), dim3(g.stride / 256u, (g.nb + 7u) & ~7u), dim3(64), 0, stream, B, g, deep_iters, deep_dbg, d0, bigrot_max);
         }
         // medium groups (9 .. K1_MED_MAX rotations) by text, 8 bytes per round; what they shed goes to the lane kernels' lists.
-        // CJS_DEEP_MED = rounds (default 8: depths d0 .. d0 + 56; 0 switches the stage off)
-        static const u32 med_rounds = []() -> u32 { const char* e = getenv("CJS_DEEP_MED"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v > 64u ? 64u : v; }();
+        // CJS_DEEP_MED = rounds (8: depths d0 .. d0 + 56).  Default 0 since round 3: the task levels of k1_front.hip sort these
+        // groups deeper than the stage did, and its 27 launches (an empty one is 5 us) sat on every sub-batch's critical path -
+        // 10^8-byte streams, ms per step with 8 / 0 rounds: enwik 10.13 / 9.94, E8S-A 19.65 / 19.07, random ASCII 9.86 / 9.70,
+        // E8S-B 12.72 / 12.60, text 9.00 / 8.72; the repetitive shapes of tests/gpu_perf_probe.py 1-25 % faster, none slower.
+        static const u32 med_rounds = []() -> u32 { const char* e = getenv("CJS_DEEP_MED"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 0u; return v > 64u ? 64u : v; }();
         // the stage (and the long walks of the lane kernels) only when at most 1/32 of the rotations sit in medium groups
         static const u32 med_div = []() -> u32 { const char* e = getenv("CJS_DEEP_MED_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 32u; return v ? v : 32u; }();
         const u32 medrot_max = (u32)(total_n / med_div);
