@@ -1119,7 +1119,9 @@ static_assert(K1R_ROWS % 4u == 0 && K1R_SW <= 64u && K1F_GBIG <= 256u, "rows are
 #define K1R_IDX(e) ((u32)((e) >> 40) & 0xFFu)
 #define K1R_LEN(e) (((u32)((e) >> 48) & 0xFFu) + 1u)
 #ifndef K1R_MINW
+#ifndef K1R_MINW
 #define K1R_MINW 4                                      // waves per SIMD the register allocation is held to
+#endif
 #endif
 
 __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g, u32 round, u32 depth, u32 final) {

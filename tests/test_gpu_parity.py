@@ -353,6 +353,33 @@ def test_compress_differential_fuzz_vs_oracle(ctx):
         assert got == oracle.bz2_compress(d, level), (case, level, total)
 
 
+def test_compress_periodic_and_tiled_streams_vs_oracle(ctx):
+    """Whole streams that are ONE pattern tiled (periods 1 .. 65 537 bytes: constant, 'ab', 44-byte lines, RLE1's own
+    4 + count period, a 30 kB text, periods around 255/256 and around the block capacity) at lengths around the block
+    boundaries: every rotation of such a block ties with its neighbours for most of the block, which is the doubling rounds'
+    worst case (17 full rounds) - the stream must still equal the oracle's bit for bit."""
+    rng = np.random.RandomState(20260926)
+    text = synth.text_like(70000, 77)
+    pats = [np.array([0], np.uint8), np.frombuffer(b"ab", np.uint8), np.frombuffer(b"the quick brown fox jumps over the lazy dog\n", np.uint8),
+            np.frombuffer(b"\0\0\0\0\xfb", np.uint8), rng.randint(0, 256, size=255).astype(np.uint8), rng.randint(97, 101, size=256).astype(np.uint8),
+            text[:1000], text[:30011], text[:65537], np.concatenate([np.full(300, 65, np.uint8), text[:700]])]
+    n = 0
+    for level in (1, 2):
+        cap = level * 100000 - 19
+        for pat in pats:
+            for total in (cap - 1, cap + 1, 2 * cap + 5, 3 * cap - 2):
+                if (n + level) % 3 == 0 and pat.size > 2:       # a third of the larger cases: enough, the oracle is the slow side
+                    n += 1
+                    continue
+                n += 1
+                d = np.tile(pat, total // pat.size + 1)[:total]
+                if n % 4 == 0:                                   # a foreign tail: the period breaks inside the last block
+                    d = d.copy()
+                    d[-37:] = rng.randint(0, 256, size=37)
+                got = ctx.compress(d, level)
+                assert got == oracle.bz2_compress(d, level), (level, pat.size, total)
+
+
 def test_bwtc_round_trip_fuzz(ctx):
     """BWTC.compressFile -> BWTC.decompressFile on random inputs, all levels (DefSum 1-5, Fenwick 6-9);
     encoder parity itself is pinned by the 26 reference-made BWTC streams above."""
