@@ -129,7 +129,8 @@ __device__ void ha_allocate(I* a, int len, int maxlen) {
 //      index falls to <= 1), no relocation iff parent(node 0) >= reloc (:114-124, :207-212),
 //   4. leaves per depth = 2 * nodes(depth - 1) - nodes(depth) (allocateNodeLengths :131-148: `avail` slots, minus the
 //      internal nodes, are leaves), handed out from the END of the sorted array, smallest depth first.
-// Returns false, with `a` untouched, when the tree is too deep: the caller runs the serial relocation path.
+//   5. a tree deeper than maxlen: the relocation branch (:157-188), level by level by the whole wave (see below).
+// Returns false, with `a` untouched, only for maxlen beyond HA_DCAP - 1: the caller then runs the serial path.
 // anc, dist: len ints each; cnt: 128 ints; all lanes of the wave call this.
 #define HA_DCAP 63
 template <typename I>
@@ -163,11 +164,56 @@ __device__ bool ha_depths_wave(I* a, int len, int maxlen, int* anc, int* dist, i
         const int dstar = low ? (int)__ffsll((long long)low) - 1 : 64;
         reloc = __shfl(start, dstar < maxlen - 2 ? dstar : maxlen - 2);
     }
-    const int deep = dist[0];                              // the first node made is the deepest; leaves reach deep + 1 <= maxlen
-    if (par0 < reloc) return false;
-    const int above = __shfl_up(c, 1);
-    const int nl = lane >= 1 ? 2 * above - c : 0;
-    cnt[64 + lane] = (int)wave_incl_scan_u32((u32)nl);     // leaves of depth <= lane
+    int deep = dist[0];                                    // the first node made is the deepest; leaves reach deep + 1 <= maxlen
+    if (par0 < reloc) {
+        // allocateNodeLengthsWithRelocation :157-188 with the wave walking the levels together: the one search per level
+        // (ha_first(a, len, last - 1, nodes_to_move) = the nodes whose parent lies below `last`, at least nodes_to_move)
+        // is a count over all nodes, the leaves of a level are noted and handed out at the end as in the other branch.
+        // Skewed alphabets (HTML, binaries: E8S-A) take this branch for most tables.
+        if (maxlen > HA_DCAP - 1) return false;
+        const int ntm = reloc;
+        int fl = 0;
+        for (u32 v = (u32)(reloc - 1); v; v >>= 1) fl++;                       // Util.fls
+        const int insert_depth = maxlen - fl;
+        int first = root;
+        int depth = insert_depth == 1 ? 2 : 1;
+        int left = insert_depth == 1 ? ntm - 2 : ntm;
+        cnt[64 + lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int avail = depth << 1; avail > 0; depth++) {
+            const int last = first;
+            if (first > ntm) {
+                int below = 0;
+                for (int k0 = 0; k0 < root; k0 += 64) {
+                    const int k = k0 + lane;
+                    below += (int)__popcll(__ballot(k < root && ha_mod(a[k], len) < last));
+                }
+                first = below > ntm ? below : ntm;
+            }
+            int offset = 0;
+            if (depth >= insert_depth) {
+                const int capv = 1 << (depth - insert_depth);
+                offset = left < capv ? left : capv;
+            } else if (depth == insert_depth - 1) {
+                offset = 1;
+                if (a[first] == (I)last) first++;
+            }
+            const int fill = avail - (last - first + offset);
+            if (lane == 0 && fill > 0) cnt[64 + depth] = fill;
+            left -= offset;
+            avail = (last - first + offset) << 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int f = cnt[64 + lane];
+        const int cum = (int)wave_incl_scan_u32((u32)f);
+        __builtin_amdgcn_wave_barrier();
+        cnt[64 + lane] = cum;
+        deep = depth - 2;                                  // the loop below looks at depths 1 .. deep; the last one used is depth - 1
+    } else {
+        const int above = __shfl_up(c, 1);
+        const int nl = lane >= 1 ? 2 * above - c : 0;
+        cnt[64 + lane] = (int)wave_incl_scan_u32((u32)nl); // leaves of depth <= lane
+    }
     __builtin_amdgcn_wave_barrier();
     for (int j = lane; j < len; j += 64) {
         const int r = len - j;                             // j-th smallest weight = r-th leaf from the end
