@@ -296,6 +296,9 @@ __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptile
 }
 #endif
 
+// Round 3: the tile's rotation indices are first put in bucket order in LDS (a counting sort with the ranks the LDS atomics
+// hand out), then written: the ~4 indices a tile has for a bucket are neighbours in SB and leave in one request instead of
+// four (one 4-byte write request per rotation was what the kernel waited for: 10^8 requests, 0.48 ms per 10^8 bytes).
 __global__ __launch_bounds__(1024) void k1f_scatter(K1Buf B, BatchGeom g, u32 ptiles) {
     u32 b, t;
     if (!xcd_block_tile(g.nb, b, t)) return;
@@ -303,26 +306,46 @@ __global__ __launch_bounds__(1024) void k1f_scatter(K1Buf B, BatchGeom g, u32 pt
     const u32 t0 = t * K1F_PT;
     if (t0 >= n) return;
     __shared__ u32 cnt[K1F_NB], base[K1F_NB];
+    __shared__ u32 stage[K1F_PT], dst[K1F_PT];
+    __shared__ u32 sh[20];
     const u32 tid = threadIdx.x;
     const u32* th = B.tileHist + ((size_t)b * ptiles + t) * K1F_NB;
     for (u32 d = tid; d < K1F_NB; d += 1024) { cnt[d] = 0; base[d] = th[d]; }
     __syncthreads();
     const u16* bid = (const u16*)(B.KA + (size_t)b * g.stride);
     u32* SB = B.SB + (size_t)b * g.stride;
-    u32 dv[K1F_PT / 1024];
+    u32 dv[K1F_PT / 1024], rk[K1F_PT / 1024];
 #pragma unroll
     for (int it = 0; it < K1F_PT / 1024; it++) {
         const u32 j = t0 + (u32)it * 1024u + tid;
         dv[it] = j < n ? bid[j] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int it = 0; it < K1F_PT / 1024; it++) {
-        const u32 j = t0 + (u32)it * 1024u + tid;
-        if (dv[it] != 0xFFFFFFFFu) {
-            const u32 r = atomicAdd(&cnt[dv[it]], 1u);
-            SB[base[dv[it]] + r] = j;
-        }
+    for (int it = 0; it < K1F_PT / 1024; it++)
+        if (dv[it] != 0xFFFFFFFFu) rk[it] = atomicAdd(&cnt[dv[it]], 1u);
+    __syncthreads();
+    {   // cnt[] -> first slot of every bucket in the tile's staging order
+        constexpr u32 R = K1F_NB >= 1024 ? K1F_NB / 1024 : 1;
+        const u32 d0 = tid * R;
+        u32 c[R], sum = 0;
+#pragma unroll
+        for (u32 r = 0; r < R; r++) { c[r] = d0 + r < K1F_NB ? cnt[d0 + r] : 0u; sum += c[r]; }
+        u32 total;
+        u32 run = block_excl_scan_1024(sum, sh, &total);
+#pragma unroll
+        for (u32 r = 0; r < R; r++) { if (d0 + r < K1F_NB) cnt[d0 + r] = run; run += c[r]; }
     }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < K1F_PT / 1024; it++)
+        if (dv[it] != 0xFFFFFFFFu) {
+            const u32 slot = cnt[dv[it]] + rk[it];
+            stage[slot] = t0 + (u32)it * 1024u + tid;
+            dst[slot] = base[dv[it]] + rk[it];
+        }
+    __syncthreads();
+    const u32 total = n - t0 < K1F_PT ? n - t0 : K1F_PT;
+    for (u32 slot = tid; slot < total; slot += 1024) SB[dst[slot]] = stage[slot];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -79,4 +79,7 @@ cd $R
 timeout 300 python tests/gpu_decode_probe.py 1000000000 2>&1 | grep decompress | tail -1 | tee $O/r03_decode_1e9.log
 timeout 300 python bench.py --codec bwtc 2>/dev/null | tail -1 > $O/r03_bench_bwtc.json; cut -c1-200 $O/r03_bench_bwtc.json
 [ -x build/gather ] && ./build/gather 2>/dev/null | grep -E "^gather|^walk" > $O/r03_gather_microbench.txt
+# 6. kernel timeline of the default two-stream flow (which kernels overlap, what is launch-bound): tests/timeline_report.py
+cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O -o r03_tl_enwik -- python $R/tests/gpu_r2_probe.py run enwik --reps 3 > $O/tl_enwik.log 2>&1
+cd $R && python tests/timeline_report.py $O/r03_tl_enwik_kernel_trace.csv --all > $O/r03_timeline_enwik.txt 2>&1; head -3 $O/r03_timeline_enwik.txt
 ls $O | head -80
