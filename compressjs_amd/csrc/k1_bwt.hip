@@ -370,6 +370,7 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
     __shared__ u32 hc[K1_HT / 32 + 4], hn[K1_HT / 32 + 4];
     __shared__ int prevh[64];
     __shared__ int inHead;
+    __shared__ u32 inHeadOld;                             // the head before the tile was a head in the previous round too
     __shared__ u32 red[2];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32* HC = B.HC + (size_t)b * g.hstride;
@@ -418,7 +419,10 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
                 }
             }
         }
-        if (lane == 0) inHead = found;
+        if (lane == 0) {
+            inHead = found;
+            inHeadOld = found >= 0 ? (HC[(u32)found >> 5] >> ((u32)found & 31u)) & 1u : 1u;
+        }
     }
     __syncthreads();
     u32* ISA = B.ISA + (size_t)b * g.stride;
@@ -441,13 +445,26 @@ __device__ __forceinline__ void update_ranks_tile(const K1Buf& B, const BatchGeo
         if (actc == 0) continue;                                      // wave-uniform
         const u32 q = q0 + lane;
         if ((actc >> lane) & 1u) {
+            // Heads are only ever added.  If the head this position now belongs to was a head in the previous round as well,
+            // every member of the old group already carries it as its rank (whichever member sits here now): nothing to
+            // write - the scattered 4-byte stores are what this kernel waits for (one write request each).  The pass before
+            // the first round (slot_out 0) builds the array and writes everything.
             const u32 wq = q >> 5;
             const u32 mask = hn[wq] & (0xFFFFFFFFu >> (31u - (q & 31u)));
-            u32 r;
-            if (mask) r = base + wq * 32u + 31u - (u32)__clz((int)mask);
-            else if (prevh[wq] >= 0) r = base + (u32)prevh[wq];
-            else r = (u32)inHead;
-            ISA[pre_s[it]] = r;
+            u32 r, old;
+            if (mask) {
+                const u32 bit = 31u - (u32)__clz((int)mask);
+                r = base + wq * 32u + bit;
+                old = (hc[wq] >> bit) & 1u;
+            } else if (prevh[wq] >= 0) {
+                const u32 pr = (u32)prevh[wq];
+                r = base + pr;
+                old = (hc[pr >> 5] >> (pr & 31u)) & 1u;
+            } else {
+                r = (u32)inHead;
+                old = inHeadOld;
+            }
+            if (slot_out == 0 || !old) ISA[pre_s[it]] = r;
         }
     }
     if (nact) atomicAdd(&red[1], nact);
