@@ -1379,7 +1379,8 @@ int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u
     for (u32 r = 0; r < rounds; r++) {
         // the lists shrink from round to round (text: by a quarter to a third): later rounds launch fewer workgroups, each walks
         // its share of the tiles (an empty workgroup still costs its dispatch)
-        u32 tiles = (full >> r) / 8u;                 // a workgroup walks ~8 tiles (software pipeline), later rounds fewer
+        static const u32 tdiv = []() -> u32 { const char* e = getenv("CJS_RTILE_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();
+        u32 tiles = (full >> r) / tdiv;               // a workgroup walks ~8 tiles (software pipeline), later rounds fewer
         if (tiles < 16u) tiles = 16u;
         hipLaunchKernelGGL(k1r_round, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
     }
