@@ -1942,21 +1942,35 @@ __global__ void k1_sp_reset(K1Buf B, int parity) {
 // ---------------------------------------------------------------------------------------------
 // BWT gather (lib/BWT.js:407-414)
 // ---------------------------------------------------------------------------------------------
+// Four suffix-array entries per thread: one 16-byte load, four text gathers in flight, one 4-byte store (round 3; one entry per
+// thread was 4x the workgroups and a byte store each).
 __global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g) {
     u32 b, tt;
     if (!xcd_block_tile(g.nb, b, tt)) return;
     const u32 n = B.nlen[b];
-    const u32 p = tt * 256u + threadIdx.x;
-    if (p >= n) return;
+    const u32 p0 = (tt * 256u + threadIdx.x) * 4u;
+    if (p0 >= n) return;
     const u8* T = B.T + (size_t)b * g.tstride;
-    const u32 s = B.SA[(size_t)b * g.stride + p];
-    B.U[(size_t)b * g.stride + p] = T[s == 0 ? n - 1 : s - 1];
-    if (s == 0) B.pidx[b] = p;
+    const u32* SA = B.SA + (size_t)b * g.stride;
+    u8* U = B.U + (size_t)b * g.stride;
+    if (p0 + 4u <= n) {
+        const uint4 v = *(const uint4*)(SA + p0);          // stride is a multiple of 4 entries: 16-byte aligned
+        const u32 s[4] = {v.x, v.y, v.z, v.w};
+        u32 out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            out |= (u32)T[s[k] == 0 ? n - 1 : s[k] - 1] << (8 * k);
+            if (s[k] == 0) B.pidx[b] = p0 + (u32)k;
+        }
+        *(u32*)(U + p0) = out;
+    } else {
+        for (u32 p = p0; p < n; p++) {
+            const u32 s = SA[p];
+            U[p] = T[s == 0 ? n - 1 : s - 1];
+            if (s == 0) B.pidx[b] = p;
+        }
+    }
 }
-
-// linear mode: BWT.bwtransform (lib/BWT.js:328-350 + computeBWT :153-192) and BWT.suffixsort:
-//   U[0] = T[n-1]; ranks r of suffixes != 0 give T[SA[r]-1], shifted by one below the rank of
-//   suffix 0; pidx = that rank + 1.  SAout (optional) receives the suffix array itself.
 __global__ __launch_bounds__(256) void k1_finish_linear(K1Buf B, BatchGeom g, int* SAout) {
     const u32 b = blockIdx.y;
     const u32 n = B.nlen[b];
@@ -2310,7 +2324,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     g_k1_last_sparse_rounds = sparse_rounds;
     g_k1_last_rounds = round;
     if (B.linear) hipLaunchKernelGGL(k1_finish_linear, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g, B.SAout);
-    else hipLaunchKernelGGL(k1_finish, dim3((max_n + 255) / 256, (g.nb + 7u) & ~7u), dim3(256), 0, stream, B, g);
+    else hipLaunchKernelGGL(k1_finish, dim3((max_n + 1023) / 1024, (g.nb + 7u) & ~7u), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
