@@ -14,7 +14,7 @@ first = [i for i, k in enumerate(K) if k[2] == K[0][2]]
 # steps: a new step starts where the gap to the previous kernel's end exceeds 300 us
 steps, cur, last_end = [], [], None
 for k in K:
-    if last_end is not None and k[0] - last_end > 30_000 and k[2] == 'k0_tile_last' and cur:
+    if last_end is not None and k[2] == 'k0_tile_last' and cur:
         steps.append(cur); cur = []
     cur.append(k); last_end = max(last_end or 0, k[1])
 if cur: steps.append(cur)
