@@ -532,11 +532,12 @@ __device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u3
                         for (u32 i = gs; i < ge; i += 4u) {
                             u64 c0[4];
                             u32 c1[4];
+                            // four cells in a row, read as pairs (ds_read2): cells past the group's end are read too and masked
+                            // below - the arrays end in four spare cells.  (Clamping the index kept every read on its own.)
 #pragma unroll
                             for (u32 u = 0; u < 4u; u++) {
-                                const u32 ii = i + u < ge ? i + u : ge - 1u;
-                                c0[u] = S.k0[ii];
-                                c1[u] = S.k1[ii];
+                                c0[u] = S.k0[i + u];
+                                c1[u] = S.k1[i + u];
                             }
 #pragma unroll
                             for (u32 u = 0; u < 4u; u++) {
@@ -805,7 +806,7 @@ __device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, co
                 for (u32 j = o; j < e; j += 4u) {
                     u64 c[4];
 #pragma unroll
-                    for (u32 u = 0; u < 4u; u++) c[u] = key[j + u < e ? j + u : e - 1u];
+                    for (u32 u = 0; u < 4u; u++) c[u] = key[j + u];     // (past the leaf's end: masked below; key[] has four spare cells)
 #pragma unroll
                     for (u32 u = 0; u < 4u; u++) {
                         const bool in = j + u < e;
@@ -831,8 +832,8 @@ __device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, co
 
 // The __shared__ arrays of a bucket-sort workgroup and their views (macro: __shared__ must be declared in the kernel)
 #define K1F_DECLARE_LDS(S, Q)                                                                                                        \
-    __shared__ u64 key[K1F_C];                                                                                                       \
-    __shared__ u32 key1[K1F_C];                                                                                                      \
+    __shared__ u64 key[K1F_C + 4];                                                                                                   \
+    __shared__ u32 key1[K1F_C + 4];                                                                                                  \
     __shared__ u32 sx[K1F_C];                                                                                                        \
     __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];                                                     \
     __shared__ u32 misc[K1F_E * K1F_NW + 8];                                                                                         \
