@@ -432,6 +432,27 @@ __device__ __forceinline__ u32 k1f_next_head(const u32* hb, u32 q) {
     return w * 32u + (u32)__ffs((int)m) - 1u;
 }
 
+// bits q and q + 1 of a bitmap (bit 0 / bit 1 of the result) from ONE read of two adjacent words, and the group around q
+// (largest head <= q, smallest head > q) starting from that same read: k1f_bsort is bound by its LDS instruction stream,
+// and the probes `bit(q) && bit(q + 1)`, prev_head(q), next_head(q) were four to five reads of the same two words.
+__device__ __forceinline__ u32 k1f_bits2(const u32* hb, u32 q) {
+    const u32 w = q >> 5;
+    const u64 v = (u64)hb[w] | ((u64)hb[w + 1u] << 32);
+    return (u32)(v >> (q & 31u)) & 3u;
+}
+__device__ __forceinline__ void k1f_group(const u32* hb, u32 q, u32& gs, u32& ge) {
+    const u32 w = q >> 5;
+    const u32 w0 = hb[w], w1 = hb[w + 1u];
+    u32 m = w0 & (0xFFFFFFFFu >> (31u - (q & 31u)));
+    u32 ww = w;
+    while (!m) m = hb[--ww];
+    gs = ww * 32u + 31u - (u32)__clz((int)m);
+    u32 m2 = (q & 31u) == 31u ? 0u : (w0 & (0xFFFFFFFEu << (q & 31u)));
+    ww = w;
+    if (!m2) { m2 = w1; ww = w + 1u; while (!m2) m2 = hb[++ww]; }
+    ge = ww * 32u + (u32)__ffs((int)m2) - 1u;
+}
+
 // LDS of a bucket-sort workgroup (views into the kernel's __shared__ arrays)
 struct K1fS {
     u64* k0;        // [K1F_C]  key, first 8 bytes (position order)
@@ -498,8 +519,8 @@ __device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u3
             for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 128u) {
                 const u32 qa = r0 + lane, qb = r0 + 64u + lane;
                 const bool ina = qa < hi[j], inb = qb < hi[j];
-                const bool acta = ina && !(k1f_bit(S.hb, qa) && k1f_bit(S.hb, qa + 1u)) && !k1f_bit(S.fb, qa);
-                const bool actb = inb && !(k1f_bit(S.hb, qb) && k1f_bit(S.hb, qb + 1u)) && !k1f_bit(S.fb, qb);
+                const bool acta = ina && k1f_bits2(S.hb, qa) != 3u && !k1f_bit(S.fb, qa);
+                const bool actb = inb && k1f_bits2(S.hb, qb) != 3u && !k1f_bit(S.fb, qb);
                 u64 ka = 0, kb = 0;
                 u32 la = 0, lb = 0;
                 if (acta) { u32 p = S.sx[qa] + dm; if (p >= n) p -= n; k1f_load_be96(T, p, ka, la); }
@@ -521,7 +542,8 @@ __device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u3
                 const bool act = q < hi[j] && S.nqp[q] == K1F_NQ_PEND;
                 if (__ballot(act) == 0ull) continue;
                 if (act) {
-                    const u32 gs = k1f_prev_head(S.hb, q), ge = k1f_next_head(S.hb, q);
+                    u32 gs, ge;
+                    k1f_group(S.hb, q, gs, ge);
                     const u64 m0 = S.k0[q];
                     const u32 m1 = S.k1[q];
                     if (ge - gs > K1F_GBIG) {
@@ -628,8 +650,10 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
             }
             const u32 q = q0 + lane;
             bool listed = false;
-            if (q < cnt && !(k1f_bit(S.hb, q) && k1f_bit(S.hb, q + 1u))) {
-                const u32 gs = k1f_prev_head(S.hb, q), gl = k1f_next_head(S.hb, q) - gs;
+            if (q < cnt && k1f_bits2(S.hb, q) != 3u) {
+                u32 gs, ge_;
+                k1f_group(S.hb, q, gs, ge_);
+                const u32 gl = ge_ - gs;
                 listed = gl <= K1F_GBIG && !k1f_bit(S.fb, q);
                 gsv[it] = (q - gs) | ((gl - 1u) << 8);
                 // a group this workgroup could not split (above K1F_GBIG rotations, or frozen): a task of the next level
