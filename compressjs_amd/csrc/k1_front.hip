@@ -432,6 +432,8 @@ __device__ __forceinline__ u32 k1f_next_head(const u32* hb, u32 q) {
     return w * 32u + (u32)__ffs((int)m) - 1u;
 }
 
+struct alignas(16) K1fPair { u64 x, y; };             // two LDS cells in one 16-byte read
+
 // bits q and q + 1 of a bitmap (bit 0 / bit 1 of the result) from ONE read of two adjacent words, and the group around q
 // (largest head <= q, smallest head > q) starting from that same read: k1f_bsort is bound by its LDS instruction stream,
 // and the probes `bit(q) && bit(q + 1)`, prev_head(q), next_head(q) were four to five reads of the same two words.
@@ -748,10 +750,16 @@ __device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, co
             const u64 mine = Q.smp[si];
             const u32 per = LS / parts, j0 = part * per;
             u32 r = 0;
-#pragma unroll 8
-            for (u32 j = j0; j < j0 + per; j++) {
-                const u64 o = Q.smp[j];
-                r += (o < mine || (o == mine && j < si)) ? 1u : 0u;
+            if (per >= 2u) {                              // (per is a power of two: two samples per 16-byte read)
+#pragma unroll 4
+                for (u32 j = j0; j < j0 + per; j += 2u) {
+                    const K1fPair o = *(const K1fPair*)&Q.smp[j];
+                    r += (o.x < mine || (o.x == mine && j < si)) ? 1u : 0u;
+                    r += (o.y < mine || (o.y == mine && j + 1u < si)) ? 1u : 0u;
+                }
+            } else {
+                const u64 o = Q.smp[j0];
+                r += (o < mine || (o == mine && j0 < si)) ? 1u : 0u;
             }
             atomicAdd(&Q.srank[si], r);
         }
@@ -862,7 +870,7 @@ __device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, co
     __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];                                                     \
     __shared__ u32 misc[K1F_E * K1F_NW + 8];                                                                                         \
     /* scratch: the local sample sort (samples, splitters, ranks) and, later, the deepening's new positions */                     \
-    __shared__ u64 scr64[256];                                                                                                       \
+    __shared__ __attribute__((aligned(16))) u64 scr64[256];                                                                          \
     static_assert((2 * K1F_LK + 4) * 4 + K1F_C <= K1F_C * 4, "leaf bookkeeping fits key1[]");                                        \
     static_assert((K1F_LS + K1F_LK) * 8 + K1F_LS * 4 <= 256 * 8 && K1F_C * 2 <= 256 * 8 && K1F_C >= 256 && K1F_C < 0x7FF0,            \
                   "scratch: samples + splitters + ranks, later K1F_C u16 new positions");                                            \
