@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     u32* ocnt = B.rcnt + (size_t)(round + 1u) * B.rstride + b;
     u32* SA = B.SA + (size_t)b * g.stride;
     u32* HN = B.HN + (size_t)b * g.hstride;
-    __shared__ u64 kA[K1R_N], kB[K1R_N], kC[K1R_N];
+    __shared__ u64 kA[K1R_N + 2], kB[K1R_N + 2], kC[K1R_N + 2];   // (+2: the ranking loop reads cells in pairs, one past a group's end)
     __shared__ u32 sb[2][K1R_SW], pre[2][K1R_SW + 1];
     __shared__ u32 obase;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
@@ -1292,10 +1292,9 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
                     u64 c0[2], c1[2], c2[2];
 #pragma unroll
                     for (u32 u = 0; u < 2u; u++) {
-                        const u32 jj = j + u < ge ? j + u : ge - 1u;
-                        c0[u] = kA[jj];
-                        c1[u] = kB[jj];
-                        c2[u] = kC[jj];
+                        c0[u] = kA[j + u];                // pairs (ds_read2_b64); the cell past the group's end is masked below
+                        c1[u] = kB[j + u];
+                        c2[u] = kC[j + u];
                     }
 #pragma unroll
                     for (u32 u = 0; u < 2u; u++) {
