@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     u64 eC[K1R_RPW], eN[K1R_RPW], eNN[K1R_RPW];
     u32 dC[K1R_RPW][7];
     u64 pv_e[K1R_RPW];                                  // survivors of the previous tile: their new entries ...
-    u32 pv_i[K1R_RPW];                                  // ... and slots relative to the tile's reservation (~0: none)
+    u32 pv_q[K1R_RPW];                                  // ... and their positions in the tile's survivor bitmap (~0: none)
     u32 abase = 0, par = 0;
     bool pv_valid = false;
     u32 tc = t0;
@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     load_tile(tc, eC);
     load_tile(tc + G, eN);
 #pragma unroll
-    for (u32 it = 0; it < K1R_RPW; it++) { pv_e[it] = 0; pv_i[it] = 0xFFFFFFFFu; }
+    for (u32 it = 0; it < K1R_RPW; it++) { pv_e[it] = 0; pv_q[it] = 0xFFFFFFFFu; }
     gather(eC, dC);
     for (; tc * K1R_T < cnt; tc += G) {
 #ifdef K1F_TRACE
@@ -1264,12 +1264,15 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
         if (tid == 0 && pv_valid) obase = abase;
         lds_barrier();
         K1R_STAMP(0);
-        // 3. the previous tile's survivors to the next round's list
+        // 3. the previous tile's survivors to the next round's list: slot = survivors before it in that tile's bitmap (the
+        //    other parity: counted by wave 0 after the previous step's ranking; this step's first barrier made it visible -
+        //    a barrier of its own for that cost 15 % of the kernel)
         if (pv_valid && !final) {
 #pragma unroll
             for (u32 it = 0; it < K1R_RPW; it++)
-                if (pv_i[it] != 0xFFFFFFFFu) {
-                    const u32 idx = obase + pv_i[it];
+                if (pv_q[it] != 0xFFFFFFFFu) {
+                    const u32 q = pv_q[it];
+                    const u32 idx = obase + pre[par ^ 1u][q >> 5] + (u32)__popc(sb[par ^ 1u][q >> 5] & ((1u << (q & 31u)) - 1u));
                     if (idx < g.stride) Lout[idx] = pv_e[it];
                 }
         }
@@ -1283,7 +1286,6 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
             qn[it] = 0xFFFFFFFFu;
-            pv_i[it] = 0xFFFFFFFFu;
             if (own(eC[it], i)) {
                 const u32 gs = i - K1R_IDX(eC[it]), ge = gs + K1R_LEN(eC[it]);
                 const u64 m0 = kA[i], m1 = kB[i], m2 = kC[i];
@@ -1340,14 +1342,9 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
             const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
             if (lane == 0) abase = total ? atomicAdd(ocnt, total) : 0u;
         }
-        lds_barrier();
         K1R_STAMP(3);
 #pragma unroll
-        for (u32 it = 0; it < K1R_RPW; it++)
-            if (qn[it] != 0xFFFFFFFFu) {
-                const u32 q = qn[it];
-                pv_i[it] = pre[par][q >> 5] + (u32)__popc(sb[par][q >> 5] & ((1u << (q & 31u)) - 1u));
-            }
+        for (u32 it = 0; it < K1R_RPW; it++) pv_q[it] = qn[it];
         K1R_STAMP(4);
         // 7. rotate
 #pragma unroll
@@ -1365,8 +1362,9 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
         lds_barrier();
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++)
-            if (pv_i[it] != 0xFFFFFFFFu) {
-                const u32 idx = obase + pv_i[it];
+            if (pv_q[it] != 0xFFFFFFFFu) {
+                const u32 q = pv_q[it];
+                const u32 idx = obase + pre[par ^ 1u][q >> 5] + (u32)__popc(sb[par ^ 1u][q >> 5] & ((1u << (q & 31u)) - 1u));
                 if (idx < g.stride) Lout[idx] = pv_e[it];
             }
     }
