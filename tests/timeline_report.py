@@ -19,6 +19,8 @@ for k in K:
     cur.append(k); last_end = max(last_end or 0, k[1])
 if cur: steps.append(cur)
 S = [st for st in steps if any(k[2] == 'k1f_bsort' for k in st)][-1]
+ends = [i for i, k in enumerate(S) if k[2] == 'k5_end']       # the call ends with k5_end (+ the read-back of the stream state)
+if ends: S = S[:min(len(S), ends[0] + 2)]
 t0 = S[0][0]
 span = max(k[1] for k in S) - t0
 print('kernels %d span %.3f ms' % (len(S), span / 1e6))
