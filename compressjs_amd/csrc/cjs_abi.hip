@@ -364,9 +364,10 @@ extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
     c->device = device;
     c->batch_blocks = batch_blocks ? batch_blocks : 128;
     // Two streams by default, each driven by its own host thread (issue_blocks): the latency-bound kernels of one half of
-    // the batch (k34_tables: one workgroup per block, the sparse rounds, the small scans, K1's read-backs) overlap with
+    // the batch (K3/K4: four workgroups per block, the sparse rounds, the small scans, K1's read-backs) overlap with
     // the bandwidth-bound ones of the other.  Measured, 10^8 bytes, ms per step with 1 / 2 / 3 / 4 streams: enwik
-    // 14.86 / 14.35 / 14.73 / 17.72, E8S-A 23.94 / 21.45 / 21.90 / 27.48, random ASCII 12.81 / 12.07 / 12.58 / 15.35.
+    // 14.86 / 14.35 / 14.73 / 17.72, E8S-A 23.94 / 21.45 / 21.90 / 27.48, random ASCII 12.81 / 12.07 / 12.58 / 15.35 (round 2;
+    // round 3, enwik: one stream 9.4, two 8.7, three 8.7, four 11.6 - the main stream and four more share four hardware queues).
     // CJS_STREAMS=1 gives every kernel the GPU to itself: what per-kernel timings (bench.py's roofline leg, rocprof
     // summaries) are taken with.
     c->nstreams = batch_blocks && batch_blocks < 32 ? 1 : 2;
