@@ -479,18 +479,22 @@ def test_deep_refinement_variants_same_bytes(ctx):
         "import numpy as np\n"
         "from compressjs_amd import synth\n"
         "from compressjs_amd.bzip2 import Context\n"
-        "d = np.concatenate([synth.enwik_like(24_000_000, 2025), synth.runs_mixed(1_000_000, 2), synth.periodic(900_000, b'abcab'),\n"
+        "d = np.concatenate([synth.enwik_like(16_000_000, 2025), synth.runs_mixed(1_000_000, 2), synth.periodic(900_000, b'abcab'),\n"
         "                    np.tile(synth.text_like(70_000, 3), 20)])\n"
         "c = Context(0, 32)\n"
         "print(hashlib.sha256(c.compress(d, 9)).hexdigest(), hashlib.sha256(c.compress(d[:9_000_000], 4)).hexdigest())\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
+    # (round 3: the round-2 flow, no / two in-bucket iterations, the medium-group stage back on, one and three streams,
+    # unequal shares of a batch, the text stages forced on / off by the predictor's threshold)
     for env_add in ({"CJS_DEEP_ITERS": "0"}, {}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "3"}, {"CJS_SORT_BYTES": "8"},
-                    {"CJS_SORT_BYTES": "6"}, {"CJS_SORT_BYTES": "8", "CJS_DEEP_ITERS": "0"}):
+                    {"CJS_SORT_BYTES": "6"}, {"CJS_SORT_BYTES": "8", "CJS_DEEP_ITERS": "0"},
+                    {"CJS_ROUNDS": "0"}, {"CJS_BSORT_ITERS": "0", "CJS_DEEP_MED": "8"}, {"CJS_BSORT_ITERS": "2", "CJS_STREAMS": "1"},
+                    {"CJS_SHARES": "300:700", "CJS_DEEP_BIG_DIV": "1"}, {"CJS_DEEP_BIG_DIV": "1000000", "CJS_SPARSE_DIV": "1"}):
         env = dict(os.environ, **env_add)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
     assert all(o == outs[0] for o in outs), outs
-    d = synth.enwik_like(24_000_000, 2025)
+    d = synth.enwik_like(16_000_000, 2025)
     a = ctx.compress(d[:2_700_000], 9)
     assert a == oracle.bz2_compress(d[:2_700_000], 9)
 
