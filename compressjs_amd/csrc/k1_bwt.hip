@@ -2242,7 +2242,8 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
     }
     int round = 0;
-    const u32 large_grid = g.nb * 4 < 1024 ? (g.nb * 4 < 64 ? 64 : g.nb * 4) : 1024;
+    static const u32 lgm = []() -> u32 { const char* e = getenv("CJS_LARGE_MUL"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();   // (workgroups of k1_sort_large per block: 4 -> 8, 44-byte period 29.7 -> 26.9 ms per 5*10^7 bytes)
+    const u32 large_grid = g.nb * lgm < 1024 ? (g.nb * lgm < 64 ? 64 : g.nb * lgm) : 1024;
     int parity = 0;
     // If a doubling round splits no group, the classes "equal h-prefix" and "equal 2h-prefix" coincide, and
     // then so do all later ones (s ~2h s' gives s+h ~h s'+h = s+h ~2h s'+h, i.e. s+2h ~h s'+2h): what is left are
