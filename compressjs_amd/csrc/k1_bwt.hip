@@ -1129,18 +1129,23 @@ __global__ __launch_bounds__(DNT, 4) void k1_deep(K1Buf B, BatchGeom g, u32 iter
 // PASS2 = true: those survivors with the long cap - only if there are at most `limit` of them (decided here, on the
 // device: tiled / periodic inputs have ALL their rotations in such groups, and walking 4 KB for each costs more than
 // the rank rounds that sort them otherwise: 200 kB of text tiled 29 -> 81 ms when tried).
+// Round 3: when at most limit / 8 groups are left (one per 2048 positions), the second pass walks them up to K1_DEEP_LONG_CAP bytes
+// instead of capd: a handful of long duplicated passages (E8S-B: 28 775 pairs that tie for up to 16 kB) otherwise costs the whole
+// rank machinery - k1_update_ranks' 10^8 scattered stores and a dozen sparse rounds, 1.4 ms per 10^8 bytes - for 57 550 rotations.
+#define K1_DEEP_LONG_CAP 60000u
 template <bool PASS2>
-__device__ __forceinline__ bool deep_pass2_wanted(const K1Buf& B, u32 limit) {
+__device__ __forceinline__ bool deep_pass2_wanted(const K1Buf& B, u32 limit, u32& capd) {
     if (!PASS2) return true;
     u32 t = 0;
     for (u32 i = threadIdx.x & 63u; i < 2u * 8u * K1_DEEP_SUB; i += 64u) t += B.deepCnt[2u * 8u * K1_DEEP_SUB + i];
     for (u32 off = 32; off > 0; off >>= 1) t += __shfl_xor(t, (int)off);
+    if (t <= limit / 8u && capd < K1_DEEP_LONG_CAP) capd = K1_DEEP_LONG_CAP;
     return t <= limit;
 }
 
 template <bool PASS2>
 __global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 capd, u32 limit) {
-    if (!deep_pass2_wanted<PASS2>(B, limit)) return;
+    if (!deep_pass2_wanted<PASS2>(B, limit, capd)) return;
     // gridDim.x is a multiple of 8 * K1_DEEP_SUB: workgroup -> (XCD region, sub-region, slice of the sub-region)
     const u32 xr = (blockIdx.x & 7u) * K1_DEEP_SUB + ((blockIdx.x >> 3) & (K1_DEEP_SUB - 1u));
     const u32 r = blockIdx.x / (8u * K1_DEEP_SUB), nr = gridDim.x / (8u * K1_DEEP_SUB);
@@ -1174,7 +1179,7 @@ __global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 c
 // equal keys (own depth per run) until the group is resolved or a run ties up to capd (left as it is).
 template <bool PASS2>
 __global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 capd, u32 limit) {
-    if (!deep_pass2_wanted<PASS2>(B, limit)) return;
+    if (!deep_pass2_wanted<PASS2>(B, limit, capd)) return;
     __shared__ u64 lk[K1_DEEP_LANE * 256];
     __shared__ u32 lv[K1_DEEP_LANE * 256];
     __shared__ u16 ld[K1_DEEP_LANE * 256];
