@@ -288,10 +288,23 @@ __global__ __launch_bounds__(256) void k2_emit(Pipe P) {
     u16* A = P.A + (size_t)b * g.stride;
     // thread owns 16 consecutive runs
     const u32 r0 = t0 + tid * 16u;
+    // MTF indices and run boundaries of the thread's 16 runs in five vector loads, kept for both walks (round 3: they were 16 + 32
+    // scalar loads, 16 or 64 bytes apart from lane to lane - a request per lane and load - and read twice)
+    u8 jb[16];
+    u32 rp[17];
+    const bool full = r0 + 16u <= nr;                                 // (RHpos[nr] is the sentinel k2_scan_tiles wrote)
+    if (full) {
+        __builtin_memcpy(jb, __builtin_assume_aligned(J + r0, 16), 16);
+        __builtin_memcpy(rp, __builtin_assume_aligned(RHpos + r0, 4), 68);
+    } else {
+        for (int k = 0; k < 16; k++) { jb[k] = r0 + k < nr ? J[r0 + k] : 0; rp[k] = r0 + k <= nr ? RHpos[r0 + k] : 0u; }
+        rp[16] = r0 + 16u <= nr ? RHpos[r0 + 16u] : 0u;
+    }
     u32 mine = 0;
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 r = r0 + k;
-        if (r < nr) { u32 z; mine += run_symbols(J[r], RHpos[r + 1] - RHpos[r], z); }
+        if (r < nr) { u32 z; mine += run_symbols(jb[k], rp[k + 1] - rp[k], z); }
     }
     if (r0 <= nr - 1 && nr - 1 < r0 + 16u) mine += 1u;                 // EOB
     const u32 ex = block_excl_scan_256(mine, sh);
@@ -301,12 +314,13 @@ __global__ __launch_bounds__(256) void k2_emit(Pipe P) {
     const bool staged = total <= K2_STAGE;
     const u32 tile_off = P.symCnt[(size_t)b * g.rtiles + t];
     u32 off = ex;                                                      // tile-relative
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 r = r0 + k;
         if (r >= nr) break;
-        const u32 j = J[r];
+        const u32 j = jb[k];
         u32 z;
-        run_symbols(j, RHpos[r + 1] - RHpos[r], z);
+        run_symbols(j, rp[k + 1] - rp[k], z);
 #define K2_PUT(sym) do { if (staged) stage[off] = (u16)(sym); else A[tile_off + off] = (u16)(sym); off++; atomicAdd(&hist[(sym)], 1u); } while (0)
         if (j) K2_PUT(j + 1u);
         while (z) {                                   // lib/Bzip2.js:783-794

@@ -309,10 +309,24 @@ __global__ __launch_bounds__(256) void k5_pack(Pipe P) {
     const u16* A = P.A + (size_t)b * g.stride;
     const u8* sel = P.sel + (size_t)b * P.selPitch;
     const u32 i0 = t0 + tid * 16u;
+    // The thread's 16 symbols in two 16-byte loads and its (at most two) selectors in two byte loads, kept for both walks
+    // (round 3: 16 + 16 two-byte loads 32 bytes apart from lane to lane, twice over, were 64 requests per load instruction).
+    u32 aw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) aw[k] = 0;
+    const u32 g0 = i0 / CJS_GROUP, gb = (g0 + 1u) * CJS_GROUP;        // symbols below gb use selector g0, the others g0 + 1
+    u32 s0 = 0, s1 = 0;
+    if (i0 < pos) {
+        if (i0 + 16u <= pos) __builtin_memcpy(aw, __builtin_assume_aligned(A + i0, 16), 32);
+        else for (u32 k = 0; i0 + k < pos; k++) aw[k >> 1] |= (u32)A[i0 + k] << (16u * (k & 1u));
+        s0 = sel[g0];
+        if (gb < i0 + 16u && gb < pos) s1 = sel[g0 + 1u];
+    }
     u32 mine = 0;
+#pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 i = i0 + k;
-        if (i < pos) mine += lens[sel[i / CJS_GROUP]][A[i]];
+        if (i < pos) mine += lens[i < gb ? s0 : s1][(aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
     }
     const u32 ex = block_excl_scan_256(mine, sh);
     if (i0 >= pos) return;
@@ -323,7 +337,7 @@ __global__ __launch_bounds__(256) void k5_pack(Pipe P) {
     for (int k = 0; k < 16; k++) {
         const u32 i = i0 + k;
         if (i >= pos) break;
-        const u32 gsel = sel[i / CJS_GROUP], sym = A[i];
+        const u32 gsel = i < gb ? s0 : s1, sym = (aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
         const u32 l = lens[gsel][sym];
         acc = (acc << l) | codes[gsel][sym];
         nacc += l;
