@@ -263,7 +263,10 @@ __global__ __launch_bounds__(256) void k2_symcount(Pipe P) {
         const u32 r = t0 + k * 256u + threadIdx.x;
         if (r < nr) { u32 z; c += run_symbols(J[r], RHpos[r + 1] - RHpos[r], z); }
     }
-    atomicAdd(&tot, c);
+    {   // one LDS atomic per wave (256 lanes on one word queued)
+        const u32 ws = wave_sum_dpp(c);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(&tot, ws);
+    }
     __syncthreads();
     if (threadIdx.x == 0) P.symCnt[(size_t)b * g.rtiles + t] = tot;
 }

@@ -226,7 +226,10 @@ __global__ __launch_bounds__(256) void k5_lensum(Pipe P) {
         const u32 i = t0 + k * 256u + tid;
         if (i < pos) c += lens[sel[i / CJS_GROUP]][A[i]];
     }
-    atomicAdd(&tot, c);
+    {   // one LDS atomic per wave (256 lanes on one word queued)
+        const u32 ws = wave_sum_dpp(c);
+        if ((threadIdx.x & 63u) == 0u) atomicAdd(&tot, ws);
+    }
     __syncthreads();
     if (tid == 0) P.tileBits[(size_t)b * g.rtiles + t] = tot;
 }
