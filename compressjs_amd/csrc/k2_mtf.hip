@@ -213,17 +213,43 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
         __builtin_amdgcn_wave_barrier();
         if (valid) occ[w][c] = 0;
         u32 idx = 0;
+        // Symbols that do not occur in the step: their last occurrence is the table entry, and it can only be later than p for a
+        // run head whose own previous occurrence lies BEFORE the step (p >= base beats every table entry).  Those run heads are the
+        // first occurrences of the step's distinct symbols - a dozen lanes: for each of them the count over all such symbols is
+        // four ballots (lane l of Lr[k] holds symbol 64 k + l).  Round 3; the loop over every symbol of the alphabet that this
+        // replaces was 85 (text) to 240 (binaries) iterations per step whoever needed them.
+        u64 need = __ballot(valid && own == 0ull);
+        u32 nrest = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) nrest += (u32)__popcll(usedw[k] & ~occm[k]);
+        // (one iteration per first occurrence here costs about four of the iterations per absent symbol below: random ASCII has
+        // 60 first occurrences per step and 95 symbols, text a dozen and 95, binaries two dozen and 250)
+        const bool by_lane = (u32)__popcll(need) * 4u < nrest;
+        if (by_lane) {
+            while (need) {                                 // wave-uniform
+                const int j = __ffsll((long long)need) - 1;
+                need &= need - 1;
+                const int pj = __builtin_amdgcn_readlane(p, j);
+                u32 c2 = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) c2 += (u32)__popcll(__ballot(Lr[k] > pj) & usedw[k] & ~occm[k]);
+                if ((int)lane == j) idx = c2;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                u64 um = usedw[k] & ~occm[k];
+                while (um) {                               // wave-uniform
+                    const int sl = __ffsll((long long)um) - 1;
+                    um &= um - 1;
+                    idx += (__builtin_amdgcn_readlane(Lr[k], sl) > p) ? 1u : 0u;
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            // symbols that do not occur in the step: their last occurrence is the table entry
-            u64 um = usedw[k] & ~occm[k];
-            while (um) {                                   // wave-uniform
-                const int sl = __ffsll((long long)um) - 1;
-                um &= um - 1;
-                idx += (__builtin_amdgcn_readlane(Lr[k], sl) > p) ? 1u : 0u;
-            }
             // symbols that occur: last occurrence before my lane from the ballot, else the table
-            um = occm[k];
+            u64 um = occm[k];
             while (um) {
                 const int sl = __ffsll((long long)um) - 1;
                 um &= um - 1;
