@@ -661,7 +661,7 @@ static int64_t compress_segmented(cjs_ctx* c, const uint8_t* in, uint64_t in_len
             }
             void** kws = seg & 1 ? &c->planws : &c->k0ws;            // alternate: the previous segment's tables may still be read
             size_t* kwb = seg & 1 ? &c->planws_bytes : &c->k0ws_bytes;
-            if (seg & 1) { c->plan_level = 0; c->plan_blocks = 0; }  // a cjs_bz2_plan result does not survive this call
+            if (seg & 1) { c->plan_level = 0; c->plan_blocks = 0; c->scan_level = 0; }  // a cjs_bz2_plan / _plan_scan result does not survive this call
             rci = grow(kws, kwb, k0_bytes(eoff - s, cap));
             if (rci) { rc = rci; goto done; }
             K0Buf K;
@@ -930,6 +930,7 @@ extern "C" int64_t cjs_bz2_plan(cjs_ctx* c, const void* d_in, uint64_t in_len, i
     const u32 cap = (u32)level * 100000u - 19u;
     c->plan_level = 0;                               // no valid plan while this one is being made
     c->plan_blocks = 0;
+    c->scan_level = 0;                               // c->plan is re-carved: an earlier cjs_bz2_plan_scan's tables are gone
     int rc = grow(&c->planws, &c->planws_bytes, k0_bytes(in_len, cap));
     if (rc) return rc;
     k0_carve(c->plan, (const u8*)d_in, in_len, cap, c->planws);

@@ -17,6 +17,7 @@
 // The "stable sort + take upper half" is done without sorting: a cost histogram finds the
 // median cost c*, and an ordered prefix count decides which groups with cost == c* stay.
 #include "pipeline.h"
+#include <atomic>
 
 #define HB_PITCH 264
 #ifdef K34_TRACE
@@ -566,9 +567,17 @@ __global__ __launch_bounds__(1024) void k34_split(Pipe P, u32 it) {
 
 int k34_run(Pipe P, hipStream_t stream) {
     const size_t dyn = (size_t)16 * K34_STAGE_WORDS * 4;
-    static const bool lds_ok = hipFuncSetAttribute((const void*)k34_assign, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * K34_STAGE_WORDS * 4)) == hipSuccess
-                            && hipFuncSetAttribute((const void*)k34_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * K34_STAGE_WORDS * 4)) == hipSuccess;
-    if (!lds_ok || P.selPitch > K34_MAX_SEL) return CJS_E_HIP;
+    // per device (cjs_bz2_compress_multi runs contexts on several devices from one process): set once for each device id that
+    // comes by, and retried on the next call if it failed
+    static std::atomic<unsigned> lds_set[64];
+    int dev = 0;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || !lds_set[dev].load(std::memory_order_acquire)) {
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)k34_assign, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * K34_STAGE_WORDS * 4)));
+        HIP_CHECK_RET(hipFuncSetAttribute((const void*)k34_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * K34_STAGE_WORDS * 4)));
+        if (dev >= 0 && dev < 64) lds_set[dev].store(1u, std::memory_order_release);
+    }
+    if (P.selPitch > K34_MAX_SEL) return CJS_E_ARG;
     for (u32 it = 0; it + 2u <= CJS_MAX_GROUPS; it++) {
         hipLaunchKernelGGL(k34_assign, dim3(P.g.nb * K34_SPLIT), dim3(1024), dyn, stream, P, it);
         if (it + 3u <= CJS_MAX_GROUPS) hipLaunchKernelGGL(k34_split, dim3(P.g.nb * K34_SPLIT), dim3(1024), dyn, stream, P, it);

@@ -273,8 +273,11 @@ def plan_bases(meta, level: int):
             delta = _g(ink + lh) - _g(ink) - _g(lh)          # the head run costs what the tail of a longer run costs
             if ink + lh >= 4:
                 # a run of four or more bytes straddles the slice start: this rank's own prefix is wrong inside it, so no
-                # block boundary may fall into its cost span
-                c0, c1 = G, G + _g(ink + lh) - _g(ink)
+                # block boundary may fall into its cost span - measured from the run's FIRST byte (in an earlier slice), not
+                # from the slice start: a boundary on the run's first byte restarts the run in the new block, and the previous
+                # rank plans exactly that block, while this rank (phase 0, no run check at its own first byte) would emit a
+                # second block at its slice start (norun(99981) + 'A' * 10 + norun(99979) cut at 99986, level 1)
+                c0, c1 = G - _g(ink), G + _g(ink + lh) - _g(ink)
                 if c0 // cap != c1 // cap or c0 % cap == 0 or c1 % cap == 0:
                     ok = False
         base = G + delta                                     # G(lo + i) = base + C_own(i) beyond the head run
@@ -301,10 +304,10 @@ def sharded_compress_parallel(ctx, d_win: torch.Tensor, own_len: int, lo: int, t
       2. ONE all_gather (7 integers per rank) gives every rank the stream's cost prefix at its slice start, hence the phase
          of the block boundaries inside its slice: it plans the blocks that START in its slice (cjs_bz2_plan_phase) and
          encodes them, the margin completing the last one;
-      3. a second all_gather (bits, CRC fold, block count: the one the other drivers have too) carries the flag "could not
-         plan on my own" (a boundary inside a run of four or more equal bytes, a block longer than the margin, a boundary
-         run longer than 4 KB): if any rank raises it, all fall back to `fallback()` (a callable that runs one of the other
-         drivers), else segments are shifted, sent and assembled as before.
+      3. one all_reduce of a flag "could not plan on my own" (a boundary inside a run of four or more equal bytes, a block
+         longer than the margin, a boundary run longer than 4 KB, any local error): if any rank raises it, all fall back to
+         `fallback()` (a callable that runs one of the other drivers), else the (bits, CRC fold, block count) all_gather of
+         the other drivers follows and segments are shifted, sent and assembled as before.
     Returns the stream on rank 0, None elsewhere."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -333,19 +336,25 @@ def sharded_compress_parallel(ctx, d_win: torch.Tensor, own_len: int, lo: int, t
     mark("all_gather summaries")
     phase, ok = plan_bases([(m[0], m[1], m[2], m[3], m[4], m[5], bool(m[6])) for m in meta], level)[rank]
     nb = -1
-    if ok:
-        nb = ctx.plan_phase(own_len, phase, lo + own_len >= total)
-    mark("plan")
-    bad = nb < 0
     bits, fold, cnt = 0, 0, 0
-    if not bad and nb:
-        if seg is None:
-            seg = torch.zeros((own_len + margin_bytes(level)) * 3 // 2 + (1 << 20), dtype=torch.uint8, device=dev)
-        bits, fold, cnt = ctx.encode_blocks(0, nb, seg)
-    elif seg is None:
+    # a local failure of any kind becomes the fall-back flag: every rank must reach the collective below, or the others hang
+    # (ADVICE r3); the fall-back driver then raises the same error on this rank where every rank sees it
+    try:
+        if ok:
+            nb = ctx.plan_phase(own_len, phase, lo + own_len >= total)
+        mark("plan")
+        if nb > 0:
+            if seg is None:
+                seg = torch.zeros((own_len + margin_bytes(level)) * 3 // 2 + (1 << 20), dtype=torch.uint8, device=dev)
+            bits, fold, cnt = ctx.encode_blocks(0, nb, seg)
+    except Exception:                                        # noqa: BLE001
+        nb = -1
+    bad = nb < 0
+    if seg is None:
         seg = torch.zeros(1 << 12, dtype=torch.uint8, device=dev)
     mark("encode")
-    # the flag travels with the (bits, fold, count) all_gather of the assembly: bits = -1
+    # one small all_reduce carries the flag "could not plan on my own" (it precedes the assembly's all_gather: a rank that
+    # falls back never enters _assemble)
     flag = torch.tensor([1 if bad else 0], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)

@@ -172,6 +172,37 @@ def test_parallel_plan_equals_serial_plan():
             else:
                 refused += 1
         assert accepted >= 8 and refused >= 1, (accepted, refused)
+        # a block boundary exactly on (and around) the first byte of a run that straddles a cut: the serial plan
+        # is [0, 99981, ...]; the slice that starts inside the run must refuse or agree, never add a block at its own start
+        cap1 = 99981
+        swept = 0
+        for pre in range(cap1 - 3, cap1 + 4):
+            for runlen, into in ((10, 5), (10, 1), (4, 2), (7, 6), (300, 5)):
+                d = np.concatenate([synth.lcg_ascii(pre, 3), np.full(runlen, 65, np.uint8), synth.lcg_ascii(cap1 - 2, 4)])
+                d[pre - 1], d[pre + runlen] = 66, 67                   # the run is exactly runlen long
+                cut = pre + into
+                n = d.size
+                t = torch.from_numpy(d)
+                nser = ctx.plan(t, level)
+                serial = [ctx.plan_block_start(k) for k in range(nser)]
+                meta = []
+                for lo, hi in ((0, cut), (cut, n)):
+                    w = t[lo:min(n, hi + margin_bytes(level))]
+                    ctx.plan_scan(w, level)
+                    meta.append((hi - lo, ctx.plan_cost(hi - lo)) + _edge_runs(w[:hi - lo]))
+                got, ok_all = [], True
+                for (lo, hi), (phase, ok) in zip(((0, cut), (cut, n)), plan_bases(meta, level)):
+                    w = t[lo:min(n, hi + margin_bytes(level))]
+                    ctx.plan_scan(w, level)
+                    nb = ctx.plan_phase(hi - lo, phase, hi == n) if ok else -1
+                    if nb < 0:
+                        ok_all = False
+                        break
+                    got += [lo + ctx.plan_block_start(k) for k in range(nb)]
+                if ok_all:
+                    assert got == serial, (pre, runlen, into, got, serial)
+                swept += 1
+        assert swept == 35
         ctx.close()
     finally:
         _lib._lib = saved
