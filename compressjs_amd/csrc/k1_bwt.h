@@ -16,6 +16,17 @@
 #define K1F_LEVELS 14u          // task levels of the front end (two per 8 bytes of depth: partition, then sort)
 #define K1_STAT_RTRACE 128      // stats[128..135]: K1F_TRACE builds, stage clocks of k1r_round
 #define K1_STATS 144
+// list entries of the refinement rounds (k1r_round) and the doubling rounds (k1_dbl.hip): one per rotation that still ties,
+// a group = consecutive entries:  (group length - 1) << 52 | index in the group << 44 | rotation index << 22 | suffix-array position
+#define K1E_POS(e) ((u32)(e) & 0x3FFFFFu)
+#define K1E_S(e) ((u32)((e) >> 22) & 0x3FFFFFu)
+#define K1E_IDX(e) ((u32)((e) >> 44) & 0xFFu)
+#define K1E_LEN(e) (((u32)((e) >> 52) & 0xFFu) + 1u)
+#define K1E_KEEP (1ull << 60)          // doubling rounds: the rotation's rank (= position of its group head) did not change this round
+#define K1E_MAKE(len1, idx, s, pos) (((u64)(len1) << 52) | ((u64)(idx) << 44) | ((u64)(s) << 22) | (u64)(pos))
+// doubling rounds (k1_dbl.hip)
+#define K1D_MAXR 24            // rounds at most (h0 >= 8, n < 2^22: 19 doublings + the tie-break round)
+#define K1D_GS 256u            // groups up to this size are list entries (ranked by counting inside a tile); larger ones are descriptors
 #define K1_DM_SUB 64u      // sub-lists per class of the medium rounds (one counter each: a single counter serialises millions of appends)
 #define K1_SPREAD 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS
@@ -86,6 +97,10 @@ struct K1Buf {
     u64* rlist[2];    // [nb][stride]   refinement rounds (k1r_round): entries of the rotations that still tie, in/out
     u32* rcnt;        // [K1R_MAXR + 1][rstride]  entries per round and block
     u32 rstride;
+    u32* dcnt;        // [K1D_MAXR + 2][rstride]  doubling rounds: list entries per round and block
+    u32* dchg;        // [K1D_MAXR + 2][rstride]  != 0: a group of the block split in that round (none: only identical rotations are left)
+    u32* dtot;        // [rstride]                positions in unsorted groups per block before the doubling rounds (k1_count_unsorted)
+    u32* dbn;         // [K1D_MAXR + 2][4]        per round: descriptors of medium groups, of large groups, chunks
     uint4* btask;     // [K1F_LEVELS][btaskCap]  task levels of the front end (k1f_task): (block, position, length, depth | flag)
     u32* bcnt;        // [K1F_LEVELS]            tasks per level
     u32 btaskCap;
@@ -104,5 +119,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
 // K1-deep tile kernel does that work); purerot_max: the predictor threshold (see k1f_bsort)
 int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max);
 int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth);
+// k1_dbl.hip: ranks of every rotation from (SA, HN), then list-driven prefix doubling from depth h0 until every group is resolved
+int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h0);
 #define K1F_STEP 12u           // text bytes per in-bucket iteration / refinement round: what ONE 16-byte aligned load yields at any alignment
 size_t k1_front_tilehist_words(const BatchGeom& g);   // u32 per block the front end needs in tileHist

@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include "devutil.h"
 #include <stdlib.h>
+#include <vector>
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     if (b == 0) for (u32 i = gid; i < 32u * 2u * K1_SPREAD; i += gridDim.x * blockDim.x) B.spread[i] = 0;
     if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rstride; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
     if (b == 0 && gid < K1F_LEVELS) B.bcnt[gid] = 0;
+    if (b == 0) for (u32 i = gid; i < 2u * (K1D_MAXR + 2u) * B.rstride + B.rstride + (K1D_MAXR + 2u) * 4u; i += gridDim.x * blockDim.x) B.dcnt[i] = 0;   // dcnt, dchg, dtot, dbn (contiguous)
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
         u32 w;
@@ -1459,6 +1461,7 @@ __global__ __launch_bounds__(256) void k1_count_unsorted(K1Buf B, BatchGeom g) {
     if (threadIdx.x == 0) {
         const u32 t = part[0] + part[1] + part[2] + part[3];
         if (t) atomicAdd(&B.spread[((size_t)K1_COUNT_SLOT * 2 + 1) * K1_SPREAD + ((blockIdx.x * 29u + b) & (K1_SPREAD - 1u))], t);
+        if (t) atomicAdd(&B.dtot[b], t);                  // per block, for k1d_build (at most ~110 adds per word)
     }
 }
 
@@ -2021,6 +2024,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
     tot += 2 * al256((size_t)g.nb * (g.stride / K1_MED_MAX + 1) * 8);   // listL cur/next
     tot += 2 * al256(e * 8);                                   // rlist in/out
     tot += al256((size_t)(K1R_MAXR + 1) * ((g.nb + 7u) & ~7u) * 4);   // rcnt
+    tot += al256(((size_t)(2u * (K1D_MAXR + 2u) + 1u) * ((g.nb + 7u) & ~7u) + (K1D_MAXR + 2u) * 4u) * 4);   // dcnt, dchg, dtot, dbn
     tot += al256((size_t)K1F_LEVELS * g.nb * (g.stride / 256) * sizeof(uint4)) + 256;   // btask, bcnt
     return tot;
 }
@@ -2063,6 +2067,11 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     B.rlist[1] = (u64*)p; p += al256(e * 8);
     B.rstride = (g.nb + 7u) & ~7u;
     B.rcnt = (u32*)p; p += al256((size_t)(K1R_MAXR + 1) * B.rstride * 4);
+    B.dcnt = (u32*)p;
+    B.dchg = B.dcnt + (size_t)(K1D_MAXR + 2u) * B.rstride;
+    B.dtot = B.dchg + (size_t)(K1D_MAXR + 2u) * B.rstride;
+    B.dbn = B.dtot + B.rstride;
+    p += al256(((size_t)(2u * (K1D_MAXR + 2u) + 1u) * B.rstride + (K1D_MAXR + 2u) * 4u) * 4);
     B.btaskCap = g.nb * (g.stride / 256);
     B.btask = (uint4*)p; p += al256((size_t)K1F_LEVELS * B.btaskCap * sizeof(uint4));
     B.bcnt = (u32*)p;
@@ -2153,11 +2162,6 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const size_t hbytes = (size_t)g.nb * g.hstride * 4;
     const u64 total_n = (u64)g.nb * max_n;
     static const bool k1_trace = getenv("CJS_K1_TRACE") != nullptr;
-    static const u64 sparse_div = []() -> u64 { const char* e = getenv("CJS_SPARSE_DIV"); const u64 v = e ? strtoull(e, nullptr, 10) : 8; return v ? v : 8; }();
-    static const u64 sparse_min = []() -> u64 {              // tests lower this to reach the sparse phase
-        const char* e = getenv("CJS_SPARSE_MIN");
-        return e ? (u64)strtoull(e, nullptr, 10) : (u64)(1u << 20);
-    }();
     static const u32 deep_tile = []() -> u32 { const char* e = getenv("CJS_DEEP_TILE"); return e ? (u32)strtoul(e, nullptr, 10) : 256u; }();
     static const u32 deep_dbg = []() -> u32 { const char* e = getenv("CJS_DEEP_DBG"); return e ? (u32)strtoul(e, nullptr, 10) : 0u; }();   // timing experiments: 1 = no phase 1, 2 = no phase 2
     const bool deep = deep_iters > 0 && !B.linear;
@@ -2225,108 +2229,47 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             hipLaunchKernelGGL(k1_deep_small<true>, dim3(lane_grid), dim3(256), 0, stream, B, g, lane_cap, limit);
         }
     }
-    const bool early = deep && total_n >= sparse_min;
-    bool sparse = false, all_sorted = false;
-    u64 unsorted0 = 0;                         // rotations in unsorted groups before the first rank pass (when counted)
-    if (!B.linear && total_n >= sparse_min) {
-        // nothing left to sort?  (one tiny kernel + a 512-byte read-back; the rank pass it can save costs 1.1 ms per 10^8)
-        static thread_local u32 cnt0[K1_SPREAD];
-        hipLaunchKernelGGL(k1_count_unsorted, dim3((g.hstride + 255u) / 256u, g.nb), dim3(256), 0, stream, B, g);
-        HIP_CHECK_RET(hipMemcpyAsync(cnt0, B.spread + ((size_t)K1_COUNT_SLOT * 2 + 1) * K1_SPREAD, sizeof cnt0, hipMemcpyDeviceToHost, stream));
+    // What still ties after the stages above (long repeats, identical rotations, groups the text stages did not take; in linear
+    // mode and on the A/B paths everything beyond the first d0 bytes): k1_count_unsorted finds the blocks that hold groups,
+    // k1_dbl.hip ranks their rotations and runs the list-driven doubling rounds from h = d0 - every group shares at least the
+    // d0 bytes of the first sort.  No counter is read back: blocks without groups cost nothing but the launches.
+    hipLaunchKernelGGL(k1_count_unsorted, dim3((g.hstride + 255u) / 256u, g.nb), dim3(256), 0, stream, B, g);
+    // The one read-back K1 keeps (CJS_K1_SYNC=0: none): when no block holds a group - the text stages finished the batch, the
+    // usual case on text - the ~90 launches of the doubling stage (4.6 us each when they find their lists empty: 0.35 ms per
+    // 10^8 bytes, measured) are not enqueued at all.  Everything after this point is steered on the device.
+    static const bool k1_sync = []() { const char* e = getenv("CJS_K1_SYNC"); return !e || atoi(e) != 0; }();
+    bool any_group = true;
+    if (k1_sync && !B.linear) {
+        std::vector<u32> tt(g.nb);
+        HIP_CHECK_RET(hipMemcpyAsync(tt.data(), B.dtot, (size_t)g.nb * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK_RET(hipStreamSynchronize(stream));
-        u64 c = 0;
-        for (u32 i = 0; i < K1_SPREAD; i++) c += cnt0[i];
-        if (k1_trace) fprintf(stderr, "[k1] rotations in unsorted groups before the first rank pass: %llu (of %llu)\n", (unsigned long long)c, (unsigned long long)total_n);
-        all_sorted = c == 0;
-        unsorted0 = c;
+        any_group = false;
+        for (u32 bb = 0; bb < g.nb; bb++) any_group = any_group || tt[bb] != 0u;
     }
-    // K1-deep ran and little is left: the first rank pass also emits the descriptor lists and the doubling rounds START sparse
-    const bool sparse0 = early && !all_sorted && unsorted0 * sparse_div < total_n;
-    if (!all_sorted) {
-        hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, 0, sparse0 ? 1 : 0);
-        { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
+    if (any_group) {
+        const int rc = k1_dbl_run(B, g, max_n, stream, d0);
+        if (rc) return rc;
     }
-    int round = 0;
-    static const u32 lgm = []() -> u32 { const char* e = getenv("CJS_LARGE_MUL"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();   // (workgroups of k1_sort_large per block: 4 -> 8, 44-byte period 29.7 -> 26.9 ms per 5*10^7 bytes)
-    const u32 large_grid = g.nb * lgm < 1024 ? (g.nb * lgm < 64 ? 64 : g.nb * lgm) : 1024;
-    int parity = 0;
-    // If a doubling round splits no group, the classes "equal h-prefix" and "equal 2h-prefix" coincide, and
-    // then so do all later ones (s ~2h s' gives s+h ~h s'+h = s+h ~2h s'+h, i.e. s+2h ~h s'+2h): what is left are
-    // identical rotations, and only the tie-break round (descending index) remains to be run.  Periodic and
-    // tiled inputs reach that state after a few rounds instead of ceil(log2(n/8)).
-    bool force_final = false;                  // (decided in tile rounds only: their two counters are exact)
-    u64 prev_actpos = 0;                       // rotations in unsorted groups before the current round (0: not known yet)
-    if (sparse0) { sparse = true; parity = 0; }
-    if (sparse0 && k1_trace) {
-        u32 hs[4];
-        HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats + K1_STAT_LIST, sizeof hs, hipMemcpyDeviceToHost, stream));
+    if (k1_trace) {
+        static thread_local u32 dc[(K1D_MAXR + 2) * 4];
+        HIP_CHECK_RET(hipMemcpyAsync(dc, B.dbn, sizeof dc, hipMemcpyDeviceToHost, stream));
+        std::vector<u32> cn((size_t)(K1D_MAXR + 2) * B.rstride), tt(B.rstride);
+        HIP_CHECK_RET(hipMemcpyAsync(cn.data(), B.dcnt, cn.size() * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK_RET(hipMemcpyAsync(tt.data(), B.dtot, tt.size() * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK_RET(hipStreamSynchronize(stream));
-        fprintf(stderr, "[k1] groups left after K1-deep: %u of <= 8 rotations, %u of 9..64, %u of 65..%u, %u larger\n", hs[0], hs[1], hs[2], (u32)K1_MED_MAX, hs[3]);
-    }
-    else if (early && !all_sorted) prev_actpos = unsorted0;
-    for (u64 h = d0; !all_sorted; h <<= 1) {
-        const int mode = (h >= max_n || force_final) ? 1 : 0;      // last round: identical rotations by descending index
-        if (!sparse) {
-            const bool try_sparse = mode == 0 && total_n >= sparse_min;
-            // descriptor lists for a switch to the sparse phase are only worth emitting when the switch is near:
-            // the unsorted share roughly halves per round, so emit once it was below 1/4 before this round (unknown before round 0: emit)
-            const bool emit_lists = try_sparse && prev_actpos * 4 < total_n;
-            HIP_CHECK_RET(hipMemcpyAsync(B.HN, B.HC, hbytes, hipMemcpyDeviceToDevice, stream));
-            hipLaunchKernelGGL(k1_refine, gridHX, dim3(256), 0, stream, B, g, (u32)h, mode, round);
-            hipLaunchKernelGGL(k1_sort_large, dim3(large_grid), dim3(1024), 0, stream, B, g, (u32)h, mode, round);
-            hipLaunchKernelGGL(k1_update_ranks, gridU, dim3(256), 0, stream, B, g, round + 1, emit_lists ? 1 : 0);
-            { u32* t = B.HC; B.HC = B.HN; B.HN = t; u8* f = B.FC; B.FC = B.FN; B.FN = f; }
-            if (try_sparse) {
-                // How much is still unsorted?  One small read-back per tile round: a list-driven
-                // round costs what the unsorted groups cost, a tile round a fixed ~0.7 ms per 10^8
-                // positions -- but while most positions are still unsorted the tile round is the
-                // faster one (measured on tiled/periodic inputs), so switch below 1/8.  The lists
-                // were already filled by k1_update_ranks; they are dropped if we stay.
-                u32 hs[K1_STATS];
-                static thread_local u32 spr[2 * 2 * K1_SPREAD];
-                HIP_CHECK_RET(hipMemcpyAsync(spr, B.spread + (size_t)round * 2 * K1_SPREAD, sizeof spr, hipMemcpyDeviceToHost, stream));
-                HIP_CHECK_RET(hipStreamSynchronize(stream));
-                for (int rr = 0; rr < 2; rr++) {
-                    u32 a = 0, c = 0;
-                    for (u32 i = 0; i < K1_SPREAD; i++) { a += spr[(rr * 2 + 0) * K1_SPREAD + i]; c += spr[(rr * 2 + 1) * K1_SPREAD + i]; }
-                    hs[K1_STAT_ACTIVE + round + rr] = a;
-                    hs[K1_STAT_ACTPOS + round + rr] = c;
-                }
-                const u64 actpos = hs[K1_STAT_ACTPOS + round + 1];
-                if (actpos == 0) { round++; break; }           // everything sorted: no tie round needed
-                if (k1_trace) fprintf(stderr, "[k1] tile round %d (h=%llu): groups %u -> %u, rotations in groups %u -> %u\n", round, (unsigned long long)h,
-                                      hs[K1_STAT_ACTIVE + round], hs[K1_STAT_ACTIVE + round + 1], hs[K1_STAT_ACTPOS + round], hs[K1_STAT_ACTPOS + round + 1]);
-                if (hs[K1_STAT_ACTIVE + round + 1] == hs[K1_STAT_ACTIVE + round] && actpos == hs[K1_STAT_ACTPOS + round])
-                    force_final = true;                        // this round split nothing
-                prev_actpos = actpos;
-                if (emit_lists && actpos * sparse_div < total_n) { sparse = true; parity = 0; }
-                else hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, 0);
-            }
-        } else {
-            hipLaunchKernelGGL(k1_sp_tiny, dim3(1024), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
-            hipLaunchKernelGGL(k1_sp_small, dim3(2048), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
-            hipLaunchKernelGGL(k1_sp_medium, dim3(512), dim3(256), 0, stream, B, g, (u32)h, mode, parity);
-            hipLaunchKernelGGL(k1_sp_large, dim3(256), dim3(1024), 0, stream, B, g, (u32)h, mode, parity);
-            hipLaunchKernelGGL(k1_sp_update, dim3(1024), dim3(256), 0, stream, B, g, parity);
-            hipLaunchKernelGGL(k1_sp_reset, dim3(1), dim3(64), 0, stream, B, parity);
-            parity ^= 1;
-            sparse_rounds++;
-            // The lists for the next round were filled by this one; once they are all empty every group is
-            // sorted and the remaining doubling rounds (always ceil(log2(n/8)) of them) would be no-ops.
-            // One 16-byte read-back every other round: it costs a stream sync, a skipped round six launches.
-            if (mode == 0 && (sparse_rounds & 1) == 0) {
-                u32 hs[K1_STATS - K1_STAT_LIST];
-                HIP_CHECK_RET(hipMemcpyAsync(hs, B.stats + K1_STAT_LIST, sizeof hs, hipMemcpyDeviceToHost, stream));
-                HIP_CHECK_RET(hipStreamSynchronize(stream));
-                const u32* nx = hs + parity * 4;
-                const u64 groups = (u64)nx[0] + nx[1] + nx[2] + nx[3];
-                if (k1_trace) fprintf(stderr, "[k1] sparse round %d (h=%llu): next lists %u %u %u %u\n", sparse_rounds, (unsigned long long)h, nx[0], nx[1], nx[2], nx[3]);
-                if (groups == 0) { round++; break; }
-            }
+        u64 un = 0;
+        for (u32 bb = 0; bb < g.nb; bb++) un += tt[bb];
+        fprintf(stderr, "[k1] rotations in unsorted groups before the doubling rounds: %llu (of %llu); per round entries / medium (<= 1024 + larger) / large / chunks:", (unsigned long long)un, (unsigned long long)total_n);
+        for (u32 r = 0; r < K1D_MAXR + 1u; r++) {
+            u64 e = 0;
+            for (u32 bb = 0; bb < g.nb; bb++) e += cn[(size_t)r * B.rstride + bb];
+            if (!e && !dc[r * 4] && !dc[r * 4 + 1] && !dc[r * 4 + 3]) break;
+            fprintf(stderr, " [%u] %llu/%u+%u/%u/%u", r, (unsigned long long)e, dc[r * 4 + 3], dc[r * 4], dc[r * 4 + 1], dc[r * 4 + 2]);
+            sparse_rounds = (int)r + 1;
         }
-        round++;
-        if (mode == 1) break;
+        fprintf(stderr, "\n");
     }
+    const int round = sparse_rounds;
     g_k1_last_sparse_rounds = sparse_rounds;
     g_k1_last_rounds = round;
     if (B.linear) hipLaunchKernelGGL(k1_finish_linear, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g, B.SAout);

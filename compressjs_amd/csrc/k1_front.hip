@@ -683,7 +683,7 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
             const u32 q = (u32)it * K1F_BT + tid;
             if ((bal[it] >> lane) & 1ull) {
                 const u32 idx = S.misc[(u32)it * K1F_NW + w] + (u32)__popcll(bal[it] & lt);
-                if (idx < g.stride) L[idx] = ((u64)gsv[it] << 40) | ((u64)S.sx[q] << 20) | (u64)(pos0 + q);
+                if (idx < g.stride) L[idx] = ((u64)gsv[it] << 44) | ((u64)S.sx[q] << 22) | (u64)(pos0 + q);
             }
         }
     } else {
@@ -1142,7 +1142,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
 // list-driven refinement rounds
 // ---------------------------------------------------------------------------------------------
 // What k1f_bsort leaves tied (groups of 2..K1F_GBIG = 256 rotations, sharing `depth` bytes) sits in per-block lists, one
-// 8-byte entry per rotation:  (group length - 1) << 48 | index in the group << 40 | rotation index << 20 | suffix-array
+// 8-byte entry per rotation (K1E_MAKE, k1_bwt.h):  (group length - 1) << 52 | index in the group << 44 | rotation index << 22 | suffix-array
 // position;  a group = consecutive entries.  A round takes K1R_STEP = 24 more text bytes off every listed rotation: a
 // workgroup owns the groups that START in its K1R_T entries (it reads K1R_W = 256 entries ahead for the tail of the last
 // one; an entry knows where its group starts, so there is no bitmap), fetches the keys (a dwordx4 + a dwordx3 load per
@@ -1172,10 +1172,10 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
 #define K1R_RPW (K1R_ROWS / 4u)                         // rows per wave
 #define K1R_SW (K1R_N / 32u)                            // words of the survivor bitmap
 static_assert(K1R_ROWS % 4u == 0 && K1R_SW <= 64u && K1F_GBIG <= 256u, "rows are dealt to four waves; one wave scans the bitmap; 8-bit group fields");
-#define K1R_POS(e) ((u32)(e) & 0xFFFFFu)
-#define K1R_S(e) ((u32)((e) >> 20) & 0xFFFFFu)
-#define K1R_IDX(e) ((u32)((e) >> 40) & 0xFFu)
-#define K1R_LEN(e) (((u32)((e) >> 48) & 0xFFu) + 1u)
+#define K1R_POS(e) K1E_POS(e)
+#define K1R_S(e) K1E_S(e)
+#define K1R_IDX(e) K1E_IDX(e)
+#define K1R_LEN(e) K1E_LEN(e)
 #ifndef K1R_MINW
 #ifndef K1R_MINW
 #define K1R_MINW 4                                      // waves per SIMD the register allocation is held to
@@ -1317,7 +1317,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
                     if (!final) {
                         qn[it] = q;
                         atomicOr(&sb[par][q >> 5], 1u << (q & 31u));
-                        pv_e[it] = ((u64)(eqt - 1u) << 48) | ((u64)eqb << 40) | ((u64)s << 20) | (u64)pos;
+                        pv_e[it] = K1E_MAKE(eqt - 1u, eqb, s, pos);
                     } else if (eqb) {
                         atomicAnd(&HN[pos >> 5], ~(1u << (pos & 31u)));
                     } else if (eqt <= K1_DEEP_LANE && n >= 64u) {

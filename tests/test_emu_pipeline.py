@@ -123,9 +123,9 @@ def test_invalid_level_code(emu_ctx):
     assert L.cjs_bz2_compress(h, d.ctypes.data, 4, 10, out.ctypes.data, 256) == -20
 
 
-def test_sparse_phase_of_suffix_sort():
-    """K1 switches to list-driven rounds when few positions remain unsorted (normally only for
-    >= 2^20 positions); force it on a small input in a fresh process and compare with the oracle."""
+def test_doubling_rounds_of_suffix_sort():
+    """Passages repeated far apart outlast the text stages: the list-driven doubling rounds (k1_dbl.hip) must run for several
+    rounds (counted with CJS_K1_TRACE, which reads the lists' counters back) and give the oracle's transform."""
     import os
     import subprocess
     import sys
@@ -147,8 +147,8 @@ assert p.value == po and (u == uo).all()
 assert L.cjs_dbg_k1_sparse_rounds() >= 3, L.cjs_dbg_k1_sparse_rounds()
 print("ok", L.cjs_dbg_k1_rounds(), L.cjs_dbg_k1_sparse_rounds())
 ''' % (stagelib.ROOT, os.path.join(stagelib.ROOT, "tests"))
-    env = dict(os.environ, CJS_SPARSE_MIN="100")
-    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600)
+    env = dict(os.environ, CJS_K1_TRACE="1")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600, stderr=subprocess.DEVNULL)
     assert out.decode().startswith("ok")
 
 
@@ -436,13 +436,13 @@ for d in cases:
     res.append((L.cjs_dbg_k1_rounds(), L.cjs_dbg_k1_sparse_rounds()))
 print("ok", res)
 ''' % (stagelib.ROOT, os.path.join(stagelib.ROOT, "tests"))
-    env = dict(os.environ, CJS_SPARSE_MIN="100", **env_add)
-    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900).decode()
+    env = dict(os.environ, CJS_K1_TRACE="1", **env_add)                  # (the trace reads the rounds' list counters back)
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, timeout=900, stderr=subprocess.DEVNULL).decode()
     assert out.startswith("ok")
     if not env_add:
         rounds = eval(out[2:])
         assert rounds[1] == (0, 0) and rounds[2] == (0, 0), rounds      # phrase-reuse text, random: no doubling round at all
-        assert rounds[0][1] >= 1, rounds                                  # 700-byte repeats: left to the (sparse) doubling rounds
+        assert rounds[0][1] >= 1, rounds                                  # 700-byte repeats: left to the doubling rounds
 
 
 def _bwt_batch(L, blocks):
