@@ -118,6 +118,16 @@ __device__ __forceinline__ u32 k1d_key(const u32* ISA, u32 n, u32 s, u64 h, u32 
 // to P' = {s ~ s' in P and s+h ~ s'+h in P}; P' = P gives s+kh ~ s'+kh for all k, members of a group agree on h bytes, so s and
 // s' agree everywhere - identical rotations (linear mode: suffixes that ran into the padding together), which no further
 // doubling round can tell apart.  Periodic and tiled inputs reach that state after a few rounds instead of log2(n / h0).
+// The tie-break itself needs no sort in cyclic mode: a group of identical rotations is the COMPLETE class of one rotation
+// (identical rotations have equal keys in every round, so nothing ever separates them), i.e. all L = n / p rotations
+// s, s + p, s + 2p, ... of a block with period p, and descending start index puts rotation s at position
+// start + L - 1 - s / p.  (Rounds 1-3 sorted the keys n - 1 - s: for `periodic ab` two groups of 450 000 per block, one
+// workgroup each, 20 ms.)  Linear mode (suffixes that ran into the padding together) sorts.
+__device__ __forceinline__ bool k1d_tie_pos(u32 n, u32 start, u32 L, u32 s, u32& pos) {
+    const u32 p = n / L;
+    pos = start + L - 1u - s / p;
+    return p * L == n && s / p < L;        // (always; a group that is no such class falls back to the sort)
+}
 __device__ __forceinline__ u32 k1d_mode(const K1Buf& B, u32 r, u32 b, u32 final_h) {
     return (final_h || (r > 0u && B.dchg[(size_t)(r - 1u) * B.rstride + b] == 0u)) ? 1u : 0u;
 }
@@ -387,10 +397,15 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
             u64* Lt = B.rlist[1] + (size_t)tC.b * g.stride;
             u32* SA = B.SA + (size_t)tC.b * g.stride;
             u32 changed = 0;
+            const bool tie = tC.mode != 0u && !linear;      // (uniform) the tie-break of a cyclic block: positions by formula
 #pragma unroll
             for (u32 it = 0; it < K1D_RPT; it++) {
                 const u32 i = (it * 4u + w) * 64u + lane;
-                if (own(eC[it], i)) {
+                u32 tpos = 0;
+                if (tie && own(eC[it], i) && k1d_tie_pos(tC.n, K1E_POS(eC[it]) - K1E_IDX(eC[it]), K1E_LEN(eC[it]), K1E_S(eC[it]), tpos)) {
+                    SA[tpos] = K1E_S(eC[it]);
+                    Lt[tC.e0 + i] = K1E_MAKE(0u, 0u, K1E_S(eC[it]), tpos) | K1E_KEEP;      // final; k1d_update has nothing to do for it
+                } else if (own(eC[it], i)) {
                     const u32 gs = i - K1E_IDX(eC[it]), ge = gs + K1E_LEN(eC[it]);
                     const u32 m = kC[it];
                     u32 less = 0, eqb = 0, eqt = 0;
@@ -514,6 +529,16 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
         u32* R = B.SB + (size_t)b * g.stride + start;
         const bool radix = n < K1D_RADIX_MAXN;
         __syncthreads();
+        if (mode && !B.linear && (n / len) * len == n) {    // (uniform) the tie-break of a cyclic block: positions by formula
+            const u32 pp = n / len;
+            for (u32 i = tid; i < len; i += 256) cv[i] = SA[i];
+            __syncthreads();
+            for (u32 i = tid; i < len; i += 256) {
+                SA[len - 1u - cv[i] / pp] = cv[i];
+                R[i] = K1D_RKEEP;
+            }
+            continue;
+        }
         for (u32 i = tid; i < len; i += 256) {
             const u32 s = SA[i];
             cv[i] = s;
@@ -714,6 +739,13 @@ __global__ __launch_bounds__(1024) void k1d_large(K1Buf B, BatchGeom g, u32 r, u
         u32* KA = B.KA + (size_t)b * g.stride + start;
         u32* KB = B.KB + (size_t)b * g.stride + start;
         __syncthreads();
+        if (mode && !linear && (n / L) * L == n) {          // (uniform) the tie-break of a cyclic block: positions by formula -
+            const u32 pp = n / L;                           // the members are r, r + p, ..., r + (L - 1) p: written, not permuted
+            const u32 rr = SA[0] % pp;
+            __syncthreads();
+            for (u32 i = tid; i < L; i += 1024) SA[i] = rr + (L - 1u - i) * pp;
+            continue;
+        }
         // Repetitive inputs keep huge groups alive for log2(n) rounds in which all but ~2h keys of a group are equal.  A pivot
         // taken from the middle of the group is then the majority key: count the two sides while gathering the keys, and if
         // both are small do ONE stable 3-way partition pass (the sides are sorted in LDS) instead of three radix passes.
@@ -733,6 +765,12 @@ __global__ __launch_bounds__(1024) void k1d_large(K1Buf B, BatchGeom g, u32 r, u
         if (lane == 0) { if (myl) atomicAdd(&s_side[0], myl); if (myg) atomicAdd(&s_side[1], myg); }
         __syncthreads();
         const u32 nlt = s_side[0], ngt = s_side[1];
+        if (nlt == 0u && ngt == 0u) {
+            // every key equals the pivot (periodic input: every round but the last): the group stays as it is, ranks and all -
+            // only its descriptor goes on to the next round
+            if (tid == 0) k1d_push_big(B, r + 1u, b, start, L);
+            continue;
+        }
         if (n < (1u << 21) && nlt <= K1D_MAJ_SIDE && ngt <= K1D_MAJ_SIDE && (nlt + ngt) * 4u < L) {   // (key << 11 | index) needs keys < 2^21
             const u32 neq = L - nlt - ngt;
             u32 runE = 0, runL = 0, runG = 0;

@@ -1182,13 +1182,24 @@ static_assert(K1R_ROWS % 4u == 0 && K1R_SW <= 64u && K1F_GBIG <= 256u, "rows are
 #endif
 #endif
 
-__global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g, u32 round, u32 depth, u32 final) {
+__global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g, u32 round, u32 depth, u32 final_host) {
     u32 b, t0;
     if (!xcd_block_tile(g.nb, b, t0)) return;
     u32 cnt = B.rcnt[(size_t)round * B.rstride + b];
     if (cnt > g.stride) cnt = g.stride;
     if (t0 * K1R_T >= cnt) return;
+    // The last round of a block is the one the host launched last - or the first one that finds its list (nearly) as long as
+    // the round before found it: ties that 24 more bytes do not resolve are long repeats (tiled or HTML-like input: 11 rounds
+    // over all of a block's rotations, 19 of 47 ms on `200k text tiled`), which the doubling rounds settle in log steps.  The
+    // same counters for every workgroup of the block: one decision.
+    // Only while a sizeable part of the block still ties: the last few hundred entries of a text block (boilerplate passages) are
+    // cheaper to walk to the end (the lane kernels take them) than to rank the whole block for (k1d_build).
+    u32 final = final_host;
     const u32 n = B.nlen[b];
+    if (round >= 1u && cnt >= n / 16u) {
+        const u32 prev = B.rcnt[(size_t)(round - 1u) * B.rstride + b];
+        if ((u64)cnt * 8u > (u64)prev * 7u) final = 1u;
+    }
     const u8* T = B.T + (size_t)b * g.tstride;
     const u64* Lin = B.rlist[round & 1u] + (size_t)b * g.stride;
     u64* Lout = B.rlist[(round & 1u) ^ 1u] + (size_t)b * g.stride;
@@ -1319,10 +1330,22 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
                         atomicOr(&sb[par][q >> 5], 1u << (q & 31u));
                         pv_e[it] = K1E_MAKE(eqt - 1u, eqb, s, pos);
                     } else if (eqb) {
-                        atomicAnd(&HN[pos >> 5], ~(1u << (pos & 31u)));
-                    } else if (eqt <= K1_DEEP_LANE && n >= 64u) {
+                        // (not a head: its bit is cleared by the group's first member, below)
+                    } else {
+                        // the first member of a group that outlasted the rounds clears the head bits of the others - positions
+                        // pos + 1 .. pos + eqt - 1, word by word: one or two atomics per GROUP (one per member was 37 M of them in the
+                        // last round of `200k text tiled`, where every rotation survives: 12 of that round's 13 ms)
+                        for (u32 p0 = pos + 1u, pe = pos + eqt; p0 < pe;) {
+                            const u32 wend = (p0 | 31u) + 1u, e2 = wend < pe ? wend : pe;
+                            const u32 m = (e2 - p0 == 32u ? 0xFFFFFFFFu : ((1u << (e2 - p0)) - 1u)) << (p0 & 31u);
+                            atomicAnd(&HN[p0 >> 5], ~m);
+                            p0 = e2;
+                        }
+                    }
+                    if (final && !eqb && eqt <= K1_DEEP_LANE && n >= 64u && final_host) {
                         // a group that outlasted the rounds: 2..8 rotations go to the lane kernels' second pass (their walk wraps
-                        // around the block at most once per step: not for blocks shorter than a step)
+                        // around the block at most once per step: not for blocks shorter than a step); not when the block stopped
+                        // early - its ties are long repeats, which are the doubling rounds' business
                         const u32 cls = eqt == 2u ? 0u : 1u;
                         const u32 xr = (b & 7u) * K1_DEEP_SUB + ((pos >> 10) & (K1_DEEP_SUB - 1u)), rcap2 = B.listSCap / (8u * K1_DEEP_SUB);
                         const u32 idx = atomicAdd(&B.deepCnt[(2u + cls) * 8u * K1_DEEP_SUB + xr], 1u);
