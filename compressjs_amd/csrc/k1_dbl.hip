@@ -506,10 +506,8 @@ __device__ __forceinline__ void k1d_cmpx(u32* ck, u32* cv, u32 lo, u32 hi) {
 static_assert(K1_MED_MAX == 4096, "12 index bits next to 20 key bits");
 template <u32 CAP>
 __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 h, u32 final_h) {
-    constexpr u32 K1D_MW = CAP / 32u;
-    static_assert(K1D_MW >= 32u && K1D_MW <= 128u && (K1D_MW & 1u) == 0u, "one wave scans the bitmap words, two per lane");
+    static_assert(CAP == 1024u || CAP == 4096u, "CAP / 256 positions per thread, at most 32");
     __shared__ u32 ck[CAP], cv[CAP], cx[CAP];
-    __shared__ u32 hb[K1D_MW + 2], fm[K1D_MW], pre[K1D_MW];
     __shared__ u32 wh[4][128], dsum[128];
     __shared__ u32 sbase;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
@@ -545,8 +543,6 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
             const u32 k = k1d_key(ISA, n, s, h, hm, mode, B.linear);
             ck[i] = radix ? (k << 12) | i : k;
         }
-        for (u32 i = tid; i < K1D_MW + 2u; i += 256) hb[i] = 0;
-        for (u32 i = tid; i < K1D_MW; i += 256) fm[i] = 0;
         __syncthreads();
         u32* sorted = ck;                                   // radix: the packed words in order; bitonic: keys in ck, rotations in cv
         if (radix) {
@@ -620,56 +616,98 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
                 }
             }
         }
-        // heads of the sorted group -> LDS bitmap (bit len is a sentinel head)
-        const u32 ksh = radix ? 12u : 0u;
-        for (u32 i = tid; i <= len; i += 256) {
-            const bool head = i == 0 || i == len || (sorted[i] >> ksh) != (sorted[i - 1] >> ksh);
-            if (head) atomicOr(&hb[i >> 5], 1u << (i & 31u));
-        }
-        __syncthreads();
-        // suffix array, ranks, and what every position belongs to: (head, length of the sub-group)
-        bool split = false;
-        for (u32 i = tid; i < len; i += 256) {
-            const u32 sv = radix ? cv[sorted[i] & 4095u] : cv[i];
-            SA[i] = sv;
-            u32 wi = i >> 5;                               // last head <= i
-            u32 m = hb[wi] & (0xFFFFFFFFu >> (31u - (i & 31u)));
-            while (!m) m = hb[--wi];
-            const u32 hp = wi * 32u + 31u - (u32)__clz((int)m);
-            R[i] = hp ? start + hp : K1D_RKEEP;            // (the first sub-group keeps the group's rank)
-            u32 wj = i >> 5;                               // next head > i
-            u32 mm = (i & 31u) == 31u ? 0u : (hb[wj] & (0xFFFFFFFEu << (i & 31u)));
-            while (!mm) mm = hb[++wj];
-            const u32 sl = wj * 32u + (u32)__ffs((int)mm) - 1u - hp;
-            split = split || hp > 0u;
-            if (sl >= 2u && sl <= K1D_GS) atomicOr(&fm[i >> 5], 1u << (i & 31u));
-            else if (sl > K1D_GS && hp == i) k1d_push_big(B, r + 1u, b, start + i, sl);
-        }
-        if (__ballot(split) && lane == 0u) atomicOr(&B.dchg[(size_t)r * B.rstride + b], 1u);
-        __syncthreads();
-        if (w == 0) {                                       // entries before every bitmap word, their slots in the block's list
-            const bool in = 2u * lane < K1D_MW;
-            const u32 c0 = in ? (u32)__popc(fm[2u * lane]) : 0u, c1 = in ? (u32)__popc(fm[2u * lane + 1u]) : 0u;
-            const u32 inc = wave_incl_scan_u32(c0 + c1);
-            if (in) { pre[2u * lane] = inc - c0 - c1; pre[2u * lane + 1u] = inc - c1; }
-            const u32 total = (u32)__shfl((int)inc, 63);
-            if (lane == 0) sbase = total ? atomicAdd(&B.dcnt[(size_t)(r + 1u) * B.rstride + b], total) : 0u;
-        }
-        __syncthreads();
-        u64* L = B.rlist[0] + (size_t)b * g.stride;
-        for (u32 i = tid; i < len; i += 256) {
-            if (!((fm[i >> 5] >> (i & 31u)) & 1u)) continue;
-            u32 wi = i >> 5;
-            u32 m = hb[wi] & (0xFFFFFFFFu >> (31u - (i & 31u)));
-            while (!m) m = hb[--wi];
-            const u32 hp = wi * 32u + 31u - (u32)__clz((int)m);
-            u32 wj = i >> 5;
-            u32 mm = (i & 31u) == 31u ? 0u : (hb[wj] & (0xFFFFFFFEu << (i & 31u)));
-            while (!mm) mm = hb[++wj];
-            const u32 sl = wj * 32u + (u32)__ffs((int)mm) - 1u - hp;
-            const u32 sv = radix ? cv[sorted[i] & 4095u] : cv[i];
-            const u32 idx = sbase + pre[i >> 5] + (u32)__popc(fm[i >> 5] & ((1u << (i & 31u)) - 1u));
-            if (idx < g.stride) L[idx] = K1E_MAKE(sl - 1u, i - hp, sv, start + i);
+        // Heads, ranks and sub-group lengths from the sorted group.  Every thread takes CH consecutive positions; the last head at or
+        // before a position and the first head behind it come from one max-scan and one min-scan over the threads' ranges (the first
+        // version walked a head bitmap word by word for every position - in the early rounds, where most keys of a group are equal,
+        // a dependent chain of up to len / 32 LDS reads per position, twice: half of the kernel's time).
+        {
+            constexpr u32 CH = CAP / 256u;
+            const u32 ksh = radix ? 12u : 0u;
+            const u32 p0 = tid * CH;
+            u32 hmask = 0;                                  // heads among my positions
+            u32 sv[CH];
+            {
+                u32 kprev = (p0 > 0u && p0 <= len) ? sorted[p0 - 1u] >> ksh : 0u;
+#pragma unroll
+                for (u32 c = 0; c < CH; c++) {
+                    const u32 i = p0 + c;
+                    sv[c] = 0;
+                    if (i < len) {
+                        const u32 x = sorted[i], k = x >> ksh;
+                        if (i == 0u || k != kprev) hmask |= 1u << c;
+                        kprev = k;
+                        sv[c] = radix ? cv[x & 4095u] : cv[i];
+                    }
+                }
+            }
+            // last head (+1; 0: none) at or before the end of my range, first head (len: none) at or behind its start
+            u32 lastp = hmask ? p0 + 32u - (u32)__clz((int)hmask) : 0u;
+            u32 firstp = hmask ? p0 + (u32)__ffs((int)hmask) - 1u : len;
+            u32 vmax = lastp, vmin = firstp;
+            for (u32 off = 1; off < 64u; off <<= 1) {
+                const u32 a = __shfl_up(vmax, off), c2 = __shfl_down(vmin, off);
+                if (lane >= off && a > vmax) vmax = a;
+                if (lane + off < 64u && c2 < vmin) vmin = c2;
+            }
+            __syncthreads();                                // (wh is free: the passes are done)
+            if (lane == 63u) wh[0][w] = vmax;
+            if (lane == 0u) wh[0][8u + w] = vmin;
+            __syncthreads();
+            u32 before = __shfl_up(vmax, 1u), behind = __shfl_down(vmin, 1u);      // exclusive, inside the wave
+            if (lane == 0u) before = 0u;
+            if (lane == 63u) behind = len;
+            for (u32 ww = 0; ww < w; ww++) before = wh[0][ww] > before ? wh[0][ww] : before;
+            for (u32 ww = w + 1u; ww < 4u; ww++) behind = wh[0][8u + ww] < behind ? wh[0][8u + ww] : behind;
+            // per position: head hp (scan from the left), next head nh (from the right)
+            u32 hpv[CH], slv[CH];
+            {
+                u32 run = before;                           // (+1 encoding)
+#pragma unroll
+                for (u32 c = 0; c < CH; c++) { if ((hmask >> c) & 1u) run = p0 + c + 1u; hpv[c] = run - 1u; }
+                u32 nx = behind;
+#pragma unroll
+                for (u32 cc = 0; cc < CH; cc++) {
+                    const u32 c = CH - 1u - cc;
+                    slv[c] = nx - hpv[c];                   // length of the sub-group position p0 + c belongs to
+                    if ((hmask >> c) & 1u) nx = p0 + c;
+                }
+            }
+            // suffix array, ranks; members of sub-groups of 2..K1D_GS become entries (counted here, placed below)
+            bool split = false;
+            u32 mine = 0;
+#pragma unroll
+            for (u32 c = 0; c < CH; c++) {
+                const u32 i = p0 + c;
+                if (i < len) {
+                    SA[i] = sv[c];
+                    R[i] = hpv[c] ? start + hpv[c] : K1D_RKEEP;        // (the first sub-group keeps the group's rank)
+                    split = split || hpv[c] > 0u;
+                    if (slv[c] >= 2u && slv[c] <= K1D_GS) mine++;
+                    else if (slv[c] > K1D_GS && hpv[c] == i) k1d_push_big(B, r + 1u, b, start + i, slv[c]);
+                }
+            }
+            if (__ballot(split) && lane == 0u) atomicOr(&B.dchg[(size_t)r * B.rstride + b], 1u);
+            const u32 inc = wave_incl_scan_u32(mine);
+            __syncthreads();
+            if (lane == 63u) wh[1][w] = inc;
+            __syncthreads();
+            u32 slot = inc - mine;
+            for (u32 ww = 0; ww < w; ww++) slot += wh[1][ww];
+            if (tid == 255u) {
+                const u32 total = slot + mine;
+                sbase = total ? atomicAdd(&B.dcnt[(size_t)(r + 1u) * B.rstride + b], total) : 0u;
+            }
+            __syncthreads();
+            u64* L = B.rlist[0] + (size_t)b * g.stride;
+            slot += sbase;
+#pragma unroll
+            for (u32 c = 0; c < CH; c++) {
+                const u32 i = p0 + c;
+                if (i < len && slv[c] >= 2u && slv[c] <= K1D_GS) {
+                    if (slot < g.stride) L[slot] = K1E_MAKE(slv[c] - 1u, i - hpv[c], sv[c], start + i);
+                    slot++;
+                }
+            }
         }
     }
 }
