@@ -466,7 +466,6 @@ static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap
     P.outCapBytes = out_cap & ~(uint64_t)3;
     P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
     P.g.nb = nb;
-    P.k1.largeCap = nb * (g.htiles + 1);
     int rc = k0_batch(K, P, f, cap, st);
     if (rc) return rc;
     return pipe_run_block_stages(P, cap, st, 4);
@@ -1166,8 +1165,7 @@ extern "C" int64_t cjs_bwtc_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_
             Pipe& P = Ps[si];
             pipe_carve(P, g, c->ws[si]);
             P.g.nb = nb;
-            P.k1.largeCap = nb * (g.htiles + 1);
-            P.k1.linear = 1;
+                    P.k1.linear = 1;
             u32* nls = nl.data() + (size_t)si * c->sub_blocks;
             u32 max_n = 0;
             for (u32 b = 0; b < nb; b++) {

@@ -2,19 +2,15 @@
 #pragma once
 #include "cjs_common.h"
 
-#define K1_STAT_ACTIVE 0    // stats[0..31]  : unsorted-group starts entering round r
-#define K1_STAT_LARGE 32    // stats[32..63] : large groups registered in round r
-#define K1_STAT_ACTPOS 64   // stats[64..95] : positions still in unsorted groups entering round r
-#define K1_STAT_LIST 96     // stats[96..103]: sparse-phase list counters [parity][4 size classes]
-#define K1_DEEP_SUB 64u     // k1_deep list sub-regions per XCD region (power of two)
+#define K1_DEEP_SUB 64u     // list sub-regions per XCD region of the lane kernels (power of two)
 #define K1_STAT_BIGROT 116     // stats[116..123]: rotations in 8-byte groups of more than 64 members, counted by k1f_bsort (8 spread words)
-#define K1_STAT_MEDROT 112     // stats[112]: rotations in the groups k1_emit_medium listed (65..K1_MED_MAX rotations each)
-#define K1_STAT_FRONT_BIG 104  // stats[104]: buckets of the sample-sort front end that did not fit LDS
+#define K1_STAT_FRONT_BIG 104  // stats[104]: buckets of the sample-sort front end that did not fit LDS (105..110: K1F_TRACE stage clocks)
 #define K1_STAT_PUREROT 124    // stats[124]: rotations in front-end buckets of ONE 8-byte key (> 64 members) or beyond LDS, counted by k1f_scan
 #define K1_DEEP_LANE 8u        // groups up to this size go to the lane kernels (k1_deep_pairs / k1_deep_small): one lane each
 #define K1R_MAXR 40            // refinement rounds at most
 #define K1F_LEVELS 14u          // task levels of the front end (two per 8 bytes of depth: partition, then sort)
 #define K1_STAT_RTRACE 128      // stats[128..135]: K1F_TRACE builds, stage clocks of k1r_round
+#define K1_MED_MAX 4096     // doubling rounds: largest group a workgroup sorts in LDS
 #define K1_STATS 144
 // list entries of the refinement rounds (k1r_round) and the doubling rounds (k1_dbl.hip): one per rotation that still ties,
 // a group = consecutive entries:  (group length - 1) << 52 | index in the group << 44 | rotation index << 22 | suffix-array position
@@ -68,39 +64,30 @@ struct K1Buf {
     int* SAout;       // linear mode: optional copy of the suffix array [nb][stride]
     const u8* T;      // [nb][tstride]  T_ext[i] = T[i mod n]
     u32* SA;          // [nb][stride]   suffix array (result)
-    u32* SB;          // [nb][stride]   ping-pong
-    u32* ISA;         // [nb][stride]   rank (= position of the group head) of every rotation
-    u32* KA;          // [nb][stride]   keys of large groups (ping)
-    u32* KB;          // [nb][stride]   keys of large groups (pong)
-    u32* HC;          // [nb][hstride]  head bitmap, current
-    u32* HN;          // [nb][hstride]  head bitmap, next
-    u32* HX;          // [nb][hstride]  head bitmap after the 8-byte sort (input of k1_deep)
-    u8* FC;           // [nb][htiles]   tile flags, current: bit0 = an unsorted group starts here,
-    u8* FN;           //                                     bit1 = holds a position of an unsorted group
+    u32* SB;          // [nb][stride]   ping-pong of the front end; doubling rounds: R, the new rank of every position of a big group
+    u32* ISA;         // [nb][stride]   rank (= position of the group head) of every rotation (doubling rounds)
+    u32* KA;          // [nb][stride]   scratch: bucket ids of the task levels; keys of large groups (ping)
+    u32* KB;          // [nb][stride]   scratch: keys of large groups (pong), then the lengths of their sub-groups at the heads
+    u32* HN;          // [nb][hstride]  head bitmap: bit p set = suffix-array position p starts a group (bits at and beyond n are set)
     const u32* nlen;  // [nb]           block lengths
-    u32* tileHist;    // [nb][rtiles][256]  (front end: [nb][ptiles][K1F_NB])
+    u32* tileHist;    // [nb][ptiles][K1F_NB]  front end: per-tile bucket counts
     u64* fsplit;      // [nb][K1F_NB]       front end: bucket d holds the keys in [fsplit[d-1], fsplit[d])
     u32* fstart;      // [nb][K1F_NB+1]     front end: first suffix-array position of every bucket
     u32* stats;       // [K1_STATS]
-    u32* deepCnt;     // [2 passes][2 classes][8 XCD regions][K1_DEEP_SUB]  entries in each k1_deep list sub-region
-                      //   (pass 1: what the tile kernel and the medium rounds listed; pass 2: what tied up to the short cap)
-    u32* spread;      // [32 rounds][2][K1_SPREAD]  per-round (group starts, rotations in groups), spread over
-                      //                            K1_SPREAD words: ~10^5 tiles adding to ONE word cost 1 ms per launch
-    u32* dmCnt;       // [2 parities][2 classes (9..64, 65..K1_MED_MAX)][K1_DM_SUB]  entries of the medium rounds' sub-lists
-    uint2* large;     // [largeCap]     (block, start position)
-    u32 largeCap;
-    u64* listT[2];    // sparse phase: descriptors of groups of <= 8 rotations (cur/next)
-    u64* listS[2];    //               9..64 rotations
-    u64* listM[2];    //               65..K1_MED_MAX rotations
-    u64* listL[2];    //               more than K1_MED_MAX rotations
+    u32* deepCnt;     // [2 passes][2 classes][8 XCD regions][K1_DEEP_SUB]  entries in each list sub-region of the lane kernels
+                      //   (pass 2: what the last refinement round handed over; pass 1 is not filled any more)
+    u64* listT[2];    // doubling rounds: descriptors of groups of K1D_GS+1 .. 1024 rotations (cur/next)
+    u64* listS[2];    // lane kernels' lists (pairs / groups of 3..8); [0] also the chunks of the doubling rounds' large groups
+    u64* listM[2];    // descriptors of groups of 1025 .. K1_MED_MAX rotations
+    u64* listL[2];    // ... of more than K1_MED_MAX
     u32 listTCap, listSCap, listMCap, listLCap;
-    u64* rlist[2];    // [nb][stride]   refinement rounds (k1r_round): entries of the rotations that still tie, in/out
-    u32* rcnt;        // [K1R_MAXR + 1][rstride]  entries per round and block
+    u64* rlist[2];    // [nb][stride]   entry lists: refinement rounds (in/out), doubling rounds ([0] the round's list, [1] its re-ordered copy)
+    u32* rcnt;        // [K1R_MAXR + 1][rstride]  refinement rounds: entries per round and block
     u32 rstride;
     u32* dcnt;        // [K1D_MAXR + 2][rstride]  doubling rounds: list entries per round and block
     u32* dchg;        // [K1D_MAXR + 2][rstride]  != 0: a group of the block split in that round (none: only identical rotations are left)
     u32* dtot;        // [rstride]                positions in unsorted groups per block before the doubling rounds (k1_count_unsorted)
-    u32* dbn;         // [K1D_MAXR + 2][4]        per round: descriptors of medium groups, of large groups, chunks
+    u32* dbn;         // [K1D_MAXR + 2][4]        per round: descriptors of medium groups (1025..), of large groups, chunks, medium groups (..1024)
     uint4* btask;     // [K1F_LEVELS][btaskCap]  task levels of the front end (k1f_task): (block, position, length, depth | flag)
     u32* bcnt;        // [K1F_LEVELS]            tasks per level
     u32 btaskCap;
@@ -121,5 +108,6 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
 int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth);
 // k1_dbl.hip: ranks of every rotation from (SA, HN), then list-driven prefix doubling from depth h0 until every group is resolved
 int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h0);
+#define K1R_STEP 24u           // text bytes a refinement round (k1r_round) takes off every listed rotation
 #define K1F_STEP 12u           // text bytes per in-bucket iteration / refinement round: what ONE 16-byte aligned load yields at any alignment
 size_t k1_front_tilehist_words(const BatchGeom& g);   // u32 per block the front end needs in tileHist

@@ -1162,7 +1162,6 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
 // The LAST round (`final`) writes what still ties (long repeats, identical rotations) to the suffix array, clears the
 // head bits of its non-heads, and hands groups of 2..8 to the second pass of the lane kernels (k1_deep_pairs<true> /
 // k1_deep_small<true>: up to CJS_DEEP_LANE_CAP bytes); what they leave, and bigger groups, the doubling rounds of k1_run take.
-#define K1R_STEP 24u
 #ifndef K1R_T
 #define K1R_T 1024u          // entries a workgroup owns per step (512 -> 1024, round 3: 80 % of the 1280 slots of a step are owned instead of 67 %,
 #endif                          // half as many barriers and pipeline prologues per entry; 10^8-byte enwik, ms per step with 512 / 768 / 1024 / 1280 / 1792: 9.7 / 9.10 / 9.03 / 9.10 / 9.49)
@@ -1432,8 +1431,7 @@ int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u
     for (u32 r = 0; r < rounds; r++) {
         // the lists shrink from round to round (text: by a quarter to a third): later rounds launch fewer workgroups, each walks
         // its share of the tiles (an empty workgroup still costs its dispatch)
-        static const u32 tdiv = []() -> u32 { const char* e = getenv("CJS_RTILE_DIV"); const u32 v = e ? (u32)strtoul(e, nullptr, 10) : 8u; return v ? v : 8u; }();
-        u32 tiles = (full >> r) / tdiv;               // a workgroup walks ~8 tiles (software pipeline), later rounds fewer
+        u32 tiles = (full >> r) / 8u;                 // a workgroup walks ~8 tiles (software pipeline), later rounds fewer
         if (tiles < 16u) tiles = 16u;
         hipLaunchKernelGGL(k1r_round, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
     }

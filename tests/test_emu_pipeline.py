@@ -180,7 +180,7 @@ def test_linear_bwt_and_suffix_array(golden):
 
 def test_bwt_entry_points_above_one_megabyte():
     """BWT.bwtransform / suffixsort on a block of more than 2^20 bytes (the reference's test/bwtest.js and suftest.js
-    go up to sample5.ref = 2 130 640): ranks packed into 22 bits, the LSD passes instead of the sample-sort front end."""
+    go up to sample5.ref = 2 130 640): ranks packed into 22 bits, most buckets of the front end beyond LDS (task levels)."""
     L = _lib.load(stagelib.EMU_SO)
     d = np.ascontiguousarray(synth.text_like((1 << 20) + 70_001, 9))
     u = np.zeros(d.size, np.uint8)
@@ -402,14 +402,15 @@ def test_decoder_differential_fuzz_vs_oracle(emu_ctx):
     assert decode_fuzz.fuzz(L, h, seed=20260925, cases=150) == 150
 
 
-@pytest.mark.parametrize("env_add", [{}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "2"}, {"CJS_DEEP_ITERS": "0"},
-                                     {"CJS_SORT_BYTES": "8"}, {"CJS_SORT_BYTES": "6"}, {"CJS_SORT_BYTES": "6", "CJS_DEEP_ITERS": "0"}])
+@pytest.mark.parametrize("env_add", [{}, {"CJS_TEXT_BYTES": "0"}, {"CJS_TEXT_BYTES": "44", "CJS_DEEP_LANE_CAP": "0"},
+                                     {"CJS_BSORT_ITERS": "0", "CJS_DEEP_BIG_DIV": "1"}, {"CJS_BSORT_ITERS": "2"},
+                                     {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}])
 def test_deep_refinement_of_suffix_sort(env_add):
-    """K1-deep resolves groups by comparing the text inside LDS before any rank exists; what it leaves
-    (long repeats, identical rotations, groups that stay big) goes to the doubling rounds, which then start
-    in the sparse phase or are skipped.  Both kernels (wave / workgroup per tile), a short iteration cap and
-    'off' against the oracle, on inputs that end in each of the three continuations; and the radix sort over 6 / 7 (default) / 8
-    bytes (CJS_SORT_BYTES: K1-deep and the doubling rounds start at that depth)."""
+    """The text stages (in-bucket iterations, list-driven refinement rounds, lane kernels) resolve groups by comparing the
+    text before any rank exists; what they leave (long repeats, identical rotations, groups that stay big) goes to the
+    doubling rounds, which are skipped when nothing is left.  The knobs of k1_bwt.hip (k1_knobs) against the oracle, on inputs
+    that end in each continuation: text stages off, a short cap with no lane kernels, no / two in-bucket iterations, the
+    predictor forcing the text stages on / off, no read-back."""
     import os
     import subprocess
     import sys
@@ -484,14 +485,13 @@ def _front_blocks():
 def test_sample_sort_front_end(variant):
     """k1_front.hip (sample-sort front end of the suffix sort) on blocks large enough to be partitioned: text,
     random, periodic (pure buckets), runs, a moderately heavy key; `tiny_buckets` is a build with a 256-rotation
-    bucket capacity and 2 samples per bucket, so that the oversize path runs all the time (the CJS_FRONT=0 path: see
-    test_bwt_entry_points_above_one_megabyte).  BWT + origPtr of every block against the oracle."""
+    bucket capacity and 2 samples per bucket, so that the oversize path (task levels) runs all the time - the path blocks
+    above ~1.1 MB take as a matter of course (test_bwt_entry_points_above_one_megabyte).  BWT + origPtr of every block
+    against the oracle."""
     env = dict(os.environ)
     code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'));"
             "sys.path.insert(0, os.path.join(%r, 'tests', 'golden'));"
             "import test_emu_pipeline as t; t._front_check(%r)" % (ROOT, ROOT, ROOT, variant))
-    if variant == "lsd_passes":
-        env["CJS_FRONT"] = "0"
     import subprocess
     import sys
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=3000)

@@ -467,11 +467,11 @@ def test_two_streams_with_host_threads_same_bytes():
 
 
 def test_deep_refinement_variants_same_bytes(ctx):
-    """K1-deep (text-comparison refinement in front of the doubling rounds) is a faster route to the same
-    order: off (CJS_DEEP_ITERS=0), the default wave-per-tile kernel, the workgroup-per-tile kernel and a short
-    iteration cap (most ties left to the sparse phase), and the radix sort over 6 / 7 / 8 bytes (CJS_SORT_BYTES) must all give
-    the same bytes on phrase-reuse text, and
-    those bytes must be the oracle's on the leading blocks."""
+    """The text stages in front of the doubling rounds are a faster route to the same order.  K1's knobs (k1_bwt.hip,
+    k1_knobs) must all give the same bytes on phrase-reuse text + runs + periodic + tiled input, and those bytes must be the
+    oracle's on the leading blocks: no text stages at all (doubling from 8 bytes), the default, one refinement round only and no
+    lane kernels (most ties left to the doubling rounds) on one stream, no in-bucket iteration with the predictor forcing the text
+    stages on and unequal shares of a batch, the predictor forcing them off with no read-back at all."""
     import subprocess
     import sys
     code = (
@@ -485,12 +485,9 @@ def test_deep_refinement_variants_same_bytes(ctx):
         "print(hashlib.sha256(c.compress(d, 9)).hexdigest(), hashlib.sha256(c.compress(d[:9_000_000], 4)).hexdigest())\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    # (round 3: the round-2 flow, no / two in-bucket iterations, the medium-group stage back on, one and three streams,
-    # unequal shares of a batch, the text stages forced on / off by the predictor's threshold)
-    for env_add in ({"CJS_DEEP_ITERS": "0"}, {}, {"CJS_DEEP_TILE": "1024"}, {"CJS_DEEP_ITERS": "3"}, {"CJS_SORT_BYTES": "8"},
-                    {"CJS_SORT_BYTES": "6"}, {"CJS_SORT_BYTES": "8", "CJS_DEEP_ITERS": "0"},
-                    {"CJS_ROUNDS": "0"}, {"CJS_BSORT_ITERS": "0", "CJS_DEEP_MED": "8"}, {"CJS_BSORT_ITERS": "2", "CJS_STREAMS": "1"},
-                    {"CJS_SHARES": "300:700", "CJS_DEEP_BIG_DIV": "1"}, {"CJS_DEEP_BIG_DIV": "1000000", "CJS_SPARSE_DIV": "1"}):
+    for env_add in ({"CJS_TEXT_BYTES": "0"}, {}, {"CJS_TEXT_BYTES": "44", "CJS_DEEP_LANE_CAP": "0", "CJS_STREAMS": "1"},
+                    {"CJS_BSORT_ITERS": "0", "CJS_DEEP_BIG_DIV": "1", "CJS_SHARES": "300:700"},
+                    {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}):
         env = dict(os.environ, **env_add)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
     assert all(o == outs[0] for o in outs), outs
