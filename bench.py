@@ -11,19 +11,24 @@ when the timed region starts, complete .bz2 stream resident in HBM (rank 0) when
 (tests/workloads.py): enwik (default: synthetic enwik8-shaped text with phrase reuse), e8sa (SURVEY.md 8d E8S-A:
 the reference's test/sample5.ref || sample4.ref tiled), lcg (configs[3]: random printable ASCII), text, e8sb.
 Weak scaling: N GPUs compress an N x 10^8-byte stream; every rank holds its 10^8-byte slice (+ a 3.6 MB margin) only,
-planning is chained through the ranks, the encoded segments are gathered to rank 0 (compressjs_amd/dist.py).  Prints ONE JSON line (rank 0).
+every rank plans its own slice (one all_gather of per-slice RLE1 totals, no chain through the ranks), the encoded segments
+are gathered to rank 0 (compressjs_amd/dist.py).  Prints ONE JSON line (rank 0).
 
 What the line carries besides the driver's contract:
   config.bit_exact_vs_reference_digest   sha256 of the WHOLE stream == what the reference itself (node 12) produced
                                          on the same bytes (tests/golden/golden_big.json), all 112 blocks
   config.pcie_inclusive_mb_s             the same step through cjs_bz2_compress (host buffer in, host buffer out)
-  roofline                               dominant kernel, timed with HIP events on the library's stream in a
-                                         single-stream pass after the timed region; traffic from the committed
-                                         PMC pass of this build (profiles/r02_pmc_traffic.json), e2e = 16 B/B
-  cpu_baseline                           kind "reference": Bzip2.compressFile of cscott/compressjs under node 12 on
-                                         the SAME 10^8 bytes, 1 thread, timed in the build container (the reference
-                                         does not exist on the GPU box); all_cores = nproc node processes on equal
-                                         slices; port = the C restatement (oracle/) timed live on this box."""
+  roofline                               the kernel with the largest total time ON THIS WORKLOAD, found and timed with HIP
+                                         events around every launch of K1's main kernels on the library's stream in a
+                                         single-stream pass after the timed region (kernel_ms_per_step lists them all);
+                                         traffic from the PMC passes of profiles/r04_pmc_traffic.json (stamped with the
+                                         build they were collected on; null when none for this workload), e2e = 16 B/B
+  cpu_baseline                           kind "reference": Bzip2.compressFile of cscott/compressjs under node, timed ON THIS
+                                         BOX IN THIS RUN on the first 10^7 bytes of the same stream (staged copy under
+                                         oracle/_ref/refsrc, git-ignored; digest compared with the GPU's for the same prefix);
+                                         whole_stream = the same call on all 10^8 bytes, timed in the build container;
+                                         all_cores = nproc node processes on equal slices; port = the C restatement
+                                         (oracle/) timed live on this box."""
 from __future__ import annotations
 
 import argparse
@@ -42,11 +47,47 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-DOMINANT = "k1f_bsort"          # kernel the roofline object is about (k1_front.hip)
-# ALGORITHMIC bytes of one k1f_bsort launch per rotation (DESIGN.md section 3, K1 front end): 4 (index read) +
-# 8 (key bytes of the rotation's text) + 4 (suffix-array entry written); head bits are 1/8 byte.
-DOMINANT_ALG_BYTES = 16.0
+# K1's main kernels (K1P_* classes of csrc/k1_bwt.h) and the ALGORITHMIC HBM bytes one element of a launch costs:
+#   k1f_bsort   per rotation: 4 (index read) + 8 (key bytes of the rotation's text) + 4 (suffix-array entry written)
+#   k1r_round   per list entry and round: 8 (entry read) + 8 (entry written) + 4 (suffix-array entry; the 24 key bytes come from L2-resident text)
+#   k1d_build   per rotation: 4 (suffix-array entry read) + 4 (rank written)
+#   k1d_round   per list entry and round: 8 (entry read) + 4 (rank gathered) + 8 (entry written)
+#   k1d_update  per list entry and round: 8 (entry read) + 4 (rank written) + 8 (entry of the next round's list)
+# k1d_med / k1d_large / k1f_task work on groups whose sizes the host never sees: timed, but no byte figure.
+KERNELS = [("k1f_bsort", 16.0), ("k1r_round", 20.0), ("k1d_build", 8.0), ("k1d_round", 20.0), ("k1d_med", None), ("k1d_large", None),
+           ("k1d_update", 20.0), ("k1f_task", None)]
 E2E_ALG_BYTES = 16.0            # 14 + 4 rho + c bytes per input byte, nominal 16 for enwik8-shaped text
+
+
+def reference_baseline(ctx, host: np.ndarray, level: int, nbytes: int):
+    """cscott/compressjs itself (node, the copy __graft_entry__.build() stages under oracle/_ref/refsrc) on the first `nbytes`
+    of the stream, one thread, timed by the reference runner (process.hrtime around Bzip2.compressFile) on THIS box in THIS
+    run; its output digest is compared with the GPU's for the same bytes.  None when node or the staged copy is missing."""
+    import shutil
+    import subprocess
+    import tempfile
+    ref = os.path.join(ROOT, "oracle", "_ref", "refsrc")
+    node = shutil.which("node")
+    if not node or not os.path.exists(os.path.join(ref, "main.js")):
+        return None
+    sample = np.ascontiguousarray(host[:nbytes])
+    with tempfile.TemporaryDirectory(prefix="cjsref-") as tmp:
+        inp, jobs, res = os.path.join(tmp, "in.bin"), os.path.join(tmp, "jobs.json"), os.path.join(tmp, "res.json")
+        sample.tofile(inp)
+        json.dump([{"id": "prefix", "kind": "bz2", "input": inp, "level": level}], open(jobs, "w"))
+        try:
+            subprocess.check_call([node, "--max-old-space-size=4096", os.path.join(ROOT, "tests", "golden", "ref_runner.js"), jobs, res],
+                                  env=dict(os.environ, COMPRESSJS_REF=ref), timeout=900, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            r = json.load(open(res))[0]
+        except Exception:                                    # noqa: BLE001
+            return None
+    ours = ctx.compress(sample, level)
+    same = bool(hashlib.sha256(ours).hexdigest() == r["out_sha256"] and len(ours) == r["out_len"])
+    ver = subprocess.check_output([node, "--version"]).decode().strip()
+    return dict(value=round(sample.size / r["seconds"] / 1e6, 4), unit="MB/s", cores=1, kind="reference",
+                sample="Bzip2.compressFile(buf, null, %d) of cscott/compressjs under node %s on the first %d bytes of this run's stream, "
+                       "%.1f s, timed on this box in this run" % (level, ver, sample.size, r["seconds"]),
+                same_bytes_as_gpu=same)
 
 
 def port_baseline(data: np.ndarray, level: int, sample_bytes: int):
@@ -125,6 +166,7 @@ def main():
     ap.add_argument("--level", type=int, default=9)
     ap.add_argument("--workload", default="enwik", choices=["enwik", "text", "lcg", "e8sa", "e8sb"])
     ap.add_argument("--cpu-sample", type=int, default=12_000_000)
+    ap.add_argument("--ref-sample", type=int, default=10_000_000, help="bytes of the stream the reference (node) is timed on, on this box")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--full-verify", action="store_true", help="N > 1: rebuild the whole job stream on rank 0 and decode / compare it even when a pinned digest exists")
     ap.add_argument("--batch", type=int, default=128, help="bzip2 blocks in flight (over all streams)")
@@ -275,33 +317,42 @@ def main():
                 assert nn == len(comp) and hashlib.sha256(hbuf[:nn].tobytes()).hexdigest() == sha
                 tt = tt[1:]
                 pcie = round(total / min(tt) / 1e6, 1)
-        # ---- roofline leg: the dominant kernel alone on the GPU (one stream), HIP events around every launch ---
-        avg_ms, launches, elements = 0.0, 0, 0
+        # ---- roofline leg: K1's main kernels alone on the GPU (one stream), HIP events around every launch; the one with the
+        #      largest total on this workload is the line's dominant kernel -----------------------------------------------
+        prof_steps, kms, dom = 3, {}, None
+        avg_ms, launches, elements, alg_per_el = 0.0, 0, 0, None
         if world == 1:
             os.environ["CJS_STREAMS"] = "1"
             ctx1 = Context(local, args.batch)
             ctx1.compress_device(d_in, d_out, args.level)
             ctx1.L.cjs_profile_enable(ctx1.h, 1)
-            for _ in range(3):
+            for _ in range(prof_steps):
                 ctx1.compress_device(d_in, d_out, args.level)
-            pms, pl, pe = C.c_float(0), C.c_uint32(0), C.c_uint64(0)
-            ctx1.L.cjs_profile_read(ctx1.h, C.byref(pms), C.byref(pl), C.byref(pe))
+            torch.cuda.synchronize()
+            rows = []
+            for cls, (name, per_el) in enumerate(KERNELS):
+                pms, pl, pe = C.c_float(0), C.c_uint32(0), C.c_uint64(0)
+                ctx1.L.cjs_profile_read_class(ctx1.h, cls, C.byref(pms), C.byref(pl), C.byref(pe))
+                rows.append((name, per_el, float(pms.value), int(pl.value), int(pe.value)))
+                kms[name] = round(pms.value / prof_steps, 4)
             ctx1.L.cjs_profile_enable(ctx1.h, 0)
             ctx1.close()
-            launches, elements = int(pl.value), int(pe.value)
-            avg_ms = pms.value / max(launches, 1)
-        alg_bytes = DOMINANT_ALG_BYTES * (elements / launches if launches else args.size)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE passes of THIS build on THIS workload, collected by
-        # tests/gpu_round_end.sh into profiles/r03_pmc_traffic.json (separate --pmc runs; FETCH_SIZE doubled as the
-        # MI355X guide prescribes for gfx950).  null when no pass for this workload/size is committed.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        if os.path.exists(tpath):
+            os.environ.pop("CJS_STREAMS", None)
+            dom, alg_per_el, tot_ms, launches, elements = max(rows, key=lambda r: r[2])
+            avg_ms = tot_ms / max(launches, 1)
+        alg_bytes = None if (alg_per_el is None or not launches) else alg_per_el * elements / launches
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if (alg_bytes and avg_ms > 0) else None
+        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE passes of this workload (separate --pmc runs, tests/gpu_r4_pmc.sh;
+        # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), committed as profiles/r04_pmc_traffic.json together with
+        # the build they were collected on.  null when no pass for this workload / size / kernel is committed.
+        traffic, traffic_build = None, None
+        tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        if os.path.exists(tpath) and dom:
             tj = json.load(open(tpath))
-            ent = tj.get("%s:%d" % (args.workload, args.size), {}).get(DOMINANT)
-            if ent:
-                traffic = ent["traffic_bytes_per_launch"]
+            ent = tj.get("%s:%d" % (args.workload, args.size), {}).get(dom)
+            if ent and launches:
+                traffic = round(ent["traffic_bytes_per_step"] * prof_steps / launches)
+                traffic_build = tj.get("build")
         # ---- SURVEY.md 8(d)'s real-text headline (E8S-A: test/sample5.ref || sample4.ref tiled) in the same line --------------
         e8 = {"mb_s": None, "ms": None, "exact": None}
         if world == 1 and args.workload != "e8sa" and workloads.have_fixtures() and not args.no_verify:
@@ -322,16 +373,23 @@ def main():
             del d2, h2
         wall = elapsed / args.steps
         ref_line = None
+        if world == 1 and not args.no_verify:
+            ref_line = reference_baseline(ctx, host, args.level, min(args.ref_sample, total))
+        whole = None
         if g is not None and "mb_per_s" in g and world == 1:
             ac = gold.get("%s:%d:allcores:%d" % (args.workload, total, args.level))       # this workload's own all-cores timing, or none
-            ref_line = {"value": g["mb_per_s"], "unit": "MB/s", "cores": 1, "kind": "reference",
-                        "sample": "Bzip2.compressFile(buf, null, %d) of cscott/compressjs under node 12 on the whole %d-byte "
-                                  "stream of this run (same sha256 in and out), %.1f s, timed in the build container "
-                                  "(tests/golden/make_golden_big.py); /root/reference does not exist on the GPU box"
-                                  % (args.level, g["in_len"], g["seconds"]),
-                        "all_cores": None if not ac else {"value": ac["sum_mb_per_s"], "unit": "MB/s", "processes": ac["processes"],
-                                                          "sample": "%d node processes on equal slices of this stream, summed" % ac["processes"]},
-                        "port": port}
+            whole = {"value": g["mb_per_s"], "unit": "MB/s", "cores": 1,
+                     "sample": "the same call on the whole %d-byte stream of this run (same sha256 in and out as this line), %.1f s, "
+                               "timed in the build container (tests/golden/make_golden_big.py)" % (g["in_len"], g["seconds"]),
+                     "all_cores": None if not ac else {"value": ac["sum_mb_per_s"], "unit": "MB/s", "processes": ac["processes"],
+                                                       "sample": "%d node processes on equal slices of this stream, summed" % ac["processes"]}}
+        if ref_line is not None:
+            ref_line["whole_stream"] = whole
+            ref_line["port"] = port
+        elif whole is not None:
+            ref_line = dict(whole, kind="reference", port=port)
+            ref_line["sample"] = ("Bzip2.compressFile(buf, null, %d) of cscott/compressjs under node 12: " % args.level) + ref_line["sample"] + \
+                                 "; no node / staged reference on this box"
         elif port is not None:
             ref_line = dict(port, kind="port")
         line = {
@@ -359,10 +417,11 @@ def main():
                        "pcie_inclusive_mb_s": pcie,
                        "gpu_decode_mb_s": decode_mb_s,
                        "sha256": sha},
-            "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 2),
-                         "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 5),
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 2),
+                         "peak": 8000.0, "unit": "GB/s", "frac": None if achieved is None else round(achieved / 8000.0, 5),
                          "avg_launch_ms": round(avg_ms, 4), "launches": launches,
-                         "alg_bytes_per_launch": alg_bytes, "traffic": traffic,
+                         "alg_bytes_per_launch": alg_bytes, "traffic": traffic, "traffic_build": traffic_build,
+                         "kernel_ms_per_step": kms,
                          "e2e": {"alg_bytes_per_input_byte": E2E_ALG_BYTES,
                                  "achieved": round(E2E_ALG_BYTES * total / wall / 1e9, 2),
                                  "frac": round(E2E_ALG_BYTES * total / wall / 8e12, 5)}},

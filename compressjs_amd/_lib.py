@@ -16,7 +16,7 @@ SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_lcg_ascii_devic
            "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_plan_block_start", "cjs_bwtc_last_times", "cjs_bz2_plan_scan", "cjs_bz2_plan_cost", "cjs_bz2_plan_phase", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
            "cjs_bwtc_compress_bound",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
-           "cjs_profile_read", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
+           "cjs_profile_read", "cjs_profile_read_class", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
            "cjs_suffixsort", "cjs_unbwt_linear", "cjs_huff_lengths", "cjs_huff_lengths_batch",
            "cjs_bz2_decompress", "cjs_bz2_decompress_device", "cjs_bz2_decompress_block", "cjs_bz2_table",
            "cjs_bz2_last_size", "cjs_bz2_fetch", "cjs_shift_bits", "cjs_bwtc_decompress", "cjs_bwtc_last_size", "cjs_bwtc_fetch", "cjs_bz2_last_detail", "cjs_bz2_last_decode_ms",
@@ -88,6 +88,8 @@ def load(path: str | None = None):
     L.cjs_stream.argtypes = [vp]
     L.cjs_profile_enable.restype = C.c_int32
     L.cjs_profile_enable.argtypes = [vp, C.c_int]
+    L.cjs_profile_read_class.restype = C.c_int32
+    L.cjs_profile_read_class.argtypes = [vp, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     L.cjs_profile_read.restype = C.c_int32
     L.cjs_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32),
                                    C.POINTER(C.c_uint64)]

@@ -333,6 +333,7 @@ struct cjs_ctx {
     u32 last_blocks;
     // optional per-kernel timing of the dominant kernel (bench.py roofline leg)
     K1Prof prof;
+    BatchGeom prof_g;          // geometry of the last sub-batch issued (where cjs_profile_read_class finds K1's counters)
     // state of cjs_bz2_plan
     K0Buf plan;
     int plan_level;
@@ -465,6 +466,7 @@ static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap
     P.out = (u32*)d_out;
     P.outCapBytes = out_cap & ~(uint64_t)3;
     P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
+    if (c->prof.enabled) c->prof_g = g;
     P.g.nb = nb;
     int rc = k0_batch(K, P, f, cap, st);
     if (rc) return rc;
@@ -1326,18 +1328,39 @@ extern "C" float cjs_last_device_ms(const cjs_ctx* c) { return c ? c->last_ms : 
 extern "C" uint32_t cjs_last_block_count(const cjs_ctx* c) { return c ? c->last_blocks : 0; }
 extern "C" void* cjs_stream(const cjs_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-// Per-kernel timing of the dominant kernel (k1f_bsort; k1_scatter with CJS_FRONT=0) with HIP events on the
-// library's own stream, for bench.py's roofline leg.
+// Per-kernel timing of K1's main kernels with HIP events on the library's own streams, for bench.py's roofline leg
+// (K1P_* classes of k1_bwt.h: 0 k1f_bsort, 1 k1r_round, 2 k1d_build, 3 k1d_round, 4 k1d_med, 5 k1d_large, 6 k1d_update,
+// 7 k1f_task).  cjs_profile_enable(1) clears the records; the classes can be read in any order while they stand.
 extern "C" int32_t cjs_profile_enable(cjs_ctx* c, int on) {
     if (!c) return CJS_E_ARG;
     return k1_prof_enable(c->prof, on);
 }
-extern "C" int32_t cjs_profile_read(cjs_ctx* c, float* total_ms, uint32_t* launches, uint64_t* elements) {
-    if (!c) return CJS_E_ARG;
+extern "C" int32_t cjs_profile_read_class(cjs_ctx* c, uint32_t cls, float* total_ms, uint32_t* launches, uint64_t* elements) {
+    if (!c || cls >= K1_PROF_CLASSES) return CJS_E_ARG;
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return CJS_E_HIP - (int)e;
     u64 el = 0;
-    const int rc = k1_prof_read(c->prof, total_ms, launches, &el);
+    const int rc = k1_prof_read(c->prof, cls, total_ms, launches, &el);
+    if (rc) return rc;
+    if (cls == K1P_DROUND || cls == K1P_DUPDATE) {
+        // list entries the doubling rounds walked: the counters of the LAST sub-batch of stream 0 (what a one-stream pass over
+        // equal batches leaves), times the k1_dbl_run calls recorded
+        const BatchGeom g = c->prof_g;
+        if (!g.nb) { if (elements) *elements = 0; return CJS_OK; }
+        Pipe P;
+        pipe_carve(P, g, c->ws[0]);
+        std::vector<u32> cn((size_t)(K1D_MAXR + 2) * P.k1.rstride);
+        e = hipMemcpy(cn.data(), P.k1.dcnt, cn.size() * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return CJS_E_HIP - (int)e;
+        u64 tot = 0;
+        for (u32 v : cn) tot += v;
+        el = tot * c->prof.dbl_runs;
+    }
     if (elements) *elements = el;
-    return rc;
+    return CJS_OK;
+}
+extern "C" int32_t cjs_profile_read(cjs_ctx* c, float* total_ms, uint32_t* launches, uint64_t* elements) {
+    return cjs_profile_read_class(c, K1P_BSORT, total_ms, launches, elements);
 }
 
 // ---------------------------------------------------------------------------------------------

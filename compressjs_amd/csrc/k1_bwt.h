@@ -46,17 +46,36 @@ static_assert(K1F_LOG_NB != 0u, "K1F_NB: 512, 1024, 2048 or 4096");
                             // request of k1f_scatter carries; k1f_scatter / k1f_scan 0.40 / 0.07 -> 0.30 / 0.04 ms per 10^8 bytes)
 #endif
 
-// HIP-event timing of one kernel's launches (k1_scatter), filled by k1_run when enabled.
-#define K1_PROF_MAX 4096
+// HIP-event timing of K1's main kernels, launch by launch, on the stream they are launched on (bench.py's roofline leg picks
+// the kernel with the largest total for the workload at hand).  Filled by the host drivers when enabled.
+#define K1_PROF_MAX 8192
+#define K1_PROF_CLASSES 8
+enum { K1P_BSORT = 0, K1P_RROUND = 1, K1P_DBUILD = 2, K1P_DROUND = 3, K1P_DMED = 4, K1P_DLARGE = 5, K1P_DUPDATE = 6, K1P_TASK = 7 };
 struct K1Prof {
     int enabled;
-    u32 used;                 // event pairs recorded since the last read
-    u64 elements;             // elements those launches processed
-    hipEvent_t* ev;           // [2*K1_PROF_MAX]
+    u32 used;                             // event pairs recorded since the profile was enabled
+    u64 elements[K1_PROF_CLASSES];        // elements the launches of a class processed (where the host knows them)
+    u32 dbl_runs;                         // k1_dbl_run calls (the entries of their lists are read back from the workspace)
+    unsigned char* cls;                   // [K1_PROF_MAX] class of every pair
+    hipEvent_t* ev;                       // [2 * K1_PROF_MAX]
 };
 int k1_prof_enable(K1Prof& p, int on);
-int k1_prof_read(K1Prof& p, float* total_ms, u32* launches, u64* elements);
+int k1_prof_read(K1Prof& p, u32 cls, float* total_ms, u32* launches, u64* elements);
 void k1_prof_destroy(K1Prof& p);
+// slots are reserved atomically: sub-batches on different streams are driven by different host threads
+static inline u32 k1_prof_begin(K1Prof* pr, u32 cls, hipStream_t stream) {
+    if (!pr || !pr->enabled) return K1_PROF_MAX;
+    const u32 slot = __atomic_fetch_add(&pr->used, 1u, __ATOMIC_RELAXED);
+    if (slot >= K1_PROF_MAX) return K1_PROF_MAX;
+    pr->cls[slot] = (unsigned char)cls;
+    (void)hipEventRecord(pr->ev[2 * slot], stream);
+    return slot;
+}
+static inline void k1_prof_end(K1Prof* pr, u32 slot, hipStream_t stream, u64 elements) {
+    if (slot >= K1_PROF_MAX) return;
+    (void)hipEventRecord(pr->ev[2 * slot + 1], stream);
+    __atomic_fetch_add(&pr->elements[pr->cls[slot]], elements, __ATOMIC_RELAXED);
+}
 
 struct K1Buf {
     K1Prof* prof;     // optional

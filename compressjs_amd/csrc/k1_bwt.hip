@@ -537,33 +537,41 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
 int k1_prof_enable(K1Prof& p, int on) {
     if (on && !p.ev) {
         p.ev = new hipEvent_t[2 * K1_PROF_MAX];
+        p.cls = new unsigned char[K1_PROF_MAX];
         for (int i = 0; i < 2 * K1_PROF_MAX; i++) HIP_CHECK_RET(hipEventCreate(&p.ev[i]));
     }
     p.enabled = on;
-    p.used = 0;
-    p.elements = 0;
+    if (on) {
+        p.used = 0;
+        p.dbl_runs = 0;
+        for (int i = 0; i < K1_PROF_CLASSES; i++) p.elements[i] = 0;
+    }
     return CJS_OK;
 }
-int k1_prof_read(K1Prof& p, float* total_ms, u32* launches, u64* elements) {
+// totals of one class since the profile was enabled (the records stay: every class can be read)
+int k1_prof_read(K1Prof& p, u32 cls, float* total_ms, u32* launches, u64* elements) {
     float tot = 0.f;
-    if (p.used > K1_PROF_MAX) p.used = K1_PROF_MAX;
-    for (u32 i = 0; i < p.used; i++) {
+    u32 n = 0;
+    const u32 used = p.used > K1_PROF_MAX ? K1_PROF_MAX : p.used;
+    for (u32 i = 0; p.ev && i < used; i++) {
+        if (p.cls[i] != cls) continue;
         float ms = 0.f;
         HIP_CHECK_RET(hipEventSynchronize(p.ev[2 * i + 1]));
         HIP_CHECK_RET(hipEventElapsedTime(&ms, p.ev[2 * i], p.ev[2 * i + 1]));
         tot += ms;
+        n++;
     }
     if (total_ms) *total_ms = tot;
-    if (launches) *launches = p.used;
-    if (elements) *elements = p.elements;
-    p.used = 0;
-    p.elements = 0;
+    if (launches) *launches = n;
+    if (elements) *elements = cls < K1_PROF_CLASSES ? p.elements[cls] : 0;
     return CJS_OK;
 }
 void k1_prof_destroy(K1Prof& p) {
     if (p.ev) {
         for (int i = 0; i < 2 * K1_PROF_MAX; i++) (void)hipEventDestroy(p.ev[i]);
         delete[] p.ev;
+        delete[] p.cls;
         p.ev = nullptr;
+        p.cls = nullptr;
     }
 }

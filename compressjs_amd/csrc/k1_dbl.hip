@@ -1001,7 +1001,11 @@ __global__ __launch_bounds__(256) void k1d_update(K1Buf B, BatchGeom g, u32 r) {
 // host
 // ---------------------------------------------------------------------------------------------
 int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h0) {
+    K1Prof* pr = B.prof;
+    if (pr && pr->enabled) __atomic_fetch_add(&pr->dbl_runs, 1u, __ATOMIC_RELAXED);
+    u32 slot = k1_prof_begin(pr, K1P_DBUILD, stream);
     hipLaunchKernelGGL(k1d_build, dim3(g.htiles, g.nb), dim3(256), 0, stream, B, g);
+    k1_prof_end(pr, slot, stream, (u64)g.nb * max_n);
     const u64 full = ((u64)g.nb * max_n + K1D_T - 1u) / K1D_T;      // tiles if every rotation were listed
     u32 bg = g.nb * 8u;                                   // workgroups of the big-group kernels
     if (bg < 64u) bg = 64u;
@@ -1020,11 +1024,19 @@ int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h
         u64 wgs = 2048u;
 #endif
         if (wgs > full) wgs = full ? full : 1u;
+        slot = k1_prof_begin(pr, K1P_DROUND, stream);
         hipLaunchKernelGGL(k1d_round, dim3((u32)wgs), dim3(256), 0, stream, B, g, r, h, final_h);
+        k1_prof_end(pr, slot, stream, 0);
+        slot = k1_prof_begin(pr, K1P_DMED, stream);
         hipLaunchKernelGGL(k1d_med<K1D_MED1>, dim3(bg * 2u), dim3(256), 0, stream, B, g, r, h, final_h);
         hipLaunchKernelGGL(k1d_med<K1_MED_MAX>, dim3(bg), dim3(256), 0, stream, B, g, r, h, final_h);
+        k1_prof_end(pr, slot, stream, 0);
+        slot = k1_prof_begin(pr, K1P_DLARGE, stream);
         hipLaunchKernelGGL(k1d_large, dim3(bg < 256u ? bg : 256u), dim3(1024), 0, stream, B, g, r, h, final_h);
+        k1_prof_end(pr, slot, stream, 0);
+        slot = k1_prof_begin(pr, K1P_DUPDATE, stream);
         hipLaunchKernelGGL(k1d_update, dim3((u32)wgs), dim3(256), 0, stream, B, g, r);
+        k1_prof_end(pr, slot, stream, 0);
         if (final_h) break;
     }
     HIP_CHECK_RET(hipGetLastError());

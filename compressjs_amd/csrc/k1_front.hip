@@ -1404,20 +1404,19 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
     hipLaunchKernelGGL(k1f_hist, dim3(ptiles, g.nb), dim3(1024), 0, stream, B, g, ptiles);
     hipLaunchKernelGGL(k1f_scan, dim3(g.nb), dim3(1024), 0, stream, B, g, ptiles);
     hipLaunchKernelGGL(k1f_scatter, dim3(ptiles, nb8), dim3(1024), 0, stream, B, g, ptiles);
-    K1Prof* pr = B.prof;
-    const u32 slot = pr && pr->enabled ? __atomic_fetch_add(&pr->used, 1u, __ATOMIC_RELAXED) : K1_PROF_MAX;
-    const bool timed = slot < K1_PROF_MAX;
-    if (timed) (void)hipEventRecord(pr->ev[2 * slot], stream);
-    hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max);
-    if (timed) {
-        (void)hipEventRecord(pr->ev[2 * slot + 1], stream);
-        __atomic_fetch_add(&pr->elements, (u64)g.nb * max_n, __ATOMIC_RELAXED);
+    {
+        const u32 slot = k1_prof_begin(B.prof, K1P_BSORT, stream);
+        hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max);
+        k1_prof_end(B.prof, slot, stream, (u64)g.nb * max_n);
     }
     // the task levels: what k1f_bsort could not finish in LDS (slices beyond K1F_C, big groups), level after level; an empty
     // level costs its launch (~2 us: the workgroups read one counter and leave)
-    for (u32 lv = 0; lv < K1F_LEVELS; lv++)
+    for (u32 lv = 0; lv < K1F_LEVELS; lv++) {
+        const u32 slot = k1_prof_begin(B.prof, K1P_TASK, stream);
         hipLaunchKernelGGL(k1f_task, dim3(g.nb * 16u < 2048u ? g.nb * 16u : 2048u), dim3(K1F_BT), 0, stream, B, g, lv, iters, lists, purerot_max,
                            lv + 1u == K1F_LEVELS ? 1u : 0u);
+        k1_prof_end(B.prof, slot, stream, 0);
+    }
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
@@ -1433,7 +1432,9 @@ int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u
         // its share of the tiles (an empty workgroup still costs its dispatch)
         u32 tiles = (full >> r) / 8u;                 // a workgroup walks ~8 tiles (software pipeline), later rounds fewer
         if (tiles < 16u) tiles = 16u;
+        const u32 slot = k1_prof_begin(B.prof, K1P_RROUND, stream);
         hipLaunchKernelGGL(k1r_round, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
+        k1_prof_end(B.prof, slot, stream, 0);
     }
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;

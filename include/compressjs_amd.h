@@ -78,9 +78,15 @@ int64_t cjs_bz2_encode_blocks(cjs_ctx* ctx, uint32_t first, uint32_t count, void
 float cjs_last_device_ms(const cjs_ctx* ctx);
 uint32_t cjs_last_block_count(const cjs_ctx* ctx);
 void* cjs_stream(const cjs_ctx* ctx);   /* the hipStream_t the library launches on */
-/* HIP-event timing of every launch of the dominant kernel (k1f_bsort, the in-LDS bucket sort of the suffix sort's
- * sample-sort front end; k1_scatter with CJS_FRONT=0): event pairs on the library's own stream, for bench.py's roofline leg. */
+/* HIP-event timing of every launch of the suffix sort's main kernels (event pairs on the library's own streams), for
+ * bench.py's roofline leg - which names the kernel with the largest total for the workload at hand.  Classes: 0 k1f_bsort
+ * (in-LDS bucket sort of the sample-sort front end), 1 k1r_round (text refinement rounds), 2 k1d_build, 3 k1d_round,
+ * 4 k1d_med, 5 k1d_large, 6 k1d_update (prefix-doubling stage), 7 k1f_task.  `elements`: rotations (classes 0, 2), list
+ * entries walked (3, 6: read back from the last sub-batch's counters - exact for a one-stream pass over equal batches).
+ * cjs_profile_enable(ctx, 1) clears the records; cjs_profile_read = class 0.  Test / bench instrumentation: no reference
+ * counterpart. */
 int32_t cjs_profile_enable(cjs_ctx* ctx, int on);
+int32_t cjs_profile_read_class(cjs_ctx* ctx, uint32_t cls, float* total_ms, uint32_t* launches, uint64_t* elements);
 int32_t cjs_profile_read(cjs_ctx* ctx, float* total_ms, uint32_t* launches, uint64_t* elements);
 
 #define CJS_E_LEVEL (-20)

@@ -22,6 +22,20 @@ with open('gpurun_out/r4pmc/%s_pmc_per_kernel.csv' % W, 'w') as o:
     o.write('kernel,' + ','.join(names) + '\n')
     for k in sorted(acc, key=lambda k: -acc[k].get('SQ_WAVE_CYCLES', 0)):
         o.write(k + ',' + ','.join('%.0f' % acc[k].get(c, 0) for c in names) + '\n')
+import json, os
+tp = 'gpurun_out/r4pmc/r04_pmc_traffic.json'
+tj = json.load(open(tp)) if os.path.exists(tp) else {}
+tj['build'] = os.environ.get('GIT_REV', 'unknown')
+tj['note'] = ('HBM traffic per kernel and STEP (one 10^8-byte compress, CJS_STREAMS=1): (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes / steps, '
+              'separate --pmc passes (tests/gpu_r4_pmc.sh); FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950, '
+              'WRITE_SIZE uncalibrated; Infinity-Cache hits are counted as traffic')
+tj['%s:100000000' % W] = {k.split('<')[0]: {'traffic_bytes_per_step': round((2 * acc[k].get('FETCH_SIZE', 0) + acc[k].get('WRITE_SIZE', 0)) * 1024 / 2),
+                                          'fetch_kb_per_step': round(acc[k].get('FETCH_SIZE', 0) / 2), 'write_kb_per_step': round(acc[k].get('WRITE_SIZE', 0) / 2)}
+                          for k in acc if acc[k].get('FETCH_SIZE', 0) + acc[k].get('WRITE_SIZE', 0) > 0 and not k.startswith('k1d_med')}
+med = [k for k in acc if k.startswith('k1d_med')]
+if med:
+    tj['%s:100000000' % W]['k1d_med'] = {'traffic_bytes_per_step': round(sum((2 * acc[k].get('FETCH_SIZE', 0) + acc[k].get('WRITE_SIZE', 0)) for k in med) * 1024 / 2)}
+json.dump(tj, open(tp, 'w'), indent=1, sort_keys=True)
 for k in sorted(acc, key=lambda k: -acc[k].get('SQ_WAVE_CYCLES', 0))[:14]:
     a = acc[k]
     wc = a.get('SQ_WAVE_CYCLES', 1) or 1
