@@ -22,7 +22,10 @@
 #define K1E_MAKE(len1, idx, s, pos) (((u64)(len1) << 52) | ((u64)(idx) << 44) | ((u64)(s) << 22) | (u64)(pos))
 // doubling rounds (k1_dbl.hip)
 #define K1D_MAXR 24            // rounds at most (h0 >= 8, n < 2^22: 19 doublings + the tie-break round)
-#define K1D_GS 256u            // groups up to this size are list entries (ranked by counting inside a tile); larger ones are descriptors
+#ifndef K1D_GS
+#define K1D_GS 256u
+#endif
+// K1D_GS: groups up to this size are list entries (ranked by counting inside a tile); larger ones are descriptors
 #define K1_DM_SUB 64u      // sub-lists per class of the medium rounds (one counter each: a single counter serialises millions of appends)
 #define K1_SPREAD 128
 #define K1_MED_MAX 4096     // sparse phase: largest group a workgroup sorts in LDS

@@ -351,7 +351,7 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     const size_t e = (size_t)g.nb * g.stride;
     const u32 nb8 = (g.nb + 7u) & ~7u;
     B.rstride = nb8;
-    B.listTCap = g.nb * (g.stride / 256u);                  // descriptors of groups of K1D_GS+1 .. 1024 rotations
+    B.listTCap = g.nb * (g.stride / K1D_GS);                // descriptors of groups of K1D_GS+1 .. 1024 rotations
     B.listSCap = g.nb * (g.stride / 8u);                    // lane kernels' lists (8 XCD regions x K1_DEEP_SUB sub-regions); chunks of large groups
     B.listMCap = g.nb * (g.stride / 1024u + 1u);            // descriptors of groups of 1025 .. K1_MED_MAX
     B.listLCap = g.nb * (g.stride / K1_MED_MAX + 1u);       // ... of larger ones

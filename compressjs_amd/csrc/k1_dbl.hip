@@ -35,12 +35,13 @@
 #include "devutil.h"
 
 #define K1D_T 1024u                       // entries a workgroup owns per step
-#define K1D_N (K1D_T + K1D_GS)            // ... and looks at
+#define K1D_WIN 256u                      // entries / positions behind its own a workgroup looks at (the tail of its last group)
+#define K1D_N (K1D_T + K1D_WIN)           // ... and looks at
 #define K1D_RPT (K1D_N / 256u)            // slots per thread
 #define K1D_FW (K1D_N / 32u)              // words of a slot bitmap
 #define K1D_BW (K1D_N / 32u + 2u)         // head-bitmap words a build window looks at
 #define K1D_INF 0x3FFFFFFF
-static_assert(K1D_N % 256u == 0 && K1D_BW <= 64u && K1D_GS <= 256u && K1_HT == K1D_T, "window geometry");
+static_assert(K1D_N % 256u == 0 && K1D_BW <= 64u && K1D_GS <= K1D_WIN && K1D_WIN <= 256u && K1_HT == K1D_T, "window geometry");
 
 #define K1D_DESC(b, start, len) (((u64)(b) << 52) | ((u64)(start) << 26) | (u64)(len))
 #define K1D_DB(d) ((u32)((d) >> 52))
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void k1d_build(K1Buf B, BatchGeom g) {
     const u32 b = blockIdx.y, n = B.nlen[b];
     const u32 lo = blockIdx.x * K1D_T;
     if (lo >= n || (B.dtot[b] == 0u && !B.linear)) return;          // (linear mode: k1_finish_linear reads the rank of suffix 0)
-    k1d_window<true>(B, g, b, lo, n - lo < K1D_T ? n - lo : K1D_T, K1D_GS, 0u);
+    k1d_window<true>(B, g, b, lo, n - lo < K1D_T ? n - lo : K1D_T, K1D_WIN, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -478,7 +479,7 @@ __device__ __forceinline__ void k1d_push_chunks(const K1Buf& B, u32 r, u32 b, u3
     for (u32 k = threadIdx.x; k < nch; k += blockDim.x) {
         const u32 cs = k * K1D_T, cl = len - cs < K1D_T ? len - cs : K1D_T;
         const u32 rest = len - cs - cl;
-        if (cbase + k < B.listSCap) B.listS[0][cbase + k] = K1D_CHUNK(b, start + cs, cl, rest < K1D_GS ? rest : K1D_GS);
+        if (cbase + k < B.listSCap) B.listS[0][cbase + k] = K1D_CHUNK(b, start + cs, cl, rest < K1D_WIN ? rest : K1D_WIN);
     }
 }
 
