@@ -762,20 +762,25 @@ extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_l
 }
 
 // ---- Bzip2.compressFile over several GPUs of one node, from ONE process (the Node addon's path to N devices) -----
-// The input is cut at the nominal segment ends E_k = (k+1) * seg_bytes; segment k goes to device k mod n.  Each device
-// thread uploads only its windows [E_(k-1) - W, E_k) of the input (all uploads start at once), then waits for s_k, the
-// start of the first block of its segment - published by segment k-1 as soon as THAT segment is planned (K0 pre-pass,
-// ~0.3 ms), not encoded - plans [s_k, E_k) as an input of its own (blocks start with a fresh RLE1 state), publishes
-// s_(k+1) = start of its last, incomplete block, and encodes the others from bit 0 into a buffer of its own.  When all
-// bit lengths are known the segments are shifted on their devices to their bit offsets and copied side by side into the
-// caller's buffer (parallel D2H, no peer traffic); the bytes two segments share are OR-ed on the host, which also folds
-// the combined CRC (linear over GF(2)) and writes header and trailer.  A block that reaches further back than the window
-// margin W (run-heavy input) makes the call fall back to one device.  = SURVEY.md 8(e) without torch.distributed.
+// The input is cut at the nominal segment ends E_k = (k+1) * seg_bytes; segment k goes to device k mod n.  Round 4: the plan of
+// a segment no longer waits for the plan of the segment before it (the reference's `do { readBlock } while`, lib/Bzip2.js:913-922,
+// is serial; rounds 2-3 kept it serial across the segments).  Segments are taken in waves of n (one per device), and per wave:
+//   A. every device uploads its window - the segment and the margin BEHIND it, [E_(k-1), E_k + W) - and scans it (K0's RLE1 cost
+//      prefix, cjs_bz2_plan_scan): the segment's cost total; the host reads the segment's first and last run off the input;
+//   B. from those summaries (the integer arithmetic of compressjs_amd/dist.py:plan_bases, restated below) every segment gets the
+//      phase of the block boundaries inside it, plans the blocks that START in it (cjs_bz2_plan_phase) and encodes them from bit 0
+//      into a buffer of its own, the margin completing the last one.
+// When all bit lengths are known the segments are shifted on their devices to their bit offsets and copied side by side into the
+// caller's buffer (parallel D2H, no peer traffic); the bytes two segments share are OR-ed on the host, which also folds the
+// combined CRC (linear over GF(2)) and writes header and trailer.  A segment that cannot be planned on its own (a block boundary
+// inside a run of four or more bytes that straddles a cut, a block longer than the margin, a boundary run beyond 4 KB) makes the
+// call fall back to one device.  = SURVEY.md 8(e) without torch.distributed.
 namespace {
 struct MSeg {
-    uint64_t w0 = 0, e = 0;         // window start, nominal end (absolute input offsets)
-    uint64_t s = 0;                 // first byte of the segment's first block
-    bool s_known = false;
+    uint64_t lo = 0, e = 0;         // the segment's bytes [lo, e) (absolute input offsets)
+    uint64_t cost = 0;              // RLE1 cost of its bytes, scanned as an input of its own
+    u32 phase = 0;                  // block boundaries lie where the slice's own cost prefix reaches phase + m * cap
+    bool ok = true;                 // can be planned on its own
     uint64_t bits = 0, off = 0;
     u32 fold = 0, count = 0;
     u8* dseg = nullptr;             // device: the segment's bit stream from bit 0
@@ -783,6 +788,45 @@ struct MSeg {
     u8 first = 0, last = 0;         // seam bytes (shifted)
 };
 static inline u32 rotl32(u32 v, u32 k) { k &= 31u; return k ? (v << k) | (v >> (32u - k)) : v; }
+// RLE1 output bytes of the first k bytes of a fresh run (k0_g in k0_rle1.hip)
+static inline uint64_t rle1_g(uint64_t k) { const uint64_t q = k / 255u, r = k % 255u; return 5u * q + (r < 4u ? r : 5u); }
+// first and last run of in[lo, e), from its first / last 4096 bytes; long_run: a boundary run that reaches beyond them
+struct EdgeRuns { int hb = -1, tb = -1; uint64_t lh = 0, lt = 0; bool long_run = false; };
+static EdgeRuns edge_runs(const uint8_t* in, uint64_t lo, uint64_t e) {
+    EdgeRuns r;
+    const uint64_t n = e - lo, EDGE = 4096;
+    if (!n) return r;
+    const uint64_t hn = n < EDGE ? n : EDGE;
+    r.hb = in[lo]; r.tb = in[e - 1];
+    while (r.lh < hn && in[lo + r.lh] == (uint8_t)r.hb) r.lh++;
+    while (r.lt < hn && in[e - 1 - r.lt] == (uint8_t)r.tb) r.lt++;
+    r.long_run = (r.lh == hn && n > hn) || (r.lt == hn && n > hn);
+    return r;
+}
+// compressjs_amd/dist.py:plan_bases for one more segment: G = cost prefix of the stream at the segment's start, (inb, ink) = the
+// run that reaches it from the left
+struct PlanChain { uint64_t G = 0; int inb = -1; uint64_t ink = 0; };
+static void plan_base(PlanChain& P, MSeg& g, const EdgeRuns& r, u32 cap) {
+    const uint64_t n = g.e - g.lo;
+    g.ok = !r.long_run;
+    int64_t delta = 0;
+    if (n && P.inb == r.hb && P.ink > 0) {
+        delta = (int64_t)rle1_g(P.ink + r.lh) - (int64_t)rle1_g(P.ink) - (int64_t)rle1_g(r.lh);      // the head run costs what the tail of a longer run costs
+        if (P.ink + r.lh >= 4) {
+            // a run of four or more bytes straddles the cut: no block boundary may fall into its cost span, measured from the run's first byte
+            const uint64_t c0 = P.G - rle1_g(P.ink), c1 = P.G + rle1_g(P.ink + r.lh) - rle1_g(P.ink);
+            if (c0 / cap != c1 / cap || c0 % cap == 0 || c1 % cap == 0) g.ok = false;
+        }
+    }
+    const uint64_t base = (uint64_t)((int64_t)P.G + delta);
+    g.phase = (u32)((cap - base % cap) % cap);
+    if (n) {
+        if (r.lh == n && P.inb == r.hb && P.ink > 0) P.ink += n;       // the whole segment continues the incoming run
+        else if (r.lh == n) { P.inb = r.hb; P.ink = n; }
+        else { P.inb = r.tb; P.ink = r.lt; }
+    }
+    P.G = (uint64_t)((int64_t)P.G + (int64_t)g.cost + delta);
+}
 }
 
 extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint8_t* in, uint64_t in_len, int level,
@@ -798,50 +842,42 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
     const uint64_t W = (uint64_t)4 * (cap + 19u);
     std::vector<MSeg> S(nseg);
     for (uint64_t k = 0; k < nseg; k++) {
+        S[k].lo = k * seg_bytes;
         S[k].e = (k + 1) * seg_bytes < in_len ? (k + 1) * seg_bytes : in_len;
-        const uint64_t pe = k ? S[k - 1].e : 0;
-        S[k].w0 = pe > W ? pe - W : 0;
     }
-    S[0].s = 0; S[0].s_known = true;
     std::mutex mu;
-    std::condition_variable cv;
     const auto t_begin = std::chrono::steady_clock::now();
     std::atomic<int> err{0};        // first error; 1 = fall back to one device (the workers read it without the lock)
-    auto fail = [&](int code) { std::lock_guard<std::mutex> g(mu); if (!err.load()) err.store(code); cv.notify_all(); };
-    // phase 1 of one segment on its context
-    auto encode_seg = [&](uint64_t k) {
+    auto fail = [&](int code) { std::lock_guard<std::mutex> g(mu); if (!err.load()) err.store(code); };
+    // phase A of one segment on its context: window into HBM, cost scan
+    auto scan_seg = [&](uint64_t k) {
         cjs_ctx* c = ctxs[k % n];
         MSeg& g = S[k];
         if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); return; }
-        const uint64_t wlen = g.e - g.w0;
+        const uint64_t we = g.e + W < in_len ? g.e + W : in_len, wlen = we - g.lo;
         int rc = grow(&c->din, &c->din_bytes, wlen + 64);
         if (rc) { fail(rc); return; }
-        hipError_t e2 = hipMemcpyAsync(c->din, in + g.w0, wlen, hipMemcpyHostToDevice, c->stream);
-        if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->stream);
+        hipError_t e2 = hipMemcpyAsync(c->din, in + g.lo, wlen, hipMemcpyHostToDevice, c->stream);
         if (e2 != hipSuccess) { fail(CJS_E_HIP - (int)e2); return; }
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&]() { return err || g.s_known; });
-            if (err) return;
-        }
-        if (g.s < g.w0) { fail(1); return; }                          // the block reaches further back than the window
-        const int64_t nb = cjs_bz2_plan(c, (const u8*)c->din + (g.s - g.w0), g.e - g.s, level);
+        int64_t v = cjs_bz2_plan_scan(c, c->din, wlen, level);
+        if (v >= 0) v = cjs_bz2_plan_cost(c, g.e - g.lo);
+        if (v < 0) { fail((int)v); return; }
+        g.cost = (uint64_t)v;
+    };
+    // phase B: the blocks that start in the segment, planned from its phase and encoded from bit 0
+    auto encode_seg = [&](uint64_t k) {
+        cjs_ctx* c = ctxs[k % n];
+        MSeg& g = S[k];
+        if (!g.ok) { fail(1); return; }
+        if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); return; }
+        const int64_t nb = cjs_bz2_plan_phase(c, g.e - g.lo, g.phase, g.e >= in_len ? 1 : 0);
+        if (nb == CJS_E_SPEC) { fail(1); return; }
         if (nb < 0) { fail((int)nb); return; }
-        u32 keep = (u32)nb;
-        if (g.e < in_len) {
-            if (nb < 2) { fail(1); return; }                          // one block swallowed the segment
-            keep = (u32)nb - 1u;
-            uint64_t bs = 0;
-            if (hipMemcpy(&bs, c->plan.blkStart + keep, 8, hipMemcpyDeviceToHost) != hipSuccess) { fail(CJS_E_HIP); return; }
-            std::lock_guard<std::mutex> lk(mu);
-            S[k + 1].s = g.s + bs;
-            S[k + 1].s_known = true;
-            cv.notify_all();
-        }
-        g.dseg_cap = ((uint64_t)cjs_bz2_compress_bound(g.e - g.s) + 3) & ~(uint64_t)3;
+        if (nb == 0) return;
+        g.dseg_cap = ((uint64_t)cjs_bz2_compress_bound(g.e - g.lo + W) + 3) & ~(uint64_t)3;
         if (hipMalloc((void**)&g.dseg, g.dseg_cap) != hipSuccess) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); return; }
         u32 fold = 0, cnt = 0;
-        const int64_t bits = cjs_bz2_encode_blocks(c, 0, keep, g.dseg, g.dseg_cap, &fold, &cnt);
+        const int64_t bits = cjs_bz2_encode_blocks(c, 0, (u32)nb, g.dseg, g.dseg_cap, &fold, &cnt);
         if (bits < 0) { fail((int)bits); return; }
         g.bits = (uint64_t)bits; g.fold = fold; g.count = cnt;
     };
@@ -862,17 +898,27 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
         if (e2 == hipSuccess && span > 2) e2 = hipMemcpy(out + fb + 1, (u8*)c->dout + 1, span - 2, hipMemcpyDeviceToHost);
         if (e2 != hipSuccess) fail(CJS_E_HIP - (int)e2);
     };
-    auto run_all = [&](const std::function<void(uint64_t)>& fn) {
+    auto run_range = [&](uint64_t k0, uint64_t k1, const std::function<void(uint64_t)>& fn) {
 #ifdef CJS_CPU_DEBUG_BUILD
-        for (uint64_t k = 0; k < nseg && !err; k++) fn(k);            // the CPU logic-debug build runs kernels on one thread
+        for (uint64_t k = k0; k < k1 && !err; k++) fn(k);             // the CPU logic-debug build runs kernels on one thread
 #else
         std::vector<std::thread> th;
         for (u32 d = 0; d < n; d++)
-            th.emplace_back([&, d]() { for (uint64_t k = d; k < nseg && !err; k += n) fn(k); });
+            th.emplace_back([&, d]() { for (uint64_t k = k0 + d; k < k1 && !err; k += n) fn(k); });
         for (auto& t : th) t.join();
 #endif
     };
-    run_all(encode_seg);
+    auto run_all = [&](const std::function<void(uint64_t)>& fn) { run_range(0, nseg, fn); };
+    {
+        PlanChain pc;
+        for (uint64_t k0 = 0; k0 < nseg && !err; k0 += n) {           // a wave: one segment per device
+            const uint64_t k1 = k0 + n < nseg ? k0 + n : nseg;
+            run_range(k0, k1, scan_seg);
+            if (err) break;
+            for (uint64_t k = k0; k < k1; k++) plan_base(pc, S[k], edge_runs(in, S[k].lo, S[k].e), cap);
+            run_range(k0, k1, encode_seg);
+        }
+    }
     int64_t result = 0;
     if (!err) {
         uint64_t pos = 32;

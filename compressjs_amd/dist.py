@@ -90,7 +90,16 @@ def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
     if world > 1:                                                 # grouped send/recv, all peers' links into the root used at once)
         root = dist.get_global_rank(group, 0) if group is not None else 0
         if rank == 0:
-            gl = [shifted] + [torch.empty(lens[r], dtype=torch.uint8, device=cdev) for r in range(1, world)]
+            # one staging buffer for all peers' segments, kept across steps (no allocation inside the timed step)
+            need = sum(lens[1:])
+            stage = getattr(ctx, "_asm_stage", None)
+            if stage is None or stage.numel() < need or stage.device != torch.device(cdev):
+                stage = torch.empty(need + (need >> 2) + 4096, dtype=torch.uint8, device=cdev)
+                ctx._asm_stage = stage
+            gl, o2 = [shifted], 0
+            for r in range(1, world):
+                gl.append(stage[o2:o2 + lens[r]])
+                o2 += lens[r]
             ops = [dist.P2POp(dist.irecv, gl[r], dist.get_global_rank(group, r) if group is not None else r, group=group)
                    for r in range(1, world)]
             for req in dist.batch_isend_irecv(ops):
@@ -106,12 +115,16 @@ def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
     if rank != 0:
         return None
     toff, tbytes, total = trailer_bytes(pos, crc)
-    final = torch.zeros(total + 8, dtype=torch.uint8, device=dev)
+    final = getattr(ctx, "_asm_final", None)                  # the output buffer is kept across steps too
+    if final is None or final.numel() < total + 8 or final.device != torch.device(dev):
+        final = torch.empty(total + (total >> 3) + 4096, dtype=torch.uint8, device=dev)
+        ctx._asm_final = final
+    final[:total + 8].zero_()
     final[:4] = torch.tensor(list(b"BZh" + bytes([48 + level])), dtype=torch.uint8, device=dev)
     for r, (b, _, _) in enumerate(meta):
         n = (b + 7) // 8 + 1
         o = offs[r] // 8
-        n = min(n, final.numel() - o)
+        n = min(n, total + 8 - o)
         final[o:o + n] |= gl[r][:n]
     tb = torch.tensor(list(tbytes), dtype=torch.uint8, device=dev)
     final[toff:toff + tb.numel()] |= tb

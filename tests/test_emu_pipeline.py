@@ -546,7 +546,12 @@ def _segmented_check():
         # placement, seam bytes, trailer); zeros / runs take its fall-back to one device
         hs = [L.cjs_create(0, 4) for _ in range(3)]
         arr = (C.c_void_p * 3)(*hs)
-        for d, lv in ((np.zeros(260_000, np.uint8), 1), (synth.enwik_like(330_000, 4), 1)):
+        runs = synth.text_like(520_000, 8).copy()          # five segments on three contexts (two waves), runs on / across the cuts,
+        runs[119_990:120_004] = 65                          # a block boundary (99 981) right where a straddling run starts: refuse or agree
+        runs[239_998:240_001] = 66
+        runs[359_000:361_500] = 67
+        for d, lv in ((np.zeros(260_000, np.uint8), 1), (synth.enwik_like(330_000, 4), 1), (synth.text_like(520_000, 7), 1), (runs, 1),
+                      (np.concatenate([synth.lcg_ascii(99_981, 3), np.full(20_030, 65, np.uint8), synth.lcg_ascii(140_000, 4)]), 1)):
             cap = int(L.cjs_bz2_compress_bound(d.size))
             out = np.full(cap, 0xAA, np.uint8)                  # stale bytes: the call must write every byte it returns
             n = L.cjs_bz2_compress_multi(arr, 3, d.ctypes.data, d.size, lv, out.ctypes.data, cap)
