@@ -11,6 +11,11 @@
  * the reference's own KATs (test/bwtest.js:38-90, test/huffman.js:15-77), whole-stream .bz2
  * digests for test/sample0..5.ref at -1/-9 and ~40 crafted / synthetic inputs.
  *
+ * Known limit, inherited from the reference: orc_huff_lengths64 follows lib/HuffmanAllocator.js statement by statement,
+ * and that algorithm indexes outside its array for weight vectors with many zeros when maxLen is far below what the
+ * pipeline uses (e.g. 16 symbols at 6 bits).  The bzip2 path always calls it with maxLen = 20 (and the fuzz test,
+ * tests/test_allocator_fuzz.py, stays at 15 bits and above), where it is in range.
+ *
  * Each function cites the reference file:line it follows (paths relative to /root/reference).
  * The one deliberate algorithmic difference: the reference builds its suffix array with SA-IS
  * (lib/BWT.js:197-300); a suffix array is unique, so this file uses plain prefix doubling with

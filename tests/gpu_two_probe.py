@@ -8,7 +8,7 @@ _ = rng.randint(0, 256, size=50_000_000)
 two = rng.randint(97, 99, size=50_000_000).astype(np.uint8)
 c = Context(0, 128)
 o = c.compress(two, 9)
-print('gpu', os.environ.get('CJS_DEEP_ITERS', 'dflt'), len(o), hashlib.sha256(o).hexdigest()[:16], 'gpu roundtrip', c.decompress(np.frombuffer(o, dtype=np.uint8)) == two.tobytes())
+print('gpu', os.environ.get("CJS_TEXT_BYTES", "dflt"), len(o), hashlib.sha256(o).hexdigest()[:16], 'gpu roundtrip', c.decompress(np.frombuffer(o, dtype=np.uint8)) == two.tobytes())
 try:
     print('libbz2 roundtrip', bz2.decompress(o) == two.tobytes())
 except Exception as e:
