@@ -1002,6 +1002,7 @@ __global__ __launch_bounds__(256) void k1d_update(K1Buf B, BatchGeom g, u32 r) {
 // host
 // ---------------------------------------------------------------------------------------------
 int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h0) {
+    if (g.nb > 4095u || max_n >= (1u << 22)) return CJS_E_UNSUPPORTED;      // 12 block bits in the descriptors, 22 position bits in the entries
     K1Prof* pr = B.prof;
     if (pr && pr->enabled) __atomic_fetch_add(&pr->dbl_runs, 1u, __ATOMIC_RELAXED);
     u32 slot = k1_prof_begin(pr, K1P_DBUILD, stream);
