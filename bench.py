@@ -282,6 +282,17 @@ def main():
                 assert hashlib.sha256(host.tobytes()).hexdigest() == g["in_sha256"], "workload generator drifted from the reference-made golden"
             vs_ref = bool(sha == g["out_sha256"] and len(comp) == g["out_len"])
         verified, port, pcie, decode_mb_s = None, None, None, None
+        prefix_ok = None
+        if digest_only and not args.no_verify:
+            # N > 1 with a pinned digest: besides the digest, an independent decoder (libbz2) on a bounded prefix of the assembled stream
+            # against what rank 0 itself holds - its own document, the first args.size bytes of the job
+            import bz2
+            limit = min(args.size, 50_000_000)
+            mine = d_in[:limit].cpu().numpy().tobytes()
+            try:
+                prefix_ok = bool(bz2.BZ2Decompressor().decompress(comp, limit) == mine)
+            except Exception:                                # noqa: BLE001
+                prefix_ok = False
         if not args.no_verify and not digest_only:
             import bz2
             # independent decoder (libbz2), bounded to keep the default run short
@@ -414,6 +425,7 @@ def main():
                        "reference_digest_made_by": None if g is None else g.get("made_by", "reference"),
                        "e8sa_mb_s": e8["mb_s"], "e8sa_ms_per_step": e8["ms"], "e8sa_bit_exact_vs_reference_digest": e8["exact"],
                        "bit_exact_vs_oracle_prefix_and_roundtrip": verified,
+                       "libbz2_prefix_roundtrip": prefix_ok,
                        "pcie_inclusive_mb_s": pcie,
                        "gpu_decode_mb_s": decode_mb_s,
                        "sha256": sha},

@@ -8,7 +8,10 @@
 #define K1_STAT_PUREROT 124    // stats[124]: rotations in front-end buckets of ONE 8-byte key (> 64 members) or beyond LDS, counted by k1f_scan
 #define K1_DEEP_LANE 8u        // groups up to this size go to the lane kernels (k1_deep_pairs / k1_deep_small): one lane each
 #define K1R_MAXR 40            // refinement rounds at most
-#define K1F_LEVELS 14u          // task levels of the front end (two per 8 bytes of depth: partition, then sort)
+#ifndef K1F_LEVELS
+#define K1F_LEVELS 14u
+#endif
+// K1F_LEVELS: task levels of the front end (two per 8 bytes of depth: partition, then sort; 6 / 8 / 14 measured in round 4: no difference)
 #define K1_STAT_RTRACE 128      // stats[128..135]: K1F_TRACE builds, stage clocks of k1r_round
 #define K1_MED_MAX 4096     // doubling rounds: largest group a workgroup sorts in LDS
 #define K1_STATS 144

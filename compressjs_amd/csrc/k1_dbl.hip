@@ -133,6 +133,10 @@ __device__ __forceinline__ u32 k1d_mode(const K1Buf& B, u32 r, u32 b, u32 final_
     return (final_h || (r > 0u && B.dchg[(size_t)(r - 1u) * B.rstride + b] == 0u)) ? 1u : 0u;
 }
 
+// Barrier of the kernels below that exchange data through LDS only (k1d_window, k1d_med, k1d_update's list walk): __syncthreads()
+// also waits for the workgroup's outstanding global stores - the scattered rank stores these kernels are made of - at every barrier.
+#define K1D_SYNC() lds_barrier()
+
 // descriptor of a group of more than K1D_GS rotations into round r's list of its size class (one atomic each: they are rare)
 #define K1D_MED1 1024u
 __device__ __forceinline__ void k1d_push_big(const K1Buf& B, u32 r, u32 b, u32 start, u32 len) {
@@ -164,7 +168,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
     u32* ISA = B.ISA + (size_t)b * g.stride;
     const u32* HN = B.HN + (size_t)b * g.hstride;
     const u32 span = cl + ahead;
-    __syncthreads();                                        // (the LDS of the previous window of this workgroup)
+    K1D_SYNC();                                        // (the LDS of the previous window of this workgroup)
     u32 sv[K1D_RPT];
 #pragma unroll
     for (u32 it = 0; it < K1D_RPT; it++) {
@@ -175,7 +179,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
     if (tid == 0) inHead = (int)lo;
     if (BITMAP) {
         if (tid < K1D_BW) hw[tid] = HN[(lo >> 5) + tid];
-        __syncthreads();
+        K1D_SYNC();
         if (w == 0) {
             const u32 word = lane < K1D_BW ? hw[lane] : 0u;
             int v = word ? (int)(lane * 32u + 31u - (u32)__clz((int)word)) : -1;
@@ -209,7 +213,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
                 if (lane == 0) inHead = found;
             }
         }
-        __syncthreads();
+        K1D_SYNC();
 #pragma unroll
         for (u32 it = 0; it < K1D_RPT; it++) {
             const u32 j = it * 256u + tid;
@@ -258,7 +262,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
             if (j < cl && hp == (int)j) wl[j] = SL[lo + j];
         }
     }
-    __syncthreads();
+    K1D_SYNC();
     // ranks of the window's own positions; members of the groups that start inside it
     u32 mlen[K1D_RPT];
     int mhp[K1D_RPT];
@@ -282,7 +286,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
             }
         }
     }
-    __syncthreads();
+    K1D_SYNC();
     if (w == 0) {
         const u32 c = lane < K1D_FW ? (u32)__popc(fm[lane]) : 0u;
         const u32 inc = wave_incl_scan_u32(c);
@@ -290,7 +294,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
         const u32 total = (u32)__shfl((int)inc, 63);
         if (lane == 0) sbase = total ? atomicAdd(&B.dcnt[(size_t)r * B.rstride + b], total) : 0u;
     }
-    __syncthreads();
+    K1D_SYNC();
     u64* L = B.rlist[0] + (size_t)b * g.stride;
 #pragma unroll
     for (u32 it = 0; it < K1D_RPT; it++) {
@@ -527,11 +531,11 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
         u32* SA = B.SA + (size_t)b * g.stride + start;
         u32* R = B.SB + (size_t)b * g.stride + start;
         const bool radix = n < K1D_RADIX_MAXN;
-        __syncthreads();
+        K1D_SYNC();
         if (mode && !B.linear && (n / len) * len == n) {    // (uniform) the tie-break of a cyclic block: positions by formula
             const u32 pp = n / len;
             for (u32 i = tid; i < len; i += 256) cv[i] = SA[i];
-            __syncthreads();
+            K1D_SYNC();
             for (u32 i = tid; i < len; i += 256) {
                 SA[len - 1u - cv[i] / pp] = cv[i];
                 R[i] = K1D_RKEEP;
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
             const u32 k = k1d_key(ISA, n, s, h, hm, mode, B.linear);
             ck[i] = radix ? (k << 12) | i : k;
         }
-        __syncthreads();
+        K1D_SYNC();
         u32* sorted = ck;                                   // radix: the packed words in order; bitonic: keys in ck, rotations in cv
         if (radix) {
             const u32 chunk = (((len + 3u) / 4u) + 63u) & ~63u;
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
             u32* dst = cx;
             for (u32 shift = 12; shift < 32u; shift += 7u) {
                 for (u32 i = tid; i < 512u; i += 256) (&wh[0][0])[i] = 0;
-                __syncthreads();
+                K1D_SYNC();
                 for (u32 i0 = lo; i0 < hi; i0 += 64u) {
                     const u32 i = i0 + lane;
                     const bool valid = i < hi;
@@ -562,23 +566,23 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
                     const u64 m = match_any(dg, 7, valid);
                     if (valid && (m & lt) == 0ull) atomicAdd(&wh[w][dg], (u32)__popcll(m));
                 }
-                __syncthreads();
+                K1D_SYNC();
                 if (tid < 128u) {
                     u32 run = 0;
 #pragma unroll
                     for (u32 ww = 0; ww < 4u; ww++) { const u32 c = wh[ww][tid]; wh[ww][tid] = run; run += c; }
                     dsum[tid] = run;
                 }
-                __syncthreads();
+                K1D_SYNC();
                 if (w == 0) {                                // exclusive scan of the 128 digit totals: two per lane
                     const u32 a0 = dsum[2u * lane], a1 = dsum[2u * lane + 1u];
                     const u32 inc = wave_incl_scan_u32(a0 + a1);
                     dsum[2u * lane] = inc - a0 - a1;
                     dsum[2u * lane + 1u] = inc - a1;
                 }
-                __syncthreads();
+                K1D_SYNC();
                 for (u32 e = tid; e < 512u; e += 256) wh[e >> 7][e & 127u] += dsum[e & 127u];
-                __syncthreads();
+                K1D_SYNC();
                 for (u32 i0 = lo; i0 < hi; i0 += 64u) {
                     const u32 i = i0 + lane;
                     const bool valid = i < hi;
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
                     __builtin_amdgcn_wave_barrier();
                     if (valid) dst[base + rank] = x;
                 }
-                __syncthreads();
+                K1D_SYNC();
                 u32* t = src; src = dst; dst = t;
             }
             sorted = src;
@@ -606,14 +610,14 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
                     const u32 lo = blk * k + off, hi = blk * k + (k - 1u - off);
                     if (hi < len) k1d_cmpx(ck, cv, lo, hi);
                 }
-                __syncthreads();
+                K1D_SYNC();
                 for (u32 j = k >> 2; j > 0; j >>= 1) {
                     for (u32 i = tid; i < (M >> 1); i += 256) {
                         const u32 lo = ((i & ~(j - 1u)) << 1) | (i & (j - 1u));
                         const u32 hi = lo | j;
                         if (hi < len) k1d_cmpx(ck, cv, lo, hi);
                     }
-                    __syncthreads();
+                    K1D_SYNC();
                 }
             }
         }
@@ -650,10 +654,10 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
                 if (lane >= off && a > vmax) vmax = a;
                 if (lane + off < 64u && c2 < vmin) vmin = c2;
             }
-            __syncthreads();                                // (wh is free: the passes are done)
+            K1D_SYNC();                                // (wh is free: the passes are done)
             if (lane == 63u) wh[0][w] = vmax;
             if (lane == 0u) wh[0][8u + w] = vmin;
-            __syncthreads();
+            K1D_SYNC();
             u32 before = __shfl_up(vmax, 1u), behind = __shfl_down(vmin, 1u);      // exclusive, inside the wave
             if (lane == 0u) before = 0u;
             if (lane == 63u) behind = len;
@@ -689,16 +693,16 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
             }
             if (__ballot(split) && lane == 0u) atomicOr(&B.dchg[(size_t)r * B.rstride + b], 1u);
             const u32 inc = wave_incl_scan_u32(mine);
-            __syncthreads();
+            K1D_SYNC();
             if (lane == 63u) wh[1][w] = inc;
-            __syncthreads();
+            K1D_SYNC();
             u32 slot = inc - mine;
             for (u32 ww = 0; ww < w; ww++) slot += wh[1][ww];
             if (tid == 255u) {
                 const u32 total = slot + mine;
                 sbase = total ? atomicAdd(&B.dcnt[(size_t)(r + 1u) * B.rstride + b], total) : 0u;
             }
-            __syncthreads();
+            K1D_SYNC();
             u64* L = B.rlist[0] + (size_t)b * g.stride;
             slot += sbase;
 #pragma unroll
@@ -936,7 +940,7 @@ __global__ __launch_bounds__(256) void k1d_update(K1Buf B, BatchGeom g, u32 r) {
             u32* ISA = B.ISA + (size_t)b * g.stride;
             u64* Lout = B.rlist[0] + (size_t)b * g.stride;
             bool sv[K1D_RPT];
-            __syncthreads();
+            K1D_SYNC();
 #pragma unroll
             for (u32 it = 0; it < K1D_RPT; it++) {
                 const u32 i = (it * 4u + w) * 64u + lane;
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(256) void k1d_update(K1Buf B, BatchGeom g, u32 r) {
                 const u64 bal = __ballot(sv[it]);
                 if (lane == 0) { sb[(it * 4u + w) * 2u] = (u32)bal; sb[(it * 4u + w) * 2u + 1u] = (u32)(bal >> 32); }
             }
-            __syncthreads();
+            K1D_SYNC();
             if (w == 0) {
                 const u32 c = lane < K1D_FW ? (u32)__popc(sb[lane]) : 0u;
                 const u32 inc = wave_incl_scan_u32(c);
@@ -956,7 +960,7 @@ __global__ __launch_bounds__(256) void k1d_update(K1Buf B, BatchGeom g, u32 r) {
                 const u32 total = (u32)__shfl((int)inc, 63);
                 if (lane == 0) obase = total ? atomicAdd(&B.dcnt[(size_t)(r + 1u) * B.rstride + b], total) : 0u;
             }
-            __syncthreads();
+            K1D_SYNC();
 #pragma unroll
             for (u32 it = 0; it < K1D_RPT; it++) {
                 const u32 i = (it * 4u + w) * 64u + lane;
