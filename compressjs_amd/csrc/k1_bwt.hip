@@ -454,6 +454,20 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         HIP_CHECK_RET(hipStreamSynchronize(stream));
         u64 bg = 0;
         for (u32 i = 0; i < 8u; i++) bg += fs[K1_STAT_BIGROT - K1_STAT_FRONT_BIG + i];
+        {   // task levels: tasks, the longest one and its depth
+            std::vector<u32> bc(K1F_LEVELS);
+            HIP_CHECK_RET(hipMemcpy(bc.data(), B.bcnt, K1F_LEVELS * 4, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[k1] task levels (tasks / longest / its depth):");
+            for (u32 lv = 0; lv < K1F_LEVELS; lv++) {
+                const u32 nt = bc[lv] < B.btaskCap ? bc[lv] : B.btaskCap;
+                std::vector<uint4> tk(nt);
+                if (nt) HIP_CHECK_RET(hipMemcpy(tk.data(), B.btask + (size_t)lv * B.btaskCap, (size_t)nt * sizeof(uint4), hipMemcpyDeviceToHost));
+                u32 ml = 0, md = 0;
+                for (const uint4& t : tk) if (t.z > ml) { ml = t.z; md = t.w & 0x7FFFFFFFu; }
+                fprintf(stderr, " [%u] %u/%u/%u", lv, nt, ml, md);
+            }
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[k1] front end: %u oversize buckets, %llu of %llu rotations in 8-byte groups above 64, %u in one-key buckets; k1f_bsort stage clocks/256 (K1F_TRACE builds): load %u  sample %u  partition %u  leaves %u  deepen %u  flush %u\n",
                 fs[0], (unsigned long long)bg, (unsigned long long)total_n, fs[K1_STAT_PUREROT - K1_STAT_FRONT_BIG], fs[1], fs[2], fs[3], fs[4], fs[5], fs[6]);
     }

@@ -975,9 +975,12 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
         u32* HN = B.HN + (size_t)b * g.hstride;
         const u32* src = inSB ? SBs : SAs;
         const u32 dm = depth % n;
-        if (B.linear && depth) {
-            // linear mode (BWT.bwtransform / suffixsort: suffixes, zero padding instead of wrap-around) sorts by the first 8 bytes
-            // only: a sub-bucket of one key is one group, as the one-key buckets of k1f_bsort are
+        if (!deepen && depth) {
+            // no text stages behind this one (linear mode: BWT.bwtransform / suffixsort sort suffixes by the first 8 bytes only; cyclic
+            // mode with the predictor on: HTML-like input, the doubling rounds take over from 8 bytes): a sub-bucket of ONE key is one
+            // group, as the one-key buckets of k1f_bsort are.  (Until round 4 the cyclic case went on partitioning such slices 8 bytes
+            // deeper, level after level - 0.8 ms per E8S-A sub-batch, one workgroup alone on a 50 000-rotation slice - for an order the
+            // doubling rounds do not need.)
             for (u32 i = tid; i < len; i += K1F_BT) SAs[i] = src[i];
             if (tid == 0) atomicOr(&HN[pos >> 5], 1u << (pos & 31u));
             continue;
