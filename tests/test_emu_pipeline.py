@@ -521,6 +521,49 @@ def _front_check(variant):
         assert pi.value == po and np.array_equal(u, uo), (variant, "linear", b.size)
 
 
+def test_doubling_rounds_variants():
+    """k1_dbl.hip's alternative code paths against the oracle: `packed_off` is a build in which no block is small enough for the
+    packed-word paths (K1D_PACK_MAXN = K1D_RADIX_MAXN = 0: k1d_round counts on plain keys, k1d_med sorts (key, rotation) pairs by
+    the bitonic network - what blocks of 2^20 bytes and more take) with the S-group threshold at 64; both builds run with the text
+    stages off (CJS_TEXT_BYTES=0: every tie goes through the doubling rounds, from 8 bytes) on text, runs, periodic and tiled
+    inputs, groups of every size class, cyclic and linear."""
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'));"
+            "sys.path.insert(0, os.path.join(%r, 'tests', 'golden'));"
+            "import test_emu_pipeline as t; t._doubling_check(sys.argv[1])" % (ROOT, ROOT, ROOT))
+    for variant in ("default", "packed_off"):
+        r = subprocess.run([sys.executable, "-c", code, variant], env=dict(os.environ, CJS_TEXT_BYTES="0"), capture_output=True, text=True, timeout=3000)
+        assert r.returncode == 0, variant + r.stdout + r.stderr
+
+
+def _doubling_check(variant):
+    so = stagelib.build_emu()
+    if variant == "packed_off":
+        so = os.path.join(ROOT, "tests", "emu", "libcjs_emu_dbl.so")
+        import subprocess
+        subprocess.check_call(["sh", os.path.join(ROOT, "tests", "emu", "build_emu.sh")], stdout=subprocess.DEVNULL,
+                              env=dict(os.environ, EMU_OUT=so, EMU_DEFS="-DK1D_PACK_MAXN=0u -DK1D_RADIX_MAXN=0u -DK1D_GS=64u"))
+    L = C.CDLL(so)
+    for f in (L.cjs_bwt_cyclic, L.cjs_bwt_linear):
+        f.restype = C.c_int32
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    rng = np.random.RandomState(3)
+    blocks = [synth.text_like(60_000, 3), synth.enwik_like(50_000, 4), synth.runs_mixed(40_000, 5),
+              synth.periodic(20_000, b"ab"), synth.periodic(44 * 500, b"the quick brown fox jumps over the lazy dog\n"),
+              synth.periodic(30_001, b"the quick brown fox jumps over the lazy dog\n"), np.tile(synth.text_like(3000, 5), 8),
+              np.full(30_000, 7, np.uint8), rng.randint(97, 99, size=40_000).astype(np.uint8),
+              np.tile(np.concatenate([np.full(9000, 1, np.uint8), np.full(9000, 2, np.uint8)]), 2)]
+    for b in blocks:
+        b = np.ascontiguousarray(b)
+        for f, o in ((L.cjs_bwt_cyclic, oracle.bwt_cyclic), (L.cjs_bwt_linear, oracle.bwt_linear)):
+            u = np.zeros(b.size, np.uint8)
+            p = C.c_uint32(0)
+            assert f(b.ctypes.data, u.ctypes.data, b.size, C.byref(p)) == 0
+            uo, po = o(b)
+            assert p.value == po and np.array_equal(u, uo), (variant, b.size, bytes(b[:12]))
+
+
 def test_segmented_host_pipeline():
     """cjs_bz2_compress on inputs longer than 1.5 segments: planned and encoded segment by segment (upload / encode /
     download overlapped by two helper threads).  CJS_SEG_BYTES=120000 makes a segment ~1.2 level-1 blocks, so the
