@@ -7,12 +7,21 @@
 // with RangeCoder.encodeFreq (lib/RangeCoder.js:79-89) over the finished triples: one division per symbol instead of
 // a tree walk with up to ten read-modify-writes (and a second one for the escape of a first occurrence).
 //
-// The tree (2 * numSyms <= 520 packed u32: high half = frequency, low half = escape count) sits in LDS.  One symbol
-// at a time (the model is a serial recurrence), but the ~10 levels of its leaf-to-root path are lanes: lane l owns node
-// (leaf >> l): reads it, reads its left sibling when the node is a right child (lt_f is the sum of those), adds the
-// update.  The siblings are not on the path, so reading all levels at once equals the reference's bottom-up walk.
-// Rescaling (every ~127 symbols) halves the leaves 64 at a time and rebuilds the inner nodes level by level.
-// All u32 wrap-around arithmetic on the packed words is kept exactly as the reference's `>>> 0` arithmetic.
+// The tree (2 * numSyms <= 520 packed u32: high half = frequency, low half = escape count) sits in LDS.
+// Round 4: the model is a serial recurrence symbol by symbol only where it has to be.  Between two rescales every symbol
+// that has been seen before just adds `increment` to the nodes of its path, so for a CHUNK of up to 64 consecutive seen
+// symbols with no rescale inside (the chunk ends where the root reaches max_prob: that symbol is its last) the triples are
+// closed forms of the tree at the chunk's start: with c_eq / c_lt = the earlier symbols of the chunk that are equal to /
+// to the left (in the tree's in-order) of symbol x of lane l,
+//     sy = leaf[x] + inc * c_eq,   lt = (sum of the left siblings of x's path) + inc * c_lt,   tot = root + inc * l
+// (every leaf to the left of x lies under exactly one left sibling of x's path; all sums on the packed words, mod 2^32, as the
+// reference's `>>> 0` arithmetic - node = sum of its leaves either way).  A lane per symbol: its own ten-level walk, the two
+// counts from a 64-step v_readlane loop; then the leaves get their increments (LDS atomics) and the inner nodes are re-summed.
+// A symbol that has not been seen (or was scaled away) ends the chunk before it and takes the serial path - the escape
+// symbol, then the symbol in the escape domain, each a walk with the ~10 levels of the path as lanes - as in round 3, where
+// EVERY symbol took such a walk (~800 clocks per symbol for a wave alone on its SIMD: 133 ms per 900 kB block, all of it
+// latency in front of the host's range coder).  Rescaling (every ~127 symbols) halves the leaves 64 at a time and rebuilds
+// the inner nodes level by level.
 #include "pipeline.h"
 
 #define K10_MAXSYM 260
@@ -47,7 +56,6 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
     __builtin_amdgcn_wave_barrier();
     k10_sum_tree(tree, numSyms, lane);
     u32 nout = 0;                                             // triples emitted (uniform)
-    u32 my_sl = 0, my_to = 0;                                 // lane (nout & 63) holds the pending triple of its row
     // one call of FenwickModel.encode's body for leaf `symbol` in the domain chosen by (mask, shift), adding `update`
     auto walk = [&](u32 symbol, u32 mask, u32 shift, u32 update) {
         const u32 leaf = numSyms + symbol;
@@ -64,9 +72,8 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
         if (on) tree[node] = val + update;
         __builtin_amdgcn_wave_barrier();
         const u32 sl = ((sy & mask) >> shift) | (((lt & mask) >> shift) << 16);
-        if (lane == (nout & 63u)) { my_sl = sl; my_to = (to & mask) >> shift; }
+        if (lane == 0) { osl[nout] = sl; oto[nout] = (to & mask) >> shift; }
         nout++;
-        if ((nout & 63u) == 0u) { osl[nout - 64u + lane] = my_sl; oto[nout - 64u + lane] = my_to; }
     };
     // _rescale :137-166 (wave-uniform call)
     auto rescale = [&]() {
@@ -89,62 +96,81 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
         k10_sum_tree(tree, numSyms, lane);
     };
     // The wave runs alone on its SIMD (a launch has one wave per block and far fewer blocks than SIMDs): every instruction costs
-    // 5-9 clocks, an LDS round trip ~50, a v_readlane into an SGPR and its use 20-30 (tests/microbench/lone_wave.hip).  So the
-    // common path is kept short: no exec masking (lanes above the path read and rewrite tree[0], which is 0 and stays 0: node
-    // = leaf >> lane is 0 there, and so is the "left sibling" index of the root), outputs go into their row by v_writelane,
-    // and the next row of symbols is requested a row ahead.
-    const u32 sh = lane < 31u ? lane : 31u;                   // leaf < 1024: lanes 10.. see node 0
-    u32 nxt = lane < nsym ? sym[lane] : 0u;
-    for (u32 r0 = 0; r0 < nsym; r0 += 64u) {
-        if (nout + 192u > ocap) {                             // a row adds at most 128 triples (wave-uniform)
+    // 5-9 clocks, an LDS round trip ~50, a v_readlane into an SGPR and its use 20-30 (tests/microbench/lone_wave.hip).
+    const u32 inc = increment << 16;
+    u32 posn = 0;
+    u32 nxt = lane < nsym ? sym[lane] : 0u;                   // the row of 64 symbols at posn (loaded a chunk ahead where possible)
+    while (posn < nsym) {
+        if (nout + 192u > ocap) {                             // a chunk adds at most 64 triples, an unseen symbol two (wave-uniform)
             if (lane == 0) ntri[b] = K10_OVERFLOW;
             return;
         }
-        const u32 mine = nxt;
-        nxt = r0 + 64u + lane < nsym ? sym[r0 + 64u + lane] : 0u;
-        const u32 rows = nsym - r0 < 64u ? nsym - r0 : 64u;
-        for (u32 t = 0; t < rows; t++) {
-            const u32 s = (u32)__builtin_amdgcn_readlane((int)mine, (int)t);
-            // path nodes and left siblings of all levels in ONE LDS round trip, the sibling sum over the row of 16 lanes by DPP
-            // row_shr adds, leaf / root values by v_readlane, the new root from registers
-            const u32 leaf = numSyms + s;
-            const u32 L = 32u - (u32)__clz((int)leaf);
-            const u32 node = leaf >> sh;
-            const u32 val = tree[node];
-            u32 sib = tree[(node & 1u) ? node - 1u : 0u];     // left sibling of a right child; the root's "sibling" is tree[0] = 0
-            pin_vgpr(sib);                                    // both reads in flight before the branch below waits for the first
-            const u32 leafv = (u32)__builtin_amdgcn_readlane((int)val, 0);
-            if ((leafv & 0xFFFF0000u) == 0u) {                // never seen (or scaled away): the escape symbol first  :53-57
-                const u32 esc = numSyms - 1u;
-                const u32 ev = tree[numSyms + esc];
-                u32 eupd = increment << 16;
-                if ((tree[1] & 0xFFFFu) == 1u) eupd = 0u - ev;                        // the last escape: zero it out  :58-60
-                walk(esc, 0xFFFF0000u, 16u, eupd);
-                if (((tree[1] & 0xFFFF0000u) >> 16) >= max_prob) rescale();           // :85 inside the escape's own encode
-                walk(s, 0x0000FFFFu, 0u, (increment << 16) - 1u);
-                if (((tree[1] & 0xFFFF0000u) >> 16) >= max_prob) rescale();
-                continue;
-            }
-            sib += (u32)__builtin_amdgcn_update_dpp(0, (int)sib, 0x111, 0xf, 0xf, true);          // row_shr:1
-            sib += (u32)__builtin_amdgcn_update_dpp(0, (int)sib, 0x112, 0xf, 0xf, true);          // row_shr:2
-            sib += (u32)__builtin_amdgcn_update_dpp(0, (int)sib, 0x114, 0xf, 0xf, true);          // row_shr:4
-            sib += (u32)__builtin_amdgcn_update_dpp(0, (int)sib, 0x118, 0xf, 0xf, true);          // row_shr:8: lane 15 = sum of lanes 0..15
-            const u32 lt = (u32)__builtin_amdgcn_readlane((int)sib, 15);
-            const u32 to = (u32)__builtin_amdgcn_readlane((int)val, (int)(L - 1u));
-            const u32 upd = increment << 16;                  // (the escape symbol itself never occurs in the data)
-            tree[node] = val + (lane < L ? upd : 0u);
-            __builtin_amdgcn_wave_barrier();
-            my_sl = (u32)cjs_writelane((int)((leafv >> 16) | ((lt >> 16) << 16)), (int)(nout & 63u), (int)my_sl);
-            my_to = (u32)cjs_writelane((int)(to >> 16), (int)(nout & 63u), (int)my_to);
-            nout++;
-            if ((nout & 63u) == 0u) { osl[nout - 64u + lane] = my_sl; oto[nout - 64u + lane] = my_to; }
-            if (((to + upd) >> 16) >= max_prob) rescale();
+        const u32 x = nxt;
+        const u32 avail = nsym - posn < 64u ? nsym - posn : 64u;
+        const u32 root = tree[1];
+        // symbols until the root reaches max_prob (the one that gets it there included): root_hi + 0x100 * k >= 0xFF00
+        const u32 root_hi = root >> 16;
+        const u32 kmax = root_hi >= max_prob ? 1u : (max_prob - root_hi + increment - 1u) / increment;
+        const u32 leafw = lane < avail ? tree[numSyms + x] : inc;          // (idle lanes count as seen)
+        const u64 unseen = __ballot((leafw & 0xFFFF0000u) == 0u);
+        u32 m = unseen ? (u32)__ffsll((long long)unseen) - 1u : 64u;      // seen symbols in front of the first unseen one
+        if (m > avail) m = avail;
+        if (m > kmax) m = kmax;
+        if (m == 0u) {
+            // the symbol at posn has never been seen (or was scaled away): the escape symbol first  :53-57, one symbol, serial
+            const u32 sx = (u32)__builtin_amdgcn_readlane((int)x, 0);
+            const u32 esc = numSyms - 1u;
+            const u32 ev = tree[numSyms + esc];
+            u32 eupd = inc;
+            if ((tree[1] & 0xFFFFu) == 1u) eupd = 0u - ev;                            // the last escape: zero it out  :58-60
+            walk(esc, 0xFFFF0000u, 16u, eupd);
+            if (((tree[1] & 0xFFFF0000u) >> 16) >= max_prob) rescale();               // :85 inside the escape's own encode
+            walk(sx, 0x0000FFFFu, 0u, inc - 1u);
+            if (((tree[1] & 0xFFFF0000u) >> 16) >= max_prob) rescale();
+            posn += 1u;
+            nxt = posn + lane < nsym ? sym[posn + lane] : 0u;
+            continue;
         }
+        const bool on = lane < m;
+        // left siblings of the lane's own path (packed sum), leaf and root at the chunk's start
+        u32 lt = 0;
+        {
+            u32 node = numSyms + x;
+#pragma unroll
+            for (int lv = 0; lv < 10; lv++) {
+                const bool take = on && node > 1u && (node & 1u);
+                const u32 sv = tree[take ? node - 1u : 0u];                           // tree[0] = 0
+                lt += take ? sv : 0u;
+                node >>= 1;
+            }
+        }
+        // earlier symbols of the chunk equal to mine / to the LEFT of mine in the tree: the leaves under the left siblings of a path
+        // are the leaves before it in the tree's in-order, and with numSyms no power of two the leaves sit on two levels - in-order is
+        // the order of the leaf indices shifted to a common bit length, not the order of the symbols
+        const u32 leafi = numSyms + x;
+        const u32 ko = leafi << (10u - (32u - (u32)__clz((int)leafi)));             // (leaf < 1024: bit length <= 10)
+        u32 ceq = 0, clt = 0;
+        for (u32 j = 0; j + 1u < m; j++) {                                            // (uniform trip count; lane j + 1 .. see symbol j)
+            const u32 kj = (u32)__builtin_amdgcn_readlane((int)ko, (int)j);
+            const bool before = j < lane;
+            ceq += (before && kj == ko) ? 1u : 0u;
+            clt += (before && kj < ko) ? 1u : 0u;
+        }
+        const u32 sy = leafw + inc * ceq, ltv = lt + inc * clt, to = root + inc * lane;
+        if (on) {
+            osl[nout + lane] = (sy >> 16) | ((ltv >> 16) << 16);
+            oto[nout + lane] = to >> 16;
+            atomicAdd(&tree[numSyms + x], inc);
+        }
+        nout += m;
+        posn += m;
+        nxt = posn + lane < nsym ? sym[posn + lane] : 0u;                             // (in flight while the tree is re-summed)
+        __builtin_amdgcn_wave_barrier();
+        k10_sum_tree(tree, numSyms, lane);
+        if ((tree[1] >> 16) >= max_prob) rescale();
     }
-    if (nout & 63u) { if (lane < (nout & 63u)) { osl[(nout & ~63u) + lane] = my_sl; oto[(nout & ~63u) + lane] = my_to; } }
     if (lane == 0) ntri[b] = nout;
 }
-
 int k10_model_run(Pipe P, u32* sylt, u32* tot, u32* ntri, u32 ostride, u32 ocap, hipStream_t stream) {
     hipLaunchKernelGGL(k10_model, dim3(P.g.nb), dim3(64), 0, stream, (const u16*)P.A, P.g.stride, (const u32*)P.pos, (const u32*)P.alpha, sylt, tot, ntri, ostride, ocap);
     HIP_CHECK_RET(hipGetLastError());
