@@ -99,7 +99,17 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
     // 5-9 clocks, an LDS round trip ~50, a v_readlane into an SGPR and its use 20-30 (tests/microbench/lone_wave.hip).
     const u32 inc = increment << 16;
     u32 posn = 0;
-    u32 nxt = lane < nsym ? sym[lane] : 0u;                   // the row of 64 symbols at posn (loaded a chunk ahead where possible)
+    // the symbols of rows wbase / wbase + 64 (aligned rows of 64) in two registers; a chunk starts anywhere in the first and takes
+    // its symbols by two shuffles - the next row is requested as soon as the window slides, a chunk or two before it is needed
+    u32 wbase = 0;
+    u32 r0 = lane < nsym ? sym[lane] : 0u, r1 = 64u + lane < nsym ? sym[64u + lane] : 0u;
+    auto window = [&]() -> u32 {
+        while (posn - wbase >= 64u) { wbase += 64u; r0 = r1; r1 = wbase + 64u + lane < nsym ? sym[wbase + 64u + lane] : 0u; }
+        const u32 off = posn - wbase + lane;                  // 0 .. 126
+        const u32 a0 = (u32)__shfl((int)r0, (int)(off & 63u)), a1 = (u32)__shfl((int)r1, (int)(off & 63u));
+        return off < 64u ? a0 : a1;
+    };
+    u32 nxt = window();
     while (posn < nsym) {
         if (nout + 192u > ocap) {                             // a chunk adds at most 64 triples, an unseen symbol two (wave-uniform)
             if (lane == 0) ntri[b] = K10_OVERFLOW;
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
             walk(sx, 0x0000FFFFu, 0u, inc - 1u);
             if (((tree[1] & 0xFFFF0000u) >> 16) >= max_prob) rescale();
             posn += 1u;
-            nxt = posn + lane < nsym ? sym[posn + lane] : 0u;
+            nxt = window();
             continue;
         }
         const bool on = lane < m;
@@ -149,12 +159,20 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
         // the order of the leaf indices shifted to a common bit length, not the order of the symbols
         const u32 leafi = numSyms + x;
         const u32 ko = leafi << (10u - (32u - (u32)__clz((int)leafi)));             // (leaf < 1024: bit length <= 10)
-        u32 ceq = 0, clt = 0;
-        for (u32 j = 0; j + 1u < m; j++) {                                            // (uniform trip count; lane j + 1 .. see symbol j)
-            const u32 kj = (u32)__builtin_amdgcn_readlane((int)ko, (int)j);
-            const bool before = j < lane;
-            ceq += (before && kj == ko) ? 1u : 0u;
-            clt += (before && kj < ko) ? 1u : 0u;
+        // both counts from ten ballots, most significant bit first: the lanes that agree with me on the bits so far and have a 0 where
+        // I have a 1 are to my left (a 63-step v_readlane loop did the same in ~3 000 clocks of the wave's ~20 000 per chunk)
+        u32 ceq, clt = 0;
+        {
+            const u64 lt_lanes = lanemask_lt();
+            u64 same = __ballot(on) & lt_lanes;               // earlier lanes of the chunk that still agree with my key
+#pragma unroll
+            for (int bit = 9; bit >= 0; bit--) {
+                const bool mine1 = (ko >> bit) & 1u;
+                const u64 ones = __ballot(((ko >> bit) & 1u) != 0u);
+                clt += mine1 ? (u32)__popcll(same & ~ones) : 0u;
+                same &= mine1 ? ones : ~ones;
+            }
+            ceq = (u32)__popcll(same);
         }
         const u32 sy = leafw + inc * ceq, ltv = lt + inc * clt, to = root + inc * lane;
         if (on) {
@@ -164,7 +182,7 @@ __global__ __launch_bounds__(64) void k10_model(const u16* A, u32 stride, const 
         }
         nout += m;
         posn += m;
-        nxt = posn + lane < nsym ? sym[posn + lane] : 0u;                             // (in flight while the tree is re-summed)
+        nxt = window();
         __builtin_amdgcn_wave_barrier();
         k10_sum_tree(tree, numSyms, lane);
         if ((tree[1] >> 16) >= max_prob) rescale();
