@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 c
 // phrase-reuse text after the text stages -- the rank pass (10^8 random 4-byte stores, 1.1 ms) and the doubling rounds are skipped.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k1_count_unsorted(K1Buf B, BatchGeom g) {
-    const u32 b = blockIdx.y, n = B.nlen[b];
+    const u32 b = blockIdx.y, n = B.nfront[b];
     const u32 wi = blockIdx.x * 256u + threadIdx.x;
     const u32* HN = B.HN + (size_t)b * g.hstride;
     u32 c = 0;
@@ -376,6 +376,9 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     take((void**)&B.dcnt, ((size_t)(2u * (K1D_MAXR + 2u) + 1u) * nb8 + (K1D_MAXR + 2u) * 4u) * 4);      // dcnt, dchg, dtot, dbn (contiguous: zeroed as one)
     take((void**)&B.btask, (size_t)K1F_LEVELS * B.btaskCap * sizeof(uint4));
     take((void**)&B.bcnt, 256);
+    take((void**)&B.nfront, (size_t)nb8 * 4);
+    take((void**)&B.per, (size_t)nb8 * 4);
+    take((void**)&B.ptab, (size_t)g.nb * 256 * 4);
     B.dchg = B.dcnt ? B.dcnt + (size_t)(K1D_MAXR + 2u) * nb8 : nullptr;
     B.dtot = B.dcnt ? B.dchg + (size_t)(K1D_MAXR + 2u) * nb8 : nullptr;
     B.dbn = B.dcnt ? B.dtot + nb8 : nullptr;
@@ -393,7 +396,8 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
     k1_layout(B, g, [&](void** field, size_t bytes) { *field = p; p += al256(bytes); });
 }
 
-static int g_k1_last_sparse_rounds = 0, g_k1_last_rounds = 0;
+static int g_k1_last_sparse_rounds = 0, g_k1_last_rounds = 0, g_k1_last_periodic = 0;
+extern "C" int cjs_dbg_k1_periodic_blocks() { return g_k1_last_periodic; }
 extern "C" int cjs_dbg_k1_sparse_rounds() { return g_k1_last_sparse_rounds; }
 extern "C" int cjs_dbg_k1_rounds() { return g_k1_last_rounds; }
 
@@ -403,6 +407,7 @@ struct K1Knobs {
     u32 text_bytes;    // CJS_TEXT_BYTES    depth up to which the refinement rounds compare the text (default 264; 0: no text stages, doubling from 8 bytes)
     u32 big_div;       // CJS_DEEP_BIG_DIV  text stages are skipped when more than 1/DIV of the rotations sit in one-key buckets (default 8)
     u32 lane_cap;      // CJS_DEEP_LANE_CAP bytes the lane kernels walk a pair / small group that outlasted the rounds (default 4096; 0: not at all)
+    bool period;       // CJS_K1_PERIOD     0: no closed form for blocks with a small period (k1_period.hip): they take the general path
     bool sync;         // CJS_K1_SYNC       0: no read-back at all (every launch of the doubling stage is enqueued whatever is left)
     bool trace;        // CJS_K1_TRACE      counters of the stages on stderr (reads them back: not for timing)
 };
@@ -420,6 +425,7 @@ static const K1Knobs& k1_knobs() {
         q.big_div = num("CJS_DEEP_BIG_DIV", 8u, 1u << 30);
         if (!q.big_div) q.big_div = 8u;
         q.lane_cap = num("CJS_DEEP_LANE_CAP", 4096u, 60000u);
+        q.period = num("CJS_K1_PERIOD", 1u, 1u) != 0u;
         q.sync = num("CJS_K1_SYNC", 1u, 1u) != 0u;
         q.trace = getenv("CJS_K1_TRACE") != nullptr;
         return q;
@@ -442,6 +448,18 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const u64 total_n = (u64)g.nb * max_n;
     int rounds_with_work = 0;
     hipLaunchKernelGGL(k1_init, dim3((g.hstride + 255) / 256, g.nb), dim3(256), 0, stream, B, g);
+    {
+        const int rc = k1_period_run(B, g, max_n, stream, K.period ? 1u : 0u);
+        if (rc) return rc;
+    }
+    if (K.trace) {
+        std::vector<u32> per(g.nb);
+        HIP_CHECK_RET(hipMemcpyAsync(per.data(), B.per, (size_t)g.nb * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK_RET(hipStreamSynchronize(stream));
+        g_k1_last_periodic = 0;
+        for (u32 b = 0; b < g.nb; b++) g_k1_last_periodic += per[b] ? 1 : 0;
+        fprintf(stderr, "[k1] blocks with a period <= 64: %d of %u\n", g_k1_last_periodic, g.nb);
+    }
     // the text stages: cyclic mode, blocks whose indices fit the list entries' 22 bits
     const bool fused = !B.linear && K.text_bytes > d0 && max_n < (1u << 22);
     {

@@ -62,7 +62,7 @@ __device__ __forceinline__ void k1f_cmpx(u64& a, u64& c, bool up) {
 
 __global__ __launch_bounds__(1024) void k1f_sample(K1Buf B, BatchGeom g) {
     const u32 b = blockIdx.x;
-    const u32 n = B.nlen[b];
+    const u32 n = B.nfront[b];
     const u32 tid = threadIdx.x;
     u64* sp = B.fsplit + (size_t)b * K1F_NB;
     if (n <= K1F_C) {                                   // one bucket holds the whole block
@@ -152,7 +152,7 @@ static inline u32 k1f_ptiles(const BatchGeom& g) { return (g.stride + K1F_PT - 1
 
 __global__ __launch_bounds__(1024) void k1f_hist(K1Buf B, BatchGeom g, u32 ptiles) {
     const u32 b = blockIdx.y, t = blockIdx.x;
-    const u32 n = B.nlen[b];
+    const u32 n = B.nfront[b];
     const u32 t0 = t * K1F_PT;
     const u32 tid = threadIdx.x;
     u32* th = B.tileHist + ((size_t)b * ptiles + t) * K1F_NB;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(1024) void k1f_hist(K1Buf B, BatchGeom g, u32 ptile
 #if K1F_NB <= 1024
 __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptiles) {
     const u32 b = blockIdx.x;
-    const u32 n = B.nlen[b];
+    const u32 n = B.nfront[b];
     const u32 nt = (n + K1F_PT - 1) / K1F_PT;
     constexpr u32 Q = 1024 / K1F_NB;                    // tile ranges summed in parallel
     __shared__ u32 part[Q][K1F_NB];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptile
 // more buckets than threads: thread t owns buckets t, t + 1024, ...
 __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptiles) {
     const u32 b = blockIdx.x;
-    const u32 n = B.nlen[b];
+    const u32 n = B.nfront[b];
     const u32 nt = (n + K1F_PT - 1) / K1F_PT;
     constexpr u32 R = K1F_NB / 1024;
     __shared__ u32 sh[20];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptile
 __global__ __launch_bounds__(1024) void k1f_scatter(K1Buf B, BatchGeom g, u32 ptiles) {
     u32 b, t;
     if (!xcd_block_tile(g.nb, b, t)) return;
-    const u32 n = B.nlen[b];
+    const u32 n = B.nfront[b];
     const u32 t0 = t * K1F_PT;
     if (t0 >= n) return;
     __shared__ u32 cnt[K1F_NB], base[K1F_NB];
@@ -894,7 +894,7 @@ __device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, co
 __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
     u32 b, d;
     if (!xcd_block_tile(g.nb, b, d)) return;
-    const u32 n = B.nlen[b];
+    const u32 n = B.nfront[b];
     if (n == 0) return;
     const u32* fs = B.fstart + (size_t)b * (K1F_NB + 1);
     const u32 start = fs[d], end = fs[d + 1];

@@ -526,14 +526,15 @@ def test_doubling_rounds_variants():
     packed-word paths (K1D_PACK_MAXN = K1D_RADIX_MAXN = 0: k1d_round counts on plain keys, k1d_med sorts (key, rotation) pairs by
     the bitonic network - what blocks of 2^20 bytes and more take) with the S-group threshold at 64; both builds run with the text
     stages off (CJS_TEXT_BYTES=0: every tie goes through the doubling rounds, from 8 bytes) on text, runs, periodic and tiled
-    inputs, groups of every size class, cyclic and linear."""
+    inputs, groups of every size class, cyclic and linear.  CJS_K1_PERIOD=0: the periodic blocks go through the rounds too (their
+    closed form has its own test below)."""
     import subprocess
     import sys
     code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'));"
             "sys.path.insert(0, os.path.join(%r, 'tests', 'golden'));"
             "import test_emu_pipeline as t; t._doubling_check(sys.argv[1])" % (ROOT, ROOT, ROOT))
     for variant in ("default", "packed_off"):
-        r = subprocess.run([sys.executable, "-c", code, variant], env=dict(os.environ, CJS_TEXT_BYTES="0"), capture_output=True, text=True, timeout=3000)
+        r = subprocess.run([sys.executable, "-c", code, variant], env=dict(os.environ, CJS_TEXT_BYTES="0", CJS_K1_PERIOD="0"), capture_output=True, text=True, timeout=3000)
         assert r.returncode == 0, variant + r.stdout + r.stderr
 
 
@@ -562,6 +563,62 @@ def _doubling_check(variant):
             assert f(b.ctypes.data, u.ctypes.data, b.size, C.byref(p)) == 0
             uo, po = o(b)
             assert p.value == po and np.array_equal(u, uo), (variant, b.size, bytes(b[:12]))
+
+
+def test_periodic_blocks_closed_form():
+    """k1_period.hip: blocks with a linear period p <= 64 get their suffix array from the closed form (phase order, one sign
+    for the order inside a phase, the p - 1 rotations that start in the last period placed by binary search).  Every p in 1..64
+    with block lengths that are and are not multiples of p, alphabets of 2..256 symbols (non-primitive period words included:
+    the detector must find the smallest period), periods beyond 64 and near-periodic blocks (one defect: early, late, last
+    byte), which must fall through to the general sort; all against the oracle.  CJS_K1_TRACE counts the blocks taken."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle, stagelib
+L = C.CDLL(stagelib.build_emu())
+L.cjs_bwt_cyclic_batch.restype = C.c_int32
+L.cjs_bwt_cyclic_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+rng = np.random.default_rng(11)
+cap = 8192
+def run(blocks):
+    nb = len(blocks)
+    T = np.zeros((nb, cap), np.uint8); nl = np.zeros(nb, np.uint32)
+    for i, d in enumerate(blocks):
+        T[i, :d.size] = d; nl[i] = d.size
+    U = np.zeros((nb, cap), np.uint8); P = np.zeros(nb, np.uint32)
+    assert L.cjs_bwt_cyclic_batch(T.ctypes.data, nl.ctypes.data, nb, cap, U.ctypes.data, P.ctypes.data) == 0
+    for i, d in enumerate(blocks):
+        uo, po = oracle.bwt_cyclic(d)
+        assert P[i] == po and (U[i, :d.size] == uo).all(), (d.size, bytes(d[:70]))
+    return L.cjs_dbg_k1_periodic_blocks()
+def mk(p, n, alpha):
+    return np.tile(rng.integers(0, alpha, p).astype(np.uint8), n // p + 2)[:n].copy()
+per, oth = [], []
+for p in range(1, 65):
+    for k in range(2):
+        n = int(rng.integers(4096, 8000))
+        if k == 1:
+            n = (n // p) * p
+        per.append(mk(p, n, int(rng.choice([2, 3, 4, 256]))))
+per.append(np.frombuffer(b"\0\0\0\0\xfb" * 1000 + b"\0\0\0", np.uint8).copy())      # zeros after RLE1
+per.append(np.frombuffer(b"ab" * 2500 + b"a", np.uint8).copy())
+for p in (65, 70, 100, 1000):
+    q = rng.integers(0, 256, p).astype(np.uint8); q[0] = 255; q[1:] %%= 255
+    oth.append(np.tile(q, 6000 // p + 2)[:6000].copy())
+for at in (5999, 3000, 2047, 100):
+    d = mk(7, 6000, 3); d[at] ^= 1; oth.append(d)
+oth.append(mk(3, 4000, 2))                                  # too short for the closed form
+seen = 0
+for i in range(0, len(per), 16):
+    seen += run(per[i:i + 16])
+assert seen == len(per), (seen, len(per))
+assert run(oth) == 0
+print("ok", seen)
+''' % (stagelib.ROOT, os.path.join(stagelib.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CJS_K1_TRACE="1"), capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
 
 
 def test_segmented_host_pipeline():
