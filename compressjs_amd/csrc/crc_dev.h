@@ -37,14 +37,16 @@ constexpr CrcPw crc_pw_make() {
 }
 static __device__ const CrcPw CRC_PW = crc_pw_make();
 
-// All threads of the block (>= 256) call this; tabs[CRC_TAB_WORDS], pw[40] and *acc are LDS scratch.  The CRC of
-// in[s, e) (init 0xffffffff, final complement) is returned to every thread.
+// All threads of the block (>= 256) call these; tabs[CRC_TAB_WORDS], pw[40] and *acc are LDS scratch.
+// crc_range_raw: what the bytes in[ps, pe) contribute to the raw remainder (init 0) of a message that ends at e; the
+// contributions of the parts of a message XOR together, and crc = ~(their sum ^ 0xffffffff x^(8 len)) - crc_range_block: the
+// CRC of in[s, e) (init 0xffffffff, final complement) by one workgroup.  Both return their value to every thread.
 // Four bytes per step (slicing by four: table k = the effect of a byte followed by k zero bytes), every table entry eight
 // times over so that the 64 look-ups of a wave spread over the LDS banks (entry v, copy lane & 7): with one 1 KB table the
 // slices were a chain of one conflicted look-up per byte (128 us for 112 blocks; the look-ups, not the loads, were the time).
 #define CRC_REP 8u
 #define CRC_TAB_WORDS (4u * 256u * CRC_REP)
-__device__ __forceinline__ u32 crc_range_block(const u8* in, u64 s, u64 e, u32* tabs, u32* pw, u32* acc) {
+__device__ __forceinline__ u32 crc_range_raw(const u8* in, u64 s, u64 e, u64 e_msg, u32* tabs, u32* pw, u32* acc) {
     const u32 tid = threadIdx.x;
     for (u32 t = tid; t < 1024u; t += blockDim.x) {       // lib/CRC32.js:37-70, carried on through k more zero bytes
         const u32 k = t >> 8, v = t & 255u;
@@ -99,9 +101,12 @@ __device__ __forceinline__ u32 crc_range_block(const u8* in, u64 s, u64 e, u32* 
     }
     for (; j < hi; j++) crc = (crc << 8) ^ T0[(((crc >> 24) ^ in[j]) & 0xffu) * CRC_REP];
     if (hi > lo) {
-        crc = gf_shift(crc, e - hi, pw);
+        crc = gf_shift(crc, e_msg - hi, pw);
         atomicXor(acc, crc);
     }
     __syncthreads();
-    return ~(*acc ^ gf_shift(0xffffffffu, len, pw));
+    return *acc;
+}
+__device__ __forceinline__ u32 crc_range_block(const u8* in, u64 s, u64 e, u32* tabs, u32* pw, u32* acc) {
+    return ~(crc_range_raw(in, s, e, e, tabs, pw, acc) ^ gf_shift(0xffffffffu, e - s, pw));
 }
