@@ -98,6 +98,7 @@ struct K1Buf {
     u32* nfront;      // [nb]           the length the general sort sees: nlen, or 0 where k1_period.hip wrote the suffix array
     u32* per;         // [nb]           smallest period of the block if <= 64 (k1_period.hip), else 0
     u32* ptab;        // [nb][256]      tables of a periodic block
+    u32* red;         // [nb]           period p > 64 of a block that is sorted through its first 3 p + (n mod p) bytes (k1_period.hip), else 0
     u32* tileHist;    // [nb][ptiles][K1F_NB]  front end: per-tile bucket counts
     u64* fsplit;      // [nb][K1F_NB]       front end: bucket d holds the keys in [fsplit[d-1], fsplit[d])
     u32* fstart;      // [nb][K1F_NB+1]     front end: first suffix-array position of every bucket
@@ -139,6 +140,8 @@ int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h
 // k1_period.hip: blocks with a linear period <= 64 get their suffix array from a closed form and leave the general sort
 // (nfront[b] = 0); also sets nfront for every other block: runs before the front end.  enable = 0: no block qualifies
 int k1_period_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 enable);
+// after the sort: the suffix arrays of the blocks with red[b] != 0 from those of their reduced blocks (into SB: k1_finish reads them there)
+int k1_period_expand(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
 #define K1R_STEP 24u           // text bytes a refinement round (k1r_round) takes off every listed rotation
 #define K1F_STEP 12u           // text bytes per in-bucket iteration / refinement round: what ONE 16-byte aligned load yields at any alignment
 size_t k1_front_tilehist_words(const BatchGeom& g);   // u32 per block the front end needs in tileHist

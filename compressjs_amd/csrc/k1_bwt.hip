@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 c
         const u64 dsc = L[gi];
         const u32 b = DP_B(dsc), start = DP_START(dsc);
         u32 d = DP_DEPTH(dsc);
-        const u32 n = B.nlen[b];
+        const u32 n = B.nfront[b];
         const u8* T = B.T + (size_t)b * g.tstride;
         u32* SA = B.SA + (size_t)b * g.stride + start;
         u32 mem[2];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 c
     for (u32 gi = r * 256u + tid; gi < cnt; gi += nr * 256u) {
         const u64 dsc = L[gi];
         const u32 b = DP_B(dsc), start = DP_START(dsc), gl = DP_LEN(dsc);
-        const u32 n = B.nlen[b];
+        const u32 n = B.nfront[b];
         const u8* T = B.T + (size_t)b * g.tstride;
         u32* SA = B.SA + (size_t)b * g.stride + start;
         u32 mem[K1_DEEP_LANE];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g) {
     const u32 p0 = (tt * 256u + threadIdx.x) * 4u;
     if (p0 >= n) return;
     const u8* T = B.T + (size_t)b * g.tstride;
-    const u32* SA = B.SA + (size_t)b * g.stride;
+    const u32* SA = (B.red[b] ? B.SB : B.SA) + (size_t)b * g.stride;     // (k1_period.hip: expanded from the reduced block's)
     u8* U = B.U + (size_t)b * g.stride;
     if (p0 + 4u <= n) {
         const uint4 v = *(const uint4*)(SA + p0);          // stride is a multiple of 4 entries: 16-byte aligned
@@ -379,6 +379,7 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     take((void**)&B.nfront, (size_t)nb8 * 4);
     take((void**)&B.per, (size_t)nb8 * 4);
     take((void**)&B.ptab, (size_t)g.nb * 256 * 4);
+    take((void**)&B.red, (size_t)nb8 * 4);
     B.dchg = B.dcnt ? B.dcnt + (size_t)(K1D_MAXR + 2u) * nb8 : nullptr;
     B.dtot = B.dcnt ? B.dchg + (size_t)(K1D_MAXR + 2u) * nb8 : nullptr;
     B.dbn = B.dcnt ? B.dtot + nb8 : nullptr;
@@ -456,9 +457,14 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         std::vector<u32> per(g.nb);
         HIP_CHECK_RET(hipMemcpyAsync(per.data(), B.per, (size_t)g.nb * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK_RET(hipStreamSynchronize(stream));
+        std::vector<u32> red(g.nb);
+        HIP_CHECK_RET(hipMemcpyAsync(red.data(), B.red, (size_t)g.nb * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK_RET(hipStreamSynchronize(stream));
         g_k1_last_periodic = 0;
-        for (u32 b = 0; b < g.nb; b++) g_k1_last_periodic += per[b] ? 1 : 0;
-        fprintf(stderr, "[k1] blocks with a period <= 64: %d of %u\n", g_k1_last_periodic, g.nb);
+        int nred = 0;
+        for (u32 b = 0; b < g.nb; b++) { g_k1_last_periodic += per[b] ? 1 : 0; nred += red[b] ? 1 : 0; }
+        g_k1_last_periodic += nred << 16;
+        fprintf(stderr, "[k1] of %u blocks: %d with a period <= 64 (closed form), %d with a longer period (sorted through their first 3 periods)\n", g.nb, g_k1_last_periodic & 0xFFFF, nred);
     }
     // the text stages: cyclic mode, blocks whose indices fit the list entries' 22 bits
     const bool fused = !B.linear && K.text_bytes > d0 && max_n < (1u << 22);
@@ -560,6 +566,10 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     }
     g_k1_last_sparse_rounds = rounds_with_work;             // (known with CJS_K1_TRACE only)
     g_k1_last_rounds = rounds_with_work;
+    if (!B.linear && K.period) {
+        const int rc = k1_period_expand(B, g, max_n, stream);
+        if (rc) return rc;
+    }
     if (B.linear) hipLaunchKernelGGL(k1_finish_linear, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g, B.SAout);
     else hipLaunchKernelGGL(k1_finish, dim3((max_n + 1023) / 1024, (g.nb + 7u) & ~7u), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());

@@ -308,7 +308,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
 
 // ISA for every rotation of the blocks that still hold groups (dtot[b] != 0, k1_count_unsorted), and round 0's lists
 __global__ __launch_bounds__(256) void k1d_build(K1Buf B, BatchGeom g) {
-    const u32 b = blockIdx.y, n = B.nlen[b];
+    const u32 b = blockIdx.y, n = B.nfront[b];
     const u32 lo = blockIdx.x * K1D_T;
     if (lo >= n || (B.dtot[b] == 0u && !B.linear)) return;          // (linear mode: k1_finish_linear reads the rank of suffix 0)
     k1d_window<true>(B, g, b, lo, n - lo < K1D_T ? n - lo : K1D_T, K1D_WIN, 0u);
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
         const u32 ntile = k1d_tile_prefix(cnt_row, q, g.stride, tpre, scr);
         if (q.wg >= ntile) continue;                        // (uniform)
         if (tid < q.slots) {
-            const u32 bb = q.first + q.step * tid, nn = B.nlen[bb];
+            const u32 bb = q.first + q.step * tid, nn = B.nfront[bb];
             s_cnt[tid] = cnt_row[bb] < g.stride ? cnt_row[bb] : g.stride;
             s_n[tid] = nn;
             s_hm[tid] = nn ? (h >> 32 ? (u32)(h % nn) : (u32)h % nn) : 0u;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
     for (u32 gi = blockIdx.x; gi < cnt; gi += gridDim.x) {
         const u64 d = list[gi];
         const u32 b = K1D_DB(d), start = K1D_DSTART(d), len = K1D_DLEN(d);
-        const u32 n = B.nlen[b];
+        const u32 n = B.nfront[b];
         const u32 mode = k1d_mode(B, r, b, final_h);
         const u32 hm = (u32)(h % n);
         const u32* ISA = B.ISA + (size_t)b * g.stride;
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(1024) void k1d_large(K1Buf B, BatchGeom g, u32 r, u
     for (u32 gi = blockIdx.x; gi < cnt; gi += gridDim.x) {
         const u64 d = B.listL[r & 1u][gi];
         const u32 b = K1D_DB(d), start = K1D_DSTART(d), L = K1D_DLEN(d);
-        const u32 n = B.nlen[b];
+        const u32 n = B.nfront[b];
         const u32 mode = k1d_mode(B, r, b, final_h), linear = B.linear;
         const u32 hm = (u32)(h % n);
         const u32* ISA = B.ISA + (size_t)b * g.stride;

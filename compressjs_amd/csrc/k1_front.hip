@@ -968,7 +968,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
         const uint4 tk = B.btask[(size_t)level * B.btaskCap + li];
         const u32 b = tk.x, pos = tk.y, len = tk.z, depth = tk.w & ~K1F_TASK_SB;
         const bool inSB = (tk.w & K1F_TASK_SB) != 0u;
-        const u32 n = B.nlen[b];
+        const u32 n = B.nfront[b];
         const u8* T = B.T + (size_t)b * g.tstride;
         u32* SBs = B.SB + (size_t)b * g.stride + pos;
         u32* SAs = B.SA + (size_t)b * g.stride + pos;
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     // Only while a sizeable part of the block still ties: the last few hundred entries of a text block (boilerplate passages) are
     // cheaper to walk to the end (the lane kernels take them) than to rank the whole block for (k1d_build).
     u32 final = final_host;
-    const u32 n = B.nlen[b];
+    const u32 n = B.nfront[b];
     if (round >= 1u && cnt >= n / 16u) {
         const u32 prev = B.rcnt[(size_t)(round - 1u) * B.rstride + b];
         if ((u64)cnt * 8u > (u64)prev * 7u) final = 1u;

@@ -19,6 +19,18 @@
 //   * the p - 1 rotations with L < p are placed by comparing them with regular ones segment by segment (each comparison is at
 //     most a few table look-ups: first mismatch of two phases) - a binary search in every phase class, whose members a total
 //     order keeps on one side of the newcomer.
+// Longer periods (64 < p <= n / 4: tiled inputs) have no table-sized closed form, but the block need not be sorted whole: with
+// n' = 3 p + (n mod p) and T' = T[0, n'), rotation i' of T' is a prefix of rotation i' + (n - n') of T and the rotations of T'
+// are distinct, so the general sort of T' orders the LAST n' rotations of T; the missing ones (the first k = (n - n') / p of every
+// phase c, all regular) sit next to the first member f = c + k p of their phase that T' has - before it in ascending index order
+// or after it in descending order, the sign of the phase-internal order above: f and the missing members share at least
+// n' - c >= 2 p + 1 characters, and a rotation of another phase that shared them would either be regular (and differ within p)
+// or start in the last period with a first segment below p and then agree with W_(c + L) for p characters: the pure periodic
+// rotation W_c[0, n), which lies on ONE side of all of them.  (n' = 2 p + (n mod p) is not enough: brute force over small cases
+// finds rotations in between.)  n mod p = 0: T' = P, every rotation of P stands for n / p identical ones, larger index first.
+// k1p_find / k1p_verify find the period, k1p_reduce hands T' to the sort (nfront[b] = n', the wrap-around bytes behind it, head
+// bits), k1p_expand_* write the block's suffix array into SB afterwards.  sample3.ref tiled: 56 blocks of 900 k sort as 56 of 27 k.
+//
 // k1p_detect (smallest period <= 64 of a block, from a 2 KB prefix first: ordinary text fails there after a few dozen compares),
 // k1p_tables (phase order, class bases, insertion points of the irregular rotations), k1p_fill (the suffix array, head bits).
 #include "k1_bwt.h"
@@ -32,7 +44,12 @@
 #define K1P_PHASE 67
 #define K1P_THR 131
 #define K1P_NIRR 195
-#define K1P_FAIL 196
+#define K1P_FAIL 196             // [2]: first position where the candidate of stage 0 / 1 does not hold (0xFFFFFFFF: it holds)
+#define K1P_CAND 200             // [2]: candidates for a period beyond 64 (stage 0 / 1)
+#define K1P_RASC 202             // reduced block: phase-internal order ascending
+#define K1P_RK 203               // reduced block: periods left out
+#define K1P_RN 204               // reduced block: its length n'
+#define K1P_RED_MINN 16384u      // shorter blocks are not reduced
 
 // first mismatch of W_a and W_b (a != b): offset | (W_a < W_b) << 7, in LDS
 __device__ __forceinline__ u32 k1p_seg_cmp(const u8* dt, u32 p, u32 n, u32 i, u32 j) {
@@ -83,26 +100,74 @@ __global__ __launch_bounds__(256) void k1p_detect(K1Buf B, BatchGeom g, u32 enab
     if (tid == 0) {
         B.per[b] = period;
         B.nfront[b] = period ? 0u : n;
-        B.ptab[(size_t)b * 256u + K1P_FAIL] = 0u;
+        u32* tab = B.ptab + (size_t)b * 256u;
+        tab[K1P_FAIL] = tab[K1P_FAIL + 1u] = 0xFFFFFFFFu;    // k1p_verify: the first position where the candidate does not hold
+        tab[K1P_CAND] = tab[K1P_CAND + 1u] = 0xFFFFFFFFu;    // k1p_find: the smallest candidate
+        B.red[b] = 0u;
     }
 }
 
-// the candidate against the whole block (a block with a period p' <= 64 has it on its prefix too, where the smallest period
-// divides it - and then holds for the whole block: one candidate decides)
-__global__ __launch_bounds__(256) void k1p_verify(K1Buf B, BatchGeom g) {
+// Candidates for a longer period: positions 64 < j <= n / 4 where 32 bytes of the block come again, and 32 bytes elsewhere come
+// again at the same distance; the smallest one is the candidate.  Every period passes, so a candidate that then holds for the
+// whole block (k1p_verify) is the block's smallest period.
+//   stage 0: the block's first 32 bytes and the 32 at n / 2.
+//   stage 1: for the blocks whose first candidate (k1p_detect's or stage 0's) failed - a file of equal lines, tiled: the line
+//     length matches both probes and breaks where the file ends.  k1p_verify left the first position where it broke: the 32 bytes around that place hold the
+//     irregularity, and their next occurrence is one true period on (second probe: the block's first 32 bytes).
+__global__ __launch_bounds__(256) void k1p_find(K1Buf B, BatchGeom g, u32 enable, u32 stage) {
+    const u32 b = blockIdx.y, n = B.nlen[b], tid = threadIdx.x;
+    if (!enable || B.linear || n < K1P_RED_MINN || (stage == 0u && B.per[b])) return;          // (a short candidate goes first)
+    u32* tab = B.ptab + (size_t)b * 256u;
+    u32 x1 = 0, x2 = n / 2u, jmax = n / 4u;
+    if (stage) {
+        const u32 c0 = B.per[b] ? B.per[b] : tab[K1P_CAND], m0 = tab[K1P_FAIL];                 // (k1p_detect's candidate: the lines may be short)
+        if (c0 == 0xFFFFFFFFu || m0 == 0xFFFFFFFFu) return;   // no first candidate, or it holds
+        x1 = m0 + c0 >= 16u ? m0 + c0 - 16u : 0u;             // T[m0] != T[m0 + c0]: around the later one
+        x2 = 0u;
+        if (x1 + 32u + 65u >= n) return;
+        if (jmax > n - x1 - 32u) jmax = n - x1 - 32u;
+    }
+    const u32 t0 = 65u + blockIdx.x * 4096u;
+    if (t0 > jmax) return;
+    const u8* T = B.T + (size_t)b * g.tstride;
+    __shared__ u32 pat[8];
+    __shared__ u8 tile[4096 + 32];
+    if (tid < 8) { const u8* q = T + x1 + tid * 4u; pat[tid] = (u32)q[0] | (u32)q[1] << 8 | (u32)q[2] << 16 | (u32)q[3] << 24; }
+    for (u32 i = tid; i < 4096u + 32u; i += 256u) tile[i] = x1 + t0 + i < n ? T[x1 + t0 + i] : 0;
+    __syncthreads();
+    for (u32 k = 0; k < 16u; k++) {
+        const u32 o = k * 256u + tid, j = t0 + o;
+        if (j > jmax) break;
+        bool m = true;
+        for (u32 w = 0; w < 8u && m; w++) {
+            const u32 v = (u32)tile[o + w * 4u] | (u32)tile[o + w * 4u + 1u] << 8 | (u32)tile[o + w * 4u + 2u] << 16 | (u32)tile[o + w * 4u + 3u] << 24;
+            m = v == pat[w];
+        }
+        if (!m) continue;
+        for (u32 i = 0; i < 32u && m; i++) m = T[x2 + i] == T[x2 + j + i];
+        if (m) atomicMin(&tab[K1P_CAND + stage], j);
+    }
+}
+
+// the candidate against the whole block; stage 0 also checks the short candidate of k1p_detect (a block with a period p' <= 64
+// has it on its prefix too, where the smallest period divides it - and then holds for the whole block: one candidate decides)
+__global__ __launch_bounds__(256) void k1p_verify(K1Buf B, BatchGeom g, u32 stage) {
     const u32 b = blockIdx.y, tid = threadIdx.x;
-    const u32 p = B.per[b];
-    if (!p) return;
+    u32* tab = B.ptab + (size_t)b * 256u;
+    const u32 p = stage == 0u && B.per[b] ? B.per[b] : tab[K1P_CAND + stage];          // (k1p_find skips the blocks with a short candidate)
+    if (p == 0xFFFFFFFFu) return;
     const u32 n = B.nlen[b];
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32 t0 = blockIdx.x * 4096u;
-    u32 f = 0;
-#pragma unroll
+    u32 first = 0xFFFFFFFFu;
     for (u32 k = 0; k < 16u; k++) {
-        const u32 i = t0 + k * 256u + tid;
-        if (i + p < n) f |= (u32)(T[i] ^ T[i + p]);
+        const u32 i = t0 + (15u - k) * 256u + tid;             // (descending: the last hit is the smallest)
+        if (i + p < n && T[i] != T[i + p]) first = i;
     }
-    if (f) B.ptab[(size_t)b * 256u + K1P_FAIL] = 1u;
+    const u64 bal = __ballot(first != 0xFFFFFFFFu);
+    if (!bal) return;
+    for (u32 off = 32; off; off >>= 1) { const u32 o = __shfl_xor(first, off); first = o < first ? o : first; }
+    if ((tid & 63u) == 0u) atomicMin(&tab[K1P_FAIL + stage], first);
 }
 
 // tables of a periodic block in ptab[b][256]:
@@ -112,7 +177,7 @@ __global__ __launch_bounds__(256) void k1p_verify(K1Buf B, BatchGeom g) {
 //   [67..130]  phase[k]: the phase with rank k
 //   [131..194] thr[u]: the irregular rotations in ascending order: regular rotations before the u-th of them
 //   [195]      irregular rotations (0 or p - 1)
-//   [196]      k1p_verify: the candidate period does not hold
+//   [196]      k1p_verify: the first position where the candidate does not hold (0xFFFFFFFF: it holds)
 __global__ __launch_bounds__(256) void k1p_tables(K1Buf B, BatchGeom g) {
     const u32 b = blockIdx.x, tid = threadIdx.x;
     const u32 p = B.per[b];
@@ -120,7 +185,7 @@ __global__ __launch_bounds__(256) void k1p_tables(K1Buf B, BatchGeom g) {
     const u32 n = B.nlen[b];
     const u8* T = B.T + (size_t)b * g.tstride;
     u32* tab = B.ptab + (size_t)b * 256u;
-    if (tab[K1P_FAIL]) {                                  // (uniform) not periodic after all: the general sort takes the block
+    if (tab[K1P_FAIL] != 0xFFFFFFFFu) {                   // (uniform) not periodic after all: the general sort takes the block
         if (tid == 0) { B.per[b] = 0u; B.nfront[b] = n; }
         return;
     }
@@ -230,11 +295,160 @@ __global__ __launch_bounds__(256) void k1p_fill(K1Buf B, BatchGeom g) {
     for (u32 w = t0 / 32u + tid; w < (t0 + 4096u) / 32u && w * 32u < n; w += 256u) HN[w] = 0xFFFFFFFFu;       // (bits at and beyond n are set already)
 }
 
+// a verified longer period: the reduced block goes to the sort
+__global__ __launch_bounds__(256) void k1p_reduce(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.x, tid = threadIdx.x;
+    u32* tab = B.ptab + (size_t)b * 256u;
+    const u32 n = B.nlen[b];
+    u32 p = 0;                                               // the verified candidate
+    if (!B.per[b]) {
+        if (tab[K1P_CAND] != 0xFFFFFFFFu && tab[K1P_FAIL] == 0xFFFFFFFFu) p = tab[K1P_CAND];
+        else if (tab[K1P_CAND + 1u] != 0xFFFFFFFFu && tab[K1P_FAIL + 1u] == 0xFFFFFFFFu) p = tab[K1P_CAND + 1u];
+    }
+    const u32 r0 = p ? n % p : 0u;
+    const u32 nr = r0 ? 3u * p + r0 : p;
+    // (uniform) no period found, or too little to gain
+    if (!p || (u64)nr * 5u > (u64)n * 4u) return;            // (red[b] = 0 since k1p_detect)
+    if (tid == 0) B.red[b] = p;
+    u8* T = (u8*)B.T + (size_t)b * g.tstride;
+    __shared__ u32 first;
+    if (tid == 0) first = 0xFFFFFFFFu;
+    __syncthreads();
+    // the sign of the order inside a phase: W_r0 against W_0 (they differ within p characters)
+    if (r0) {
+        for (u32 c0 = 0; c0 < p; c0 += 256u) {
+            const u32 t = c0 + tid;
+            if (t < p && T[r0 + t] != T[t]) atomicMin(&first, t);
+            __syncthreads();
+            const u32 seen = first;                          // (every thread reads it between the two barriers: one decision)
+            __syncthreads();
+            if (seen != 0xFFFFFFFFu) break;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const u32 d = first;
+        tab[K1P_RASC] = r0 && d != 0xFFFFFFFFu && T[r0 + d] < T[d] ? 1u : 0u;
+        tab[K1P_RK] = (n - nr) / p;
+        tab[K1P_RN] = nr;
+#ifdef CJS_CPU_DEBUG_BUILD
+        if (getenv("K1P_DBG")) fprintf(stderr, "[k1p] b %u n %u p %u r0 %u nr %u k %u d %u asc %u (T[r0+d]=%u T[d]=%u)\n", b, n, p, r0, nr, (n - nr) / p, d, tab[K1P_RASC], d != 0xFFFFFFFFu ? T[r0 + d] : 0, d != 0xFFFFFFFFu ? T[d] : 0);
+#endif
+        B.nfront[b] = nr;
+    }
+    __syncthreads();
+    // what the sort reads behind the block's end (k0_pad's 64 bytes): T'[nr + t] = T'[t]; k1p_expand_scan puts the block's own bytes back
+    if (r0 && tid < 64u) T[nr + tid] = T[tid];
+    // head bits at and beyond nr
+    u32* HN = B.HN + (size_t)b * g.hstride;
+    for (u32 w = nr / 32u + tid; w * 32u < n; w += 256u) HN[w] = w == nr / 32u ? (HN[w] | (0xFFFFFFFFu << (nr & 31u))) : 0xFFFFFFFFu;
+}
+
+// ---- after the sort: SB <- the suffix array of the whole block ----------------------------------------------
+// (a block's slice of tileHist: ceil(stride / K1F_PT) x K1F_NB words, far more than its stride / 4096 tile counts)
+__device__ __forceinline__ size_t k1p_th(const BatchGeom& g, u32 b) { return (size_t)b * ((g.stride + K1F_PT - 1u) / K1F_PT) * K1F_NB; }
+// entry t of the reduced block's suffix array (rotation e of T') becomes rotation e + k p of T at position t + k C(t), C(t) = the
+// entries before t with e < p (the first members of their phases: each brings the k missing ones along)
+__global__ __launch_bounds__(256) void k1p_expand_count(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.y, tid = threadIdx.x;
+    const u32 p = B.red[b];
+    if (!p) return;
+    const u32 nr = B.ptab[(size_t)b * 256u + K1P_RN];
+    const u32 t0 = blockIdx.x * 4096u;
+    if (t0 >= nr) return;
+    const u32* SA = B.SA + (size_t)b * g.stride;
+    u32 c = 0;
+    for (u32 k = 0; k < 16u; k++) { const u32 t = t0 + k * 256u + tid; if (t < nr && SA[t] < p) c++; }
+    __shared__ u32 tot;
+    if (tid == 0) tot = 0;
+    __syncthreads();
+    for (u32 off = 32; off; off >>= 1) c += __shfl_xor(c, off);
+    if ((tid & 63u) == 0) atomicAdd(&tot, c);
+    __syncthreads();
+    if (tid == 0) B.tileHist[k1p_th(g, b) + blockIdx.x] = tot;                 // (the front end's counts are long used)
+}
+__global__ __launch_bounds__(256) void k1p_expand_scan(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.x, tid = threadIdx.x;
+    const u32 p = B.red[b];
+    if (!p) return;
+    const u32 n = B.nlen[b];
+    const u32 nr = B.ptab[(size_t)b * 256u + K1P_RN];
+    const u32 nt = (nr + 4095u) / 4096u;                     // <= 220
+    u32* th = B.tileHist + k1p_th(g, b);
+    __shared__ u32 sc[256];
+    const u32 v = tid < nt ? th[tid] : 0u;
+    sc[tid] = v;
+    __syncthreads();
+    for (u32 off = 1; off < 256u; off <<= 1) {
+        const u32 a = tid >= off ? sc[tid - off] : 0u;
+        __syncthreads();
+        sc[tid] += a;
+        __syncthreads();
+    }
+    if (tid < nt) th[tid] = sc[tid] - v;
+    // the block's own bytes behind the reduced block again (k1_finish gathers from the whole block)
+    const u32 r0 = n % p;
+    u8* T = (u8*)B.T + (size_t)b * g.tstride;
+    if (r0 && tid < 64u) T[nr + tid] = T[r0 + tid];
+}
+__global__ __launch_bounds__(256) void k1p_expand_write(K1Buf B, BatchGeom g) {
+    const u32 b = blockIdx.y, tid = threadIdx.x;
+    const u32 p = B.red[b];
+    if (!p) return;
+    const u32* tab = B.ptab + (size_t)b * 256u;
+    const u32 nr = tab[K1P_RN], k = tab[K1P_RK];
+    const bool asc = tab[K1P_RASC] != 0u;
+    const u32 t0 = blockIdx.x * 4096u;
+    if (t0 >= nr) return;
+    const u32* SA = B.SA + (size_t)b * g.stride;
+    u32* out = B.SB + (size_t)b * g.stride;
+    __shared__ u32 wsum[4];
+    u32 run = B.tileHist[k1p_th(g, b) + blockIdx.x];
+    const u32 lane = tid & 63u, w = tid >> 6;
+    for (u32 r = 0; r < 16u; r++) {                          // rows of 256 consecutive entries
+        const u32 t = t0 + r * 256u + tid;
+        const u32 e = t < nr ? SA[t] : 0xFFFFFFFFu;
+        const bool fl = e < p;
+        const u64 bal = __ballot(fl);
+        if (lane == 0) wsum[w] = (u32)__popcll(bal);
+        __syncthreads();
+        u32 before = (u32)__popcll(bal & ((1ull << lane) - 1ull));
+        for (u32 q = 0; q < w; q++) before += wsum[q];
+        const u32 rowtot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+        if (t < nr) {
+            const u32 base = t + k * (run + before), i = e + k * p;
+            if (!fl) out[base] = i;
+            else if (asc) {
+                for (u32 j = 0; j < k; j++) out[base + j] = e + j * p;
+                out[base + k] = i;
+            } else {
+                out[base] = i;
+                for (u32 j = 0; j < k; j++) out[base + 1u + j] = e + (k - 1u - j) * p;
+            }
+        }
+        run += rowtot;
+    }
+}
+
+int k1_period_expand(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
+    const u32 tiles = (max_n * 4u / 5u + 4095u) / 4096u + 1u;                 // a reduced block is at most 4/5 of its block
+    hipLaunchKernelGGL(k1p_expand_count, dim3(tiles, g.nb), dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1p_expand_scan, dim3(g.nb), dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1p_expand_write, dim3(tiles, g.nb), dim3(256), 0, stream, B, g);
+    HIP_CHECK_RET(hipGetLastError());
+    return CJS_OK;
+}
+
 int k1_period_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 enable) {
     hipLaunchKernelGGL(k1p_detect, dim3(g.nb), dim3(256), 0, stream, B, g, enable);
-    hipLaunchKernelGGL(k1p_verify, dim3((max_n + 4095u) / 4096u, g.nb), dim3(256), 0, stream, B, g);
+    for (u32 stage = 0; stage < 2u; stage++) {
+        hipLaunchKernelGGL(k1p_find, dim3((max_n / 4u + 4095u) / 4096u, g.nb), dim3(256), 0, stream, B, g, enable, stage);
+        hipLaunchKernelGGL(k1p_verify, dim3((max_n + 4095u) / 4096u, g.nb), dim3(256), 0, stream, B, g, stage);
+    }
     hipLaunchKernelGGL(k1p_tables, dim3(g.nb), dim3(256), 0, stream, B, g);
     hipLaunchKernelGGL(k1p_fill, dim3((max_n + 4095u) / 4096u, g.nb), dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1p_reduce, dim3(g.nb), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

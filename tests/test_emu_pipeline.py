@@ -621,6 +621,61 @@ print("ok", seen)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
 
 
+def test_long_period_blocks_sorted_through_three_periods():
+    """k1_period.hip, periods beyond 64: a block T of period p (n >= 16384, 3 p + n mod p <= 0.8 n) is sorted as its first
+    n' = 3 p + (n mod p) bytes (n' = p when p divides n) and expanded - every phase's missing members next to the first one the
+    reduced block has, in the phase's index order.  Period words of four kinds (binary, text, random bytes, half zeros: the last
+    and files of equal lines tiled need the second detection stage), p from 65 to n / 4, multiples of p and not; transform AND origPtr against
+    the oracle (the order inside a phase only shows in origPtr and in the bytes in front of rotation 0)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle, stagelib
+from compressjs_amd import synth
+L = C.CDLL(stagelib.build_emu())
+L.cjs_bwt_cyclic_batch.restype = C.c_int32
+L.cjs_bwt_cyclic_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+rng = np.random.default_rng(1)
+cap = 40000
+def run(blocks):
+    nb = len(blocks)
+    T = np.zeros((nb, cap), np.uint8); nl = np.zeros(nb, np.uint32)
+    for i, d in enumerate(blocks):
+        T[i, :d.size] = d; nl[i] = d.size
+    U = np.zeros((nb, cap), np.uint8); P = np.zeros(nb, np.uint32)
+    assert L.cjs_bwt_cyclic_batch(T.ctypes.data, nl.ctypes.data, nb, cap, U.ctypes.data, P.ctypes.data) == 0
+    for i, d in enumerate(blocks):
+        uo, po = oracle.bwt_cyclic(d)
+        assert P[i] == po and (U[i, :d.size] == uo).all(), (d.size, int(P[i]), po)
+    return L.cjs_dbg_k1_periodic_blocks() >> 16
+blocks = []
+for it in range(32):
+    n = int(rng.integers(16384, 39000))
+    p = int(rng.integers(65, n // 4))
+    kind = it %% 4
+    if kind == 0: P = rng.integers(0, 2, p).astype(np.uint8)
+    elif kind == 1: P = synth.text_like(p, it)
+    elif kind == 2: P = rng.integers(0, 256, p).astype(np.uint8)
+    else: P = np.concatenate([np.zeros(p // 2, np.uint8), rng.integers(0, 3, p - p // 2).astype(np.uint8)])
+    if it %% 5 == 0: n = (n // p) * p
+    blocks.append(np.tile(P, n // p + 2)[:n].copy())
+for fl, n, ll in ((3000, 30001, 81), (4000, 36000, 81), (3001, 30001, 4), (2999, 38000, 1)):   # a file of equal lines (cut in a line), tiled: found by the second stage
+    f = np.concatenate([np.tile(synth.text_like(ll, 3), fl // ll + 1)[:fl - 9], np.frombuffer(b"the end.\n", np.uint8)])
+    blocks.append(np.tile(f, n // fl + 1)[:n].copy())
+d = np.tile(synth.text_like(3000, 9), 10)[:29000].copy(); d[-1] ^= 1; blocks.append(d)       # one foreign byte: the general sort
+d = np.tile(synth.text_like(9000, 9), 4)[:30000].copy(); blocks.append(d)                    # 3 p + r0 > 0.8 n: not worth reducing
+seen = 0
+for i in range(0, len(blocks), 8):
+    seen += run(blocks[i:i + 8])
+assert 26 <= seen <= 36, seen
+print("ok", seen)
+''' % (stagelib.ROOT, os.path.join(stagelib.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CJS_K1_TRACE="1"), capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
+
+
 def test_segmented_host_pipeline():
     """cjs_bz2_compress on inputs longer than 1.5 segments: planned and encoded segment by segment (upload / encode /
     download overlapped by two helper threads).  CJS_SEG_BYTES=120000 makes a segment ~1.2 level-1 blocks, so the

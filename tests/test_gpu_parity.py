@@ -466,12 +466,64 @@ def test_two_streams_with_host_threads_same_bytes():
     assert outs[0] == outs[1] == outs[2], outs
 
 
+def test_periodic_blocks_closed_form_vs_oracle():
+    """k1_period.hip through cjs_bwt_cyclic_batch: blocks with a linear period p <= 64 (every p, lengths that are and are not
+    multiples of p, small and full alphabets, up to the -9 block capacity), near-periodic blocks and periods beyond 64 (which
+    must take the general sort): transform and origPtr equal the oracle's for every block."""
+    L = _lib.load()
+    L.cjs_bwt_cyclic_batch.restype = C.c_int32
+    L.cjs_bwt_cyclic_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+
+    def mk(p, n, alpha):
+        return np.tile(rng.integers(0, alpha, p).astype(np.uint8), n // p + 2)[:n].copy()
+
+    def run(blocks, cap):
+        nb = len(blocks)
+        T = np.zeros((nb, cap), np.uint8)
+        nl = np.zeros(nb, np.uint32)
+        for i, d in enumerate(blocks):
+            T[i, :d.size] = d
+            nl[i] = d.size
+        U = np.zeros((nb, cap), np.uint8)
+        P = np.zeros(nb, np.uint32)
+        assert L.cjs_bwt_cyclic_batch(T.ctypes.data, nl.ctypes.data, nb, cap, U.ctypes.data, P.ctypes.data) == 0
+        for i, d in enumerate(blocks):
+            uo, po = oracle.bwt_cyclic(d)
+            assert P[i] == po and np.array_equal(U[i, :d.size], uo), (d.size, bytes(d[:70]))
+
+    blocks = []
+    for p in range(1, 65):
+        n = int(rng.integers(4096, 30000))
+        blocks.append(mk(p, n if p % 2 else (n // p) * p, int(rng.choice([2, 3, 4, 256]))))
+    for at in (5999, 3000, 2047, 100):
+        d = mk(7, 6000, 3)
+        d[at] ^= 1
+        blocks.append(d)
+    blocks += [mk(65, 9000, 256), mk(100, 9000, 4), mk(3, 4000, 2)]
+    run(blocks, 32768)
+    big = [mk(1, 899981, 256), mk(2, 899981, 2), mk(5, 899980, 256), mk(44, 899981, 64), mk(64, 899981, 3), mk(63, 63 * 14000, 2)]
+    d = mk(9, 899981, 4)
+    d[-1] ^= 1
+    big.append(d)
+    # periods beyond 64 (k1p_find / k1p_reduce / k1p_expand_*): the block is sorted through its first 3 p + n mod p bytes
+    text = synth.text_like(200_000, 5)
+    for p, n in ((65, 899981), (8700, 899981), (8700, 8700 * 100), (70_001, 899981), (200_000, 899981), (224_995, 899981), (1000, 16384)):
+        w = text[:p] if p > 300 else rng.integers(0, 3, p).astype(np.uint8)
+        big.append(np.tile(w, n // p + 2)[:n].copy())
+    d = np.tile(text[:50_000], 19)[:899981].copy()
+    d[-1] ^= 1                                               # one foreign byte: the general sort
+    big.append(d)
+    run(big, 899981)
+
+
 def test_deep_refinement_variants_same_bytes(ctx):
     """The text stages in front of the doubling rounds are a faster route to the same order.  K1's knobs (k1_bwt.hip,
     k1_knobs) must all give the same bytes on phrase-reuse text + runs + periodic + tiled input, and those bytes must be the
     oracle's on the leading blocks: no text stages at all (doubling from 8 bytes), the default, one refinement round only and no
     lane kernels (most ties left to the doubling rounds) on one stream, no in-bucket iteration with the predictor forcing the text
-    stages on and unequal shares of a batch, the predictor forcing them off with no read-back at all."""
+    stages on and unequal shares of a batch, the predictor forcing them off with no read-back at all, no closed form for the
+    periodic blocks (k1_period.hip off: they go through the doubling rounds)."""
     import subprocess
     import sys
     code = (
@@ -487,7 +539,7 @@ def test_deep_refinement_variants_same_bytes(ctx):
     outs = []
     for env_add in ({"CJS_TEXT_BYTES": "0"}, {}, {"CJS_TEXT_BYTES": "44", "CJS_DEEP_LANE_CAP": "0", "CJS_STREAMS": "1"},
                     {"CJS_BSORT_ITERS": "0", "CJS_DEEP_BIG_DIV": "1", "CJS_SHARES": "300:700"},
-                    {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}):
+                    {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}, {"CJS_K1_PERIOD": "0"}):
         env = dict(os.environ, **env_add)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
     assert all(o == outs[0] for o in outs), outs
