@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void k1p_expand_write(K1Buf B, BatchGeom g) {
 }
 
 int k1_period_expand(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
+    if (max_n < K1P_RED_MINN) return CJS_OK;                                  // (no block of the batch can have been reduced)
     const u32 tiles = (max_n * 4u / 5u + 4095u) / 4096u + 1u;                 // a reduced block is at most 4/5 of its block
     hipLaunchKernelGGL(k1p_expand_count, dim3(tiles, g.nb), dim3(256), 0, stream, B, g);
     hipLaunchKernelGGL(k1p_expand_scan, dim3(g.nb), dim3(256), 0, stream, B, g);
@@ -441,9 +442,10 @@ int k1_period_expand(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream)
 }
 
 int k1_period_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 enable) {
+    if (max_n == 0u) max_n = 1u;                                              // (a batch of empty blocks: the grids below must not be empty)
     hipLaunchKernelGGL(k1p_detect, dim3(g.nb), dim3(256), 0, stream, B, g, enable);
     for (u32 stage = 0; stage < 2u; stage++) {
-        hipLaunchKernelGGL(k1p_find, dim3((max_n / 4u + 4095u) / 4096u, g.nb), dim3(256), 0, stream, B, g, enable, stage);
+        hipLaunchKernelGGL(k1p_find, dim3(max_n / 16384u + 1u, g.nb), dim3(256), 0, stream, B, g, enable, stage);
         hipLaunchKernelGGL(k1p_verify, dim3((max_n + 4095u) / 4096u, g.nb), dim3(256), 0, stream, B, g, stage);
     }
     hipLaunchKernelGGL(k1p_tables, dim3(g.nb), dim3(256), 0, stream, B, g);
