@@ -1035,7 +1035,10 @@ int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h
         k1_prof_end(pr, slot, stream, 0);
         slot = k1_prof_begin(pr, K1P_DMED, stream);
         hipLaunchKernelGGL(k1d_med<K1D_MED1>, dim3(bg * 2u), dim3(256), 0, stream, B, g, r, h, final_h);
-        hipLaunchKernelGGL(k1d_med<K1_MED_MAX>, dim3(bg), dim3(256), 0, stream, B, g, r, h, final_h);
+        // (a group of 1025 .. 4096 is a chain of ~20 us for its workgroup, and E8S-A's first round has 8 500 of them, sizes all over the range: four times
+        // the workgroups of round 4's first version even the shares out - 13.2 -> 12.8 ms per 10^8 bytes; 2 x .. 8 x measure alike.  Running the three
+        // group kernels on a second stream NEXT TO k1d_round was tried too: they are not independent of it - the stream's digest moved - and gained 1 %)
+        hipLaunchKernelGGL(k1d_med<K1_MED_MAX>, dim3(bg * 4u), dim3(256), 0, stream, B, g, r, h, final_h);
         k1_prof_end(pr, slot, stream, 0);
         slot = k1_prof_begin(pr, K1P_DLARGE, stream);
         hipLaunchKernelGGL(k1d_large, dim3(bg < 256u ? bg : 256u), dim3(1024), 0, stream, B, g, r, h, final_h);
