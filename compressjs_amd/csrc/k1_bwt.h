@@ -136,7 +136,8 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
 int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max);
 int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth);
 // k1_dbl.hip: ranks of every rotation from (SA, HN), then list-driven prefix doubling from depth h0 until every group is resolved
-int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h0);
+//   check_h != 0: from the round with that h on the host looks after every round whether anything is left and stops launching if not
+int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h0, u32 check_h);
 // k1_period.hip: blocks with a linear period <= 64 get their suffix array from a closed form and leave the general sort
 // (nfront[b] = 0); also sets nfront for every other block: runs before the front end.  enable = 0: no block qualifies
 int k1_period_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 enable);

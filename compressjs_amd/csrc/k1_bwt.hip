@@ -409,6 +409,7 @@ struct K1Knobs {
     u32 big_div;       // CJS_DEEP_BIG_DIV  text stages are skipped when more than 1/DIV of the rotations sit in one-key buckets (default 8)
     u32 lane_cap;      // CJS_DEEP_LANE_CAP bytes the lane kernels walk a pair / small group that outlasted the rounds (default 4096; 0: not at all)
     bool period;       // CJS_K1_PERIOD     0: no closed form for blocks with a small period (k1_period.hip): they take the general path
+    u32 check_h;       // CJS_K1_CHECK_H    from the doubling round with this h on the host looks at the lists after every round and stops when they are empty (default 8192; 0: never)
     bool sync;         // CJS_K1_SYNC       0: no read-back at all (every launch of the doubling stage is enqueued whatever is left)
     bool trace;        // CJS_K1_TRACE      counters of the stages on stderr (reads them back: not for timing)
 };
@@ -427,6 +428,7 @@ static const K1Knobs& k1_knobs() {
         if (!q.big_div) q.big_div = 8u;
         q.lane_cap = num("CJS_DEEP_LANE_CAP", 4096u, 60000u);
         q.period = num("CJS_K1_PERIOD", 1u, 1u) != 0u;
+        q.check_h = num("CJS_K1_CHECK_H", 8192u, 1u << 22);
         q.sync = num("CJS_K1_SYNC", 1u, 1u) != 0u;
         q.trace = getenv("CJS_K1_TRACE") != nullptr;
         return q;
@@ -542,7 +544,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         for (u32 bb = 0; bb < g.nb; bb++) any_group = any_group || tt[bb] != 0u;
     }
     if (any_group) {
-        const int rc = k1_dbl_run(B, g, max_n, stream, d0);
+        const int rc = k1_dbl_run(B, g, max_n, stream, d0, K.sync ? K.check_h : 0u);
         if (rc) return rc;
     }
     if (K.trace) {

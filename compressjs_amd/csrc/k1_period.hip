@@ -371,19 +371,25 @@ __global__ __launch_bounds__(256) void k1p_expand_scan(K1Buf B, BatchGeom g) {
     if (!p) return;
     const u32 n = B.nlen[b];
     const u32 nr = B.ptab[(size_t)b * 256u + K1P_RN];
-    const u32 nt = (nr + 4095u) / 4096u;                     // <= 220
+    const u32 nt = (nr + 4095u) / 4096u;                     // <= 176 for a bzip2 block, <= 820 for the 2^22 bytes cjs_bwt_cyclic_batch takes
     u32* th = B.tileHist + k1p_th(g, b);
     __shared__ u32 sc[256];
-    const u32 v = tid < nt ? th[tid] : 0u;
-    sc[tid] = v;
-    __syncthreads();
-    for (u32 off = 1; off < 256u; off <<= 1) {
-        const u32 a = tid >= off ? sc[tid - off] : 0u;
+    u32 carry = 0;
+    for (u32 c0 = 0; c0 < nt; c0 += 256u) {                  // (uniform)
+        const u32 i = c0 + tid;
+        const u32 v = i < nt ? th[i] : 0u;
+        sc[tid] = v;
         __syncthreads();
-        sc[tid] += a;
+        for (u32 off = 1; off < 256u; off <<= 1) {
+            const u32 a = tid >= off ? sc[tid - off] : 0u;
+            __syncthreads();
+            sc[tid] += a;
+            __syncthreads();
+        }
+        if (i < nt) th[i] = carry + sc[tid] - v;
+        carry += sc[255];
         __syncthreads();
     }
-    if (tid < nt) th[tid] = sc[tid] - v;
     // the block's own bytes behind the reduced block again (k1_finish gathers from the whole block)
     const u32 r0 = n % p;
     u8* T = (u8*)B.T + (size_t)b * g.tstride;

@@ -515,6 +515,8 @@ def test_periodic_blocks_closed_form_vs_oracle():
     d[-1] ^= 1                                               # one foreign byte: the general sort
     big.append(d)
     run(big, 899981)
+    # beyond the bzip2 block sizes (BWT.bwtransform2 takes any length): a reduced block of more than 256 tiles
+    run([np.tile(synth.text_like(300_000, 6), 7)[:2_000_000].copy(), np.tile(np.frombuffer(b"abcde", np.uint8), 300_000)[:1_499_999].copy()], 2_000_000)
 
 
 def test_deep_refinement_variants_same_bytes(ctx):
