@@ -336,7 +336,7 @@ __device__ __forceinline__ void walk_groups(const u16* A, u32 pos, u32 nSel, u32
 //                   LDS rows and adds them to the block's next frequency rows (fr2, two sets used alternately).
 // The kernel boundary is the barrier between the walks; nothing waits inside a kernel.
 #ifndef K34_SPLIT
-#define K34_SPLIT 4
+#define K34_SPLIT 2              // (round 3: 4, equal to 2 then; round 4, ms per 10^8 bytes with 1 / 2 / 3 / 4 / 8: enwik 8.77 / 8.53 / 8.60 / 8.58 / 8.97, E8S-A 12.68 / 12.37 / 12.39 / 12.51 / 13.18)
 #endif
 #define K34_MAX_SEL 18432        // selectors of a block, at most ((900000 + 19) / 50 rounded up; k34_run checks selPitch)
 // -DK34_TRACE builds: 100 MHz stamps between the phases of block 0 / workgroup 0, summed over the iterations into
