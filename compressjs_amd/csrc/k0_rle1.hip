@@ -576,17 +576,21 @@ __global__ __launch_bounds__(64) void k0_pad(K0Buf K, Pipe P, u32 first_block) {
 }
 
 // ---- CRC -----------------------------------------------------------------------------------------------
-// K0_CRC_PARTS x 1024 slices per block: a slice is a serial chain of dependent LDS look-ups, and a block of long runs consumes
-// tens of megabytes of input (5*10^7 zeros are two blocks: 1.5 ms with one workgroup each)
-#define K0_CRC_PARTS 4u
+// Up to K0_CRC_PARTS x 1024 slices per block: a slice is a serial chain of dependent LDS look-ups, and a block of long runs consumes
+// tens of megabytes of input (5*10^7 zeros are two blocks: 1.5 ms with one workgroup each).  One part per 2 MB of input: an
+// ordinary block (0.9 MB) is one workgroup's work as before - the table set-up of three more costs more than they save (99 -> 119 us).
+#define K0_CRC_PARTS 16u
 __global__ __launch_bounds__(1024) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
     const u32 b = blockIdx.y, kb = first_block + b;
     if (kb >= *K.nBlocks) return;
+    const u64 s = K.blkStart[kb], e = K.blkEnd[kb];
+    const u64 want = 1u + (e - s) / (2u << 20);
+    const u32 parts = want < K0_CRC_PARTS ? (u32)want : K0_CRC_PARTS;
+    if (blockIdx.x >= parts) return;                       // (uniform)
     __shared__ u32 tab[CRC_TAB_WORDS];
     __shared__ u32 pw[40];
     __shared__ u32 acc;
-    const u64 s = K.blkStart[kb], e = K.blkEnd[kb];
-    const u64 part = (((e - s + K0_CRC_PARTS - 1u) / K0_CRC_PARTS) + 15u) & ~(u64)15;
+    const u64 part = (((e - s + parts - 1u) / parts) + 15u) & ~(u64)15;
     const u64 ps = s + blockIdx.x * part < e ? s + blockIdx.x * part : e;
     const u64 pe = ps + part < e ? ps + part : e;
     if (ps >= pe) return;                                  // (uniform)
