@@ -129,22 +129,40 @@ __global__ __launch_bounds__(256) void k1p_find(K1Buf B, BatchGeom g, u32 enable
         if (jmax > n - x1 - 32u) jmax = n - x1 - 32u;
     }
     const u32 t0 = 65u + blockIdx.x * 4096u;
-    if (t0 > jmax) return;
+    if (t0 > jmax + 3u) return;                              // (a tile starts up to 3 distances early, see below)
     const u8* T = B.T + (size_t)b * g.tstride;
+    // The tile as ALIGNED words (byte loads of 4 KB per workgroup were most of the kernel's 30 us per 10^8 bytes of text): it starts at
+    // the word that holds distance t0, so a thread's 16 consecutive distances begin on a word and slide a 64-bit window over five
+    // of them with shifts known at compile time; the up to 3 distances in front of t0 belong to the tile before (checked twice).
     __shared__ u32 pat[8];
-    __shared__ u8 tile[4096 + 32];
+    __shared__ u32 tw[4096 / 4 + 12];
     if (tid < 8) { const u8* q = T + x1 + tid * 4u; pat[tid] = (u32)q[0] | (u32)q[1] << 8 | (u32)q[2] << 16 | (u32)q[3] << 24; }
-    for (u32 i = tid; i < 4096u + 32u; i += 256u) tile[i] = x1 + t0 + i < n ? T[x1 + t0 + i] : 0;
+    const u32 al = (x1 + t0) & ~3u;                          // (T + b * tstride is 128-byte aligned)
+    const u32* T4 = (const u32*)(T + al);
+    for (u32 i = tid; i < 4096u / 4u + 12u; i += 256u) tw[i] = al + i * 4u < n + 64u ? T4[i] : 0u;     // (k0_pad's 64 bytes behind n are readable)
     __syncthreads();
+    const u8* tb = (const u8*)tw;
+    const u32 p0 = pat[0];
+    u32 w[5];
+#pragma unroll
+    for (u32 q = 0; q < 5u; q++) w[q] = tw[tid * 4u + q];
+    u32 hit = 0;
+#pragma unroll
     for (u32 k = 0; k < 16u; k++) {
-        const u32 o = k * 256u + tid, j = t0 + o;
-        if (j > jmax) break;
+        const u32 q = k >> 2, sft = (k & 3u) * 8u;
+        const u32 v = sft ? (u32)((((u64)w[q + 1u] << 32) | w[q]) >> sft) : w[q];
+        hit |= (v == p0 ? 1u : 0u) << k;
+    }
+    while (hit) {
+        const u32 k = (u32)__builtin_ctz(hit);
+        hit &= hit - 1u;
+        const u32 o = tid * 16u + k, j = al + o - x1;
+        if (j < 65u || j > jmax) continue;
         bool m = true;
-        for (u32 w = 0; w < 8u && m; w++) {
-            const u32 v = (u32)tile[o + w * 4u] | (u32)tile[o + w * 4u + 1u] << 8 | (u32)tile[o + w * 4u + 2u] << 16 | (u32)tile[o + w * 4u + 3u] << 24;
-            m = v == pat[w];
+        for (u32 ww = 1; ww < 8u && m; ww++) {
+            const u8* q = tb + o + ww * 4u;
+            m = ((u32)q[0] | (u32)q[1] << 8 | (u32)q[2] << 16 | (u32)q[3] << 24) == pat[ww];
         }
-        if (!m) continue;
         for (u32 i = 0; i < 32u && m; i++) m = T[x2 + i] == T[x2 + j + i];
         if (m) atomicMin(&tab[K1P_CAND + stage], j);
     }
