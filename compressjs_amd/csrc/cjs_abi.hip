@@ -459,7 +459,7 @@ static int grow(void** p, size_t* have, size_t need) {
 // cross-stream dependency is the stream cursor: k5_blockscan of sub-batch j needs the cursor left by
 // sub-batch j-1 (an event); everything before it overlaps freely.
 static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap, u32 f, u32 nb, u32 si, void* d_out,
-                         uint64_t out_cap, Pipe& P) {
+                         uint64_t out_cap, Pipe& P, u32 total_blocks) {
     hipStream_t st = c->sub[si];
     pipe_carve(P, g, c->ws[si]);
     P.ss = c->d_ss;
@@ -468,7 +468,9 @@ static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap
     P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
     if (c->prof.enabled) c->prof_g = g;
     P.g.nb = nb;
-    int rc = k0_batch(K, P, f, cap, st);
+    // (CRC workgroups per block: one per 2 MB of input a block of this call consumes on average - long runs make that tens of megabytes)
+    const u64 per_block = K.in_len / (total_blocks ? total_blocks : 1u);
+    int rc = k0_batch(K, P, f, cap, st, (u32)(1u + per_block / (2u << 20)));
     if (rc) return rc;
     return pipe_run_block_stages(P, cap, st, 4);
 }
@@ -508,7 +510,7 @@ static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 coun
         for (u32 j = si; j < nsub; j += ns) {
             const u32 f = sfirst[j], nb = scount[j];
             Pipe P;
-            int rc = err.load() ? err.load() : run_sub_batch(c, K, g, cap, f, nb, si, d_out, out_cap, P);
+            int rc = err.load() ? err.load() : run_sub_batch(c, K, g, cap, f, nb, si, d_out, out_cap, P, first + count);
             while (recorded.load(std::memory_order_acquire) != j) std::this_thread::yield();
             if (!rc && !err.load()) rc = k5_run(P, cap, c->sub[si], j ? c->evScan[(j - 1) % ns] : nullptr, c->evScan[si]);
             if (rc) { int z = 0; err.compare_exchange_strong(z, rc); }

@@ -576,17 +576,17 @@ __global__ __launch_bounds__(64) void k0_pad(K0Buf K, Pipe P, u32 first_block) {
 }
 
 // ---- CRC -----------------------------------------------------------------------------------------------
-// Up to K0_CRC_PARTS x 1024 slices per block: a slice is a serial chain of dependent LDS look-ups, and a block of long runs consumes
-// tens of megabytes of input (5*10^7 zeros are two blocks: 1.5 ms with one workgroup each).  One part per 2 MB of input: an
-// ordinary block (0.9 MB) is one workgroup's work as before - the table set-up of three more costs more than they save (99 -> 119 us).
+// gridDim.x x 1024 slices per block: a slice is a serial chain of dependent LDS look-ups, and a block of long runs consumes tens
+// of megabytes of input (5*10^7 zeros are two blocks: 1.5 ms with one workgroup each).  The host picks the parts from the input
+// bytes per block of the call (k0_batch): one per 2 MB, at most K0_CRC_PARTS - an ordinary block (0.9 MB) is one workgroup's work
+// as before.  (Deciding per block on the device - a grid of 16 parts, 15 of which leave at once - made the kernel 2.4 times slower
+// on text: 840 workgroups of 1024 threads and 33 KB of LDS are not free to place even when they do nothing.)
 #define K0_CRC_PARTS 16u
 __global__ __launch_bounds__(1024) void k0_crc(K0Buf K, Pipe P, u32 first_block) {
     const u32 b = blockIdx.y, kb = first_block + b;
     if (kb >= *K.nBlocks) return;
     const u64 s = K.blkStart[kb], e = K.blkEnd[kb];
-    const u64 want = 1u + (e - s) / (2u << 20);
-    const u32 parts = want < K0_CRC_PARTS ? (u32)want : K0_CRC_PARTS;
-    if (blockIdx.x >= parts) return;                       // (uniform)
+    const u32 parts = gridDim.x;
     __shared__ u32 tab[CRC_TAB_WORDS];
     __shared__ u32 pw[40];
     __shared__ u32 acc;
@@ -756,11 +756,13 @@ int k0_phase_plan(K0Buf K, u32 cap, u64 phase, u64 own_len, u32 last, u64 total,
 }
 
 // RLE1 text + CRC of blocks [first_block, first_block + P.g.nb) into the batch P
-int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream) {
+int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream, u32 crc_parts) {
+    if (crc_parts < 1u) crc_parts = 1u;
+    if (crc_parts > K0_CRC_PARTS) crc_parts = K0_CRC_PARTS;
     const u32 gx = cap / K0_TILE + 2;
     hipLaunchKernelGGL(k0_materialize, dim3(gx, P.g.nb), dim3(256), 0, stream, K, P, first_block, cap);
     hipLaunchKernelGGL(k0_pad, dim3(P.g.nb), dim3(64), 0, stream, K, P, first_block);
-    hipLaunchKernelGGL(k0_crc, dim3(K0_CRC_PARTS, P.g.nb), dim3(1024), 0, stream, K, P, first_block);
+    hipLaunchKernelGGL(k0_crc, dim3(crc_parts, P.g.nb), dim3(1024), 0, stream, K, P, first_block);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

@@ -105,7 +105,7 @@ int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after = nullptr, hi
 int k5_stream_begin(Pipe P, int level, hipStream_t stream);
 int k5_stream_end(Pipe P, hipStream_t stream);
 int k5_shift_bits_run(const u8* d_in, u64 nbytes, u32 s, u8* d_out, hipStream_t stream);
-int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream);
+int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream, u32 crc_parts);   // crc_parts: workgroups per block of k0_crc (1 .. 16)
 size_t pipe_bytes(const BatchGeom& g);
 void pipe_carve(Pipe& P, const BatchGeom& g, void* base);
 int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto, hipEvent_t after = nullptr,
