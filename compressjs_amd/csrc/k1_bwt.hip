@@ -535,13 +535,16 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     // The one read-back K1 keeps (CJS_K1_SYNC=0: none): when no block holds a group - the text stages finished the batch, the
     // usual case on text - the ~90 launches of the doubling stage (4.6 us each when they find their lists empty: 0.35 ms per
     // 10^8 bytes, measured) are not enqueued at all.  Everything after this point is steered on the device.
-    bool any_group = true;
+    // (The same look tells whether any block was reduced by k1_period.hip: if none, the expansion's launches are left out too - empty
+    // kernels are only cheap on an idle GPU: next to the other stream's k2_mtf one of them sat 190 us in the queue.)
+    bool any_group = true, any_red = true;
     if (K.sync && !B.linear) {
-        std::vector<u32> tt(g.nb);
+        std::vector<u32> tt(2u * g.nb);
         HIP_CHECK_RET(hipMemcpyAsync(tt.data(), B.dtot, (size_t)g.nb * 4, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK_RET(hipMemcpyAsync(tt.data() + g.nb, B.red, (size_t)g.nb * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK_RET(hipStreamSynchronize(stream));
-        any_group = false;
-        for (u32 bb = 0; bb < g.nb; bb++) any_group = any_group || tt[bb] != 0u;
+        any_group = any_red = false;
+        for (u32 bb = 0; bb < g.nb; bb++) { any_group = any_group || tt[bb] != 0u; any_red = any_red || tt[g.nb + bb] != 0u; }
     }
     if (any_group) {
         const int rc = k1_dbl_run(B, g, max_n, stream, d0, K.sync ? K.check_h : 0u);
@@ -568,7 +571,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     }
     g_k1_last_sparse_rounds = rounds_with_work;             // (known with CJS_K1_TRACE only)
     g_k1_last_rounds = rounds_with_work;
-    if (!B.linear && K.period) {
+    if (!B.linear && K.period && any_red) {
         const int rc = k1_period_expand(B, g, max_n, stream);
         if (rc) return rc;
     }

@@ -51,6 +51,8 @@
 #define K1P_RK 203               // reduced block: periods left out
 #define K1P_RN 204               // reduced block: its length n'
 #define K1P_RED_MINN 16384u      // shorter blocks are not reduced
+#define K1P_GRID 16u             // workgroups per block of the tile kernels (each walks its tiles: these kernels run for every batch and mostly
+                                 // find nothing to do; a grid sized for the work is thousands of idle workgroups queueing behind the other stream)
 
 // first mismatch of W_a and W_b (a != b): offset | (W_a < W_b) << 7, in LDS
 __device__ __forceinline__ u32 k1p_seg_cmp(const u8* dt, u32 p, u32 n, u32 i, u32 j) {
@@ -128,15 +130,17 @@ __global__ __launch_bounds__(256) void k1p_find(K1Buf B, BatchGeom g, u32 enable
         if (x1 + 32u + 65u >= n) return;
         if (jmax > n - x1 - 32u) jmax = n - x1 - 32u;
     }
-    const u32 t0 = 65u + blockIdx.x * 4096u;
-    if (t0 > jmax + 3u) return;                              // (a tile starts up to 3 distances early, see below)
     const u8* T = B.T + (size_t)b * g.tstride;
-    // The tile as ALIGNED words (byte loads of 4 KB per workgroup were most of the kernel's 30 us per 10^8 bytes of text): it starts at
-    // the word that holds distance t0, so a thread's 16 consecutive distances begin on a word and slide a 64-bit window over five
-    // of them with shifts known at compile time; the up to 3 distances in front of t0 belong to the tile before (checked twice).
     __shared__ u32 pat[8];
     __shared__ u32 tw[4096 / 4 + 12];
     if (tid < 8) { const u8* q = T + x1 + tid * 4u; pat[tid] = (u32)q[0] | (u32)q[1] << 8 | (u32)q[2] << 16 | (u32)q[3] << 24; }
+    // (few workgroups, each walking its tiles: these kernels run for every batch and mostly find nothing to do - a grid sized for the
+    // work would be thousands of idle workgroups that queue behind the other stream's kernels)
+    for (u32 t0 = 65u + blockIdx.x * 4096u; t0 <= jmax + 3u; t0 += gridDim.x * 4096u) {      // (a tile starts up to 3 distances early, see below)
+    __syncthreads();
+    // The tile as ALIGNED words (byte loads of 4 KB per workgroup were most of the kernel's 30 us per 10^8 bytes of text): it starts at
+    // the word that holds distance t0, so a thread's 16 consecutive distances begin on a word and slide a 64-bit window over five
+    // of them with shifts known at compile time; the up to 3 distances in front of t0 belong to the tile before (checked twice).
     const u32 al = (x1 + t0) & ~3u;                          // (T + b * tstride is 128-byte aligned)
     const u32* T4 = (const u32*)(T + al);
     for (u32 i = tid; i < 4096u / 4u + 12u; i += 256u) tw[i] = al + i * 4u < n + 64u ? T4[i] : 0u;     // (k0_pad's 64 bytes behind n are readable)
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(256) void k1p_find(K1Buf B, BatchGeom g, u32 enable
         for (u32 i = 0; i < 32u && m; i++) m = T[x2 + i] == T[x2 + j + i];
         if (m) atomicMin(&tab[K1P_CAND + stage], j);
     }
+    }
 }
 
 // the candidate against the whole block; stage 0 also checks the short candidate of k1p_detect (a block with a period p' <= 64
@@ -177,12 +182,12 @@ __global__ __launch_bounds__(256) void k1p_verify(K1Buf B, BatchGeom g, u32 stag
     if (p == 0xFFFFFFFFu) return;
     const u32 n = B.nlen[b];
     const u8* T = B.T + (size_t)b * g.tstride;
-    const u32 t0 = blockIdx.x * 4096u;
     u32 first = 0xFFFFFFFFu;
-    for (u32 k = 0; k < 16u; k++) {
-        const u32 i = t0 + (15u - k) * 256u + tid;             // (descending: the last hit is the smallest)
-        if (i + p < n && T[i] != T[i + p]) first = i;
-    }
+    for (u32 t0 = blockIdx.x * 4096u; t0 + p < n && first == 0xFFFFFFFFu; t0 += gridDim.x * 4096u)     // (tiles in ascending order: the first hit of a thread is its smallest)
+        for (u32 k = 0; k < 16u; k++) {
+            const u32 i = t0 + (15u - k) * 256u + tid;         // (descending inside a tile: the last hit is the smallest)
+            if (i + p < n && T[i] != T[i + p]) first = i;
+        }
     const u64 bal = __ballot(first != 0xFFFFFFFFu);
     if (!bal) return;
     for (u32 off = 32; off; off >>= 1) { const u32 o = __shfl_xor(first, off); first = o < first ? o : first; }
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void k1p_fill(K1Buf B, BatchGeom g) {
     __syncthreads();
     u32* SA = B.SA + (size_t)b * g.stride;
     u32* HN = B.HN + (size_t)b * g.hstride;
-    const u32 t0 = blockIdx.x * 4096u;
+    for (u32 t0 = blockIdx.x * 4096u; t0 < n; t0 += gridDim.x * 4096u) {
     for (u32 t = t0 + tid; t < t0 + 4096u && t < nreg; t += 256u) {
         u32 lo = 0, hi = p;                               // the phase class: the last k with st[k] <= t
         while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (st[mid] <= t) lo = mid; else hi = mid; }
@@ -312,6 +317,7 @@ __global__ __launch_bounds__(256) void k1p_fill(K1Buf B, BatchGeom g) {
         SA[t + a] = i;
     }
     for (u32 w = t0 / 32u + tid; w < (t0 + 4096u) / 32u && w * 32u < n; w += 256u) HN[w] = 0xFFFFFFFFu;       // (bits at and beyond n are set already)
+    }
 }
 
 // a verified longer period: the reduced block goes to the sort
@@ -370,18 +376,20 @@ __global__ __launch_bounds__(256) void k1p_expand_count(K1Buf B, BatchGeom g) {
     const u32 p = B.red[b];
     if (!p) return;
     const u32 nr = B.ptab[(size_t)b * 256u + K1P_RN];
-    const u32 t0 = blockIdx.x * 4096u;
-    if (t0 >= nr) return;
     const u32* SA = B.SA + (size_t)b * g.stride;
-    u32 c = 0;
-    for (u32 k = 0; k < 16u; k++) { const u32 t = t0 + k * 256u + tid; if (t < nr && SA[t] < p) c++; }
     __shared__ u32 tot;
-    if (tid == 0) tot = 0;
-    __syncthreads();
-    for (u32 off = 32; off; off >>= 1) c += __shfl_xor(c, off);
-    if ((tid & 63u) == 0) atomicAdd(&tot, c);
-    __syncthreads();
-    if (tid == 0) B.tileHist[k1p_th(g, b) + blockIdx.x] = tot;                 // (the front end's counts are long used)
+    for (u32 tile = blockIdx.x; tile * 4096u < nr; tile += gridDim.x) {       // (uniform)
+        const u32 t0 = tile * 4096u;
+        u32 c = 0;
+        for (u32 k = 0; k < 16u; k++) { const u32 t = t0 + k * 256u + tid; if (t < nr && SA[t] < p) c++; }
+        if (tid == 0) tot = 0;
+        __syncthreads();
+        for (u32 off = 32; off; off >>= 1) c += __shfl_xor(c, off);
+        if ((tid & 63u) == 0) atomicAdd(&tot, c);
+        __syncthreads();
+        if (tid == 0) B.tileHist[k1p_th(g, b) + tile] = tot;                  // (the front end's counts are long used)
+        __syncthreads();
+    }
 }
 __global__ __launch_bounds__(256) void k1p_expand_scan(K1Buf B, BatchGeom g) {
     const u32 b = blockIdx.x, tid = threadIdx.x;
@@ -420,45 +428,45 @@ __global__ __launch_bounds__(256) void k1p_expand_write(K1Buf B, BatchGeom g) {
     const u32* tab = B.ptab + (size_t)b * 256u;
     const u32 nr = tab[K1P_RN], k = tab[K1P_RK];
     const bool asc = tab[K1P_RASC] != 0u;
-    const u32 t0 = blockIdx.x * 4096u;
-    if (t0 >= nr) return;
     const u32* SA = B.SA + (size_t)b * g.stride;
     u32* out = B.SB + (size_t)b * g.stride;
     __shared__ u32 wsum[4];
-    u32 run = B.tileHist[k1p_th(g, b) + blockIdx.x];
     const u32 lane = tid & 63u, w = tid >> 6;
-    for (u32 r = 0; r < 16u; r++) {                          // rows of 256 consecutive entries
-        const u32 t = t0 + r * 256u + tid;
-        const u32 e = t < nr ? SA[t] : 0xFFFFFFFFu;
-        const bool fl = e < p;
-        const u64 bal = __ballot(fl);
-        if (lane == 0) wsum[w] = (u32)__popcll(bal);
-        __syncthreads();
-        u32 before = (u32)__popcll(bal & ((1ull << lane) - 1ull));
-        for (u32 q = 0; q < w; q++) before += wsum[q];
-        const u32 rowtot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
-        if (t < nr) {
-            const u32 base = t + k * (run + before), i = e + k * p;
-            if (!fl) out[base] = i;
-            else if (asc) {
-                for (u32 j = 0; j < k; j++) out[base + j] = e + j * p;
-                out[base + k] = i;
-            } else {
-                out[base] = i;
-                for (u32 j = 0; j < k; j++) out[base + 1u + j] = e + (k - 1u - j) * p;
+    for (u32 tile = blockIdx.x; tile * 4096u < nr; tile += gridDim.x) {       // (uniform)
+        const u32 t0 = tile * 4096u;
+        u32 run = B.tileHist[k1p_th(g, b) + tile];
+        for (u32 r = 0; r < 16u; r++) {                      // rows of 256 consecutive entries
+            const u32 t = t0 + r * 256u + tid;
+            const u32 e = t < nr ? SA[t] : 0xFFFFFFFFu;
+            const bool fl = e < p;
+            const u64 bal = __ballot(fl);
+            if (lane == 0) wsum[w] = (u32)__popcll(bal);
+            __syncthreads();
+            u32 before = (u32)__popcll(bal & ((1ull << lane) - 1ull));
+            for (u32 q = 0; q < w; q++) before += wsum[q];
+            const u32 rowtot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            __syncthreads();
+            if (t < nr) {
+                const u32 base = t + k * (run + before), i = e + k * p;
+                if (!fl) out[base] = i;
+                else if (asc) {
+                    for (u32 j = 0; j < k; j++) out[base + j] = e + j * p;
+                    out[base + k] = i;
+                } else {
+                    out[base] = i;
+                    for (u32 j = 0; j < k; j++) out[base + 1u + j] = e + (k - 1u - j) * p;
+                }
             }
+            run += rowtot;
         }
-        run += rowtot;
     }
 }
 
 int k1_period_expand(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     if (max_n < K1P_RED_MINN) return CJS_OK;                                  // (no block of the batch can have been reduced)
-    const u32 tiles = (max_n * 4u / 5u + 4095u) / 4096u + 1u;                 // a reduced block is at most 4/5 of its block
-    hipLaunchKernelGGL(k1p_expand_count, dim3(tiles, g.nb), dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1p_expand_count, dim3(K1P_GRID, g.nb), dim3(256), 0, stream, B, g);
     hipLaunchKernelGGL(k1p_expand_scan, dim3(g.nb), dim3(256), 0, stream, B, g);
-    hipLaunchKernelGGL(k1p_expand_write, dim3(tiles, g.nb), dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1p_expand_write, dim3(K1P_GRID, g.nb), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
@@ -467,11 +475,11 @@ int k1_period_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u3
     if (max_n == 0u) max_n = 1u;                                              // (a batch of empty blocks: the grids below must not be empty)
     hipLaunchKernelGGL(k1p_detect, dim3(g.nb), dim3(256), 0, stream, B, g, enable);
     for (u32 stage = 0; stage < 2u; stage++) {
-        hipLaunchKernelGGL(k1p_find, dim3(max_n / 16384u + 1u, g.nb), dim3(256), 0, stream, B, g, enable, stage);
-        hipLaunchKernelGGL(k1p_verify, dim3((max_n + 4095u) / 4096u, g.nb), dim3(256), 0, stream, B, g, stage);
+        hipLaunchKernelGGL(k1p_find, dim3(K1P_GRID / 2u, g.nb), dim3(256), 0, stream, B, g, enable, stage);
+        hipLaunchKernelGGL(k1p_verify, dim3(K1P_GRID, g.nb), dim3(256), 0, stream, B, g, stage);
     }
     hipLaunchKernelGGL(k1p_tables, dim3(g.nb), dim3(256), 0, stream, B, g);
-    hipLaunchKernelGGL(k1p_fill, dim3((max_n + 4095u) / 4096u, g.nb), dim3(256), 0, stream, B, g);
+    hipLaunchKernelGGL(k1p_fill, dim3(2u * K1P_GRID, g.nb), dim3(256), 0, stream, B, g);
     hipLaunchKernelGGL(k1p_reduce, dim3(g.nb), dim3(256), 0, stream, B, g);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
