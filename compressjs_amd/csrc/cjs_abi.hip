@@ -282,6 +282,7 @@ done:
 // =============================================================================================
 // Product entry points
 // =============================================================================================
+#define CJS_PIN_WORDS 8192u  // pinned words per stream for K1's read-backs
 #define CJS_NSTREAMS 4       // sub-batches in flight: latency-bound stages of one sub-batch
                              // (Huffman optimiser, scans, sparse sort rounds) overlap the
                              // bandwidth-bound stages of the others
@@ -315,6 +316,7 @@ struct cjs_ctx {
     hipEvent_t evReady;        // pre-pass + output zeroing done
     hipEvent_t evScan[CJS_NSTREAMS];   // k5_blockscan of the last sub-batch issued on that stream
     hipEvent_t evDone[CJS_NSTREAMS];   // everything issued on that stream
+    u32* pin[CJS_NSTREAMS];            // pinned host memory for K1's small read-backs of that stream's sub-batch (CJS_PIN_WORDS u32)
     u32 nstreams;              // streams in use (<= CJS_NSTREAMS; env CJS_STREAMS overrides)
     u32 batch_blocks;          // blocks in flight over all streams
     u32 sub_blocks;            // blocks per sub-batch, at most (what every stream's workspace is sized for)
@@ -405,6 +407,7 @@ extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
         ok = ok && hipMalloc(&c->ws[i], c->ws_bytes) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->evScan[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&c->pin[i], CJS_PIN_WORDS * 4) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&c->evReady, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_ss, 256) == hipSuccess;
@@ -421,6 +424,7 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
         (void)hipFree(c->ws[i]);
         if (c->evScan[i]) (void)hipEventDestroy(c->evScan[i]);
         if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]);
+        if (c->pin[i]) (void)hipHostFree(c->pin[i]);
         if (c->sub[i]) (void)hipStreamDestroy(c->sub[i]);
     }
     (void)hipFree(c->d_ss); (void)hipFree(c->k0ws); (void)hipFree(c->planws); (void)hipFree(c->din); (void)hipFree(c->dout);
@@ -467,6 +471,7 @@ static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap
     P.outCapBytes = out_cap & ~(uint64_t)3;
     P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
     if (c->prof.enabled) c->prof_g = g;
+    P.k1.hpin = c->pin[si]; P.k1.hpinWords = CJS_PIN_WORDS;
     P.g.nb = nb;
     // (CRC workgroups per block: one per 2 MB of input a block of this call consumes on average - long runs make that tens of megabytes)
     const u64 per_block = K.in_len / (total_blocks ? total_blocks : 1u);

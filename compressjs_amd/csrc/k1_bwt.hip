@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     if (b == 0) for (u32 i = gid; i < 4u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
     if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rstride; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
     if (b == 0 && gid < K1F_LEVELS) B.bcnt[gid] = 0;
-    if (b == 0) for (u32 i = gid; i < 2u * (K1D_MAXR + 2u) * B.rstride + B.rstride + (K1D_MAXR + 2u) * 4u; i += gridDim.x * blockDim.x) B.dcnt[i] = 0;   // dcnt, dchg, dtot, dbn (contiguous)
+    if (b == 0) for (u32 i = gid; i < 2u * (K1D_MAXR + 2u) * B.rstride + 2u * B.rstride + (K1D_MAXR + 2u) * 4u; i += gridDim.x * blockDim.x) B.dcnt[i] = 0;   // dcnt, dchg, dtot, dbn, dred (contiguous)
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
         u32 w;
@@ -373,7 +373,7 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     for (int k = 0; k < 2; k++) take((void**)&B.listL[k], (size_t)B.listLCap * 8);
     for (int k = 0; k < 2; k++) take((void**)&B.rlist[k], e * 8);
     take((void**)&B.rcnt, (size_t)(K1R_MAXR + 1) * nb8 * 4);
-    take((void**)&B.dcnt, ((size_t)(2u * (K1D_MAXR + 2u) + 1u) * nb8 + (K1D_MAXR + 2u) * 4u) * 4);      // dcnt, dchg, dtot, dbn (contiguous: zeroed as one)
+    take((void**)&B.dcnt, ((size_t)(2u * (K1D_MAXR + 2u) + 2u) * nb8 + (K1D_MAXR + 2u) * 4u) * 4);      // dcnt, dchg, dtot, dbn, dred (contiguous: zeroed as one; dtot .. dred read back as one)
     take((void**)&B.btask, (size_t)K1F_LEVELS * B.btaskCap * sizeof(uint4));
     take((void**)&B.bcnt, 256);
     take((void**)&B.nfront, (size_t)nb8 * 4);
@@ -383,6 +383,7 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     B.dchg = B.dcnt ? B.dcnt + (size_t)(K1D_MAXR + 2u) * nb8 : nullptr;
     B.dtot = B.dcnt ? B.dchg + (size_t)(K1D_MAXR + 2u) * nb8 : nullptr;
     B.dbn = B.dcnt ? B.dtot + nb8 : nullptr;
+    B.dred = B.dcnt ? B.dbn + (K1D_MAXR + 2u) * 4u : nullptr;
 }
 
 size_t k1_workspace_bytes(const BatchGeom& g) {
@@ -393,6 +394,7 @@ size_t k1_workspace_bytes(const BatchGeom& g) {
 }
 
 void k1_carve(K1Buf& B, const BatchGeom& g, void* ws) {
+    B.hpin = nullptr; B.hpinWords = 0;
     char* p = (char*)ws;
     k1_layout(B, g, [&](void** field, size_t bytes) { *field = p; p += al256(bytes); });
 }
@@ -539,12 +541,17 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     // kernels are only cheap on an idle GPU: next to the other stream's k2_mtf one of them sat 190 us in the queue.)
     bool any_group = true, any_red = true;
     if (K.sync && !B.linear) {
-        std::vector<u32> tt(2u * g.nb);
-        HIP_CHECK_RET(hipMemcpyAsync(tt.data(), B.dtot, (size_t)g.nb * 4, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK_RET(hipMemcpyAsync(tt.data() + g.nb, B.red, (size_t)g.nb * 4, hipMemcpyDeviceToHost, stream));
+        // (ONE copy - dtot, dbn and dred lie behind one another -, into pinned memory when the caller has some: a second pageable copy was
+        // issued 65 us after the first on the kernel timeline)
+        const size_t words = (size_t)(B.dred - B.dtot) + g.nb;
+        std::vector<u32> pageable;
+        u32* tt = B.hpin;
+        if (!tt || words > B.hpinWords) { pageable.resize(words); tt = pageable.data(); }
+        HIP_CHECK_RET(hipMemcpyAsync(tt, B.dtot, words * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK_RET(hipStreamSynchronize(stream));
         any_group = any_red = false;
-        for (u32 bb = 0; bb < g.nb; bb++) { any_group = any_group || tt[bb] != 0u; any_red = any_red || tt[g.nb + bb] != 0u; }
+        const u32* dr = tt + (B.dred - B.dtot);
+        for (u32 bb = 0; bb < g.nb; bb++) { any_group = any_group || tt[bb] != 0u; any_red = any_red || dr[bb] != 0u; }
     }
     if (any_group) {
         const int rc = k1_dbl_run(B, g, max_n, stream, d0, K.sync ? K.check_h : 0u);

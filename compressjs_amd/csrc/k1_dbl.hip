@@ -1053,12 +1053,19 @@ int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h
             // group classes): inputs whose ties end within a few KB - text, HTML: E8S-A's last entries are those of the round with h = 8192 - have
             // nothing left by then, and every later round would be five empty launches (7 rounds: 0.25 ms per 10^8 bytes, on both streams at
             // once: E8S-A 12.75 -> 12.5 ms).  Lists that are empty stay empty.  Inputs that tie for longer (tiled) pay a stream sync per round.
-            std::vector<u32> left(B.rstride + 4u);
-            HIP_CHECK_RET(hipMemcpyAsync(left.data(), B.dcnt + (size_t)(r + 1u) * B.rstride, (size_t)B.rstride * 4, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK_RET(hipMemcpyAsync(left.data() + B.rstride, B.dbn + (size_t)(r + 1u) * 4u, 16, hipMemcpyDeviceToHost, stream));
+            // (the block totals of every later round and the descriptor counts lie in one stretch - dcnt rows r + 1 .., dchg, dtot, dbn: one copy;
+            // rows beyond r + 1 are still zero, dchg and dtot are skipped when summing)
+            const u32* from = B.dcnt + (size_t)(r + 1u) * B.rstride;
+            const size_t words = (size_t)(B.dbn + (size_t)(K1D_MAXR + 2u) * 4u - from);
+            std::vector<u32> pageable;
+            u32* left = B.hpin;
+            if (!left || words > B.hpinWords) { pageable.resize(words); left = pageable.data(); }
+            HIP_CHECK_RET(hipMemcpyAsync(left, from, words * 4, hipMemcpyDeviceToHost, stream));
             HIP_CHECK_RET(hipStreamSynchronize(stream));
             u64 any = 0;
-            for (u32 v : left) any += v;
+            for (u32 i = 0; i < B.rstride; i++) any += left[i];
+            const u32* dbn = left + (B.dbn - from) + (size_t)(r + 1u) * 4u;
+            for (u32 i = 0; i < 4u; i++) any += dbn[i];
             if (!any) break;
         }
     }
