@@ -380,8 +380,8 @@ __global__ void k5_end(Pipe P) {
     P.ss->bits = p;
 }
 
-int k5_stream_begin(Pipe P, int level, hipStream_t stream) {
-    HIP_CHECK_RET(hipMemsetAsync(P.out, 0, P.outCapBytes, stream));
+int k5_stream_begin(Pipe P, int level, hipStream_t stream, bool zero) {
+    if (zero) HIP_CHECK_RET(hipMemsetAsync(P.out, 0, P.outCapBytes, stream));     // (k5_pack ORs its words into the stream)
     hipLaunchKernelGGL(k5_begin, dim3(1), dim3(64), 0, stream, P, level);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
