@@ -309,6 +309,57 @@ struct PinnedU32 {
 };
 struct BwtcGroupJob { std::vector<BwtcBlockJob> blocks; PinnedU32 a, t; std::vector<u16> sym; bool busy = false; size_t nready = 0; };   // nready: leading blocks whose data has landed
 
+// One persistent helper thread per extra stream: a sub-batch is issued from a host thread of its own (K1's read-backs block the thread that
+// waits for them), and a thread made per call pays for its creation and its first HIP call (30-170 us before its first launch, seen on the
+// kernel timeline) every time.
+struct CjsHelper {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, busy = false, quit = false;
+    void loop() {
+        for (;;) {
+            std::function<void()> j;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&]() { return has_job || quit; });
+                if (!has_job) return;
+                j = std::move(job);
+                has_job = false;
+            }
+            j();
+            {
+                std::lock_guard<std::mutex> g(mu);
+                busy = false;
+            }
+            cv.notify_all();
+        }
+    }
+    void post(std::function<void()> j) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            job = std::move(j);
+            has_job = true;
+            busy = true;
+            if (!th.joinable()) th = std::thread([this]() { loop(); });
+        }
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&]() { return !busy; });
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            quit = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+
 struct cjs_ctx {
     int device;
     hipStream_t stream;        // stream 0: pre-pass, framing, timing events
@@ -317,6 +368,7 @@ struct cjs_ctx {
     hipEvent_t evScan[CJS_NSTREAMS];   // k5_blockscan of the last sub-batch issued on that stream
     hipEvent_t evDone[CJS_NSTREAMS];   // everything issued on that stream
     u32* pin[CJS_NSTREAMS];            // pinned host memory for K1's small read-backs of that stream's sub-batch (CJS_PIN_WORDS u32)
+    CjsHelper* helper[CJS_NSTREAMS];   // [i]: the host thread that issues stream i's sub-batches (i >= 1; stream 0's are issued by the caller)
     u32 nstreams;              // streams in use (<= CJS_NSTREAMS; env CJS_STREAMS overrides)
     u32 batch_blocks;          // blocks in flight over all streams
     u32 sub_blocks;            // blocks per sub-batch, at most (what every stream's workspace is sized for)
@@ -425,6 +477,7 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
         if (c->evScan[i]) (void)hipEventDestroy(c->evScan[i]);
         if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]);
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+        if (c->helper[i]) { c->helper[i]->stop(); delete c->helper[i]; }
         if (c->sub[i]) (void)hipStreamDestroy(c->sub[i]);
     }
     (void)hipFree(c->d_ss); (void)hipFree(c->k0ws); (void)hipFree(c->planws); (void)hipFree(c->din); (void)hipFree(c->dout);
@@ -524,10 +577,12 @@ static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 coun
     };
     if (ns <= 1) worker(0);
     else {
-        std::vector<std::thread> th;
-        for (u32 i = 1; i < ns; i++) th.emplace_back(worker, i);
+        for (u32 i = 1; i < ns; i++) {
+            if (!c->helper[i]) c->helper[i] = new CjsHelper();
+            c->helper[i]->post([&worker, i]() { worker(i); });
+        }
         worker(0);
-        for (auto& t : th) t.join();
+        for (u32 i = 1; i < ns; i++) c->helper[i]->wait();
     }
     if (err.load()) return err.load();
     for (u32 i = 0; i < ns; i++) {
