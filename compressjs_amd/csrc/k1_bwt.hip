@@ -406,8 +406,7 @@ extern "C" int cjs_dbg_k1_rounds() { return g_k1_last_rounds; }
 
 // The knobs of K1, read once per process (A/B runs and the variant tests; the defaults are what the numbers in DESIGN.md are for)
 struct K1Knobs {
-    u32 bsort_iters;   // CJS_BSORT_ITERS   in-bucket deepening iterations of k1f_bsort (12 bytes each; default 0 since the end of round 4: the refinement rounds
-                       //                   take the groups from 8 bytes - ms per 10^8 bytes with 1 / 0: enwik 8.42 / 8.20, text 7.75 / 7.65, E8S-B 8.85 / 8.69, lcg 8.94 / 8.77)
+    u32 bsort_iters;   // CJS_BSORT_ITERS   in-bucket deepening iterations of k1f_bsort (12 bytes each; default 1: the groups it lists share 20 bytes)
     u32 text_bytes;    // CJS_TEXT_BYTES    depth up to which the refinement rounds compare the text (default 264; 0: no text stages, doubling from 8 bytes)
     u32 big_div;       // CJS_DEEP_BIG_DIV  text stages are skipped when more than 1/DIV of the rotations sit in one-key buckets (default 8)
     u32 lane_cap;      // CJS_DEEP_LANE_CAP bytes the lane kernels walk a pair / small group that outlasted the rounds (default 4096; 0: not at all)
@@ -425,7 +424,7 @@ static const K1Knobs& k1_knobs() {
             return v > hi ? hi : (u32)v;
         };
         K1Knobs q;
-        q.bsort_iters = num("CJS_BSORT_ITERS", 0u, 64u);
+        q.bsort_iters = num("CJS_BSORT_ITERS", 1u, 64u);
         q.text_bytes = num("CJS_TEXT_BYTES", 264u, 32000u);
         q.big_div = num("CJS_DEEP_BIG_DIV", 8u, 1u << 30);
         if (!q.big_div) q.big_div = 8u;

@@ -403,13 +403,13 @@ def test_decoder_differential_fuzz_vs_oracle(emu_ctx):
 
 
 @pytest.mark.parametrize("env_add", [{}, {"CJS_TEXT_BYTES": "0"}, {"CJS_TEXT_BYTES": "44", "CJS_DEEP_LANE_CAP": "0"},
-                                     {"CJS_BSORT_ITERS": "1", "CJS_DEEP_BIG_DIV": "1"}, {"CJS_BSORT_ITERS": "2"},
+                                     {"CJS_BSORT_ITERS": "0", "CJS_DEEP_BIG_DIV": "1"}, {"CJS_BSORT_ITERS": "2"},
                                      {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}])
 def test_deep_refinement_of_suffix_sort(env_add):
     """The text stages (in-bucket iterations, list-driven refinement rounds, lane kernels) resolve groups by comparing the
     text before any rank exists; what they leave (long repeats, identical rotations, groups that stay big) goes to the
     doubling rounds, which are skipped when nothing is left.  The knobs of k1_bwt.hip (k1_knobs) against the oracle, on inputs
-    that end in each continuation: text stages off, a short cap with no lane kernels, one / two in-bucket iterations (the default has none), the
+    that end in each continuation: text stages off, a short cap with no lane kernels, no / two in-bucket iterations, the
     predictor forcing the text stages on / off, no read-back."""
     import os
     import subprocess

@@ -523,7 +523,7 @@ def test_deep_refinement_variants_same_bytes(ctx):
     """The text stages in front of the doubling rounds are a faster route to the same order.  K1's knobs (k1_bwt.hip,
     k1_knobs) must all give the same bytes on phrase-reuse text + runs + periodic + tiled input, and those bytes must be the
     oracle's on the leading blocks: no text stages at all (doubling from 8 bytes), the default, one refinement round only and no
-    lane kernels (most ties left to the doubling rounds) on one stream, one in-bucket iteration with the predictor forcing the text
+    lane kernels (most ties left to the doubling rounds) on one stream, no in-bucket iteration with the predictor forcing the text
     stages on and unequal shares of a batch, the predictor forcing them off with no read-back at all, no closed form for the
     periodic blocks (k1_period.hip off: they go through the doubling rounds)."""
     import subprocess
@@ -540,7 +540,7 @@ def test_deep_refinement_variants_same_bytes(ctx):
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for env_add in ({"CJS_TEXT_BYTES": "0"}, {}, {"CJS_TEXT_BYTES": "44", "CJS_DEEP_LANE_CAP": "0", "CJS_STREAMS": "1"},
-                    {"CJS_BSORT_ITERS": "1", "CJS_DEEP_BIG_DIV": "1", "CJS_SHARES": "300:700"},
+                    {"CJS_BSORT_ITERS": "0", "CJS_DEEP_BIG_DIV": "1", "CJS_SHARES": "300:700"},
                     {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}, {"CJS_K1_PERIOD": "0"}):
         env = dict(os.environ, **env_add)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
