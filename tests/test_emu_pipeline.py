@@ -93,6 +93,24 @@ def test_multi_batch_equals_single(emu_ctx):
     assert _compress(emu_ctx, d, 1) == oracle.bz2_compress(d, 1)
 
 
+def test_long_runs_count_bytes_and_split_crc(emu_ctx):
+    """Inputs of long runs: a block then consumes megabytes of input - k0_crc splits it over several workgroups (one part per 2 MB:
+    the parts' raw remainders XOR into the constant term k0_pad left) and k0_materialize finds the count byte behind a run's fourth
+    byte eight input bytes at a time (runs of every length 4..270 at every alignment, cut by block ends and by the end of the input)."""
+    rng = np.random.RandomState(11)
+    d = np.concatenate([np.zeros(5_000_000, np.uint8), synth.text_like(3000, 1), np.full(2_600_000, 65, np.uint8), np.zeros(7, np.uint8)])
+    assert _compress(emu_ctx, d, 1) == oracle.bz2_compress(d, 1)
+    parts = []
+    for k in range(700):
+        parts.append(np.full(int(rng.randint(4, 271)), int(rng.randint(0, 3)), np.uint8))
+        parts.append(rng.randint(3, 256, size=int(rng.randint(0, 9))).astype(np.uint8))
+    d = np.concatenate(parts)
+    for cut in (d.size, d.size - 1, d.size - 5, 99981 + 3, 99981 + 4, 99981 + 5):
+        assert _compress(emu_ctx, d[:cut], 1) == oracle.bz2_compress(d[:cut], 1), cut
+    for off in range(1, 9):                                  # the same runs at other alignments of the input
+        assert _compress(emu_ctx, d[off:60000 + off], 1) == oracle.bz2_compress(d[off:60000 + off], 1), off
+
+
 def test_bwt_kats(emu):
     L = _lib.load(stagelib.EMU_SO)
     for inp, out, idx in [(b"bcababa", b"cbbaaab", 5), (b"abab", b"bbaa", 1), (b"aaaa", b"aaaa", 3),
