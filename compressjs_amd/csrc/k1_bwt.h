@@ -134,7 +134,7 @@ void k1_carve(K1Buf& B, const BatchGeom& g, void* ws);
 // enqueue the whole K1 pipeline on `stream`; max_n = largest block length in the batch
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
 // k1_front.hip: rotations of every block sorted by their first 8 bytes into B.SA, group heads into B.HN
-// iters: in-bucket deepening iterations of k1f_bsort (K1F_STEP = 12 bytes each); lists: fill the round lists (0: neither - the
+// iters: 0 = the bucket sort compares 8 bytes, else K1F_KEYB = 16 (cyclic mode with lists); lists: fill the round lists (0: neither - the
 // K1-deep tile kernel does that work); purerot_max: the predictor threshold (see k1f_bsort)
 int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max);
 int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth);
@@ -147,5 +147,5 @@ int k1_period_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u3
 // after the sort: the suffix arrays of the blocks with red[b] != 0 from those of their reduced blocks (into SB: k1_finish reads them there)
 int k1_period_expand(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
 #define K1R_STEP 24u           // text bytes a refinement round (k1r_round) takes off every listed rotation
-#define K1F_STEP 12u           // text bytes per in-bucket iteration / refinement round: what ONE 16-byte aligned load yields at any alignment
+#define K1F_KEYB 16u           // text bytes the bucket sort (k1f_bsort / k1f_task) compares in its one pass (round 5; rounds 3-4: 8, then 12 more per in-bucket iteration)
 size_t k1_front_tilehist_words(const BatchGeom& g);   // u32 per block the front end needs in tileHist

@@ -406,7 +406,7 @@ extern "C" int cjs_dbg_k1_rounds() { return g_k1_last_rounds; }
 
 // The knobs of K1, read once per process (A/B runs and the variant tests; the defaults are what the numbers in DESIGN.md are for)
 struct K1Knobs {
-    u32 bsort_iters;   // CJS_BSORT_ITERS   in-bucket deepening iterations of k1f_bsort (12 bytes each; default 1: the groups it lists share 20 bytes)
+    u32 bsort_iters;   // CJS_BSORT_ITERS   1 (default): the bucket sort compares 16 bytes (the groups it lists share 16); 0: 8 bytes
     u32 text_bytes;    // CJS_TEXT_BYTES    depth up to which the refinement rounds compare the text (default 264; 0: no text stages, doubling from 8 bytes)
     u32 big_div;       // CJS_DEEP_BIG_DIV  text stages are skipped when more than 1/DIV of the rotations sit in one-key buckets (default 8)
     u32 lane_cap;      // CJS_DEEP_LANE_CAP bytes the lane kernels walk a pair / small group that outlasted the rounds (default 4096; 0: not at all)
@@ -424,7 +424,7 @@ static const K1Knobs& k1_knobs() {
             return v > hi ? hi : (u32)v;
         };
         K1Knobs q;
-        q.bsort_iters = num("CJS_BSORT_ITERS", 1u, 64u);
+        q.bsort_iters = num("CJS_BSORT_ITERS", 1u, 1u);
         q.text_bytes = num("CJS_TEXT_BYTES", 264u, 32000u);
         q.big_div = num("CJS_DEEP_BIG_DIV", 8u, 1u << 30);
         if (!q.big_div) q.big_div = 8u;
@@ -501,7 +501,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     }
     if (fused) {
         // the refinement rounds over what k1f_bsort and the task levels listed; a block ends them early when its list stops shrinking
-        const u32 depth0 = d0 + K1F_STEP * K.bsort_iters;
+        const u32 depth0 = K.bsort_iters ? K1F_KEYB : d0;           // bytes every listed group shares
         const int rc = k1_rounds_run(B, g, stream, depth0, K.text_bytes);
         if (rc) return rc;
         if (K.trace) {

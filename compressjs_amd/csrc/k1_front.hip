@@ -387,35 +387,72 @@ __device__ __forceinline__ void k1f_write_heads(u32* HN, u32 start, u32 end, F i
 #define K1F_BT 256                                      // threads of a bucket-sort workgroup
 #endif
 #define K1F_NW (K1F_BT / 64)                            // its waves
-#define K1F_E ((K1F_C + K1F_BT - 1) / K1F_BT)            // rotations per thread
-// measured (10^8-byte enwik stream, k1f_bsort ms, round 2): 32 leaves x 4 samples 3.66, 32 x 2 4.06, 64 x 4 3.86, 64 x 2 3.49
+#define K1F_E (K1F_C / K1F_BT)                          // rotations per thread
+static_assert(K1F_C % K1F_BT == 0 && K1F_E >= 1, "a bucket-sort workgroup's threads hold K1F_C / K1F_BT rotations each");
 #ifndef K1F_LK
-#define K1F_LK 64                                       // local sub-buckets (leaves) of a bucket, at most
+#define K1F_LK (K1F_C >= 1024 ? 64 : K1F_C / 16)        // local sub-buckets (leaves) of a bucket, at most
 #endif
 #ifndef K1F_LOVS
 #define K1F_LOVS 2                                      // local samples per leaf
 #endif
+#ifndef K1F_LEAF
+#define K1F_LEAF 24u                                    // a bucket is cut into leaves of K1F_LEAF / 2 .. K1F_LEAF rotations on average
+#endif
 #define K1F_LS (K1F_LOVS * K1F_LK)                      // local samples, at most
+static_assert(K1F_LS <= K1F_BT && K1F_LK <= 64, "one thread per local sample; leaf ids are 6 bits; the leaf counts are scanned by one wave");
 #define K1F_HW (K1F_C / 32 + 2)                         // words of the in-LDS head bitmap (bits >= cnt are set: sentinel)
 #ifndef K1F_MINW
-#define K1F_MINW 8                                      // waves per SIMD the register allocation of k1f_bsort is held to (8 workgroups per CU)
+#define K1F_MINW 7                                      // waves per SIMD the register allocation of k1f_bsort is held to (7 workgroups per CU: LDS)
 #endif
 #ifndef K1F_GBIG
-#define K1F_GBIG 256u                                   // in-bucket deepening ranks groups up to this size by counting (O(size^2), one wave)
+#define K1F_GBIG 256u                                   // groups up to this size are listed for the refinement rounds (8-bit fields of a list entry)
 #endif
+#define K1F_CAP (K1F_C - 4u)                            // rotations a bucket-sort workgroup takes (four spare key cells behind them: the ranking loops read past a leaf's end)
+#define K1F_LEAFSH 26u                                  // leaf id of a rotation travels in the top bits of its index word (n < 2^26)
 
-// 12 text bytes at T + p (any alignment) as (first 8 big-endian, next 4 big-endian): one dwordx4 load + v_alignbyte.
-// A random 8-byte gather and a random 16-byte gather cost the L2 the same line; the deepening iterations below are
-// bound by exactly those gathers, so every one of them takes as many key bytes as fit the LDS budget.
-__device__ __forceinline__ void k1f_load_be96(const u8* T, u32 p, u64& k0, u32& k1) {
+// ---- 16-byte keys: four big-endian dwords, x the most significant -------------------------------------------------
+// 16 text bytes at T + p (any alignment): one dwordx4 + one dword load, v_alignbyte.  A random gather from the L2-resident
+// text costs the same at 4 and at 16 bytes (tests/microbench/gather.hip), so the bucket sort takes all 16 at once.
+__device__ __forceinline__ uint4 k1f_load_be128(const u8* T, u32 p) {
     const u32 sh = p & 3u;
-    u32 d[4];
-    __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 16);
-    const u32 w0 = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
-    const u32 w1 = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
-    const u32 w2 = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
-    k0 = ((u64)__builtin_bswap32(w0) << 32) | (u64)__builtin_bswap32(w1);
-    k1 = __builtin_bswap32(w2);
+    u32 d[5];
+    __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 20);
+    uint4 k;
+    k.x = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[1], d[0], sh));
+    k.y = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[2], d[1], sh));
+    k.z = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[3], d[2], sh));
+    k.w = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[4], d[3], sh));
+    return k;
+}
+__device__ __forceinline__ bool k1f_eq128(const uint4& a, const uint4& b) { return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) == 0u; }
+__device__ __forceinline__ bool k1f_lt128(const uint4& a, const uint4& b) {
+    const u64 ah = ((u64)a.x << 32) | a.y, al = ((u64)a.z << 32) | a.w, bh = ((u64)b.x << 32) | b.y, bl = ((u64)b.z << 32) | b.w;
+    return ah < bh || (ah == bh && al < bl);
+}
+__device__ __forceinline__ bool k1f_ones128(const uint4& a) { return (a.x & a.y & a.z & a.w) == 0xFFFFFFFFu; }
+__device__ __forceinline__ uint4 k1f_inc128(uint4 a) {
+    a.w += 1u;
+    if (a.w == 0u) { a.z += 1u; if (a.z == 0u) { a.y += 1u; if (a.y == 0u) a.x += 1u; } }
+    return a;
+}
+// less += ((c, j) < (m, i)): the 128-bit keys compared as integers, ties by the slot numbers j, i - a STRICT order, so the ranks a
+// set of cells gets are a permutation.  On the GPU this is one carry chain: the borrow of c - m - (j < i) is the answer (five
+// VALU instructions and the add, no mask arithmetic on the scalar unit; k1f_bsort is bound by its instruction stream).
+__device__ __forceinline__ void k1f_acc_lt(u32& less, const uint4& c, u32 j, const uint4& m, u32 i) {
+#if defined(__AMDGCN__)
+    u32 t;
+    asm("v_cmp_lt_u32 vcc, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %8, %9, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %11, vcc\n\t"
+        "v_addc_co_u32 %0, vcc, 0, %0, vcc"
+        : "+v"(less), "=&v"(t)
+        : "v"(j), "v"(i), "v"(c.w), "v"(m.w), "v"(c.z), "v"(m.z), "v"(c.y), "v"(m.y), "v"(c.x), "v"(m.x)
+        : "vcc");
+#else
+    less += (k1f_lt128(c, m) || (k1f_eq128(c, m) && j < i)) ? 1u : 0u;
+#endif
 }
 
 // largest head position <= q / smallest head position > q in an LDS bitmap whose bit 0 and every bit >= cnt are set
@@ -432,11 +469,8 @@ __device__ __forceinline__ u32 k1f_next_head(const u32* hb, u32 q) {
     return w * 32u + (u32)__ffs((int)m) - 1u;
 }
 
-struct alignas(16) K1fPair { u64 x, y; };             // two LDS cells in one 16-byte read
-
 // bits q and q + 1 of a bitmap (bit 0 / bit 1 of the result) from ONE read of two adjacent words, and the group around q
-// (largest head <= q, smallest head > q) starting from that same read: k1f_bsort is bound by its LDS instruction stream,
-// and the probes `bit(q) && bit(q + 1)`, prev_head(q), next_head(q) were four to five reads of the same two words.
+// (largest head <= q, smallest head > q) starting from that same read
 __device__ __forceinline__ u32 k1f_bits2(const u32* hb, u32 q) {
     const u32 w = q >> 5;
     const u64 v = (u64)hb[w] | ((u64)hb[w + 1u] << 32);
@@ -454,164 +488,21 @@ __device__ __forceinline__ void k1f_group(const u32* hb, u32 q, u32& gs, u32& ge
     if (!m2) { m2 = w1; ww = w + 1u; while (!m2) m2 = hb[++ww]; }
     ge = ww * 32u + (u32)__ffs((int)m2) - 1u;
 }
+__device__ __forceinline__ bool k1f_bit(const u32* bm, u32 q) { return (bm[q >> 5] >> (q & 31u)) & 1u; }
 
 // LDS of a bucket-sort workgroup (views into the kernel's __shared__ arrays)
-struct K1fS {
-    u64* k0;        // [K1F_C]  key, first 8 bytes (position order)
-    u32* k1;        // [K1F_C]  key, next 4 bytes (deepening only; also the staging array of the index permutation)
-    u32* sx;        // [K1F_C]  rotation index at every position
+struct K1fL {
+    uint4* key;     // [K1F_C]  16-byte keys: arrival order, then leaf order, then sorted
+    u32* sx;        // [K1F_C]  rotation index at every position (leaf order: | leaf << K1F_LEAFSH); before that the local sample sort's scratch:
+    uint4* smp;     //   [K1F_LS] samples (aliases sx)
+    uint4* sp;      //   [K1F_LK] local splitters (aliases sx)
+    u32* srank;     //   [K1F_LS] sample ranks (aliases sx)
+    u32* cnt2;      // [K1F_LK]      rotations per leaf
+    u32* off2;      // [K1F_LK + 1]  first position of every leaf | 1 << 31 for a leaf of ONE key
     u32* hb;        // [K1F_HW] group heads (bit 0 and bits >= cnt set)
-    u32* fb;        // [K1F_HW] positions of frozen groups
-    u32* h0;        // [K1F_HW] the heads the deepening started from (they cut the bucket into the waves' ranges)
-    u32* df;        // [K1F_HW] big groups (by head position) in which some key differed: frozen from then on
-    u16* nqp;       // [K1F_C]  per iteration and position: new position | head << 15, or a K1F_NQ_* marker
-    u32* misc;      // [K1F_E * K1F_NW] workgroup-wide scratch words
+    u32* lb;        // [K1F_HW] flush: listed positions
+    u32* misc;      // [K1F_E * K1F_NW + 8] workgroup-wide scratch words
 };
-#define K1F_NQ_IDLE 0xFFFEu     // not in an active group
-#define K1F_NQ_PEND 0xFFFDu     // active, key fetched
-#define K1F_NQ_HUGE 0xFFFCu     // member of a group above K1F_GBIG: stays where it is
-
-__device__ __forceinline__ void k1f_init_bitmaps(const K1fS& S, u32 cnt) {
-    for (u32 i = threadIdx.x; i < K1F_HW; i += K1F_BT) {        // head bitmap: bit 0 and the sentinel bits (>= cnt) set
-        const u32 lo = i * 32u;
-        S.hb[i] = (lo >= cnt ? 0xFFFFFFFFu : (lo + 32u > cnt ? 0xFFFFFFFFu << (cnt - lo) : 0u)) | (i == 0 ? 1u : 0u);
-        S.fb[i] = 0;
-        S.df[i] = 0;
-    }
-}
-__device__ __forceinline__ bool k1f_bit(const u32* bm, u32 q) { return (bm[q >> 5] >> (q & 31u)) & 1u; }
-__device__ __forceinline__ u32 k1f_first_head_ge(const u32* hb, u32 x) { return x == 0u ? 0u : k1f_next_head(hb, x - 1u); }
-
-// In-bucket deepening of positions [0, cnt): sx[] and hb[] describe a slice sorted by its first `depth` bytes, groups of
-// equal prefixes marked.  The groups are dealt to the WAVES (wave w takes the groups whose head lies in the 64-position
-// chunks K1F_NW * j + w: contiguous ranges, fixed before the first iteration), and every wave then iterates ON ITS OWN -
-// no workgroup barrier inside the loop.  An iteration of a wave = passes over the rows (64 positions) of its ranges:
-//   P1 the K1F_STEP text bytes at the current depth of every rotation that still ties (one 16-byte load each),
-//   P2 rank inside the group by counting (candidates read from LDS four at a time; lanes of one group read the same
-//      address = broadcast): new position, and "opens a sub-group" for the member with no equal key before it,
-//   P3 the indices move (staged through k1[], which P2 no longer needs), P4 the new heads.
-// Exactly `iters` iterations (a wave with nothing left stops earlier): every group that is left shares depth + K1F_STEP *
-// iters bytes, which is what the list-driven rounds (k1r_round) start from.  While most rotations still tie (the first one
-// or two iterations) this is the cheapest place to take bytes off them - the bucket is in LDS anyway; later the rows of
-// a bucket are mostly idle lanes (PMC: 550 VALU instructions per wave and iteration whatever is left), which is why the
-// rest is done on compacted lists.  Groups above K1F_GBIG rotations are only tested for "all bytes equal" (then they
-// simply get deeper) and are frozen otherwise: they stay classes of equal prefixes of >= 8 bytes for the later stages.
-__device__ __forceinline__ void k1f_deepen(const K1fS& S, const u8* T, u32 n, u32 cnt, u32 depth, u32 iters) {
-    const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    for (u32 i = tid; i < K1F_HW; i += K1F_BT) S.h0[i] = S.hb[i];
-    __syncthreads();
-    u32 lo[K1F_E], hi[K1F_E];                           // the wave's ranges (wave-uniform)
-#pragma unroll
-    for (int j = 0; j < K1F_E; j++) {
-        const u32 base = ((u32)j * K1F_NW + w) * 64u;
-        lo[j] = 0; hi[j] = 0;
-        if (base < cnt) {
-            const u32 l = k1f_first_head_ge(S.h0, base);
-            if (l < base + 64u) { lo[j] = l; hi[j] = base + 64u >= cnt ? cnt : k1f_first_head_ge(S.h0, base + 64u); }
-        }
-        lo[j] = (u32)__builtin_amdgcn_readfirstlane((int)lo[j]);
-        hi[j] = (u32)__builtin_amdgcn_readfirstlane((int)hi[j]);
-    }
-    for (u32 it = 0; it < iters; it++, depth += K1F_STEP) {
-        const u32 dm = depth % n;
-        bool any = false;
-        // P1: keys of the active rotations (two rows per step: their loads are in flight together)
-#pragma unroll
-        for (int j = 0; j < K1F_E; j++) {
-            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 128u) {
-                const u32 qa = r0 + lane, qb = r0 + 64u + lane;
-                const bool ina = qa < hi[j], inb = qb < hi[j];
-                const bool acta = ina && k1f_bits2(S.hb, qa) != 3u && !k1f_bit(S.fb, qa);
-                const bool actb = inb && k1f_bits2(S.hb, qb) != 3u && !k1f_bit(S.fb, qb);
-                u64 ka = 0, kb = 0;
-                u32 la = 0, lb = 0;
-                if (acta) { u32 p = S.sx[qa] + dm; if (p >= n) p -= n; k1f_load_be96(T, p, ka, la); }
-                if (actb) { u32 p = S.sx[qb] + dm; if (p >= n) p -= n; k1f_load_be96(T, p, kb, lb); }
-                if (ina) S.nqp[qa] = (u16)(acta ? K1F_NQ_PEND : K1F_NQ_IDLE);
-                if (inb) S.nqp[qb] = (u16)(actb ? K1F_NQ_PEND : K1F_NQ_IDLE);
-                if (acta) { S.k0[qa] = ka; S.k1[qa] = la; }
-                if (actb) { S.k0[qb] = kb; S.k1[qb] = lb; }
-                any = any || __ballot(acta || actb) != 0ull;
-            }
-        }
-        if (!any) break;                                // nothing of this wave ties any more
-        __builtin_amdgcn_wave_barrier();
-        // P2: ranks
-#pragma unroll
-        for (int j = 0; j < K1F_E; j++) {
-            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
-                const u32 q = r0 + lane;
-                const bool act = q < hi[j] && S.nqp[q] == K1F_NQ_PEND;
-                if (__ballot(act) == 0ull) continue;
-                if (act) {
-                    u32 gs, ge;
-                    k1f_group(S.hb, q, gs, ge);
-                    const u64 m0 = S.k0[q];
-                    const u32 m1 = S.k1[q];
-                    if (ge - gs > K1F_GBIG) {
-                        if (S.k0[gs] != m0 || S.k1[gs] != m1) atomicOr(&S.df[gs >> 5], 1u << (gs & 31u));
-                        S.nqp[q] = (u16)K1F_NQ_HUGE;
-                    } else {
-                        u32 less = 0, eqb = 0;
-                        for (u32 i = gs; i < ge; i += 4u) {
-                            u64 c0[4];
-                            u32 c1[4];
-                            // four cells in a row, read as pairs (ds_read2): cells past the group's end are read too and masked
-                            // below - the arrays end in four spare cells.  (Clamping the index kept every read on its own.)
-#pragma unroll
-                            for (u32 u = 0; u < 4u; u++) {
-                                c0[u] = S.k0[i + u];
-                                c1[u] = S.k1[i + u];
-                            }
-#pragma unroll
-                            for (u32 u = 0; u < 4u; u++) {
-                                const bool in = i + u < ge;
-                                const bool lt = c0[u] < m0 || (c0[u] == m0 && c1[u] < m1);
-                                const bool eq = c0[u] == m0 && c1[u] == m1;
-                                less += (in && lt) ? 1u : 0u;
-                                eqb += (in && eq && i + u < q) ? 1u : 0u;
-                            }
-                        }
-                        S.nqp[q] = (u16)((gs + less + eqb) | (eqb == 0u ? 0x8000u : 0u));
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // P3: the indices to their new positions (through k1[]: a permutation inside every group)
-#pragma unroll
-        for (int j = 0; j < K1F_E; j++)
-            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
-                const u32 q = r0 + lane;
-                const u32 v = q < hi[j] ? S.nqp[q] : K1F_NQ_IDLE;
-                if (v < K1F_NQ_HUGE) S.k1[v & 0x7FFFu] = S.sx[q];
-            }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < K1F_E; j++)
-            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
-                const u32 q = r0 + lane;
-                const u32 v = q < hi[j] ? S.nqp[q] : K1F_NQ_IDLE;
-                if (v < K1F_NQ_HUGE) S.sx[q] = S.k1[q];
-            }
-        // P4: new heads; big groups in which something differed are frozen as they are
-#pragma unroll
-        for (int j = 0; j < K1F_E; j++)
-            for (u32 r0 = lo[j]; r0 < hi[j]; r0 += 64u) {
-                const u32 q = r0 + lane;
-                const u32 v = q < hi[j] ? S.nqp[q] : K1F_NQ_IDLE;
-                if (v < K1F_NQ_HUGE) {
-                    const u32 p = v & 0x7FFFu;
-                    if (v & 0x8000u) atomicOr(&S.hb[p >> 5], 1u << (p & 31u));      // (the group's own head is set already: harmless)
-                } else if (v == K1F_NQ_HUGE) {
-                    const u32 gs = k1f_prev_head(S.hb, q);
-                    if (k1f_bit(S.df, gs)) atomicOr(&S.fb[q >> 5], 1u << (q & 31u));
-                }
-            }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-}
 
 // A slice that a bucket-sort workgroup cannot finish in LDS becomes a TASK of the next level of k1f_task (below):
 // x = block, y = suffix-array position of the slice, z = its length, w = depth (bytes all its rotations share) | K1F_TASK_SB
@@ -627,16 +518,16 @@ __device__ __forceinline__ void k1f_push_task(const K1Buf& B, u32 level, u32 b, 
 }
 
 // Results of positions [0, cnt) of the slice that starts at suffix-array position `pos0` of block b: the suffix indices and the
-// head bits; with `lists`, every unfrozen group of 2..K1F_GBIG rotations goes, member by member, to the block's list of
+// head bits; with `lists`, every group of 2..K1F_GBIG rotations goes, member by member, to the block's list of
 // the first refinement round (k1r_round), and its positions are marked as heads right away: the rounds resolve them or,
-// where a tie outlasts the last round, clear the bits again.  One atomic per workgroup reserves the list slots.  The other
-// groups (above K1F_GBIG rotations, frozen) stay marked as groups and become tasks of level `task_level`, `task_depth` deep.
-__device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const BatchGeom& g, u32 b, u32 pos0, u32 cnt, bool lists,
+// where a tie outlasts the last round, clear the bits again.  One atomic per workgroup reserves the list slots.  Groups above
+// K1F_GBIG rotations stay marked as groups and become tasks of level `task_level`, `task_depth` deep.
+__device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const BatchGeom& g, u32 b, u32 pos0, u32 cnt, bool lists,
                                           u32 task_level, u32 task_depth) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     u32* SA = B.SA + (size_t)b * g.stride + pos0;
     u32* HN = B.HN + (size_t)b * g.hstride;
-    u32* lb = S.h0;                                     // listed positions (the deepening's copy of the heads is no longer needed)
+    u32* lb = S.lb;
     const u64 lt = lanemask_lt();
     u64 bal[K1F_E];
     u32 gsv[K1F_E];                                     // listed: index in the group | (length - 1) << 8
@@ -656,9 +547,9 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
                 u32 gs, ge_;
                 k1f_group(S.hb, q, gs, ge_);
                 const u32 gl = ge_ - gs;
-                listed = gl <= K1F_GBIG && !k1f_bit(S.fb, q);
+                listed = gl <= K1F_GBIG;
                 gsv[it] = (q - gs) | ((gl - 1u) << 8);
-                // a group this workgroup could not split (above K1F_GBIG rotations, or frozen): a task of the next level
+                // a group too big for the lists: a task of the next level
                 if (!listed && q == gs) k1f_push_task(B, task_level, b, pos0 + gs, gl, task_depth);
             }
             bal[it] = __ballot(listed);
@@ -691,31 +582,29 @@ __device__ __forceinline__ void k1f_flush(const K1fS& S, const K1Buf& B, const B
     }
 }
 
-// LDS of the local sample sort (stages 1-3); aliases what only the deepening uses afterwards
-struct K1fSort {
-    u64* smp;       // [K1F_LS] samples
-    u64* sp2;       // [K1F_LK] local splitters
-    u32* srank;     // [K1F_LS]
-    u32* cnt2;      // [K1F_LK]
-    u32* off2;      // [K1F_LK + 1]
-    u8* lf;         // [K1F_C] leaf of every slot
-};
-
-// `cnt` <= K1F_C rotation indices from src[] sorted in LDS by the 8 text bytes at depth `dm` (= depth mod n): on return
-// S.sx[] holds them in order and S.hb[] the heads of the groups of equal keys (bit 0 and the sentinel bits included).
-//   stage 0  indices, then keys (all loads of a stage in flight together)
-//   stage 1  a LOCAL sample sort: up to 128 of the slice's own keys ranked by counting, every 2nd a local splitter
-//   stage 2  the pairs move into <= 64 leaves (leaf order, in place: every thread still holds its pairs in registers)
-//   stage 3  every rotation ranks itself inside its leaf by counting, ALL LANES AT ONCE (a lane per rotation, the leaf's keys
-//            read from LDS four at a time: lanes of one leaf read the same address = broadcast).  Round 2 gave a whole wave
-//            to one leaf of ~14 rotations and broadcast the candidates through v_readlane: 22 % of the lanes busy.
-// bigstat: where leaves of more than 64 rotations (mostly one key) are counted (the K1-deep predictor of k1_run), or null.
-__device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, const u8* T, u32 n, const u32* src, u32 cnt, u32 dm, u32* bigstat) {
+// `cnt` <= K1F_CAP rotation indices from src[] sorted in LDS by the K1F_KEYB = 16 text bytes at depth `dm` (= depth mod n; `wide` false:
+// by the first 8 of them): on return S.sx[] holds them in order and S.hb[] the heads of the groups of equal keys (bit 0 and the sentinel
+// bits included).  Round 5: ONE sort on 16-byte keys.  Rounds 3-4 sorted by 8 bytes and then took 12 more bytes off every group that still
+// tied (77 % of the rotations of text) in a second stage with its own gathers, bitmaps, group walks and ranking loops whose trip count
+// was the size of the largest 8-byte group of a wave's rows: 1 750 VALU + 1 200 SALU instructions per wave of ~110 rotations (PMC), and
+// the instruction stream, not memory latency, was what the kernel's 3.1 ms were made of.
+//   stage 0  indices, then keys (all loads of a stage in flight together), keys to LDS in arrival order
+//   stage 1  a LOCAL sample sort: K1F_LOVS x K of the slice's own keys ranked by counting, every K1F_LOVS-th a local splitter;
+//            a key that fills a whole quantile gets a leaf of its own (nothing to rank there: heavy keys cannot blow a leaf up)
+//   stage 2  leaf of every rotation (binary search over the splitters), slot inside the leaf by an LDS counter; the cells move to
+//            leaf order IN PLACE (every thread still holds its own in registers), the leaf id rides in the index word
+//   stage 3  every POSITION ranks its cell inside its leaf by counting, all lanes at once (the leaf's cells read four at a time,
+//            lanes of one leaf read the same address = broadcast; neighbouring lanes sit in the same or the next leaf, so a wave's
+//            trip count is that of a handful of leaves).  (key, slot) is a strict order: the ranks are a permutation, one carry
+//            chain per candidate (k1f_acc_lt).  Cells past a leaf's end belong to later leaves - strictly greater keys - and
+//            behind the last rotation sit four all-ones cells: no bounds masks in the loop.
+//   stage 4  cells to their final places, heads = key differs from its predecessor's (one ballot per row of 64: no atomics).
+__device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, const u32* src, u32 cnt, u32 dm, bool wide) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    u64* key = S.k0;
+    uint4* key = S.key;
     u32* sx = S.sx;
     u32 v[K1F_E];
-    u64 k[K1F_E];
+    uint4 k[K1F_E];
 #pragma unroll
     for (int it = 0; it < K1F_E; it++) {
         const u32 i = (u32)it * K1F_BT + tid;
@@ -726,60 +615,59 @@ __device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, co
         const u32 i = (u32)it * K1F_BT + tid;
         u32 p = v[it] + dm;
         if (p >= n) p -= n;
-        k[it] = i < cnt ? k1f_load_be64(T, p) : 0ull;
+        k[it] = i < cnt ? k1f_load_be128(T, p) : make_uint4(0u, 0u, 0u, 0u);
+        if (!wide) { k[it].z = 0u; k[it].w = 0u; }
     }
 #pragma unroll
     for (int it = 0; it < K1F_E; it++) {
         const u32 i = (u32)it * K1F_BT + tid;
         if (i < cnt) key[i] = k[it];
     }
-    k1f_init_bitmaps(S, cnt);
-    if (tid < K1F_LK) Q.cnt2[tid] = 0;
+    if (tid < 4u) key[cnt + tid] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (tid < K1F_LK) S.cnt2[tid] = 0;
     u32 K = 1u;
-    while (K < K1F_LK && cnt >= 48u * K) K <<= 1;       // leaves of ~24..48 rotations (K1F_LK = 32), ~12..24 (64)
-    if (K1F_LK == 64 && K > 1u && K < 64u) K <<= 1;
+    while (K < K1F_LK && cnt >= K1F_LEAF * K) K <<= 1;
     __syncthreads();
+    u32 q[K1F_E];                                       // final position of the cell this thread ranks
+    uint4 kk[K1F_E];
+    u32 vv[K1F_E];
     if (K > 1u) {
-        // stage 1: LOVS * K samples, ranked by counting; every LOVS-th is a local splitter (equal neighbours: the heavy-key rule)
+        // stage 1: LS = LOVS * K samples (stratified over the arrival order), ranked by counting
         const u32 LS = K1F_LOVS * K;
-        // (all waves: thread t ranks sample t % LS against one LS / (K1F_BT / LS)-th of the samples, partial ranks summed in LDS)
-        const u32 parts = K1F_BT / LS < 1u ? 1u : (K1F_BT / LS > LS ? LS : K1F_BT / LS), si = tid % LS, part = tid / LS;   // powers of two
-        if (tid < LS) { Q.smp[tid] = key[(u32)((u64)tid * cnt / LS)]; Q.srank[tid] = 0; }
+        uint4 mys = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < LS) { mys = key[(u32)((u64)tid * cnt / LS)]; S.smp[tid] = mys; S.srank[tid] = 0; }
         __syncthreads();
-        if (part < parts) {
-            const u64 mine = Q.smp[si];
-            const u32 per = LS / parts, j0 = part * per;
-            u32 r = 0;
-            if (per >= 2u) {                              // (per is a power of two: two samples per 16-byte read)
-#pragma unroll 4
-                for (u32 j = j0; j < j0 + per; j += 2u) {
-                    const K1fPair o = *(const K1fPair*)&Q.smp[j];
-                    r += (o.x < mine || (o.x == mine && j < si)) ? 1u : 0u;
-                    r += (o.y < mine || (o.y == mine && j + 1u < si)) ? 1u : 0u;
+        {   // thread t ranks sample t % LS against one `parts`-th of the samples, partial ranks summed in LDS
+            const u32 parts = K1F_BT / LS > LS ? LS : K1F_BT / LS, si = tid % LS, part = tid / LS;   // powers of two; LS <= K1F_BT
+            if (part < parts) {
+                const uint4 mine = S.smp[si];
+                const u32 per = LS / parts, j0 = part * per;
+                u32 r = 0;
+                if (per >= 4u) {
+                    for (u32 j = j0; j < j0 + per; j += 4u) {
+                        uint4 c[4];
+#pragma unroll
+                        for (u32 u = 0; u < 4u; u++) c[u] = S.smp[j + u];
+#pragma unroll
+                        for (u32 u = 0; u < 4u; u++) k1f_acc_lt(r, c[u], j + u, mine, si);
+                    }
+                } else {
+                    for (u32 j = j0; j < j0 + per; j++) k1f_acc_lt(r, S.smp[j], j, mine, si);
                 }
-            } else {
-                const u64 o = Q.smp[j0];
-                r += (o < mine || (o == mine && j0 < si)) ? 1u : 0u;
+                atomicAdd(&S.srank[si], r);
             }
-            atomicAdd(&Q.srank[si], r);
         }
         __syncthreads();
-        u64 mine = 0;
-        if (tid < LS) mine = Q.smp[tid];
+        if (tid < LS) S.smp[S.srank[tid]] = mys;        // (every read of the unsorted samples is behind the barrier)
         __syncthreads();
-        if (tid < LS) Q.smp[Q.srank[tid]] = mine;
-        __syncthreads();
-        if (tid < K1F_LK) {
-            u64 vv = ~0ull;
-            if (tid + 1u < K) {
-                const u64 q = Q.smp[(tid + 1u) * K1F_LOVS];
-                vv = q;
-                if (tid >= 1u && Q.smp[tid * K1F_LOVS] == q && q != ~0ull) vv = q + 1u;
-            }
-            Q.sp2[tid] = vv;
+        if (tid + 1u < K) {                             // splitters; equal neighbours: the heavy-key rule
+            const uint4 qq = S.smp[(tid + 1u) * K1F_LOVS];
+            uint4 sv = qq;
+            if (tid >= 1u && k1f_eq128(S.smp[tid * K1F_LOVS], qq) && !k1f_ones128(qq)) sv = k1f_inc128(qq);
+            S.sp[tid] = sv;
         }
         __syncthreads();
-        // stage 2: leaf of every rotation, slot inside the leaf by an LDS counter
+        // stage 2: leaf of every rotation (number of splitters <= key), slot inside the leaf by an LDS counter
         u32 L[K1F_E];
 #pragma unroll
         for (int it = 0; it < K1F_E; it++) {
@@ -788,107 +676,115 @@ __device__ __forceinline__ void k1f_sort_lds(const K1fS& S, const K1fSort& Q, co
             if (i < cnt) {
                 u32 pos = 0;
                 for (u32 step = K >> 1; step >= 1u; step >>= 1)
-                    if (Q.sp2[pos + step - 1u] <= k[it]) pos += step;
-                L[it] = (pos << 16) | atomicAdd(&Q.cnt2[pos], 1u);
+                    if (!k1f_lt128(k[it], S.sp[pos + step - 1u])) pos += step;
+                L[it] = (pos << 16) | atomicAdd(&S.cnt2[pos], 1u);
             }
         }
         __syncthreads();
-        if (w == 0) {
-            const u32 c = lane < K ? Q.cnt2[lane] : 0u;
+        if (w == 0) {                                   // leaf starts; a leaf between the splitters v and v + 1 holds one key only
+            const u32 c = lane < K ? S.cnt2[lane] : 0u;
             const u32 inc = wave_incl_scan_u32(c);
-            if (lane < K1F_LK) Q.off2[lane] = inc - c;
-            if (lane == 0) Q.off2[K1F_LK] = cnt;
+            bool pure = false;
+            if (lane >= 1u && lane + 1u < K) pure = k1f_eq128(S.sp[lane], k1f_inc128(S.sp[lane - 1u]));
+            __builtin_amdgcn_wave_barrier();
+            if (lane < K1F_LK) S.off2[lane] = lane < K ? ((inc - c) | (pure ? 0x80000000u : 0u)) : cnt;
+            if (lane == 0) S.off2[K1F_LK] = cnt;
         }
         __syncthreads();
-        // the pairs move to leaf order IN PLACE: nobody reads the arrival-order arrays any more (own pairs are in registers)
+        // the cells move to leaf order IN PLACE: nobody reads the arrival-order array any more (own cells are in registers);
+        // the samples' scratch (it aliases sx[]) is dead as well
 #pragma unroll
         for (int it = 0; it < K1F_E; it++)
             if (L[it] != 0xFFFFFFFFu) {
-                const u32 leaf = L[it] >> 16, q = Q.off2[leaf] + (L[it] & 0xFFFFu);
-                key[q] = k[it];
-                sx[q] = v[it];
-                Q.lf[q] = (u8)leaf;
+                const u32 leaf = L[it] >> 16, p = (S.off2[leaf] & 0x7FFFFFFFu) + (L[it] & 0xFFFFu);
+                key[p] = k[it];
+                sx[p] = v[it] | (leaf << K1F_LEAFSH);
             }
-    } else {
+        __syncthreads();
+        // stage 3: position i ranks its cell inside its leaf
 #pragma unroll
         for (int it = 0; it < K1F_E; it++) {
             const u32 i = (u32)it * K1F_BT + tid;
-            if (i < cnt) { sx[i] = v[it]; Q.lf[i] = 0; }
-        }
-        if (tid == 0) { Q.cnt2[0] = cnt; Q.off2[0] = 0; Q.off2[1] = cnt; }
-        if (tid < K1F_LK) Q.sp2[tid] = ~0ull;
-    }
-    __syncthreads();
-    // stage 3: less = smaller keys, eqb = equal keys in earlier slots; members of one group (equal keys) end up next to each
-    // other and the one with eqb == 0 is its head.
-    u32 q[K1F_E];                                       // final position | head << 31
+            q[it] = 0xFFFFFFFFu;
+            if (i < cnt) {
+                const u32 vl = sx[i], leaf = vl >> K1F_LEAFSH;
+                const u32 oo = S.off2[leaf], o = oo & 0x7FFFFFFFu, e = S.off2[leaf + 1u] & 0x7FFFFFFFu;
+                const uint4 mine = key[i];
+                kk[it] = mine;
+                vv[it] = vl & ((1u << K1F_LEAFSH) - 1u);
+                u32 less = 0;
+                if (!(oo >> 31)) {
+                    for (u32 j = o; j < e; j += 4u) {
+                        uint4 c[4];
 #pragma unroll
-    for (int it = 0; it < K1F_E; it++) {
-        const u32 i = (u32)it * K1F_BT + tid;
-        q[it] = 0xFFFFFFFFu;
-        if (i < cnt) {
-            const u32 leaf = Q.lf[i];
-            const u32 o = Q.off2[leaf], e = leaf + 1u < K ? Q.off2[leaf + 1u] : cnt;
-            const u64 mine = key[i];
-            v[it] = sx[i];
-            const bool pure2 = K > 1u && leaf > 0u && leaf + 1u < K && Q.sp2[leaf] == Q.sp2[leaf - 1u] + 1u;   // one key only
-            if (pure2) q[it] = i | (i == o ? 0x80000000u : 0u);
-            else {
-                u32 less = 0, eqb = 0;
-                for (u32 j = o; j < e; j += 4u) {
-                    u64 c[4];
+                        for (u32 u = 0; u < 4u; u++) c[u] = key[j + u];
 #pragma unroll
-                    for (u32 u = 0; u < 4u; u++) c[u] = key[j + u];     // (past the leaf's end: masked below; key[] has four spare cells)
-#pragma unroll
-                    for (u32 u = 0; u < 4u; u++) {
-                        const bool in = j + u < e;
-                        less += (in && c[u] < mine) ? 1u : 0u;
-                        eqb += (in && c[u] == mine && j + u < i) ? 1u : 0u;
+                        for (u32 u = 0; u < 4u; u++) k1f_acc_lt(less, c[u], j + u, mine, i);
                     }
+                } else {
+                    less = i - o;
                 }
-                q[it] = (o + less + eqb) | (eqb == 0 ? 0x80000000u : 0u);
+                q[it] = o + less;
             }
-            if (bigstat && i == o && e - o > 64u) atomicAdd(bigstat, e - o);      // a leaf this big is (mostly) one key
+        }
+    } else {
+        // one leaf: the whole slice (fewer than K1F_LEAF rotations), ranked where it arrived
+#pragma unroll
+        for (int it = 0; it < K1F_E; it++) {
+            const u32 i = (u32)it * K1F_BT + tid;
+            q[it] = 0xFFFFFFFFu;
+            if (i < cnt) {
+                kk[it] = k[it];
+                vv[it] = v[it];
+                u32 less = 0;
+                for (u32 j = 0; j < cnt; j += 4u) {
+                    uint4 c[4];
+#pragma unroll
+                    for (u32 u = 0; u < 4u; u++) c[u] = key[j + u];
+#pragma unroll
+                    for (u32 u = 0; u < 4u; u++) k1f_acc_lt(less, c[u], j + u, k[it], i);
+                }
+                q[it] = less;
+            }
         }
     }
     __syncthreads();
+    // stage 4: cells to their final places; heads
 #pragma unroll
     for (int it = 0; it < K1F_E; it++)
-        if (q[it] != 0xFFFFFFFFu) {
-            const u32 p = q[it] & 0x7FFFFFFFu;
-            sx[p] = v[it];
-            if (q[it] >> 31) atomicOr(&S.hb[p >> 5], 1u << (p & 31u));
-        }
+        if (q[it] != 0xFFFFFFFFu) { key[q[it]] = kk[it]; sx[q[it]] = vv[it]; }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < K1F_E; it++) {
+        const u32 r0 = (u32)it * K1F_BT + w * 64u, p = r0 + lane;
+        bool head = true;
+        if (p < cnt && p > 0u) head = !k1f_eq128(key[p], key[p - 1u]);
+        const u64 bal = __ballot(head);
+        if (lane == 0) { S.hb[r0 >> 5] = (u32)bal; S.hb[(r0 >> 5) + 1u] = (u32)(bal >> 32); }
+    }
+    if (tid < 2u) S.hb[K1F_C / 32u + tid] = 0xFFFFFFFFu;
     __syncthreads();
 }
 
 // The __shared__ arrays of a bucket-sort workgroup and their views (macro: __shared__ must be declared in the kernel)
-#define K1F_DECLARE_LDS(S, Q)                                                                                                        \
-    __shared__ u64 key[K1F_C + 4];                                                                                                   \
-    __shared__ u32 key1[K1F_C + 4];                                                                                                  \
-    __shared__ u32 sx[K1F_C];                                                                                                        \
-    __shared__ u32 hbits[K1F_HW], fbits[K1F_HW], h0bits[K1F_HW], dfbits[K1F_HW];                                                     \
+#define K1F_DECLARE_LDS(S)                                                                                                           \
+    __shared__ uint4 key128[K1F_C];                                                                                                  \
+    __shared__ __attribute__((aligned(16))) u32 sx[K1F_C];                                                                           \
+    __shared__ u32 cnt2s[K1F_LK], off2s[K1F_LK + 1];                                                                                 \
+    __shared__ u32 hbits[K1F_HW], lbits[K1F_HW];                                                                                     \
     __shared__ u32 misc[K1F_E * K1F_NW + 8];                                                                                         \
-    /* scratch: the local sample sort (samples, splitters, ranks) and, later, the deepening's new positions */                     \
-    __shared__ __attribute__((aligned(16))) u64 scr64[256];                                                                          \
-    static_assert((2 * K1F_LK + 4) * 4 + K1F_C <= K1F_C * 4, "leaf bookkeeping fits key1[]");                                        \
-    static_assert((K1F_LS + K1F_LK) * 8 + K1F_LS * 4 <= 256 * 8 && K1F_C * 2 <= 256 * 8 && K1F_C >= 256 && K1F_C < 0x7FF0,            \
-                  "scratch: samples + splitters + ranks, later K1F_C u16 new positions");                                            \
-    K1fS S;                                                                                                                          \
-    S.k0 = key; S.k1 = key1; S.sx = sx; S.hb = hbits; S.fb = fbits; S.h0 = h0bits; S.df = dfbits; S.nqp = (u16*)scr64; S.misc = misc; \
-    K1fSort Q;                                                                                                                       \
-    Q.smp = scr64; Q.sp2 = scr64 + K1F_LS; Q.srank = (u32*)(scr64 + K1F_LS + K1F_LK);                                                \
-    /* leaf bookkeeping of the local sample sort lives in key1[], which only the deepening uses */                                  \
-    Q.cnt2 = key1; Q.off2 = key1 + K1F_LK; Q.lf = (u8*)(key1 + 2 * K1F_LK + 4);
+    static_assert((K1F_LS + K1F_LK) * 16 + K1F_LS * 4 <= K1F_C * 4, "the local sample sort's scratch fits sx[]");                    \
+    K1fL S;                                                                                                                          \
+    S.key = key128; S.sx = sx; S.smp = (uint4*)sx; S.sp = (uint4*)sx + K1F_LS; S.srank = sx + (K1F_LS + K1F_LK) * 4;                 \
+    S.cnt2 = cnt2s; S.off2 = off2s; S.hb = hbits; S.lb = lbits; S.misc = misc;
 
 // One workgroup per bucket (a bucket is a KEY RANGE: everything that ties on its first 8 bytes, or deeper, is inside).
-//   1. k1f_sort_lds: the bucket sorted by its first 8 bytes in LDS, groups of equal keys marked;
-//   2. k1f_deepen: `iters` in-bucket iterations of K1F_STEP more bytes (round 3);
-//   3. k1f_flush: suffix-array slice and head bits written ONCE; what still ties goes to the refinement rounds' lists, and
+//   1. k1f_sort128: the bucket sorted by its first 16 bytes in LDS (`wide`; else 8), groups of equal keys marked;
+//   2. k1f_flush: suffix-array slice and head bits written ONCE; what still ties goes to the refinement rounds' lists, and
 //      what could not be handled here (groups above K1F_GBIG rotations) to the task levels.
-// Buckets beyond LDS (cnt > K1F_C: an unlucky sample, a moderately heavy key) and buckets of ONE 8-byte key beyond LDS
-// (HTML-like input: a quarter of all rotations) are level-0 tasks.  `lists` = 0: no deepening, no lists, no tasks but the
-// oversize buckets (the K1-deep tile kernel of rounds 1-2 follows; kept for A/B runs, and linear mode).
+// Buckets beyond LDS (cnt > K1F_CAP: an unlucky sample, a moderately heavy key) and buckets of ONE 8-byte key beyond LDS
+// (HTML-like input: a quarter of all rotations) are level-0 tasks.  `lists` = 0: 8-byte keys, no lists, no tasks but the
+// oversize buckets (linear mode; cyclic mode with the text stages off).
 // `purerot_max`: with more rotations than this in one-key buckets (counted by k1f_scan) the text stages are skipped
 // altogether (CJS_DEEP_BIG_DIV = 8: HTML-like input, whose ties of hundreds of bytes prefix doubling settles faster).
 __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
@@ -909,7 +805,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     // a bucket between the splitters v and v+1 holds one key only
     const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
-    if (cnt > K1F_C && (deepen || !pure)) {
+    if (cnt > K1F_CAP && (deepen || !pure)) {
         // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB
         if (tid == 0) {
             k1f_push_task(B, 0u, b, start, cnt, (pure ? 8u : 0u) | K1F_TASK_SB);
@@ -921,26 +817,17 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     if (cnt == 1u || (pure && !deepen)) {
         for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
         k1f_write_heads(HN, start, end, [&](u32 p) { return p == start; });
-        if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (see k1_run: K1-deep predictor)
+        if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (trace only)
         return;
     }
-    K1F_DECLARE_LDS(S, Q)
+    K1F_DECLARE_LDS(S)
 #ifdef K1F_TRACE
     long long tprev_ = clock64();
 #endif
-    if (pure) {
-        // one 8-byte key (small blocks: a quantile is a few dozen rotations): a single group at depth 8, straight to the deepening
-        for (u32 i = tid; i < cnt; i += K1F_BT) sx[i] = SB[i];
-        k1f_init_bitmaps(S, cnt);
-        if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
-        __syncthreads();
-    } else {
-        k1f_sort_lds(S, Q, T, n, SB, cnt, 0u, &B.stats[K1_STAT_BIGROT + (d & 7u)]);
-    }
+    const bool wide = deepen && iters != 0u;
+    k1f_sort128(S, T, n, SB, cnt, 0u, wide);
     K1F_STAMP(3);
-    if (deepen) k1f_deepen(S, T, n, cnt, 8u, iters);
-    K1F_STAMP(4);
-    k1f_flush(S, B, g, b, start, cnt, deepen, 0u, 8u);
+    k1f_flush(S, B, g, b, start, cnt, deepen, 0u, wide ? K1F_KEYB : 8u);
     K1F_STAMP(5);
 }
 
@@ -958,7 +845,11 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
 // launched): whatever arrives is sorted by 8 bytes at its depth and left at that (the doubling rounds take it from there):
 // in LDS if it fits, else by stable LSD passes through global memory (one digit byte gathered per pass; slow, never seen).
 __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 level, u32 iters, u32 lists, u32 purerot_max, u32 last) {
-    K1F_DECLARE_LDS(S, Q)
+    K1F_DECLARE_LDS(S)
+    // scratch of the partition and of the last level's LSD passes: views into the key cells (K1F_C * 16 bytes)
+    u64* key = (u64*)key128;                            // [K1F_PS + K1F_PB] u64
+    u32* key1 = (u32*)(key + K1F_PS + K1F_PB);          // [K1F_PS] u32
+    static_assert((K1F_PS + K1F_PB) * 8 + K1F_PS * 4 <= K1F_C * 16 && 512 * 4 <= K1F_C * 16, "task scratch fits the key cells");
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     u32 ntask = B.bcnt[level];
     if (ntask > B.btaskCap) ntask = B.btaskCap;
@@ -985,15 +876,15 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             if (tid == 0) atomicOr(&HN[pos >> 5], 1u << (pos & 31u));
             continue;
         }
-        if (len <= K1F_C) {
+        if (len <= K1F_CAP) {
             if (len == 1u) {
                 if (tid == 0) { SAs[0] = src[0]; atomicOr(&HN[pos >> 5], 1u << (pos & 31u)); }
                 continue;
             }
-            k1f_sort_lds(S, Q, T, n, src, len, dm, nullptr);
             const bool go = deepen && !last;
-            if (go) k1f_deepen(S, T, n, len, depth + 8u, iters);
-            k1f_flush(S, B, g, b, pos, len, go, level + 1u, depth + 8u);
+            const bool wide = go && iters != 0u;
+            k1f_sort128(S, T, n, src, len, dm, wide);
+            k1f_flush(S, B, g, b, pos, len, go, level + 1u, depth + (wide ? K1F_KEYB : 8u));
             continue;
         }
         if (!last) {

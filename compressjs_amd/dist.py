@@ -62,6 +62,17 @@ def trailer_bytes(bit_pos: int, crc: int):
     return first, v.to_bytes(nbytes, "big"), (end + pad) // 8
 
 
+def _same_device(a, b) -> bool:
+    """torch.device('cuda') and torch.device('cuda:0') name the same device when 0 is the current one."""
+    a, b = torch.device(a), torch.device(b)
+    if a.type != b.type:
+        return False
+    if a.type != "cuda":
+        return True
+    cur = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    return (cur if a.index is None else a.index) == (cur if b.index is None else b.index)
+
+
 def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
     """Shared tail of both drivers: 24-byte all_gather -> bit offsets and CRC fold; shift own segment; variable-length
     send/recv to rank 0; rank 0 ORs the segments, writes header and trailer.  Returns the stream on rank 0, else None."""
@@ -93,7 +104,7 @@ def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
             # one staging buffer for all peers' segments, kept across steps (no allocation inside the timed step)
             need = sum(lens[1:])
             stage = getattr(ctx, "_asm_stage", None)
-            if stage is None or stage.numel() < need or stage.device != torch.device(cdev):
+            if stage is None or stage.numel() < need or not _same_device(stage.device, cdev):
                 stage = torch.empty(need + (need >> 2) + 4096, dtype=torch.uint8, device=cdev)
                 ctx._asm_stage = stage
             gl, o2 = [shifted], 0
@@ -116,7 +127,7 @@ def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
         return None
     toff, tbytes, total = trailer_bytes(pos, crc)
     final = getattr(ctx, "_asm_final", None)                  # the output buffer is kept across steps too
-    if final is None or final.numel() < total + 8 or final.device != torch.device(dev):
+    if final is None or final.numel() < total + 8 or not _same_device(final.device, dev):
         final = torch.empty(total + (total >> 3) + 4096, dtype=torch.uint8, device=dev)
         ctx._asm_final = final
     final[:total + 8].zero_()
@@ -129,7 +140,8 @@ def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
     tb = torch.tensor(list(tbytes), dtype=torch.uint8, device=dev)
     final[toff:toff + tb.numel()] |= tb
     mark("assemble")
-    return final[:total]
+    # a copy: `final` is scratch that the next call on this ctx zeroes and overwrites (a view of it changed under the caller)
+    return final[:total].clone()
 
 
 def sharded_compress(ctx, d_in: torch.Tensor, level: int, group=None, seg: torch.Tensor = None):
