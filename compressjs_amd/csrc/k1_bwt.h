@@ -8,6 +8,10 @@
 #define K1_STAT_PUREROT 124    // stats[124]: rotations in front-end buckets of ONE 8-byte key (> 64 members) or beyond LDS, counted by k1f_scan
 #define K1_DEEP_LANE 8u        // groups up to this size go to the lane kernels (k1_deep_pairs / k1_deep_small): one lane each
 #define K1R_MAXR 40            // refinement rounds at most
+#ifndef K1_RCS
+#define K1_RCS 32u              // words between two blocks' list counters (rcnt): one 128-byte line each - the counters of the blocks the 8 XCDs work on at the
+#endif                          // same time shared a line, and device-scope atomics on one line are serialised in the fabric (round 5)
+#define K1_RCNT(B, round, b) ((B).rcnt[((size_t)(round) * (B).rstride + (b)) * K1_RCS])
 #ifndef K1F_LEVELS
 #define K1F_LEVELS 14u
 #endif
@@ -111,7 +115,7 @@ struct K1Buf {
     u64* listL[2];    // ... of more than K1_MED_MAX
     u32 listTCap, listSCap, listMCap, listLCap;
     u64* rlist[2];    // [nb][stride]   entry lists: refinement rounds (in/out), doubling rounds ([0] the round's list, [1] its re-ordered copy)
-    u32* rcnt;        // [K1R_MAXR + 1][rstride]  refinement rounds: entries per round and block
+    u32* rcnt;        // [K1R_MAXR + 1][rstride][K1_RCS]  refinement rounds: entries per round and block (K1_RCNT)
     u32 rstride;
     u32* dcnt;        // [K1D_MAXR + 2][rstride]  doubling rounds: list entries per round and block
     u32* dchg;        // [K1D_MAXR + 2][rstride]  != 0: a group of the block split in that round (none: only identical rotations are left)

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && gid < K1_STATS) B.stats[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 4u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
-    if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rstride; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
+    if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rstride * K1_RCS; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
     if (b == 0 && gid < K1F_LEVELS) B.bcnt[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 2u * (K1D_MAXR + 2u) * B.rstride + 2u * B.rstride + (K1D_MAXR + 2u) * 4u; i += gridDim.x * blockDim.x) B.dcnt[i] = 0;   // dcnt, dchg, dtot, dbn, dred (contiguous)
     if (gid < g.hstride) {
@@ -372,7 +372,7 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     for (int k = 0; k < 2; k++) take((void**)&B.listM[k], (size_t)B.listMCap * 8);
     for (int k = 0; k < 2; k++) take((void**)&B.listL[k], (size_t)B.listLCap * 8);
     for (int k = 0; k < 2; k++) take((void**)&B.rlist[k], e * 8);
-    take((void**)&B.rcnt, (size_t)(K1R_MAXR + 1) * nb8 * 4);
+    take((void**)&B.rcnt, (size_t)(K1R_MAXR + 1) * nb8 * K1_RCS * 4);
     take((void**)&B.dcnt, ((size_t)(2u * (K1D_MAXR + 2u) + 2u) * nb8 + (K1D_MAXR + 2u) * 4u) * 4);      // dcnt, dchg, dtot, dbn, dred (contiguous: zeroed as one; dtot .. dred read back as one)
     take((void**)&B.btask, (size_t)K1F_LEVELS * B.btaskCap * sizeof(uint4));
     take((void**)&B.bcnt, 256);
@@ -496,7 +496,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             }
             fprintf(stderr, "\n");
         }
-        fprintf(stderr, "[k1] front end: %u oversize buckets, %llu of %llu rotations in 8-byte groups above 64, %u in one-key buckets; k1f_bsort stage clocks/256 (K1F_TRACE builds): load %u  sample %u  partition %u  leaves %u  deepen %u  flush %u\n",
+        fprintf(stderr, "[k1] front end: %u oversize buckets, %llu of %llu rotations in 8-byte groups above 64, %u in one-key buckets; k1f_bsort stage clocks/256 (K1F_TRACE builds): load %u  sample %u  partition %u  rank %u  place+heads %u  flush %u\n",
                 fs[0], (unsigned long long)bg, (unsigned long long)total_n, fs[K1_STAT_PUREROT - K1_STAT_FRONT_BIG], fs[1], fs[2], fs[3], fs[4], fs[5], fs[6]);
     }
     if (fused) {
@@ -505,7 +505,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const int rc = k1_rounds_run(B, g, stream, depth0, K.text_bytes);
         if (rc) return rc;
         if (K.trace) {
-            std::vector<u32> rc2((size_t)(K1R_MAXR + 1) * B.rstride);
+            std::vector<u32> rc2((size_t)(K1R_MAXR + 1) * B.rstride * K1_RCS);
             u32 rt[8];
             HIP_CHECK_RET(hipMemcpyAsync(rc2.data(), B.rcnt, rc2.size() * 4, hipMemcpyDeviceToHost, stream));
             HIP_CHECK_RET(hipMemcpyAsync(rt, B.stats + K1_STAT_RTRACE, sizeof rt, hipMemcpyDeviceToHost, stream));
@@ -513,7 +513,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             fprintf(stderr, "[k1] refinement rounds, entries per round:");
             for (u32 r = 0; r <= K1R_MAXR; r++) {
                 u64 tot = 0;
-                for (u32 bb = 0; bb < g.nb; bb++) tot += rc2[(size_t)r * B.rstride + bb];
+                for (u32 bb = 0; bb < g.nb; bb++) tot += rc2[((size_t)r * B.rstride + bb) * K1_RCS];
                 if (!tot) break;
                 fprintf(stderr, " %llu", (unsigned long long)tot);
             }

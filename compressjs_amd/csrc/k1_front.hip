@@ -306,7 +306,8 @@ __global__ __launch_bounds__(1024) void k1f_scatter(K1Buf B, BatchGeom g, u32 pt
     const u32 t0 = t * K1F_PT;
     if (t0 >= n) return;
     __shared__ u32 cnt[K1F_NB], base[K1F_NB];
-    __shared__ u32 stage[K1F_PT], dst[K1F_PT];
+    __shared__ u32 stage[K1F_PT];
+    __shared__ u16 sbk[K1F_PT];                         // bucket of every staged slot (the destination follows from it: no 4-byte dst[] array - 4096 buckets fit)
     __shared__ u32 sh[20];
     const u32 tid = threadIdx.x;
     const u32* th = B.tileHist + ((size_t)b * ptiles + t) * K1F_NB;
@@ -341,11 +342,14 @@ __global__ __launch_bounds__(1024) void k1f_scatter(K1Buf B, BatchGeom g, u32 pt
         if (dv[it] != 0xFFFFFFFFu) {
             const u32 slot = cnt[dv[it]] + rk[it];
             stage[slot] = t0 + (u32)it * 1024u + tid;
-            dst[slot] = base[dv[it]] + rk[it];
+            sbk[slot] = (u16)dv[it];
         }
     __syncthreads();
     const u32 total = n - t0 < K1F_PT ? n - t0 : K1F_PT;
-    for (u32 slot = tid; slot < total; slot += 1024) SB[dst[slot]] = stage[slot];
+    for (u32 slot = tid; slot < total; slot += 1024) {
+        const u32 d = sbk[slot];
+        SB[base[d] + (slot - cnt[d])] = stage[slot];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -560,7 +564,12 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
         if (tid == 0) {                                 // the rows' counts become list offsets: one global atomic reserves the slots
             u32 run = 0;
             for (u32 i = 0; i < K1F_E * K1F_NW; i++) { const u32 c = S.misc[i]; S.misc[i] = run; run += c; }
-            const u32 base = run ? atomicAdd(&B.rcnt[b], run) : 0u;
+#ifdef K1F_EXPERIMENT_NOATOMIC
+            const u32 base = pos0 / 2u;    // (timing experiment only: wrong lists)
+            if (pos0 == 0 && run) atomicAdd(&K1_RCNT(B, 0, b), run);
+#else
+            const u32 base = run ? atomicAdd(&K1_RCNT(B, 0, b), run) : 0u;
+#endif
             for (u32 i = 0; i < K1F_E * K1F_NW; i++) S.misc[i] += base;
         }
     }
@@ -599,8 +608,16 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
 //            chain per candidate (k1f_acc_lt).  Cells past a leaf's end belong to later leaves - strictly greater keys - and
 //            behind the last rotation sit four all-ones cells: no bounds masks in the loop.
 //   stage 4  cells to their final places, heads = key differs from its predecessor's (one ballot per row of 64: no atomics).
-__device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, const u32* src, u32 cnt, u32 dm, bool wide) {
+#ifdef K1F_TRACE
+#define K1F_SSTAMP(slot) do { if (trs && tid == 0) { const long long now_ = clock64(); atomicAdd(&trs[K1_STAT_FRONT_BIG + 1 + (slot)], (u32)((now_ - tprev_) >> 8)); tprev_ = now_; } } while (0)
+#else
+#define K1F_SSTAMP(slot) do { } while (0)
+#endif
+__device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, const u32* src, u32 cnt, u32 dm, bool wide, u32* trs = nullptr) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
+#ifdef K1F_TRACE
+    long long tprev_ = clock64();
+#endif
     uint4* key = S.key;
     u32* sx = S.sx;
     u32 v[K1F_E];
@@ -628,6 +645,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
     u32 K = 1u;
     while (K < K1F_LK && cnt >= K1F_LEAF * K) K <<= 1;
     __syncthreads();
+    K1F_SSTAMP(0);
     u32 q[K1F_E];                                       // final position of the cell this thread ranks
     uint4 kk[K1F_E];
     u32 vv[K1F_E];
@@ -667,6 +685,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
             S.sp[tid] = sv;
         }
         __syncthreads();
+        K1F_SSTAMP(1);
         // stage 2: leaf of every rotation (number of splitters <= key), slot inside the leaf by an LDS counter
         u32 L[K1F_E];
 #pragma unroll
@@ -701,6 +720,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
                 sx[p] = v[it] | (leaf << K1F_LEAFSH);
             }
         __syncthreads();
+        K1F_SSTAMP(2);
         // stage 3: position i ranks its cell inside its leaf
 #pragma unroll
         for (int it = 0; it < K1F_E; it++) {
@@ -749,6 +769,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
         }
     }
     __syncthreads();
+    K1F_SSTAMP(3);
     // stage 4: cells to their final places; heads
 #pragma unroll
     for (int it = 0; it < K1F_E; it++)
@@ -764,6 +785,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
     }
     if (tid < 2u) S.hb[K1F_C / 32u + tid] = 0xFFFFFFFFu;
     __syncthreads();
+    K1F_SSTAMP(4);
 }
 
 // The __shared__ arrays of a bucket-sort workgroup and their views (macro: __shared__ must be declared in the kernel)
@@ -787,48 +809,75 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
 // oversize buckets (linear mode; cyclic mode with the text stages off).
 // `purerot_max`: with more rotations than this in one-key buckets (counted by k1f_scan) the text stages are skipped
 // altogether (CJS_DEEP_BIG_DIV = 8: HTML-like input, whose ties of hundreds of bytes prefix doubling settles faster).
+#ifndef K1F_BG
+#define K1F_BG 4u                                       // buckets a bucket-sort workgroup walks (power of two): neighbours are sorted TOGETHER while they fit
+#endif
+static_assert(K1F_NB % K1F_BG == 0, "bucket groups");
 __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
-    u32 b, d;
-    if (!xcd_block_tile(g.nb, b, d)) return;
+    u32 b, dg;
+    if (!xcd_block_tile(g.nb, b, dg)) return;
     const u32 n = B.nfront[b];
     if (n == 0) return;
     const u32* fs = B.fstart + (size_t)b * (K1F_NB + 1);
-    const u32 start = fs[d], end = fs[d + 1];
-    if (end <= start) return;
-    const u32 cnt = end - start;
     const u32 tid = threadIdx.x;
     const u8* T = B.T + (size_t)b * g.tstride;
-    const u32* SB = B.SB + (size_t)b * g.stride + start;
-    u32* SA = B.SA + (size_t)b * g.stride + start;
     u32* HN = B.HN + (size_t)b * g.hstride;
     const u64* sp = B.fsplit + (size_t)b * K1F_NB;
-    // a bucket between the splitters v and v+1 holds one key only
-    const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
-    if (cnt > K1F_CAP && (deepen || !pure)) {
-        // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB
-        if (tid == 0) {
-            k1f_push_task(B, 0u, b, start, cnt, (pure ? 8u : 0u) | K1F_TASK_SB);
-            if (!pure) atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
-            atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
-        }
-        return;
-    }
-    if (cnt == 1u || (pure && !deepen)) {
-        for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
-        k1f_write_heads(HN, start, end, [&](u32 p) { return p == start; });
-        if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (trace only)
-        return;
-    }
-    K1F_DECLARE_LDS(S)
-#ifdef K1F_TRACE
-    long long tprev_ = clock64();
-#endif
     const bool wide = deepen && iters != 0u;
-    k1f_sort128(S, T, n, SB, cnt, 0u, wide);
-    K1F_STAMP(3);
-    k1f_flush(S, B, g, b, start, cnt, deepen, 0u, wide ? K1F_KEYB : 8u);
-    K1F_STAMP(5);
+    K1F_DECLARE_LDS(S)
+    // Buckets are adjacent key ranges: the union of neighbours, sorted, is the neighbours sorted one after the other.  A workgroup
+    // walks K1F_BG buckets and sorts as many of them at once as its LDS holds (a 2048-quantile is 440 rotations, a slot 1020): twice
+    // the rotations per barrier and per dependent load of the sort.
+    const u32* fsv = fs + dg * K1F_BG;                  // (wave-uniform: scalar loads)
+    for (u32 j = 0; j < K1F_BG;) {
+        const u32 d = dg * K1F_BG + j;
+        const u32 start = fsv[j];
+        u32 cnt = fsv[j + 1] - start;
+        if (cnt == 0u) { j++; continue; }
+        // a bucket between the splitters v and v+1 holds one key only
+        const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
+        if (cnt > K1F_CAP && (deepen || !pure)) {
+            // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB
+            if (tid == 0) {
+                k1f_push_task(B, 0u, b, start, cnt, (pure ? 8u : 0u) | K1F_TASK_SB);
+                if (!pure) atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
+                atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
+            }
+            j++;
+            continue;
+        }
+        const u32* SB = B.SB + (size_t)b * g.stride + start;
+        if (pure && !deepen) {
+            // one 8-byte key and no text stage behind this one: a single group as it stands
+            u32* SA = B.SA + (size_t)b * g.stride + start;
+            for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
+            k1f_write_heads(HN, start, start + cnt, [&](u32 p) { return p == start; });
+            if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (trace only)
+            j++;
+            continue;
+        }
+        // the neighbours that fit as well (never a one-key bucket that is to stay one group)
+        u32 je = j + 1u;
+#ifndef K1F_MERGE
+#define K1F_MERGE 1
+#endif
+        while (K1F_MERGE && je < K1F_BG && fsv[je + 1] - start <= K1F_CAP) {
+            const u32 d2 = dg * K1F_BG + je;
+            const bool pure2 = d2 < K1F_NB - 1u && sp[d2] == sp[d2 - 1u] + 1u;
+            if (pure2 && !deepen) break;
+            je++;
+        }
+        cnt = fsv[je] - start;
+        if (j) __syncthreads();                         // (the previous sort's flush still reads the LDS arrays)
+        k1f_sort128(S, T, n, SB, cnt, 0u, wide, B.stats);
+#ifdef K1F_TRACE
+        long long tprev_ = clock64();
+#endif
+        k1f_flush(S, B, g, b, start, cnt, deepen, 0u, wide ? K1F_KEYB : 8u);
+        K1F_STAMP(5);
+        j = je;
+    }
 }
 
 // The task levels: slices that a bucket-sort workgroup could not finish in LDS.  Level L reads the tasks level L - 1 (or
@@ -1078,7 +1127,7 @@ static_assert(K1R_ROWS % 4u == 0 && K1R_SW <= 64u && K1F_GBIG <= 256u, "rows are
 __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g, u32 round, u32 depth, u32 final_host) {
     u32 b, t0;
     if (!xcd_block_tile(g.nb, b, t0)) return;
-    u32 cnt = B.rcnt[(size_t)round * B.rstride + b];
+    u32 cnt = K1_RCNT(B, round, b);
     if (cnt > g.stride) cnt = g.stride;
     if (t0 * K1R_T >= cnt) return;
     // The last round of a block is the one the host launched last - or the first one that finds its list (nearly) as long as
@@ -1090,13 +1139,13 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     u32 final = final_host;
     const u32 n = B.nfront[b];
     if (round >= 1u && cnt >= n / 16u) {
-        const u32 prev = B.rcnt[(size_t)(round - 1u) * B.rstride + b];
+        const u32 prev = K1_RCNT(B, round - 1u, b);
         if ((u64)cnt * 8u > (u64)prev * 7u) final = 1u;
     }
     const u8* T = B.T + (size_t)b * g.tstride;
     const u64* Lin = B.rlist[round & 1u] + (size_t)b * g.stride;
     u64* Lout = B.rlist[(round & 1u) ^ 1u] + (size_t)b * g.stride;
-    u32* ocnt = B.rcnt + (size_t)(round + 1u) * B.rstride + b;
+    u32* ocnt = &K1_RCNT(B, round + 1u, b);
     u32* SA = B.SA + (size_t)b * g.stride;
     u32* HN = B.HN + (size_t)b * g.hstride;
     __shared__ u64 kA[K1R_N + 2], kB[K1R_N + 2], kC[K1R_N + 2];   // (+2: the ranking loop reads cells in pairs, one past a group's end)
@@ -1300,7 +1349,7 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
     hipLaunchKernelGGL(k1f_scatter, dim3(ptiles, nb8), dim3(1024), 0, stream, B, g, ptiles);
     {
         const u32 slot = k1_prof_begin(B.prof, K1P_BSORT, stream);
-        hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max);
+        hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB / K1F_BG, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max);
         k1_prof_end(B.prof, slot, stream, (u64)g.nb * max_n);
     }
     // the task levels: what k1f_bsort could not finish in LDS (slices beyond K1F_C, big groups), level after level; an empty
