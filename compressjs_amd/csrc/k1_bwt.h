@@ -11,7 +11,10 @@
 #ifndef K1_RCS
 #define K1_RCS 32u              // words between two blocks' list counters (rcnt): one 128-byte line each - the counters of the blocks the 8 XCDs work on at the
 #endif                          // same time shared a line, and device-scope atomics on one line are serialised in the fabric (round 5)
-#define K1_RCNT(B, round, b) ((B).rcnt[((size_t)(round) * (B).rstride + (b)) * K1_RCS])
+// per-block counters of the doubling rounds (dcnt, dchg, dtot, dred): block b's word sits at K1_BI(B, b) of its row - the blocks one XCD works on
+// (b mod 8) share lines, blocks of different XCDs never do (rstride = 8 groups of >= 32 words)
+#define K1_BI(B, b) (((b) & 7u) * ((B).rstride >> 3) + ((b) >> 3))
+#define K1_RCNT(B, round, b) ((B).rcnt[((size_t)(round) * (B).rnb8 + (b)) * K1_RCS])
 #ifndef K1F_LEVELS
 #define K1F_LEVELS 14u
 #endif
@@ -115,8 +118,9 @@ struct K1Buf {
     u64* listL[2];    // ... of more than K1_MED_MAX
     u32 listTCap, listSCap, listMCap, listLCap;
     u64* rlist[2];    // [nb][stride]   entry lists: refinement rounds (in/out), doubling rounds ([0] the round's list, [1] its re-ordered copy)
-    u32* rcnt;        // [K1R_MAXR + 1][rstride][K1_RCS]  refinement rounds: entries per round and block (K1_RCNT)
-    u32 rstride;
+    u32* rcnt;        // [K1R_MAXR + 1][nb8][K1_RCS]  refinement rounds: entries per round and block (K1_RCNT)
+    u32 rstride;      // words per row of dcnt / dchg (and of dtot, dred): 8 x (nb8 / 8 rounded up to 32), indexed by K1_BI
+    u32 rnb8;         // blocks rounded up to 8: row length of rcnt (in counters)
     u32* dcnt;        // [K1D_MAXR + 2][rstride]  doubling rounds: list entries per round and block
     u32* dchg;        // [K1D_MAXR + 2][rstride]  != 0: a group of the block split in that round (none: only identical rotations are left)
     u32* dtot;        // [rstride]                positions in unsorted groups per block before the doubling rounds (k1_count_unsorted)

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0 && gid < K1_STATS) B.stats[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 4u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
-    if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rstride * K1_RCS; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
+    if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rnb8 * K1_RCS; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
     if (b == 0 && gid < K1F_LEVELS) B.bcnt[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 2u * (K1D_MAXR + 2u) * B.rstride + 2u * B.rstride + (K1D_MAXR + 2u) * 4u; i += gridDim.x * blockDim.x) B.dcnt[i] = 0;   // dcnt, dchg, dtot, dbn, dred (contiguous)
     if (gid < g.hstride) {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k1_count_unsorted(K1Buf B, BatchGeom g) {
     __syncthreads();
     if (threadIdx.x == 0) {
         const u32 t = part[0] + part[1] + part[2] + part[3];
-        if (t) atomicAdd(&B.dtot[b], t);                  // per block (at most ~110 adds per word)
+        if (t) atomicAdd(&B.dtot[K1_BI(B, b)], t);                  // per block (at most ~110 adds per word)
     }
 }
 
@@ -350,7 +350,9 @@ template <class F>
 static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     const size_t e = (size_t)g.nb * g.stride;
     const u32 nb8 = (g.nb + 7u) & ~7u;
-    B.rstride = nb8;
+    B.rnb8 = nb8;
+    B.rstride = 8u * ((nb8 / 8u + 31u) & ~31u);
+    const u32 rs = B.rstride;
     B.listTCap = g.nb * (g.stride / K1D_GS);                // descriptors of groups of K1D_GS+1 .. 1024 rotations
     B.listSCap = g.nb * (g.stride / 8u);                    // lane kernels' lists (8 XCD regions x K1_DEEP_SUB sub-regions); chunks of large groups
     B.listMCap = g.nb * (g.stride / 1024u + 1u);            // descriptors of groups of 1025 .. K1_MED_MAX
@@ -373,16 +375,16 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     for (int k = 0; k < 2; k++) take((void**)&B.listL[k], (size_t)B.listLCap * 8);
     for (int k = 0; k < 2; k++) take((void**)&B.rlist[k], e * 8);
     take((void**)&B.rcnt, (size_t)(K1R_MAXR + 1) * nb8 * K1_RCS * 4);
-    take((void**)&B.dcnt, ((size_t)(2u * (K1D_MAXR + 2u) + 2u) * nb8 + (K1D_MAXR + 2u) * 4u) * 4);      // dcnt, dchg, dtot, dbn, dred (contiguous: zeroed as one; dtot .. dred read back as one)
+    take((void**)&B.dcnt, ((size_t)(2u * (K1D_MAXR + 2u) + 2u) * rs + (K1D_MAXR + 2u) * 4u) * 4);      // dcnt, dchg, dtot, dbn, dred (contiguous: zeroed as one; dtot .. dred read back as one)
     take((void**)&B.btask, (size_t)K1F_LEVELS * B.btaskCap * sizeof(uint4));
     take((void**)&B.bcnt, 256);
     take((void**)&B.nfront, (size_t)nb8 * 4);
     take((void**)&B.per, (size_t)nb8 * 4);
     take((void**)&B.ptab, (size_t)g.nb * 256 * 4);
     take((void**)&B.red, (size_t)nb8 * 4);
-    B.dchg = B.dcnt ? B.dcnt + (size_t)(K1D_MAXR + 2u) * nb8 : nullptr;
-    B.dtot = B.dcnt ? B.dchg + (size_t)(K1D_MAXR + 2u) * nb8 : nullptr;
-    B.dbn = B.dcnt ? B.dtot + nb8 : nullptr;
+    B.dchg = B.dcnt ? B.dcnt + (size_t)(K1D_MAXR + 2u) * rs : nullptr;
+    B.dtot = B.dcnt ? B.dchg + (size_t)(K1D_MAXR + 2u) * rs : nullptr;
+    B.dbn = B.dcnt ? B.dtot + rs : nullptr;
     B.dred = B.dcnt ? B.dbn + (K1D_MAXR + 2u) * 4u : nullptr;
 }
 
@@ -505,7 +507,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         const int rc = k1_rounds_run(B, g, stream, depth0, K.text_bytes);
         if (rc) return rc;
         if (K.trace) {
-            std::vector<u32> rc2((size_t)(K1R_MAXR + 1) * B.rstride * K1_RCS);
+            std::vector<u32> rc2((size_t)(K1R_MAXR + 1) * B.rnb8 * K1_RCS);
             u32 rt[8];
             HIP_CHECK_RET(hipMemcpyAsync(rc2.data(), B.rcnt, rc2.size() * 4, hipMemcpyDeviceToHost, stream));
             HIP_CHECK_RET(hipMemcpyAsync(rt, B.stats + K1_STAT_RTRACE, sizeof rt, hipMemcpyDeviceToHost, stream));
@@ -513,7 +515,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             fprintf(stderr, "[k1] refinement rounds, entries per round:");
             for (u32 r = 0; r <= K1R_MAXR; r++) {
                 u64 tot = 0;
-                for (u32 bb = 0; bb < g.nb; bb++) tot += rc2[((size_t)r * B.rstride + bb) * K1_RCS];
+                for (u32 bb = 0; bb < g.nb; bb++) tot += rc2[((size_t)r * B.rnb8 + bb) * K1_RCS];
                 if (!tot) break;
                 fprintf(stderr, " %llu", (unsigned long long)tot);
             }
@@ -543,7 +545,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     if (K.sync && !B.linear) {
         // (ONE copy - dtot, dbn and dred lie behind one another -, into pinned memory when the caller has some: a second pageable copy was
         // issued 65 us after the first on the kernel timeline)
-        const size_t words = (size_t)(B.dred - B.dtot) + g.nb;
+        const size_t words = (size_t)(B.dred - B.dtot) + B.rstride;
         std::vector<u32> pageable;
         u32* tt = B.hpin;
         if (!tt || words > B.hpinWords) { pageable.resize(words); tt = pageable.data(); }
@@ -551,7 +553,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         HIP_CHECK_RET(hipStreamSynchronize(stream));
         any_group = any_red = false;
         const u32* dr = tt + (B.dred - B.dtot);
-        for (u32 bb = 0; bb < g.nb; bb++) { any_group = any_group || tt[bb] != 0u; any_red = any_red || dr[bb] != 0u; }
+        for (u32 bb = 0; bb < B.rstride; bb++) { any_group = any_group || tt[bb] != 0u; any_red = any_red || dr[bb] != 0u; }   // (any order: K1_BI)
     }
     if (any_group) {
         const int rc = k1_dbl_run(B, g, max_n, stream, d0, K.sync ? K.check_h : 0u);
@@ -565,11 +567,11 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         HIP_CHECK_RET(hipMemcpyAsync(tt.data(), B.dtot, tt.size() * 4, hipMemcpyDeviceToHost, stream));
         HIP_CHECK_RET(hipStreamSynchronize(stream));
         u64 un = 0;
-        for (u32 bb = 0; bb < g.nb; bb++) un += tt[bb];
+        for (u32 bb = 0; bb < B.rstride; bb++) un += tt[bb];
         fprintf(stderr, "[k1] rotations in unsorted groups before the doubling rounds: %llu (of %llu); per round entries / medium (<= 1024 + larger) / large / chunks:", (unsigned long long)un, (unsigned long long)total_n);
         for (u32 r = 0; r < K1D_MAXR + 1u; r++) {
             u64 e = 0;
-            for (u32 bb = 0; bb < g.nb; bb++) e += cn[(size_t)r * B.rstride + bb];
+            for (u32 bb = 0; bb < B.rstride; bb++) e += cn[(size_t)r * B.rstride + bb];
             if (!e && !dc[r * 4] && !dc[r * 4 + 1] && !dc[r * 4 + 3]) break;
             fprintf(stderr, " [%u] %llu/%u+%u/%u/%u", r, (unsigned long long)e, dc[r * 4 + 3], dc[r * 4], dc[r * 4 + 1], dc[r * 4 + 2]);
             rounds_with_work = (int)r + 1;

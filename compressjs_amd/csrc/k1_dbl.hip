@@ -75,12 +75,12 @@ __device__ __forceinline__ K1dSeq k1d_seq(u32 nb, u32 b0) {
     return q;
 }
 // tpre[i] = tiles of the slots before slot i; returns their sum.  Every thread of the workgroup must call it.
-__device__ __forceinline__ u32 k1d_tile_prefix(const u32* cnt_row, const K1dSeq& q, u32 stride, u32* tpre, u32* scr) {
+__device__ __forceinline__ u32 k1d_tile_prefix(const K1Buf& B, const u32* cnt_row, const K1dSeq& q, u32 stride, u32* tpre, u32* scr) {
     const u32 tid = threadIdx.x;
     u32 carry = 0;
     for (u32 c0 = 0; c0 < q.slots; c0 += 256u) {
         u32 c = 0;
-        if (c0 + tid < q.slots) { c = cnt_row[q.first + q.step * (c0 + tid)]; if (c > stride) c = stride; c = (c + K1D_T - 1u) / K1D_T; }
+        if (c0 + tid < q.slots) { c = cnt_row[K1_BI(B, q.first + q.step * (c0 + tid))]; if (c > stride) c = stride; c = (c + K1D_T - 1u) / K1D_T; }
         const u32 ex = block_excl_scan_256(c, scr);
         if (c0 + tid < q.slots) tpre[c0 + tid] = carry + ex;
         __syncthreads();
@@ -131,7 +131,7 @@ __device__ __forceinline__ bool k1d_tie_pos(u32 n, u32 start, u32 L, u32 s, u32&
     return p * L == n && s / p < L;        // (always; a group that is no such class falls back to the sort)
 }
 __device__ __forceinline__ u32 k1d_mode(const K1Buf& B, u32 r, u32 b, u32 final_h) {
-    return (final_h || (r > 0u && B.dchg[(size_t)(r - 1u) * B.rstride + b] == 0u)) ? 1u : 0u;
+    return (final_h || (r > 0u && B.dchg[(size_t)(r - 1u) * B.rstride + K1_BI(B, b)] == 0u)) ? 1u : 0u;
 }
 
 // Barrier of the kernels below that exchange data through LDS only (k1d_window, k1d_med, k1d_update's list walk): __syncthreads()
@@ -293,7 +293,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
         const u32 inc = wave_incl_scan_u32(c);
         if (lane < K1D_FW) pre[lane] = inc - c;
         const u32 total = (u32)__shfl((int)inc, 63);
-        if (lane == 0) sbase = total ? atomicAdd(&B.dcnt[(size_t)r * B.rstride + b], total) : 0u;
+        if (lane == 0) sbase = total ? atomicAdd(&B.dcnt[(size_t)r * B.rstride + K1_BI(B, b)], total) : 0u;
     }
     K1D_SYNC();
     u64* L = B.rlist[0] + (size_t)b * g.stride;
@@ -311,7 +311,7 @@ __device__ __forceinline__ void k1d_window(const K1Buf& B, const BatchGeom& g, u
 __global__ __launch_bounds__(256) void k1d_build(K1Buf B, BatchGeom g) {
     const u32 b = blockIdx.y, n = B.nfront[b];
     const u32 lo = blockIdx.x * K1D_T;
-    if (lo >= n || (B.dtot[b] == 0u && !B.linear)) return;          // (linear mode: k1_finish_linear reads the rank of suffix 0)
+    if (lo >= n || (B.dtot[K1_BI(B, b)] == 0u && !B.linear)) return;          // (linear mode: k1_finish_linear reads the rank of suffix 0)
     k1d_window<true>(B, g, b, lo, n - lo < K1D_T ? n - lo : K1D_T, K1D_WIN, 0u);
 }
 
@@ -336,11 +336,11 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
     for (u32 b0 = 0; b0 < g.nb; b0 += 8u * K1D_NBW) {
         const K1dSeq q = k1d_seq(g.nb, b0);
         const u32 G = q.nwg;
-        const u32 ntile = k1d_tile_prefix(cnt_row, q, g.stride, tpre, scr);
+        const u32 ntile = k1d_tile_prefix(B, cnt_row, q, g.stride, tpre, scr);
         if (q.wg >= ntile) continue;                        // (uniform)
         if (tid < q.slots) {
             const u32 bb = q.first + q.step * tid, nn = B.nfront[bb];
-            s_cnt[tid] = cnt_row[bb] < g.stride ? cnt_row[bb] : g.stride;
+            s_cnt[tid] = cnt_row[K1_BI(B, bb)] < g.stride ? cnt_row[K1_BI(B, bb)] : g.stride;
             s_n[tid] = nn;
             s_hm[tid] = nn ? (h >> 32 ? (u32)(h % nn) : (u32)h % nn) : 0u;
             s_mode[tid] = k1d_mode(B, r, bb, final_h);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
                     changed |= eqt != K1E_LEN(eC[it]) ? 1u : 0u;
                 }
             }
-            if (__ballot(changed != 0u) && lane == 0) atomicOr(&B.dchg[(size_t)r * B.rstride + tC.b], 1u);
+            if (__ballot(changed != 0u) && lane == 0) atomicOr(&B.dchg[(size_t)r * B.rstride + K1_BI(B, tC.b)], 1u);
             lds_barrier();
 #pragma unroll
             for (u32 it = 0; it < K1D_RPT; it++) { eC[it] = eN[it]; eN[it] = eNN[it]; kC[it] = kN[it]; }
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
                     else if (slv[c] > K1D_GS && hpv[c] == i) k1d_push_big(B, r + 1u, b, start + i, slv[c]);
                 }
             }
-            if (__ballot(split) && lane == 0u) atomicOr(&B.dchg[(size_t)r * B.rstride + b], 1u);
+            if (__ballot(split) && lane == 0u) atomicOr(&B.dchg[(size_t)r * B.rstride + K1_BI(B, b)], 1u);
             const u32 inc = wave_incl_scan_u32(mine);
             K1D_SYNC();
             if (lane == 63u) wh[1][w] = inc;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void k1d_med(K1Buf B, BatchGeom g, u32 r, u64 
             for (u32 ww = 0; ww < w; ww++) slot += wh[1][ww];
             if (tid == 255u) {
                 const u32 total = slot + mine;
-                sbase = total ? atomicAdd(&B.dcnt[(size_t)(r + 1u) * B.rstride + b], total) : 0u;
+                sbase = total ? atomicAdd(&B.dcnt[(size_t)(r + 1u) * B.rstride + K1_BI(B, b)], total) : 0u;
             }
             K1D_SYNC();
             u64* L = B.rlist[0] + (size_t)b * g.stride;
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(1024) void k1d_large(K1Buf B, BatchGeom g, u32 r, u
             __syncthreads();
         }
         if (tid == 0) KB[s_carry - 1u] = L - (s_carry - 1u);            // the last sub-group
-        if (__ballot(split) && lane == 0) atomicOr(&B.dchg[(size_t)r * B.rstride + b], 1u);
+        if (__ballot(split) && lane == 0) atomicOr(&B.dchg[(size_t)r * B.rstride + K1_BI(B, b)], 1u);
         __threadfence_block();
         k1d_push_chunks(B, r, b, start, L);
     }
@@ -916,14 +916,14 @@ __global__ __launch_bounds__(256) void k1d_update(K1Buf B, BatchGeom g, u32 r) {
     const u32* cnt_row = B.dcnt + (size_t)r * B.rstride;
     for (u32 b0 = 0; b0 < g.nb; b0 += 8u * K1D_NBW) {
         const K1dSeq q = k1d_seq(g.nb, b0);
-        const u32 ntile = k1d_tile_prefix(cnt_row, q, g.stride, tpre, scr);
+        const u32 ntile = k1d_tile_prefix(B, cnt_row, q, g.stride, tpre, scr);
         auto load = [&](u32 f, u32& b, u32& e0, u32& cnt, u64 (&e)[K1D_RPT]) {
             b = 0; e0 = 0; cnt = 0;
             if (f < ntile) {
                 const u32 i = k1d_tile_block(tpre, q.slots, f);
                 b = q.first + q.step * i;
                 e0 = (f - tpre[i]) * K1D_T;
-                cnt = cnt_row[b] < g.stride ? cnt_row[b] : g.stride;
+                cnt = cnt_row[K1_BI(B, b)] < g.stride ? cnt_row[K1_BI(B, b)] : g.stride;
             }
             const u64* Lt = B.rlist[1] + (size_t)b * g.stride;
 #pragma unroll
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(256) void k1d_update(K1Buf B, BatchGeom g, u32 r) {
                 const u32 inc = wave_incl_scan_u32(c);
                 if (lane < K1D_FW) pre[lane] = inc - c;
                 const u32 total = (u32)__shfl((int)inc, 63);
-                if (lane == 0) obase = total ? atomicAdd(&B.dcnt[(size_t)(r + 1u) * B.rstride + b], total) : 0u;
+                if (lane == 0) obase = total ? atomicAdd(&B.dcnt[(size_t)(r + 1u) * B.rstride + K1_BI(B, b)], total) : 0u;
             }
             K1D_SYNC();
 #pragma unroll

@@ -459,6 +459,52 @@ __device__ __forceinline__ void k1f_acc_lt(u32& less, const uint4& c, u32 j, con
 #endif
 }
 
+// 8-byte keys (the bucket sort without text stages behind it: linear mode, HTML-like input): two big-endian dwords in a uint2
+__device__ __forceinline__ uint2 k1f_load_be64x2(const u8* T, u32 p) {
+    const u32 sh = p & 3u;
+    u32 d[3];
+    __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 12);
+    return make_uint2(__builtin_bswap32(__builtin_amdgcn_alignbyte(d[1], d[0], sh)), __builtin_bswap32(__builtin_amdgcn_alignbyte(d[2], d[1], sh)));
+}
+__device__ __forceinline__ void k1f_acc_lt64(u32& less, const uint2& c, u32 j, const uint2& m, u32 i) {
+#if defined(__AMDGCN__)
+    u32 t;
+    asm("v_cmp_lt_u32 vcc, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
+        "v_addc_co_u32 %0, vcc, 0, %0, vcc"
+        : "+v"(less), "=&v"(t)
+        : "v"(j), "v"(i), "v"(c.y), "v"(m.y), "v"(c.x), "v"(m.x)
+        : "vcc");
+#else
+    const u64 cc = ((u64)c.x << 32) | c.y, mm = ((u64)m.x << 32) | m.y;
+    less += (cc < mm || (cc == mm && j < i)) ? 1u : 0u;
+#endif
+}
+// the two key widths of the bucket sort behind one interface
+struct K1fK16 {
+    typedef uint4 T;
+    static __device__ __forceinline__ T load(const u8* Tx, u32 p) { return k1f_load_be128(Tx, p); }
+    static __device__ __forceinline__ T zero() { return make_uint4(0u, 0u, 0u, 0u); }
+    static __device__ __forceinline__ T ones() { return make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); }
+    static __device__ __forceinline__ bool eq(const T& a, const T& b) { return k1f_eq128(a, b); }
+    static __device__ __forceinline__ bool lt(const T& a, const T& b) { return k1f_lt128(a, b); }
+    static __device__ __forceinline__ bool is_ones(const T& a) { return k1f_ones128(a); }
+    static __device__ __forceinline__ T inc(const T& a) { return k1f_inc128(a); }
+    static __device__ __forceinline__ void acc_lt(u32& less, const T& c, u32 j, const T& m, u32 i) { k1f_acc_lt(less, c, j, m, i); }
+};
+struct K1fK8 {
+    typedef uint2 T;
+    static __device__ __forceinline__ T load(const u8* Tx, u32 p) { return k1f_load_be64x2(Tx, p); }
+    static __device__ __forceinline__ T zero() { return make_uint2(0u, 0u); }
+    static __device__ __forceinline__ T ones() { return make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu); }
+    static __device__ __forceinline__ bool eq(const T& a, const T& b) { return ((a.x ^ b.x) | (a.y ^ b.y)) == 0u; }
+    static __device__ __forceinline__ bool lt(const T& a, const T& b) { return (((u64)a.x << 32) | a.y) < (((u64)b.x << 32) | b.y); }
+    static __device__ __forceinline__ bool is_ones(const T& a) { return (a.x & a.y) == 0xFFFFFFFFu; }
+    static __device__ __forceinline__ T inc(T a) { a.y += 1u; if (a.y == 0u) a.x += 1u; return a; }
+    static __device__ __forceinline__ void acc_lt(u32& less, const T& c, u32 j, const T& m, u32 i) { k1f_acc_lt64(less, c, j, m, i); }
+};
+
 // largest head position <= q / smallest head position > q in an LDS bitmap whose bit 0 and every bit >= cnt are set
 __device__ __forceinline__ u32 k1f_prev_head(const u32* hb, u32 q) {
     u32 w = q >> 5;
@@ -613,15 +659,19 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
 #else
 #define K1F_SSTAMP(slot) do { } while (0)
 #endif
-__device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, const u32* src, u32 cnt, u32 dm, bool wide, u32* trs = nullptr) {
+template <class KT>
+__device__ __forceinline__ void k1f_sortk(const K1fL& S, const u8* T, u32 n, const u32* src, u32 cnt, u32 dm, u32* trs = nullptr) {
+    typedef typename KT::T KeyT;
+    KeyT* key = (KeyT*)S.key;
+    KeyT* smpk = (KeyT*)S.smp;
+    KeyT* spk = (KeyT*)S.sp;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
 #ifdef K1F_TRACE
     long long tprev_ = clock64();
 #endif
-    uint4* key = S.key;
     u32* sx = S.sx;
     u32 v[K1F_E];
-    uint4 k[K1F_E];
+    KeyT k[K1F_E];
 #pragma unroll
     for (int it = 0; it < K1F_E; it++) {
         const u32 i = (u32)it * K1F_BT + tid;
@@ -632,57 +682,56 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
         const u32 i = (u32)it * K1F_BT + tid;
         u32 p = v[it] + dm;
         if (p >= n) p -= n;
-        k[it] = i < cnt ? k1f_load_be128(T, p) : make_uint4(0u, 0u, 0u, 0u);
-        if (!wide) { k[it].z = 0u; k[it].w = 0u; }
+        k[it] = i < cnt ? KT::load(T, p) : KT::zero();
     }
 #pragma unroll
     for (int it = 0; it < K1F_E; it++) {
         const u32 i = (u32)it * K1F_BT + tid;
         if (i < cnt) key[i] = k[it];
     }
-    if (tid < 4u) key[cnt + tid] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (tid < 4u) key[cnt + tid] = KT::ones();
     if (tid < K1F_LK) S.cnt2[tid] = 0;
     u32 K = 1u;
     while (K < K1F_LK && cnt >= K1F_LEAF * K) K <<= 1;
     __syncthreads();
     K1F_SSTAMP(0);
     u32 q[K1F_E];                                       // final position of the cell this thread ranks
-    uint4 kk[K1F_E];
+    KeyT kk[K1F_E];
     u32 vv[K1F_E];
     if (K > 1u) {
         // stage 1: LS = LOVS * K samples (stratified over the arrival order), ranked by counting
         const u32 LS = K1F_LOVS * K;
-        uint4 mys = make_uint4(0u, 0u, 0u, 0u);
-        if (tid < LS) { mys = key[(u32)((u64)tid * cnt / LS)]; S.smp[tid] = mys; S.srank[tid] = 0; }
+        KeyT mys = KT::zero();
+        if (tid < LS) { mys = key[(u32)((u64)tid * cnt / LS)]; smpk[tid] = mys; S.srank[tid] = 0; }
         __syncthreads();
         {   // thread t ranks sample t % LS against one `parts`-th of the samples, partial ranks summed in LDS
             const u32 parts = K1F_BT / LS > LS ? LS : K1F_BT / LS, si = tid % LS, part = tid / LS;   // powers of two; LS <= K1F_BT
             if (part < parts) {
-                const uint4 mine = S.smp[si];
+                const KeyT mine = smpk[si];
                 const u32 per = LS / parts, j0 = part * per;
                 u32 r = 0;
                 if (per >= 4u) {
                     for (u32 j = j0; j < j0 + per; j += 4u) {
-                        uint4 c[4];
+                        KeyT c[4];
 #pragma unroll
-                        for (u32 u = 0; u < 4u; u++) c[u] = S.smp[j + u];
+                        for (u32 u = 0; u < 4u; u++) c[u] = smpk[j + u];
 #pragma unroll
-                        for (u32 u = 0; u < 4u; u++) k1f_acc_lt(r, c[u], j + u, mine, si);
+                        for (u32 u = 0; u < 4u; u++) KT::acc_lt(r, c[u], j + u, mine, si);
                     }
                 } else {
-                    for (u32 j = j0; j < j0 + per; j++) k1f_acc_lt(r, S.smp[j], j, mine, si);
+                    for (u32 j = j0; j < j0 + per; j++) KT::acc_lt(r, smpk[j], j, mine, si);
                 }
                 atomicAdd(&S.srank[si], r);
             }
         }
         __syncthreads();
-        if (tid < LS) S.smp[S.srank[tid]] = mys;        // (every read of the unsorted samples is behind the barrier)
+        if (tid < LS) smpk[S.srank[tid]] = mys;        // (every read of the unsorted samples is behind the barrier)
         __syncthreads();
         if (tid + 1u < K) {                             // splitters; equal neighbours: the heavy-key rule
-            const uint4 qq = S.smp[(tid + 1u) * K1F_LOVS];
-            uint4 sv = qq;
-            if (tid >= 1u && k1f_eq128(S.smp[tid * K1F_LOVS], qq) && !k1f_ones128(qq)) sv = k1f_inc128(qq);
-            S.sp[tid] = sv;
+            const KeyT qq = smpk[(tid + 1u) * K1F_LOVS];
+            KeyT sv = qq;
+            if (tid >= 1u && KT::eq(smpk[tid * K1F_LOVS], qq) && !KT::is_ones(qq)) sv = KT::inc(qq);
+            spk[tid] = sv;
         }
         __syncthreads();
         K1F_SSTAMP(1);
@@ -695,7 +744,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
             if (i < cnt) {
                 u32 pos = 0;
                 for (u32 step = K >> 1; step >= 1u; step >>= 1)
-                    if (!k1f_lt128(k[it], S.sp[pos + step - 1u])) pos += step;
+                    if (!KT::lt(k[it], spk[pos + step - 1u])) pos += step;
                 L[it] = (pos << 16) | atomicAdd(&S.cnt2[pos], 1u);
             }
         }
@@ -704,7 +753,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
             const u32 c = lane < K ? S.cnt2[lane] : 0u;
             const u32 inc = wave_incl_scan_u32(c);
             bool pure = false;
-            if (lane >= 1u && lane + 1u < K) pure = k1f_eq128(S.sp[lane], k1f_inc128(S.sp[lane - 1u]));
+            if (lane >= 1u && lane + 1u < K) pure = KT::eq(spk[lane], KT::inc(spk[lane - 1u]));
             __builtin_amdgcn_wave_barrier();
             if (lane < K1F_LK) S.off2[lane] = lane < K ? ((inc - c) | (pure ? 0x80000000u : 0u)) : cnt;
             if (lane == 0) S.off2[K1F_LK] = cnt;
@@ -729,17 +778,17 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
             if (i < cnt) {
                 const u32 vl = sx[i], leaf = vl >> K1F_LEAFSH;
                 const u32 oo = S.off2[leaf], o = oo & 0x7FFFFFFFu, e = S.off2[leaf + 1u] & 0x7FFFFFFFu;
-                const uint4 mine = key[i];
+                const KeyT mine = key[i];
                 kk[it] = mine;
                 vv[it] = vl & ((1u << K1F_LEAFSH) - 1u);
                 u32 less = 0;
                 if (!(oo >> 31)) {
                     for (u32 j = o; j < e; j += 4u) {
-                        uint4 c[4];
+                        KeyT c[4];
 #pragma unroll
                         for (u32 u = 0; u < 4u; u++) c[u] = key[j + u];
 #pragma unroll
-                        for (u32 u = 0; u < 4u; u++) k1f_acc_lt(less, c[u], j + u, mine, i);
+                        for (u32 u = 0; u < 4u; u++) KT::acc_lt(less, c[u], j + u, mine, i);
                     }
                 } else {
                     less = i - o;
@@ -758,11 +807,11 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
                 vv[it] = v[it];
                 u32 less = 0;
                 for (u32 j = 0; j < cnt; j += 4u) {
-                    uint4 c[4];
+                    KeyT c[4];
 #pragma unroll
                     for (u32 u = 0; u < 4u; u++) c[u] = key[j + u];
 #pragma unroll
-                    for (u32 u = 0; u < 4u; u++) k1f_acc_lt(less, c[u], j + u, k[it], i);
+                    for (u32 u = 0; u < 4u; u++) KT::acc_lt(less, c[u], j + u, k[it], i);
                 }
                 q[it] = less;
             }
@@ -779,13 +828,18 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
     for (int it = 0; it < K1F_E; it++) {
         const u32 r0 = (u32)it * K1F_BT + w * 64u, p = r0 + lane;
         bool head = true;
-        if (p < cnt && p > 0u) head = !k1f_eq128(key[p], key[p - 1u]);
+        if (p < cnt && p > 0u) head = !KT::eq(key[p], key[p - 1u]);
         const u64 bal = __ballot(head);
         if (lane == 0) { S.hb[r0 >> 5] = (u32)bal; S.hb[(r0 >> 5) + 1u] = (u32)(bal >> 32); }
     }
     if (tid < 2u) S.hb[K1F_C / 32u + tid] = 0xFFFFFFFFu;
     __syncthreads();
     K1F_SSTAMP(4);
+}
+
+__device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, const u32* src, u32 cnt, u32 dm, bool wide, u32* trs = nullptr) {
+    if (wide) k1f_sortk<K1fK16>(S, T, n, src, cnt, dm, trs);
+    else k1f_sortk<K1fK8>(S, T, n, src, cnt, dm, trs);
 }
 
 // The __shared__ arrays of a bucket-sort workgroup and their views (macro: __shared__ must be declared in the kernel)
@@ -810,7 +864,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
 // `purerot_max`: with more rotations than this in one-key buckets (counted by k1f_scan) the text stages are skipped
 // altogether (CJS_DEEP_BIG_DIV = 8: HTML-like input, whose ties of hundreds of bytes prefix doubling settles faster).
 #ifndef K1F_BG
-#define K1F_BG 4u                                       // buckets a bucket-sort workgroup walks (power of two): neighbours are sorted TOGETHER while they fit
+#define K1F_BG 1u                                       // buckets a bucket-sort workgroup walks (power of two; 1: measured best, see below): neighbours are sorted TOGETHER while they fit
 #endif
 static_assert(K1F_NB % K1F_BG == 0, "bucket groups");
 __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
@@ -827,8 +881,10 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     const bool wide = deepen && iters != 0u;
     K1F_DECLARE_LDS(S)
     // Buckets are adjacent key ranges: the union of neighbours, sorted, is the neighbours sorted one after the other.  A workgroup
-    // walks K1F_BG buckets and sorts as many of them at once as its LDS holds (a 2048-quantile is 440 rotations, a slot 1020): twice
-    // the rotations per barrier and per dependent load of the sort.
+    // may walk K1F_BG buckets and sort as many of them at once as its LDS holds (a 2048-quantile is 440 rotations, a slot 1020): twice
+    // the rotations per barrier and per dependent load of the sort.  Measured (round 5, enwik, ms for the kernel): one bucket per
+    // workgroup 2.08; pairs sorted together 3.32, fours 3.20; four buckets one after the other 3.62 - what this kernel lives on is
+    // the number of INDEPENDENT workgroups in flight (7 per CU), each a short chain of dependent loads and barriers; K1F_BG stays 1.
     const u32* fsv = fs + dg * K1F_BG;                  // (wave-uniform: scalar loads)
     for (u32 j = 0; j < K1F_BG;) {
         const u32 d = dg * K1F_BG + j;

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k1p_reduce(K1Buf B, BatchGeom g) {
     const u32 nr = r0 ? 3u * p + r0 : p;
     // (uniform) no period found, or too little to gain
     if (!p || (u64)nr * 5u > (u64)n * 4u) return;            // (red[b] = 0 since k1p_detect)
-    if (tid == 0) { B.red[b] = p; B.dred[b] = 1u; }
+    if (tid == 0) { B.red[b] = p; B.dred[K1_BI(B, b)] = 1u; }
     u8* T = (u8*)B.T + (size_t)b * g.tstride;
     __shared__ u32 first;
     if (tid == 0) first = 0xFFFFFFFFu;
