@@ -401,7 +401,14 @@ struct cjs_ctx {
     float dec_ms;
     std::vector<u8>* bwtc_out;  // result of the last cjs_bwtc_decompress
     BwtcGroupJob* bwtc_jobs[2]; // double buffer between the GPU stages and the coder thread of cjs_bwtc_compress
+    // the overlapped host path (compress_overlapped): persistent helper threads, copy streams, per-slice events and cursors
+    CjsHelper* io[3];           // [0] uploader, [1] downloader, [2] issues the slices of stream 0 (the caller's thread plans)
+    hipStream_t sIn, sOut;      // copy streams (non-blocking)
+    std::vector<hipEvent_t>* evPool;   // per slice: its k5_blockscan, everything of it
+    u64* snapPin;               // [CJS_SNAP_SLOTS] pinned: bit cursor behind every slice (written by k5_blockscan)
+    void* k0sl; size_t k0sl_bytes;     // K0 workspaces of the slices of one call (one each: no reuse within a call)
 };
+#define CJS_SNAP_SLOTS 4096u
 
 extern "C" void cjs_destroy(cjs_ctx* c);
 
@@ -490,6 +497,12 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
     delete c->bwtc_out;
     delete c->bwtc_jobs[0];
     delete c->bwtc_jobs[1];
+    for (int i = 0; i < 3; i++) if (c->io[i]) { c->io[i]->stop(); delete c->io[i]; }
+    if (c->evPool) { for (hipEvent_t ev : *c->evPool) (void)hipEventDestroy(ev); delete c->evPool; }
+    if (c->snapPin) (void)hipHostFree(c->snapPin);
+    (void)hipFree(c->k0sl);
+    if (c->sIn) (void)hipStreamDestroy(c->sIn);
+    if (c->sOut) (void)hipStreamDestroy(c->sOut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -806,6 +819,10 @@ done:
 #undef TRYR
 }
 
+
+#ifndef CJS_CPU_DEBUG_BUILD
+static int64_t compress_overlapped(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out, uint64_t out_cap, u32 slice_blocks);
+#endif
 extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
                                     uint64_t out_cap) {
     if (!c || (!in && in_len) || !out) return CJS_E_ARG;
@@ -822,8 +839,25 @@ extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_l
     // piece: half-size batches cost more (16.9 vs 14.2 ms per 10^8 bytes) than overlapping their copies would save.
     const uint64_t seg_env = []() -> uint64_t { const char* ev = getenv("CJS_SEG_BYTES"); return ev ? strtoull(ev, nullptr, 10) : 0; }();   // (read per call)
     const uint64_t seg_bytes = seg_env ? seg_env : (uint64_t)c->batch_blocks * ((u32)level * 100000u - 19u);
-    if (in_len > seg_bytes + seg_bytes / 2) return compress_segmented(c, in, in_len, level, out, out_cap, seg_bytes);
-    if (in_len) TRYR(hipMemcpyAsync(c->din, in, in_len, hipMemcpyHostToDevice, c->stream));
+    bool resident = false;
+#ifndef CJS_CPU_DEBUG_BUILD
+    {
+        // the overlapped path: slices of CJS_SLICE_BLOCKS blocks - any input of at least two slices.  OFF by default (0): measured on the MI355X
+        // (10^8 bytes of enwik, device-resident step 7.5 ms, one piece 9.92 ms host to host): 2 streams x slices of 28 / 40 / 56 blocks 10.9 /
+        // 10.0 / 10.2 ms, 3 streams x 40 9.65, explicit 64+48 10.0, 4 streams 10.4 - a slice of 28 blocks takes 3.5-4.5 ms from its first
+        // launch to its last however few blocks it has (a chain of ~160 launches, K1's read-back in the middle; tests/gpu_host_path_probe.py
+        // with CJS_OV_TRACE=1 prints the timeline), so what the copies gain the shorter sub-batches lose.  Same bytes either way.
+        static const u32 slice_blocks = []() -> u32 { const char* ev = getenv("CJS_SLICE_BLOCKS"); return ev ? (u32)strtoul(ev, nullptr, 10) : 0u; }();
+        const u32 cap = (u32)level * 100000u - 19u;
+        if (slice_blocks && !seg_env && in_len >= (uint64_t)slice_blocks * cap * 3 / 2) {
+            const int64_t r = compress_overlapped(c, in, in_len, level, out, out_cap, slice_blocks);
+            if (r != CJS_E_SPEC) return r;
+            resident = true;                                // a slice refused its plan (rare): the input is in HBM by now, one piece from here
+        }
+    }
+#endif
+    if (!resident && in_len > seg_bytes + seg_bytes / 2) return compress_segmented(c, in, in_len, level, out, out_cap, seg_bytes);
+    if (!resident && in_len) TRYR(hipMemcpyAsync(c->din, in, in_len, hipMemcpyHostToDevice, c->stream));
     const int64_t n = cjs_bz2_compress_device(c, c->din, in_len, level, c->dout, c->dout_bytes);
     if (n < 0) return n;
     if ((uint64_t)n > out_cap) return CJS_E_NOSPACE;
@@ -899,6 +933,279 @@ static void plan_base(PlanChain& P, MSeg& g, const EdgeRuns& r, u32 cap) {
     P.G = (uint64_t)((int64_t)P.G + (int64_t)g.cost + delta);
 }
 }
+
+// ---- host buffers in, host buffers out, ONE call, copies under the kernels (round 5) ----------------------------------------------
+// lib/Bzip2.js:879-929 + lib/Util.js:9-103 define the product as host Buffer -> host Buffer.  Until round 4 a call that fits a batch and a
+// half was upload-everything, encode, download-everything: 2.6 ms of PCIe around an 8.4 ms step (0.78 of the device-resident rate), and
+// cutting it into the segments of compress_segmented cost more than their overlap saved (every segment a pre-pass, three read-backs and a
+// drained GPU of its own).  Here the input is cut into SLICES of a few dozen blocks that flow through the context's streams without a gap:
+//   uploader    (thread, own stream) brings the input in, in order, 8 MB at a time;
+//   planner     (the caller's thread) - as soon as a slice and the margin behind it are resident: K0's tile scans over that window, the
+//               slice's RLE1 cost, and from the cost prefix of the stream so far (plan_base: the arithmetic of the multi-device plan) the
+//               phase of the block boundaries inside it: the blocks that START in the slice (k0_phase_plan); no chain through earlier plans;
+//   encoders    (one thread per stream) run slice after slice as ONE sub-batch each, alternating streams; the only dependency between
+//               slices is the bit cursor (k5_blockscan of slice j waits for that of slice j - 1: an event), as between sub-batches before;
+//   downloader  (thread, own stream) copies every byte in front of the cursor a finished slice left (k5_blockscan drops it into pinned
+//               memory) while later slices are encoded.
+// A slice that cannot be planned on its own (a boundary inside a run that straddles a cut, a block longer than the margin) sends the
+// call down the one-piece path.  Same bytes as cjs_bz2_compress_device on the whole input (tests/test_gpu_parity.py).
+namespace {
+struct OvSlice {
+    uint64_t lo = 0, e = 0, wend = 0;   // bytes [lo, e), window end (margin included)
+    K0Buf K;
+    u32 nblocks = 0;
+    hipEvent_t evScan = nullptr, evDone = nullptr;
+    float t_up = 0, t_plan = 0, t_iss0 = 0, t_iss1 = 0, t_done = 0, t_copied = 0;   // CJS_OV_TRACE: ms since the call began
+};
+}
+#ifndef CJS_CPU_DEBUG_BUILD
+static int64_t compress_overlapped(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out, uint64_t out_cap,
+                                   u32 slice_blocks) {
+    const u32 cap = (u32)level * 100000u - 19u;
+    const uint64_t W = (uint64_t)4 * (cap + 19u);
+    if (slice_blocks > c->sub_blocks) slice_blocks = c->sub_blocks;
+    // the first slice is half a slice: the encoders start after 1/8 ... of the upload instead of 1/4
+    std::vector<OvSlice> S;
+    {
+        const uint64_t sb = (uint64_t)slice_blocks * cap;
+        uint64_t lo = 0, len = sb / 2 > W ? sb / 2 : sb;
+        // CJS_SLICE_LIST="64,48": explicit slice lengths in blocks (experiments); the last one takes the rest
+        std::vector<uint64_t> lens;
+        if (const char* ev = getenv("CJS_SLICE_LIST"))
+            for (const char* q = ev; *q;) { lens.push_back((uint64_t)strtoul(q, (char**)&q, 10) * cap); if (*q == ',') q++; }
+        size_t li = 0;
+        if (!lens.empty()) len = lens[li++];
+        while (lo < in_len) {
+            OvSlice sl;
+            sl.lo = lo;
+            sl.e = lo + len < in_len ? lo + len : in_len;
+            if (lens.empty() && in_len - sl.e < sb / 4) sl.e = in_len;          // no stub at the end
+            sl.wend = sl.e + W < in_len ? sl.e + W : in_len;
+            S.push_back(sl);
+            lo = sl.e;
+            len = lens.empty() ? sb : (li < lens.size() ? lens[li++] : in_len);
+        }
+    }
+    const u32 ns = (u32)S.size();
+    if (ns < 2 || ns > CJS_SNAP_SLOTS) return CJS_E_SPEC;
+    hipError_t e;
+#define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
+    if (!c->sIn) TRYR(hipStreamCreateWithFlags(&c->sIn, hipStreamNonBlocking));
+    if (!c->sOut) TRYR(hipStreamCreateWithFlags(&c->sOut, hipStreamNonBlocking));
+    if (!c->snapPin) TRYR(hipHostMalloc((void**)&c->snapPin, CJS_SNAP_SLOTS * 8));
+    if (!c->evPool) c->evPool = new std::vector<hipEvent_t>();
+    while (c->evPool->size() < 2u * ns) {
+        hipEvent_t ev;
+        TRYR(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->evPool->push_back(ev);
+    }
+    for (int i = 0; i < 3; i++) if (!c->io[i]) c->io[i] = new CjsHelper();
+    for (u32 i = 1; i < c->nstreams; i++) if (!c->helper[i]) c->helper[i] = new CjsHelper();
+    size_t k0each = 0;
+    for (u32 k = 0; k < ns; k++) { const size_t b = (k0_bytes(S[k].wend - S[k].lo, cap) + 255) & ~(size_t)255; k0each = b > k0each ? b : k0each; }
+    int rc = grow(&c->k0sl, &c->k0sl_bytes, k0each * ns);
+    if (rc) return rc;
+    c->plan_level = 0; c->plan_blocks = 0; c->scan_level = 0;
+    u8* din = (u8*)c->din;
+    u8* dout = (u8*)c->dout;
+    const uint64_t dout_cap = c->dout_bytes;
+    const int dev = c->device;
+    const u32 nst = c->nstreams;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    static const bool ov_trace = getenv("CJS_OV_TRACE") != nullptr;
+
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t uploaded = 0;
+    u32 planned = 0;                    // slices whose plan is ready
+    u32 issued = 0;                     // slices whose launches are all enqueued (evDone recorded)
+    bool stop = false;                  // error or fall-back: everybody winds down
+    int err = 0;
+    auto fail = [&](int code) { std::lock_guard<std::mutex> g(mu); if (!err) err = code; stop = true; cv.notify_all(); };
+
+    // ---- uploader
+    c->io[0]->post([&]() {
+        if (hipSetDevice(dev) != hipSuccess) { fail(CJS_E_NOGPU); return; }
+        const uint64_t chunk = (uint64_t)8 << 20;
+        for (uint64_t off = 0; off < in_len; off += chunk) {
+            const uint64_t len = in_len - off < chunk ? in_len - off : chunk;
+            hipError_t e2 = hipMemcpyAsync(din + off, in + off, len, hipMemcpyHostToDevice, c->sIn);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->sIn);
+            if (e2 != hipSuccess) { fail(CJS_E_HIP - (int)e2); return; }
+            std::lock_guard<std::mutex> g(mu);
+            uploaded = off + len;
+            cv.notify_all();
+            if (err) return;                               // (a fall-back still wants the whole input resident)
+        }
+    });
+    // ---- downloader: the bytes in front of the cursor of every finished slice
+    uint64_t copied = 0;
+    int64_t result = -1;
+    c->io[1]->post([&]() {
+        if (hipSetDevice(dev) != hipSuccess) { fail(CJS_E_NOGPU); return; }
+        for (u32 k = 0; k < ns; k++) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&]() { return stop || issued > k; });
+                if (stop) return;
+            }
+            hipError_t e2 = hipEventSynchronize(S[k].evDone);
+            if (e2 != hipSuccess) { fail(CJS_E_HIP - (int)e2); return; }
+            S[k].t_done = now_ms();
+            const uint64_t to = c->snapPin[k] >> 3;
+            if (to > out_cap) { fail(CJS_E_NOSPACE); return; }
+            if (to > copied) {
+                e2 = hipMemcpyAsync(out + copied, dout + copied, to - copied, hipMemcpyDeviceToHost, c->sOut);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(c->sOut);
+                if (e2 != hipSuccess) { fail(CJS_E_HIP - (int)e2); return; }
+                copied = to;
+            }
+            S[k].t_copied = now_ms();
+        }
+    });
+    // ---- encoders: stream si takes slices si, si + nst, ...; the cursor events are recorded and waited for in slice order
+    std::atomic<u32> recorded(0);
+    const BatchGeom g = make_geom(c->sub_blocks, cap);
+    auto encoder = [&](u32 si) {
+        if (hipSetDevice(dev) != hipSuccess) { fail(CJS_E_NOGPU); return; }
+        for (u32 k = si; k < ns; k += nst) {
+            {
+                std::unique_lock<std::mutex> gq(mu);
+                cv.wait(gq, [&]() { return stop || planned > k; });
+                if (stop) return;
+            }
+            OvSlice& sl = S[k];
+            int r2 = CJS_OK;
+            Pipe P;
+            sl.t_iss0 = now_ms();
+            if (sl.nblocks) {
+                if (k < nst) r2 = hipStreamWaitEvent(c->sub[si], c->evReady, 0) == hipSuccess ? CJS_OK : CJS_E_HIP;
+                if (!r2) r2 = run_sub_batch(c, sl.K, g, cap, 0, sl.nblocks, si, dout, dout_cap, P, sl.nblocks);
+            }
+            while (recorded.load(std::memory_order_acquire) != k) {
+                std::this_thread::yield();
+                std::lock_guard<std::mutex> gq(mu);
+                if (stop) return;
+            }
+            if (!r2) {
+                if (sl.nblocks) {
+                    P.snap = c->snapPin + k;
+                    r2 = k5_run(P, cap, c->sub[si], k ? S[k - 1].evScan : nullptr, sl.evScan);
+                } else {
+                    // (a slice in which no block starts: the cursor stays where it is)
+                    if (k && hipStreamWaitEvent(c->sub[si], S[k - 1].evScan, 0) != hipSuccess) r2 = CJS_E_HIP;
+                    if (!r2 && hipEventRecord(sl.evScan, c->sub[si]) != hipSuccess) r2 = CJS_E_HIP;
+                    c->snapPin[k] = k ? c->snapPin[k - 1] : 32u;
+                }
+            }
+            if (!r2 && hipEventRecord(sl.evDone, c->sub[si]) != hipSuccess) r2 = CJS_E_HIP;
+            sl.t_iss1 = now_ms();
+            recorded.store(k + 1, std::memory_order_release);
+            if (r2) { fail(r2); return; }
+            std::lock_guard<std::mutex> gq(mu);
+            if (k + 1 > issued) issued = k + 1;             // (slices finish issuing in any order; the downloader walks them in order and waits per slice)
+            cv.notify_all();
+        }
+    };
+    // (issued > k implies that slice k's evDone is recorded: a later slice only gets past `recorded` behind it)
+    c->io[2]->post([&]() { encoder(0); });
+    for (u32 i = 1; i < nst; i++) c->helper[i]->post([&, i]() { encoder(i); });
+
+    // ---- planner (this thread)
+    hipStream_t st = c->stream;
+    bool fallback = false;
+    {
+        Pipe P0;
+        memset(&P0, 0, sizeof P0);
+        P0.ss = c->d_ss;
+        P0.out = (u32*)dout;
+        P0.outCapBytes = dout_cap & ~(uint64_t)3;
+        rc = k5_stream_begin(P0, level, st, true);
+        if (!rc && hipEventRecord(c->evReady, st) != hipSuccess) rc = CJS_E_HIP;
+        if (rc) fail(rc);
+        PlanChain pc;
+        for (u32 k = 0; k < ns && !rc; k++) {
+            OvSlice& sl = S[k];
+            sl.evScan = (*c->evPool)[2 * k];
+            sl.evDone = (*c->evPool)[2 * k + 1];
+            {
+                std::unique_lock<std::mutex> gq(mu);
+                cv.wait(gq, [&]() { return stop || uploaded >= sl.wend; });
+                if (stop) break;
+            }
+            sl.t_up = now_ms();
+            const uint64_t wlen = sl.wend - sl.lo, own = sl.e - sl.lo;
+            k0_carve(sl.K, din + sl.lo, wlen, cap, (char*)c->k0sl + (size_t)k * k0each);
+            rc = k0_scans(sl.K, st);
+            if (!rc && own < wlen) rc = k0_eval(sl.K, own, st);
+            if (rc) break;
+            u64 tot[2] = {0, 0};                            // [0] cost of the window, [1] of the slice
+            if (hipMemcpyAsync(&tot[0], sl.K.tileC + sl.K.ntiles, 8, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = CJS_E_HIP; break; }
+            if (own < wlen && hipMemcpyAsync(&tot[1], sl.K.specC, 8, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = CJS_E_HIP; break; }
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = CJS_E_HIP; break; }
+            MSeg ms;
+            ms.lo = sl.lo; ms.e = sl.e;
+            ms.cost = own < wlen ? tot[1] : tot[0];
+            plan_base(pc, ms, edge_runs(in, sl.lo, sl.e), cap);
+            if (!ms.ok) { fallback = true; break; }
+            rc = k0_phase_plan(sl.K, cap, ms.phase, own, sl.e >= in_len ? 1u : 0u, tot[0], st);
+            if (rc) break;
+            u32 nb = 0;
+            if (hipMemcpyAsync(&nb, sl.K.nBlocks, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CJS_E_HIP; break; }
+            if (nb == K0_PHASE_FAIL || nb > c->sub_blocks) { fallback = true; break; }
+            sl.nblocks = nb;
+            sl.t_plan = now_ms();
+            std::lock_guard<std::mutex> gq(mu);
+            planned = k + 1;
+            cv.notify_all();
+        }
+        if (rc) fail(rc);
+        if (fallback) { std::lock_guard<std::mutex> gq(mu); stop = true; cv.notify_all(); }
+    }
+    // ---- wind down
+    c->io[2]->wait();
+    for (u32 i = 1; i < nst; i++) c->helper[i]->wait();
+    c->io[1]->wait();
+    if (!stop) {
+        // trailer behind the last slice, then the rest of the stream
+        Pipe P0;
+        memset(&P0, 0, sizeof P0);
+        P0.ss = c->d_ss;
+        P0.out = (u32*)dout;
+        P0.outCapBytes = dout_cap & ~(uint64_t)3;
+        for (u32 i = 0; i < nst && i < ns; i++) if (hipStreamWaitEvent(st, S[ns - 1 - i].evDone, 0) != hipSuccess) rc = CJS_E_HIP;
+        if (!rc) rc = k5_stream_end(P0, st);
+        StreamState hs;
+        memset(&hs, 0, sizeof hs);
+        if (!rc && (hipMemcpyAsync(&hs, c->d_ss, sizeof hs, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = CJS_E_HIP;
+        if (!rc && hs.overflow) rc = CJS_E_NOSPACE;
+        if (!rc) {
+            const uint64_t total = (hs.bits + 7) >> 3;
+            if (total > out_cap) rc = CJS_E_NOSPACE;
+            else if (total > copied && hipMemcpy(out + copied, dout + copied, total - copied, hipMemcpyDeviceToHost) != hipSuccess) rc = CJS_E_HIP;
+            result = (int64_t)total;
+        }
+        if (rc) fail(rc);
+    }
+    c->io[0]->wait();                                       // (the uploader reads the caller's buffer: never leave it running)
+    (void)hipDeviceSynchronize();
+    u32 blocks = 0;
+    for (u32 k = 0; k < ns; k++) blocks += S[k].nblocks;
+    c->last_blocks = blocks;
+    c->last_ms = now_ms();
+    if (ov_trace) {
+        fprintf(stderr, "[ov] %u slices, %.2f ms:", ns, c->last_ms);
+        for (u32 k = 0; k < ns; k++) fprintf(stderr, " [%u: %u blk up %.2f plan %.2f issue %.2f-%.2f done %.2f copied %.2f]", k, S[k].nblocks, S[k].t_up, S[k].t_plan, S[k].t_iss0, S[k].t_iss1, S[k].t_done, S[k].t_copied);
+        fprintf(stderr, "\n");
+    }
+    if (err) return err;
+    if (fallback || stop) return CJS_E_SPEC;
+    return result;
+#undef TRYR
+}
+#endif
+
 
 extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint8_t* in, uint64_t in_len, int level,
                                           uint8_t* out, uint64_t out_cap) {

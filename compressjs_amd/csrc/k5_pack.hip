@@ -271,6 +271,7 @@ __global__ __launch_bounds__(64) void k5_blockscan(Pipe P) {
     if (((bits + 80u + 7u) >> 3) + 8u > P.outCapBytes) P.ss->overflow = 1;
     P.ss->bits = bits;
     P.ss->crc = crc;
+    if (P.snap) *P.snap = bits;
 }
 
 __device__ __forceinline__ void or_word(u32* out, u64 wi, u32 word) {

@@ -63,6 +63,7 @@ struct Pipe {
     StreamState* ss;   // running stream state (bit cursor, combined CRC), device resident
     u32* out;          // the .bz2 stream being assembled (byte order = memory order)
     u64 outCapBytes;
+    u64* snap;         // optional (pinned host memory): k5_blockscan leaves the bit cursor behind this batch's blocks here - everything before it is final once the batch is packed
 };
 
 // K0 (whole-input pre-pass) ----------------------------------------------------------------------

@@ -9,7 +9,7 @@ import numpy as np
 
 N = 50_000_000
 
-def shapes():
+def shapes(N=N):
     from compressjs_amd import synth
     rng = np.random.RandomState(1)
     _ = rng.randint(0, 256, size=N)

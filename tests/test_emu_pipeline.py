@@ -694,6 +694,44 @@ print("ok", seen)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
 
 
+def test_adversarial_period_words():
+    """k1_period.hip against period words chosen to break it (tests/periodwords.py: Fibonacci and Thue-Morse prefixes, (w)^m with one
+    defect, a^k b, long borders u v u, a short period with one flipped byte, tripled runs, binary noise; p in 2..64, 65..200, just
+    below n / 4 and in between; n = 0, 1, p - 1 mod p): 120 blocks of 16 384 .. 36 000 bytes, transform and origPtr against the oracle;
+    both routes (closed form, three-period reduction) must have been taken.  (1 200 such cases, no mismatch - pinned here.)"""
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle, stagelib, periodwords
+L = C.CDLL(stagelib.build_emu())
+L.cjs_bwt_cyclic_batch.restype = C.c_int32
+L.cjs_bwt_cyclic_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+rng = np.random.default_rng(77)
+cap = 36000
+B = [b for b in periodwords.blocks(cap, rng, 160, small=True) if b[1].size >= 16384 or int(b[0].split("p=")[1].split()[0]) <= 64][:120]
+closed = red = 0
+for i in range(0, len(B), 8):
+    blocks = B[i:i + 8]
+    nb = len(blocks)
+    T = np.zeros((nb, cap), np.uint8); nl = np.zeros(nb, np.uint32)
+    for j, (_, d) in enumerate(blocks):
+        T[j, :d.size] = d; nl[j] = d.size
+    U = np.zeros((nb, cap), np.uint8); P = np.zeros(nb, np.uint32)
+    assert L.cjs_bwt_cyclic_batch(T.ctypes.data, nl.ctypes.data, nb, cap, U.ctypes.data, P.ctypes.data) == 0
+    r = L.cjs_dbg_k1_periodic_blocks()
+    closed += r & 0xFFFF; red += r >> 16
+    for j, (name, d) in enumerate(blocks):
+        uo, po = oracle.bwt_cyclic(d)
+        assert P[j] == po and (U[j, :d.size] == uo).all(), name
+assert closed >= 10 and red >= 30, (closed, red)
+print("ok", len(B), closed, red)
+''' % (stagelib.ROOT, os.path.join(stagelib.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CJS_K1_TRACE="1"), capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
+
+
 def test_segmented_host_pipeline():
     """cjs_bz2_compress on inputs longer than 1.5 segments: planned and encoded segment by segment (upload / encode /
     download overlapped by two helper threads).  CJS_SEG_BYTES=120000 makes a segment ~1.2 level-1 blocks, so the

@@ -519,6 +519,73 @@ def test_periodic_blocks_closed_form_vs_oracle():
     run([np.tile(synth.text_like(300_000, 6), 7)[:2_000_000].copy(), np.tile(np.frombuffer(b"abcde", np.uint8), 300_000)[:1_499_999].copy()], 2_000_000)
 
 
+def _oracle_stream_digest(path):
+    d = np.load(path)
+    o = oracle.bz2_compress(d, 9)
+    return _sha(o), len(o)
+
+
+def test_data_shapes_level9_whole_streams_vs_oracle(ctx, tmp_path):
+    """The 13 rows of tests/gpu_perf_probe.py (two-symbol random, text, random ASCII, runs, periodic 'ab' / 44-byte lines, zeros, random
+    bytes, a 200 kB text tiled, test/sample5/4/3/2.ref tiled) at 10^7 bytes each and LEVEL 9 - the block capacity the periodic-block
+    routes, the doubling rounds and the task levels are tuned for - as whole streams against the oracle (this parity lived in
+    a builder-run log only); the oracle runs on the host's cores while the GPU compresses."""
+    import sys
+    from concurrent.futures import ProcessPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gpu_perf_probe
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        S = gpu_perf_probe.shapes(10_000_000)
+    finally:
+        os.chdir(cwd)
+    assert len(S) >= 9
+    paths = []
+    for i, (_name, d) in enumerate(S):
+        p = str(tmp_path / ("shape_%d.npy" % i))
+        np.save(p, d)
+        paths.append(p)
+    with ProcessPoolExecutor(max_workers=min(len(S), os.cpu_count() or 4)) as pool:
+        futs = [pool.submit(_oracle_stream_digest, p) for p in paths]
+        got = [ctx.compress(d, 9) for _name, d in S]
+        for (name, d), g, f in zip(S, got, futs):
+            od, ol = f.result()
+            assert len(g) == ol and _sha(g) == od, name
+
+
+def test_adversarial_period_words_vs_oracle():
+    """k1_period.hip against period words chosen to break it (tests/periodwords.py: Fibonacci and Thue-Morse prefixes, (w)^m with one
+    defect, a^k b, long borders u v u, a short period with one flipped byte, tripled runs, binary noise; p in 2..64, 65..200, just below
+    n / 4 and in between; n = 0, 1, p - 1 mod p) at the -9 block capacity, through cjs_bwt_cyclic_batch: transform and origPtr equal the
+    oracle's, and BOTH routes - the closed form and the three-period reduction - must have been taken."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import numpy as np, oracle, periodwords\n"
+        "from compressjs_amd import _lib\n"
+        "L = _lib.load()\n"
+        "L.cjs_bwt_cyclic_batch.restype = C.c_int32\n"
+        "L.cjs_bwt_cyclic_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]\n"
+        "rng = np.random.default_rng(20260927)\n"
+        "B = periodwords.blocks(899981, rng, 40)\n"
+        "cap = 899981; nb = len(B)\n"
+        "T = np.zeros((nb, cap), np.uint8); nl = np.zeros(nb, np.uint32)\n"
+        "for i, (_, d) in enumerate(B): T[i, :d.size] = d; nl[i] = d.size\n"
+        "U = np.zeros((nb, cap), np.uint8); P = np.zeros(nb, np.uint32)\n"
+        "assert L.cjs_bwt_cyclic_batch(T.ctypes.data, nl.ctypes.data, nb, cap, U.ctypes.data, P.ctypes.data) == 0\n"
+        "routes = L.cjs_dbg_k1_periodic_blocks()\n"
+        "for i, (name, d) in enumerate(B):\n"
+        "    uo, po = oracle.bwt_cyclic(d)\n"
+        "    assert P[i] == po and np.array_equal(U[i, :d.size], uo), name\n"
+        "print('ok', routes & 0xFFFF, routes >> 16)\n"
+    ) % (ROOT, ROOT)
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, CJS_K1_TRACE="1"), timeout=1500,
+                                  stderr=subprocess.DEVNULL).decode().split()
+    assert out[0] == "ok" and int(out[1]) >= 5 and int(out[2]) >= 10, out      # closed form / three-period reduction both taken
+
+
 def test_deep_refinement_variants_same_bytes(ctx):
     """The text stages in front of the doubling rounds are a faster route to the same order.  K1's knobs (k1_bwt.hip,
     k1_knobs) must all give the same bytes on phrase-reuse text + runs + periodic + tiled input, and those bytes must be the
@@ -561,6 +628,30 @@ def test_segmented_host_path_same_bytes(ctx):
     n = ctx.compress_device(d_in, d_out, 9)
     assert n == len(a) and _sha(d_out[:n].cpu().numpy().tobytes()) == _sha(a)
     assert a[:200_000] == oracle.bz2_compress(d[:3_000_000], 9)[:200_000]
+
+
+def test_overlapped_host_path_same_bytes(ctx):
+    """cjs_bz2_compress with CJS_SLICE_BLOCKS (compress_overlapped: upload, per-slice parallel plan, one sub-batch per slice on alternating
+    streams, download behind the cursor - an option, off by default): the bytes of the one-piece path, on text, on a stream whose runs
+    straddle the slice cuts (a slice that refuses its plan sends the call down the one-piece path) and at two slice sizes."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from compressjs_amd import synth\n"
+        "from compressjs_amd.bzip2 import Context\n"
+        "a = np.concatenate([synth.enwik_like(21_000_000, 31), synth.runs_mixed(2_000_000, 4), synth.lcg_ascii(9_000_000, 5)])\n"
+        "b = np.concatenate([synth.text_like(5_390_000, 2), np.full(40_000, 7, np.uint8), synth.text_like(9_000_000, 3), np.zeros(3_000_000, np.uint8), synth.text_like(4_000_000, 8)])\n"
+        "c = Context(0, 32)\n"
+        "print(hashlib.sha256(c.compress(a, 9)).hexdigest(), hashlib.sha256(c.compress(b, 9)).hexdigest(), hashlib.sha256(c.compress(a[:12_000_000], 3)).hexdigest())\n"
+    ) % ROOT
+    outs = []
+    for env_add in ({"CJS_SLICE_BLOCKS": "0"}, {"CJS_SLICE_BLOCKS": "6"}, {"CJS_SLICE_BLOCKS": "11", "CJS_STREAMS": "3"}, {"CJS_SLICE_BLOCKS": "6", "CJS_STREAMS": "1"}):
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env_add), timeout=900).decode().split()[-3:])
+    assert all(o == outs[0] for o in outs), outs
+    a = np.concatenate([synth.enwik_like(21_000_000, 31), synth.runs_mixed(2_000_000, 4), synth.lcg_ascii(9_000_000, 5)])
+    assert _sha(ctx.compress(a[:12_000_000], 3)) == outs[0][2]
 
 
 def test_multi_context_fan_out_same_bytes():
