@@ -98,7 +98,9 @@ def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
     ctx.shift_bits(seg, nbytes, my_off % 8, shifted)              # one pass (k5_shift_bits); shift_bits() below is the spec
     mark("shift")
     lens = [(b + 7) // 8 + 1 for b, _, _ in meta]                  # every segment travels at its own length (RCCL has no gatherv:
-    if world > 1:                                                 # grouped send/recv, all peers' links into the root used at once)
+    gl = None
+    use_allgather = world > 1 and os.environ.get("CJS_DIST_GATHER", "p2p") == "allgather"
+    if world > 1 and not use_allgather:                           # grouped send/recv, all peers' links into the root used at once)
         root = dist.get_global_rank(group, 0) if group is not None else 0
         if rank == 0:
             # one staging buffer for all peers' segments, kept across steps (no allocation inside the timed step)
@@ -120,6 +122,16 @@ def _assemble(ctx, seg, bits, fold, cnt, level, group, rank, world, dev, mark):
             for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, shifted.to(cdev), root, group=group)]):
                 req.wait()
             gl = None
+    elif use_allgather:
+        # CJS_DIST_GATHER=allgather: the most ordinary collective instead of grouped point-to-point (every rank receives every
+        # segment, padded to the longest: N times the traffic) - a switch for a first contact with a fabric on which the
+        # send/recv path misbehaves; same bytes
+        mx = max(lens)
+        pad = torch.zeros(mx, dtype=torch.uint8, device=cdev)
+        pad[:shifted.numel()] = shifted.to(cdev)
+        allp = [torch.empty(mx, dtype=torch.uint8, device=cdev) for _ in range(world)]
+        dist.all_gather(allp, pad, group=group)
+        gl = [allp[r][:lens[r]].to(dev) for r in range(world)] if rank == 0 else None
     else:
         gl = [shifted]
     mark("gather")
@@ -373,6 +385,9 @@ def sharded_compress_parallel(ctx, d_win: torch.Tensor, own_len: int, lo: int, t
                 seg = torch.zeros((own_len + margin_bytes(level)) * 3 // 2 + (1 << 20), dtype=torch.uint8, device=dev)
             bits, fold, cnt = ctx.encode_blocks(0, nb, seg)
     except Exception:                                        # noqa: BLE001
+        if os.environ.get('CJS_DIST_TRACE'):
+            import traceback
+            traceback.print_exc()
         nb = -1
     bad = nb < 0
     if seg is None:

@@ -28,6 +28,7 @@ def _worker(rank, world, port, q):
     data = np.concatenate([synth.text_like(230000, 21), synth.runs_mixed(40000, 2)])
     d_in = torch.from_numpy(data.copy())
     out = sharded_compress(ctx, d_in, 1)
+    out = torch.from_numpy(np.frombuffer(out.numpy().tobytes(), np.uint8).copy()) if rank == 0 else out   # (a snapshot: ADVICE r4)
     # the sliced driver: every rank holds its slice + margin only; then an input whose blocks swallow slices (fallback)
     from compressjs_amd.dist import margin_bytes, sharded_compress_sliced, slice_bounds
     outs = []
@@ -50,8 +51,19 @@ def _worker(rank, world, port, q):
             return sharded_compress_sliced(ctx, torch.from_numpy(dd[wlo:hi].copy()), wlo, dd.size, 1, d_all=lambda: torch.from_numpy(dd.copy()))
         o3 = sharded_compress_parallel(ctx, torch.from_numpy(dd[lo:whi].copy()), hi - lo, lo, dd.size, 1, fallback=fb)
         par.append(o3.numpy().tobytes() if rank == 0 else None)
+    # the same stream with the segments gathered by all_gather instead of grouped send/recv (CJS_DIST_GATHER: a switch for a first
+    # contact with a fabric on which point-to-point misbehaves)
+    clean = synth.lcg_ascii(470000, 6)                       # (plans slice by slice on four ranks: no fall-back involved)
+    lo, hi = slice_bounds(clean.size, rank, world)
+    whi = min(clean.size, hi + margin_bytes(1))
+    o4a = sharded_compress_parallel(ctx, torch.from_numpy(clean[lo:whi].copy()), hi - lo, lo, clean.size, 1)
+    o4a = o4a.numpy().tobytes() if rank == 0 else None
+    os.environ["CJS_DIST_GATHER"] = "allgather"
+    o4 = sharded_compress_parallel(ctx, torch.from_numpy(clean[lo:whi].copy()), hi - lo, lo, clean.size, 1)
+    del os.environ["CJS_DIST_GATHER"]
     if rank == 0:
-        q.put((out.numpy().tobytes(), outs, par))
+        assert o4.numpy().tobytes() == o4a
+        q.put((out.numpy().tobytes(), outs, par, o4a))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,7 +81,7 @@ def test_sharded_stream_equals_reference_stream():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, sliced, par = q.get(timeout=1800)
+    got, sliced, par, clean_stream = q.get(timeout=1800)
     for p in procs:
         p.join(timeout=1800)
         assert p.exitcode == 0
@@ -83,6 +95,7 @@ def test_sharded_stream_equals_reference_stream():
     straddle = np.concatenate([synth.text_like(270000 // world - 2, 5), np.full(9, 65, np.uint8), synth.text_like(270000, 6)])[:270000]
     assert par[1] == oracle.bz2_compress(straddle, 1)
     assert par[2] == oracle.bz2_compress(runs, 1)
+    assert clean_stream == oracle.bz2_compress(synth.lcg_ascii(470000, 6), 1)          # the parallel plan itself (no fall-back), both gathers
 
 
 def test_shift_and_trailer_helpers():
