@@ -21,7 +21,7 @@ What the line carries besides the driver's contract:
   roofline                               the kernel with the largest total time ON THIS WORKLOAD, found and timed with HIP
                                          events around every launch of K1's main kernels on the library's stream in a
                                          single-stream pass after the timed region (kernel_ms_per_step lists them all);
-                                         traffic from the PMC passes of profiles/r04_pmc_traffic.json (stamped with the
+                                         traffic from the PMC passes of profiles/r05_pmc_traffic.json (stamped with the
                                          build they were collected on; null when none for this workload), e2e = 16 B/B
   cpu_baseline                           kind "reference": Bzip2.compressFile of cscott/compressjs under node, timed ON THIS
                                          BOX IN THIS RUN on the first 10^7 bytes of the same stream (staged copy under
@@ -48,7 +48,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 # K1's main kernels (K1P_* classes of csrc/k1_bwt.h) and the ALGORITHMIC HBM bytes one element of a launch costs:
-#   k1f_bsort   per rotation: 4 (index read) + 8 (key bytes of the rotation's text) + 4 (suffix-array entry written)
+#   k1f_bsort   per rotation: 4 (index read) + 8 (key bytes of the rotation's text) + 4 (suffix-array entry written); since round 5 the kernel
+#               reads 16 key bytes per rotation (L2-resident text) and still writes one 8-byte list entry per rotation that ties: the 16 B
+#               of rounds 2-4 are kept so that the fractions compare across rounds - a lower bound
 #   k1r_round   per list entry and round: 8 (entry read) + 8 (entry written) + 4 (suffix-array entry; the 24 key bytes come from L2-resident text)
 #   k1d_build   per rotation: 4 (suffix-array entry read) + 4 (rank written)
 #   k1d_round   per list entry and round: 8 (entry read) + 4 (rank gathered) + 8 (entry written)
@@ -333,6 +335,7 @@ def main():
         prof_steps, kms, dom = 3, {}, None
         avg_ms, launches, elements, alg_per_el = 0.0, 0, 0, None
         if world == 1:
+            prev_streams = os.environ.get("CJS_STREAMS")           # (restored below: the E8S-A and PCIe legs run under the caller's setting)
             os.environ["CJS_STREAMS"] = "1"
             ctx1 = Context(local, args.batch)
             ctx1.compress_device(d_in, d_out, args.level)
@@ -348,16 +351,19 @@ def main():
                 kms[name] = round(pms.value / prof_steps, 4)
             ctx1.L.cjs_profile_enable(ctx1.h, 0)
             ctx1.close()
-            os.environ.pop("CJS_STREAMS", None)
+            if prev_streams is None:
+                os.environ.pop("CJS_STREAMS", None)
+            else:
+                os.environ["CJS_STREAMS"] = prev_streams
             dom, alg_per_el, tot_ms, launches, elements = max(rows, key=lambda r: r[2])
             avg_ms = tot_ms / max(launches, 1)
         alg_bytes = None if (alg_per_el is None or not launches) else alg_per_el * elements / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if (alg_bytes and avg_ms > 0) else None
-        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE passes of this workload (separate --pmc runs, tests/gpu_r4_pmc.sh;
-        # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), committed as profiles/r04_pmc_traffic.json together with
+        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE passes of this workload (separate --pmc runs, tests/gpu_r5_traffic.sh;
+        # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), committed as profiles/r05_pmc_traffic.json together with
         # the build they were collected on.  null when no pass for this workload / size / kernel is committed.
         traffic, traffic_build = None, None
-        tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
         if os.path.exists(tpath) and dom:
             tj = json.load(open(tpath))
             ent = tj.get("%s:%d" % (args.workload, args.size), {}).get(dom)

@@ -536,10 +536,10 @@ static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap
     P.out = (u32*)d_out;
     P.outCapBytes = out_cap & ~(uint64_t)3;
     P.k1.prof = c->prof.enabled ? &c->prof : nullptr;
-    if (c->prof.enabled) c->prof_g = g;
     P.k1.hpin = c->pin[si]; P.k1.hpinWords = CJS_PIN_WORDS;
     P.g.nb = nb;
-    // (CRC workgroups per block: one per 2 MB of input a block of this call consumes on average - long runs make that tens of megabytes)
+    // (CRC workgroups per block: one per 2 MB of input a block of this call consumes on average - long runs make that tens of megabytes;
+    // total_blocks = the blocks the planned input K holds, so that windows with a margin and sub-ranges count their own bytes)
     const u64 per_block = K.in_len / (total_blocks ? total_blocks : 1u);
     int rc = k0_batch(K, P, f, cap, st, (u32)(1u + per_block / (2u << 20)));
     if (rc) return rc;
@@ -548,6 +548,7 @@ static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap
 
 static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 count, void* d_out, uint64_t out_cap) {
     BatchGeom g = make_geom(c->sub_blocks, cap);
+    if (c->prof.enabled) c->prof_g = g;                   // (once, before the workers start: they only read it)
     // The blocks go out in batches of batch_blocks; a batch is cut into one sub-batch per stream by the streams' shares
     // (when it has at least 16 blocks per stream: below that one stream takes it whole, or sub_blocks at a time).
     std::vector<u32> sfirst, scount;
@@ -577,7 +578,7 @@ static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 coun
     std::atomic<u32> recorded(0);
     std::atomic<int> err(0);
     auto worker = [&](u32 si) {
-        if (hipSetDevice(c->device) != hipSuccess) { err = CJS_E_NOGPU; return; }
+        if (hipSetDevice(c->device) != hipSuccess) { int z = 0; err.compare_exchange_strong(z, CJS_E_NOGPU); }   // (it still walks its slots below, work skipped: the hand-off chain must complete - ADVICE r4)
         for (u32 j = si; j < nsub; j += ns) {
             const u32 f = sfirst[j], nb = scount[j];
             Pipe P;
@@ -632,10 +633,10 @@ extern "C" int64_t cjs_bz2_compress_device(cjs_ctx* c, const void* d_in, uint64_
     TRYR(hipMemsetAsync(P0.out, 0, P0.outCapBytes, c->sub[0]));
     TRYR(hipEventRecord(c->evDone[0], c->sub[0]));
     rc = k0_prepass(K, cap, st);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(c->sub[0]); return rc; }     // (the zeroing of the caller's buffer is still in flight - ADVICE r4)
     TRYR(hipStreamWaitEvent(st, c->evDone[0], 0));        // (k5_begin writes the stream header into the zeroed output)
     rc = k5_stream_begin(P0, level, st, false);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(c->sub[0]); return rc; }
     TRYR(hipEventRecord(c->evReady, st));
     // (both small read-backs of the call go through the context's pinned memory - stream 0's, which no sub-batch is using at either time:
     // a pageable copy costs tens of microseconds more, with the GPU idle behind the first one)
@@ -1239,7 +1240,7 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
         if (e2 != hipSuccess) { fail(CJS_E_HIP - (int)e2); return; }
         int64_t v = cjs_bz2_plan_scan(c, c->din, wlen, level);
         if (v >= 0) v = cjs_bz2_plan_cost(c, g.e - g.lo);
-        if (v < 0) { fail((int)v); return; }
+        if (v < 0) { (void)hipStreamSynchronize(c->stream); fail((int)v); return; }     // (the window's upload reads the caller's buffer: not left pending - ADVICE r4)
         g.cost = (uint64_t)v;
     };
     // phase B: the blocks that start in the segment, planned from its phase and encoded from bit 0
