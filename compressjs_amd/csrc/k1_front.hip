@@ -607,16 +607,15 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
             if (lane == 0) S.misc[(u32)it * K1F_NW + w] = (u32)__popcll(bal[it]);     // rows in position order: it-major, wave-minor
         }
         __syncthreads();
-        if (tid == 0) {                                 // the rows' counts become list offsets: one global atomic reserves the slots
-            u32 run = 0;
-            for (u32 i = 0; i < K1F_E * K1F_NW; i++) { const u32 c = S.misc[i]; S.misc[i] = run; run += c; }
-#ifdef K1F_EXPERIMENT_NOATOMIC
-            const u32 base = pos0 / 2u;    // (timing experiment only: wrong lists)
-            if (pos0 == 0 && run) atomicAdd(&K1_RCNT(B, 0, b), run);
-#else
-            const u32 base = run ? atomicAdd(&K1_RCNT(B, 0, b), run) : 0u;
-#endif
-            for (u32 i = 0; i < K1F_E * K1F_NW; i++) S.misc[i] += base;
+        if (w == 0) {                                   // the rows' counts become list offsets (one wave scan); one global atomic reserves the slots
+            static_assert(K1F_E * K1F_NW <= 64, "one lane per row");
+            const u32 c = lane < K1F_E * K1F_NW ? S.misc[lane] : 0u;
+            const u32 inc = wave_incl_scan_dpp(c);
+            const u32 run = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            u32 base = 0;
+            if (lane == 0 && run) base = atomicAdd(&K1_RCNT(B, 0, b), run);
+            base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+            if (lane < K1F_E * K1F_NW) S.misc[lane] = base + inc - c;
         }
     }
     for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = S.sx[i];
@@ -654,6 +653,8 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
 //            chain per candidate (k1f_acc_lt).  Cells past a leaf's end belong to later leaves - strictly greater keys - and
 //            behind the last rotation sit four all-ones cells: no bounds masks in the loop.
 //   stage 4  cells to their final places, heads = key differs from its predecessor's (one ballot per row of 64: no atomics).
+//            (Measured and dropped: a second carry chain on the keys alone in the ranking loop tells whether an equal key sits in an
+//            earlier slot, i.e. which cells open a group - no key moves, one barrier and the heads pass less, but k1f_bsort 2.10 -> 2.45 ms.)
 #ifdef K1F_TRACE
 #define K1F_SSTAMP(slot) do { if (trs && tid == 0) { const long long now_ = clock64(); atomicAdd(&trs[K1_STAT_FRONT_BIG + 1 + (slot)], (u32)((now_ - tprev_) >> 8)); tprev_ = now_; } } while (0)
 #else
