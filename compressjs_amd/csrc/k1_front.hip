@@ -397,11 +397,13 @@ static_assert(K1F_C % K1F_BT == 0 && K1F_E >= 1, "a bucket-sort workgroup's thre
 #define K1F_LK (K1F_C >= 1024 ? 64 : K1F_C / 16)        // local sub-buckets (leaves) of a bucket, at most
 #endif
 #ifndef K1F_LOVS
-#define K1F_LOVS 2                                      // local samples per leaf
+#define K1F_LOVS 1                                      // local samples per leaf
 #endif
 #ifndef K1F_LEAF
-#define K1F_LEAF 24u                                    // a bucket is cut into leaves of K1F_LEAF / 2 .. K1F_LEAF rotations on average
+#define K1F_LEAF 12u                                    // a bucket is cut into leaves of K1F_LEAF / 2 .. K1F_LEAF rotations on average
 #endif
+// (round 5, ms for k1f_bsort on enwik / E8S-A / random ASCII: 2 samples per leaf and leaves of 12..24 2.14 / 1.20 / 1.99; 20 / 28 / 40 instead of 24: 2.12 / 2.20 / 2.35;
+//  4 samples per leaf 2.29; ONE sample per leaf and leaves of 6..12 2.01 / 1.15 / 1.85 (8, 6: the same) - the ranking loop's trip count is what counts)
 #define K1F_LS (K1F_LOVS * K1F_LK)                      // local samples, at most
 static_assert(K1F_LS <= K1F_BT && K1F_LK <= 64, "one thread per local sample; leaf ids are 6 bits; the leaf counts are scanned by one wave");
 #define K1F_HW (K1F_C / 32 + 2)                         // words of the in-LDS head bitmap (bits >= cnt are set: sentinel)
