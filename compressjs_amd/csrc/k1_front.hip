@@ -1432,7 +1432,14 @@ int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u
     for (u32 r = 0; r < rounds; r++) {
         // the lists shrink from round to round (text: by a quarter to a third): later rounds launch fewer workgroups, each walks
         // its share of the tiles (an empty workgroup still costs its dispatch)
-        u32 tiles = (full >> r) / 8u;                 // a workgroup walks ~8 tiles (software pipeline), later rounds fewer
+#ifndef K1R_WALK
+#define K1R_WALK 4u         // (round 5, k1r_round ms on enwik with 16 / 8 / 4 / 2 / 1 tiles per workgroup: 2.07 / 1.87 / 1.79 / 1.76 / 1.78; on `text`, whose lists are short, 8: 0.27, 2: 0.32)
+#endif
+#ifndef K1R_SHR
+#define K1R_SHR 2u
+#endif
+        u32 tiles = full / K1R_WALK;                  // a workgroup walks ~K1R_WALK tiles (software pipeline), later rounds launch fewer
+        for (u32 q = 0; q < r; q++) tiles = K1R_SHR == 2u ? tiles / 2u : tiles * 5u / 8u;
         if (tiles < 16u) tiles = 16u;
         const u32 slot = k1_prof_begin(B.prof, K1P_RROUND, stream);
         hipLaunchKernelGGL(k1r_round, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
