@@ -881,7 +881,10 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     u32* HN = B.HN + (size_t)b * g.hstride;
     const u64* sp = B.fsplit + (size_t)b * K1F_NB;
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
-    const bool wide = deepen && iters != 0u;
+    // 16-byte keys whenever the caller wants the text stages (cyclic mode) - also when the predictor then skips them (HTML-like input): the
+    // doubling rounds start from h = 8 either way, but on groups that are already 16 bytes deep where a bucket fit the LDS (E8S-A: k1f_bsort
+    // 1.17 -> 1.41 ms, the doubling stage 7.6 -> 6.4 ms)
+    const bool wide = lists != 0u && iters != 0u;
     K1F_DECLARE_LDS(S)
     // Buckets are adjacent key ranges: the union of neighbours, sorted, is the neighbours sorted one after the other.  A workgroup
     // may walk K1F_BG buckets and sort as many of them at once as its LDS holds (a 2048-quantile is 440 rotations, a slot 1020): twice
@@ -907,8 +910,8 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
             continue;
         }
         const u32* SB = B.SB + (size_t)b * g.stride + start;
-        if (pure && !deepen) {
-            // one 8-byte key and no text stage behind this one: a single group as it stands
+        if (pure && !deepen && (!wide || cnt > K1F_CAP)) {
+            // one 8-byte key, no text stage behind this one, and no 16-byte sort either (linear mode, or beyond LDS): a single group as it stands
             u32* SA = B.SA + (size_t)b * g.stride + start;
             for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
             k1f_write_heads(HN, start, start + cnt, [&](u32 p) { return p == start; });
@@ -974,7 +977,8 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
         u32* HN = B.HN + (size_t)b * g.hstride;
         const u32* src = inSB ? SBs : SAs;
         const u32 dm = depth % n;
-        if (!deepen && depth) {
+        const bool widem = lists != 0u && iters != 0u && !last;       // 16-byte keys also without lists behind them (see k1f_bsort)
+        if (!deepen && depth && (!widem || len > K1F_CAP)) {
             // no text stages behind this one (linear mode: BWT.bwtransform / suffixsort sort suffixes by the first 8 bytes only; cyclic
             // mode with the predictor on: HTML-like input, the doubling rounds take over from 8 bytes): a sub-bucket of ONE key is one
             // group, as the one-key buckets of k1f_bsort are.  (Until round 4 the cyclic case went on partitioning such slices 8 bytes
@@ -990,7 +994,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
                 continue;
             }
             const bool go = deepen && !last;
-            const bool wide = go && iters != 0u;
+            const bool wide = widem;
             k1f_sort128(S, T, n, src, len, dm, wide);
             k1f_flush(S, B, g, b, pos, len, go, level + 1u, depth + (wide ? K1F_KEYB : 8u));
             continue;
