@@ -16,9 +16,10 @@
 #define K1_BI(B, b) (((b) & 7u) * ((B).rstride >> 3) + ((b) >> 3))
 #define K1_RCNT(B, round, b) ((B).rcnt[((size_t)(round) * (B).rnb8 + (b)) * K1_RCS])
 #ifndef K1F_LEVELS
-#define K1F_LEVELS 14u
+#define K1F_LEVELS 6u
 #endif
-// K1F_LEVELS: task levels of the front end (two per 8 bytes of depth: partition, then sort; 6 / 8 / 14 measured in round 4: no difference)
+// K1F_LEVELS: task levels of the front end (partition, then sort: 16 bytes of depth per sorting level since round 5; what is left when they run out stays a group
+// for the doubling rounds).  An empty level is a launch on every sub-batch's critical path: 14 -> 6 levels = 7.48 -> 7.35 ms per 10^8-byte enwik step (median of 16)
 #define K1_STAT_RTRACE 128      // stats[128..135]: K1F_TRACE builds, stage clocks of k1r_round
 #define K1_MED_MAX 4096     // doubling rounds: largest group a workgroup sorts in LDS
 #define K1_STATS 144

@@ -36,8 +36,9 @@ def run(names):
             n = ctx.compress_device(d_in, d_out, 9)
             t.append(ctx.last_device_ms)
         out = d_out[:n].cpu().numpy().tobytes()
-        print('[%s] %-6s %9d -> %9d  %7.2f ms  %7.1f MB/s  rounds %d sparse %d  sha %s' % (
-            tag, name, data.size, n, min(t), data.size / min(t) / 1e3, ctx.L.cjs_dbg_k1_rounds(),
+        med = sorted(t)[len(t) // 2]
+        print('[%s] %-6s %9d -> %9d  %7.2f ms (median %.2f)  %7.1f MB/s  rounds %d sparse %d  sha %s' % (
+            tag, name, data.size, n, min(t), med, data.size / min(t) / 1e3, ctx.L.cjs_dbg_k1_rounds(),
             ctx.L.cjs_dbg_k1_sparse_rounds(), hashlib.sha256(out).hexdigest()[:16]), flush=True)
 
 if __name__ == '__main__':

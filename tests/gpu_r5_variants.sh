@@ -13,7 +13,7 @@ wait
 for v in ${VARIANTS:-base:}; do
   name=${v%%:*}; D=/tmp/var_$name
   for w in $WL; do
-    cd $D && env $(echo ${ENVV:-CJS_NOP=0} | tr ',' ' ') timeout 300 python tests/gpu_r2_probe.py run $w 2>&1 | grep "^\[" | sed "s/^/$name /" | cut -c1-200
+    cd $D && env $(echo ${ENVV:-CJS_NOP=0} | tr ',' ' ') timeout 300 python tests/gpu_r2_probe.py run $w --reps ${REPS:-4} 2>&1 | grep "^\[" | sed "s/^/$name /" | cut -c1-200
     cd /tmp && CJS_STREAMS=1 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ${name}_$w -- python $D/tests/gpu_r2_probe.py run $w --reps 3 > $O/${name}_$w.log 2>&1
     python - $O/${name}_${w}_kernel_stats.csv "$name $w" "${KERN:-k1f_bsort}" <<'PY'
 import csv, sys, re
