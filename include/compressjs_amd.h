@@ -1,5 +1,5 @@
 /* compressjs_amd.h -- C ABI of libcompressjs_amd.so (MI355X-native bzip2 block pipeline).
- * (state: round 3; the full entry-point list with the reference binding of each is in INTEGRATION.md)
+ * (state: round 5; the full entry-point list with the reference binding of each is in INTEGRATION.md)
  */
 #ifndef COMPRESSJS_AMD_H
 #define COMPRESSJS_AMD_H
@@ -141,6 +141,7 @@ int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen, uint32_t 
                                uint8_t* U, uint32_t* pidx, int reps, float* ms);
 int cjs_dbg_k1_sparse_rounds(void);   /* rounds of the last K1 run that used the sparse phase */
 int cjs_dbg_k1_rounds(void);
+uint32_t cjs_dbg_rc_div(uint32_t range, uint32_t tot);   /* bwtc_host.hip: the range coder's range / tot by reciprocal (boundary test in tests/test_host_api.py) */
 int cjs_dbg_k1_periodic_blocks(void); /* k1_period.hip, last K1 run (counted under CJS_K1_TRACE only): blocks with a period <= 64 (closed form) | blocks sorted through a reduced block << 16 */
 int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,
                              int upto, cjs_dbg_stage_out* out);

@@ -176,6 +176,22 @@ static napi_value DeviceCount(napi_env env, napi_callback_info) {
     return r;
 }
 
+// result blocks of Compress: a pool of at most four (what is beyond that is freed when its Buffer is collected)
+struct StageBlock { uint8_t* data; uint64_t cap; };
+static std::vector<StageBlock*> g_stage_pool;
+static StageBlock* stage_take(uint64_t cap) {
+    for (size_t i = 0; i < g_stage_pool.size(); i++)
+        if (g_stage_pool[i]->cap >= cap) { StageBlock* b = g_stage_pool[i]; g_stage_pool.erase(g_stage_pool.begin() + (long)i); return b; }
+    StageBlock* b = new StageBlock{(uint8_t*)malloc(cap ? cap : 1), cap};
+    if (!b->data) { delete b; return nullptr; }
+    return b;
+}
+static void stage_give(StageBlock* b) {
+    if (g_stage_pool.size() < 4) g_stage_pool.push_back(b);
+    else { free(b->data); delete b; }
+}
+static void stage_finalize(napi_env, void*, void* hint) { stage_give((StageBlock*)hint); }
+
 static napi_value Compress(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
     napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr);
@@ -186,15 +202,21 @@ static napi_value Compress(napi_env env, napi_callback_info info) {
     if (level < 1 || level > 9) return throw_code(env, -20, "compress");
     if (!ensure_ctx(env)) return nullptr;
     const uint64_t cap = (uint64_t)p_bound(len);
-    // staging kept across calls: a fresh malloc would fault in every page the D2H copy touches
-    static std::vector<uint8_t> stage;
-    if (stage.size() < cap) stage.resize(cap);
+    // The result is handed to JavaScript as an EXTERNAL Buffer over the block the library wrote into - no copy (round 5; the copy into a
+    // fresh Buffer was 4 of the 14 ms of a 10^8-byte call).  Blocks come from a small pool and go back to it when the Buffer is collected:
+    // a fresh malloc would fault in every page the D2H copy touches.
+    StageBlock* blk = stage_take(cap);
+    if (!blk) { napi_throw_error(env, nullptr, "out of memory"); return nullptr; }
     // several devices configured: segments of the input go round-robin to them (cjs_bz2_compress_multi)
-    const int64_t n = g_ctxs.size() > 1 ? p_compress_multi(g_ctxs.data(), (uint32_t)g_ctxs.size(), in, len, level, stage.data(), cap)
-                                        : p_compress(g_ctx, in, len, level, stage.data(), cap);
-    if (n < 0) return throw_code(env, n, "cjs_bz2_compress");
-    napi_value out; void* dst;
-    napi_create_buffer_copy(env, (size_t)n, stage.data(), &dst, &out);
+    const int64_t n = g_ctxs.size() > 1 ? p_compress_multi(g_ctxs.data(), (uint32_t)g_ctxs.size(), in, len, level, blk->data, cap)
+                                        : p_compress(g_ctx, in, len, level, blk->data, cap);
+    if (n < 0) { stage_give(blk); return throw_code(env, n, "cjs_bz2_compress"); }
+    napi_value out;
+    if (napi_create_external_buffer(env, (size_t)n, blk->data, stage_finalize, blk, &out) != napi_ok) {
+        void* dst;                                           // (an embedder without external buffers: copy as before)
+        napi_create_buffer_copy(env, (size_t)n, blk->data, &dst, &out);
+        stage_give(blk);
+    }
     return out;
 }
 
