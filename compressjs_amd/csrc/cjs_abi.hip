@@ -407,7 +407,10 @@ struct cjs_ctx {
     std::vector<hipEvent_t>* evPool;   // per slice: its k5_blockscan, everything of it
     u64* snapPin;               // [CJS_SNAP_SLOTS] pinned: bit cursor behind every slice (written by k5_blockscan)
     void* k0sl; size_t k0sl_bytes;     // K0 workspaces of the slices of one call (one each: no reuse within a call)
+    std::vector<std::pair<void*, size_t>>* segpool;   // cjs_bz2_compress_multi: this device's segment buffers, one per wave of a call, grow-only and kept across calls
 };
+static std::atomic<int> g_multi_mallocs{0};        // hipMalloc calls of cjs_bz2_compress_multi's segment buffers (cjs_dbg_multi_mallocs: none after warm-up)
+extern "C" int cjs_dbg_multi_mallocs(void) { return g_multi_mallocs.load(); }
 #define CJS_SNAP_SLOTS 4096u
 
 extern "C" void cjs_destroy(cjs_ctx* c);
@@ -501,6 +504,7 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
     if (c->evPool) { for (hipEvent_t ev : *c->evPool) (void)hipEventDestroy(ev); delete c->evPool; }
     if (c->snapPin) (void)hipHostFree(c->snapPin);
     (void)hipFree(c->k0sl);
+    if (c->segpool) { for (auto& pr : *c->segpool) (void)hipFree(pr.first); delete c->segpool; }
     if (c->sIn) (void)hipStreamDestroy(c->sIn);
     if (c->sOut) (void)hipStreamDestroy(c->sOut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1254,7 +1258,22 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
         if (nb < 0) { fail((int)nb); return; }
         if (nb == 0) return;
         g.dseg_cap = ((uint64_t)cjs_bz2_compress_bound(g.e - g.lo + W) + 3) & ~(uint64_t)3;
-        if (hipMalloc((void**)&g.dseg, g.dseg_cap) != hipSuccess) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); return; }
+        {   // the device's buffer for its segment of this wave: from the context's pool (grow-only, kept across calls: a hipMalloc per segment
+            // and a hipFree - a device-wide sync - per segment in every call was what rounds 2-4 did)
+            if (!c->segpool) c->segpool = new std::vector<std::pair<void*, size_t>>();
+            const size_t slot = (size_t)(k / n);
+            if (c->segpool->size() <= slot) c->segpool->resize(slot + 1, std::pair<void*, size_t>(nullptr, 0));
+            std::pair<void*, size_t>& pr = (*c->segpool)[slot];
+            if (pr.second < g.dseg_cap) {
+                (void)hipFree(pr.first);
+                pr = std::pair<void*, size_t>(nullptr, 0);
+                void* pnew = nullptr;
+                g_multi_mallocs++;
+                if (hipMalloc(&pnew, g.dseg_cap + (g.dseg_cap >> 3)) != hipSuccess) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); return; }
+                pr = std::pair<void*, size_t>(pnew, g.dseg_cap + (g.dseg_cap >> 3));
+            }
+            g.dseg = (u8*)pr.first;
+        }
         u32 fold = 0, cnt = 0;
         const int64_t bits = cjs_bz2_encode_blocks(c, 0, (u32)nb, g.dseg, g.dseg_cap, &fold, &cnt);
         if (bits < 0) { fail((int)bits); return; }
@@ -1329,8 +1348,6 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
             }
         }
     }
-    for (uint64_t k = 0; k < nseg; k++)
-        if (S[k].dseg) { (void)hipSetDevice(ctxs[k % n]->device); (void)hipFree(S[k].dseg); }
     if (err == 1) return cjs_bz2_compress(ctxs[0], in, in_len, level, out, out_cap);
     if (err) return err;
     u32 blocks = 0;

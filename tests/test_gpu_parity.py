@@ -664,6 +664,13 @@ def test_multi_context_fan_out_same_bytes():
         for d, lv in ((synth.enwik_like(70_000_000, 8), 9), (synth.runs_mixed(40_000_000, 3), 9), (synth.lcg_ascii(9_000_000, 2), 1),
                       (np.zeros(50_000_000, np.uint8), 9)):
             assert _sha(compress_multi(cs, d, lv)) == _sha(one.compress(d, lv)), (d.size, lv)
+        # the per-device segment buffers are grow-only pools kept across calls: a second pass over the same inputs allocates nothing
+        L = _lib.load()
+        L.cjs_dbg_multi_mallocs.restype = C.c_int
+        before = L.cjs_dbg_multi_mallocs()
+        d = synth.enwik_like(70_000_000, 8)
+        assert _sha(compress_multi(cs, d, 9)) == _sha(one.compress(d, 9))
+        assert L.cjs_dbg_multi_mallocs() == before, "cjs_bz2_compress_multi allocated in its hot loop after warm-up"
     finally:
         for c in cs + [one]:
             c.close()
