@@ -1169,7 +1169,8 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
 // head bits of its non-heads, and hands groups of 2..8 to the second pass of the lane kernels (k1_deep_pairs<true> /
 // k1_deep_small<true>: up to CJS_DEEP_LANE_CAP bytes); what they leave, and bigger groups, the doubling rounds of k1_run take.
 #ifndef K1R_T
-#define K1R_T 1024u          // entries a workgroup owns per step (512 -> 1024, round 3: 80 % of the 1280 slots of a step are owned instead of 67 %,
+#define K1R_T 768u           // entries a workgroup owns per step (round 5: 768 - 24.6 KB of LDS, six workgroups per CU instead of five: the two-stream step 7.40 -> 7.24 ms (median of 8), the kernel
+                                // alone 1.78 -> 1.75; round 3: 512 -> 1024: 80 % of the 1280 slots of a step are owned instead of 67 %,
 #endif                          // half as many barriers and pipeline prologues per entry; 10^8-byte enwik, ms per step with 512 / 768 / 1024 / 1280 / 1792: 9.7 / 9.10 / 9.03 / 9.10 / 9.49)
 #define K1R_W K1F_GBIG
 #define K1R_N (K1R_T + K1R_W)
