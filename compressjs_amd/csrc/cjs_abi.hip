@@ -402,6 +402,8 @@ struct cjs_ctx {
     std::vector<u8>* bwtc_out;  // result of the last cjs_bwtc_decompress
     BwtcGroupJob* bwtc_jobs[2]; // double buffer between the GPU stages and the coder thread of cjs_bwtc_compress
     // the overlapped host path (compress_overlapped): persistent helper threads, copy streams, per-slice events and cursors
+    hipStream_t side;           // the block CRCs of every sub-batch (k0_crc) run here, next to K1
+    hipEvent_t evPad[CJS_NSTREAMS], evCrc[CJS_NSTREAMS];
     CjsHelper* io[3];           // [0] uploader, [1] downloader, [2] issues the slices of stream 0 (the caller's thread plans)
     hipStream_t sIn, sOut;      // copy streams (non-blocking)
     std::vector<hipEvent_t>* evPool;   // per slice: its k5_blockscan, everything of it
@@ -470,7 +472,12 @@ extern "C" cjs_ctx* cjs_create(int device, uint32_t batch_blocks) {
         ok = ok && hipEventCreateWithFlags(&c->evScan[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&c->evDone[i], hipEventDisableTiming) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&c->pin[i], CJS_PIN_WORDS * 4) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->evPad[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->evCrc[i], hipEventDisableTiming) == hipSuccess;
     }
+#ifndef CJS_CPU_DEBUG_BUILD
+    if (ok && !getenv("CJS_NO_SIDE_CRC")) ok = hipStreamCreate(&c->side) == hipSuccess;
+#endif
     ok = ok && hipEventCreateWithFlags(&c->evReady, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_ss, 256) == hipSuccess;
     ok = ok && hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess;
@@ -487,6 +494,8 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
         if (c->evScan[i]) (void)hipEventDestroy(c->evScan[i]);
         if (c->evDone[i]) (void)hipEventDestroy(c->evDone[i]);
         if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+        if (c->evPad[i]) (void)hipEventDestroy(c->evPad[i]);
+        if (c->evCrc[i]) (void)hipEventDestroy(c->evCrc[i]);
         if (c->helper[i]) { c->helper[i]->stop(); delete c->helper[i]; }
         if (c->sub[i]) (void)hipStreamDestroy(c->sub[i]);
     }
@@ -505,6 +514,7 @@ extern "C" void cjs_destroy(cjs_ctx* c) {
     if (c->snapPin) (void)hipHostFree(c->snapPin);
     (void)hipFree(c->k0sl);
     if (c->segpool) { for (auto& pr : *c->segpool) (void)hipFree(pr.first); delete c->segpool; }
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->sIn) (void)hipStreamDestroy(c->sIn);
     if (c->sOut) (void)hipStreamDestroy(c->sOut);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -545,7 +555,7 @@ static int run_sub_batch(cjs_ctx* c, const K0Buf& K, const BatchGeom& g, u32 cap
     // (CRC workgroups per block: one per 2 MB of input a block of this call consumes on average - long runs make that tens of megabytes;
     // total_blocks = the blocks the planned input K holds, so that windows with a margin and sub-ranges count their own bytes)
     const u64 per_block = K.in_len / (total_blocks ? total_blocks : 1u);
-    int rc = k0_batch(K, P, f, cap, st, (u32)(1u + per_block / (2u << 20)));
+    int rc = k0_batch(K, P, f, cap, st, (u32)(1u + per_block / (2u << 20)), c->side, c->side ? c->evPad[si] : nullptr, c->side ? c->evCrc[si] : nullptr);
     if (rc) return rc;
     return pipe_run_block_stages(P, cap, st, 4);
 }
@@ -588,7 +598,7 @@ static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 coun
             Pipe P;
             int rc = err.load() ? err.load() : run_sub_batch(c, K, g, cap, f, nb, si, d_out, out_cap, P, first + count);
             while (recorded.load(std::memory_order_acquire) != j) std::this_thread::yield();
-            if (!rc && !err.load()) rc = k5_run(P, cap, c->sub[si], j ? c->evScan[(j - 1) % ns] : nullptr, c->evScan[si]);
+            if (!rc && !err.load()) rc = k5_run(P, cap, c->sub[si], j ? c->evScan[(j - 1) % ns] : nullptr, c->evScan[si], c->side ? c->evCrc[si] : nullptr);
             if (rc) { int z = 0; err.compare_exchange_strong(z, rc); }
             recorded.store(j + 1, std::memory_order_release);
         }
@@ -1096,7 +1106,7 @@ static int64_t compress_overlapped(cjs_ctx* c, const uint8_t* in, uint64_t in_le
             if (!r2) {
                 if (sl.nblocks) {
                     P.snap = c->snapPin + k;
-                    r2 = k5_run(P, cap, c->sub[si], k ? S[k - 1].evScan : nullptr, sl.evScan);
+                    r2 = k5_run(P, cap, c->sub[si], k ? S[k - 1].evScan : nullptr, sl.evScan, c->side ? c->evCrc[si] : nullptr);
                 } else {
                     // (a slice in which no block starts: the cursor stays where it is)
                     if (k && hipStreamWaitEvent(c->sub[si], S[k - 1].evScan, 0) != hipSuccess) r2 = CJS_E_HIP;

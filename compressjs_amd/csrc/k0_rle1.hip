@@ -756,13 +756,22 @@ int k0_phase_plan(K0Buf K, u32 cap, u64 phase, u64 own_len, u32 last, u64 total,
 }
 
 // RLE1 text + CRC of blocks [first_block, first_block + P.g.nb) into the batch P
-int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream, u32 crc_parts) {
+// side / ev_pad / ev_crc (optional): the block CRCs - one workgroup per block, 90-120 us alone on the sub-batch's critical path, and nobody needs them
+// before k5_header - run on `side` behind k0_pad (ev_pad) while `stream` goes on with K1; ev_crc is recorded behind them (k5_run waits for it)
+int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream, u32 crc_parts, hipStream_t side, hipEvent_t ev_pad, hipEvent_t ev_crc) {
     if (crc_parts < 1u) crc_parts = 1u;
     if (crc_parts > K0_CRC_PARTS) crc_parts = K0_CRC_PARTS;
     const u32 gx = cap / K0_TILE + 2;
     hipLaunchKernelGGL(k0_materialize, dim3(gx, P.g.nb), dim3(256), 0, stream, K, P, first_block, cap);
     hipLaunchKernelGGL(k0_pad, dim3(P.g.nb), dim3(64), 0, stream, K, P, first_block);
-    hipLaunchKernelGGL(k0_crc, dim3(crc_parts, P.g.nb), dim3(1024), 0, stream, K, P, first_block);
+    if (side && ev_pad && ev_crc) {
+        HIP_CHECK_RET(hipEventRecord(ev_pad, stream));
+        HIP_CHECK_RET(hipStreamWaitEvent(side, ev_pad, 0));
+        hipLaunchKernelGGL(k0_crc, dim3(crc_parts, P.g.nb), dim3(1024), 0, side, K, P, first_block);
+        HIP_CHECK_RET(hipEventRecord(ev_crc, side));
+    } else {
+        hipLaunchKernelGGL(k0_crc, dim3(crc_parts, P.g.nb), dim3(1024), 0, stream, K, P, first_block);
+    }
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

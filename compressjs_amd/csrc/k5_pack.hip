@@ -396,9 +396,10 @@ int k5_stream_end(Pipe P, hipStream_t stream) {
 
 // `after` (optional): event of the previous batch's k5_blockscan -- bit offsets chain across
 // batches; `done` (optional) is recorded right after this batch's k5_blockscan.
-int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after, hipEvent_t done) {
+int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after, hipEvent_t done, hipEvent_t crc_ready) {
     const BatchGeom g = P.g;
     const u32 tiles = (max_n + 1 + K1_RT - 1) / K1_RT;
+    if (crc_ready) HIP_CHECK_RET(hipStreamWaitEvent(stream, crc_ready, 0));
     hipLaunchKernelGGL(k5_header, dim3(g.nb), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k5_lensum, dim3(g.rtiles, g.nb), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k5_tilescan, dim3(g.nb), dim3(256), 0, stream, P);

@@ -102,11 +102,11 @@ int k2_run(Pipe P, u32 max_n, hipStream_t stream);
 int k10_model_run(Pipe P, u32* sylt, u32* tot, u32* ntri, u32 ostride, u32 ocap, hipStream_t stream);
 int k34_run(Pipe P, hipStream_t stream);
 int k3_alloc_lengths_run(long long* d_arr, const u32* d_off, u32 count, int maxlen, hipStream_t stream);
-int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after = nullptr, hipEvent_t done = nullptr);
+int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after = nullptr, hipEvent_t done = nullptr, hipEvent_t crc_ready = nullptr);   // crc_ready: the block CRCs were computed on another stream (k0_batch)
 int k5_stream_begin(Pipe P, int level, hipStream_t stream, bool zero = true);   // zero = false: the caller has zeroed P.out (on another stream, next to the pre-pass)
 int k5_stream_end(Pipe P, hipStream_t stream);
 int k5_shift_bits_run(const u8* d_in, u64 nbytes, u32 s, u8* d_out, hipStream_t stream);
-int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream, u32 crc_parts);   // crc_parts: workgroups per block of k0_crc (1 .. 16)
+int k0_batch(K0Buf K, Pipe P, u32 first_block, u32 cap, hipStream_t stream, u32 crc_parts, hipStream_t side = nullptr, hipEvent_t ev_pad = nullptr, hipEvent_t ev_crc = nullptr);   // crc_parts: workgroups per block of k0_crc (1 .. 16)
 size_t pipe_bytes(const BatchGeom& g);
 void pipe_carve(Pipe& P, const BatchGeom& g, void* base);
 int pipe_run_block_stages(Pipe& P, u32 max_n, hipStream_t stream, int upto, hipEvent_t after = nullptr,
