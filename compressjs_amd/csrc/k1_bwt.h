@@ -31,6 +31,19 @@
 #define K1E_LEN(e) (((u32)((e) >> 52) & 0xFFu) + 1u)
 #define K1E_KEEP (1ull << 60)          // doubling rounds: the rotation's rank (= position of its group head) did not change this round
 #define K1E_MAKE(len1, idx, s, pos) (((u64)(len1) << 52) | ((u64)(idx) << 44) | ((u64)(s) << 22) | (u64)(pos))
+// Round 5: the byte in FRONT of a rotation - what the BWT gather (k1_finish) fetches with one random load per rotation, 10^8 of them per step - travels with the
+// rotation through the text stages instead.  k1f_scatter packs it into the index word it writes (bits 24..31 over a 22-bit index); the bucket sorts and the task
+// levels move packed words and write U next to the suffix array; the refinement rounds' entries carry it in the CARRY layout below (blocks below 2^20 bytes: 20-bit
+// fields), the lane kernels permute U with the suffix array.  Blocks whose order is finished by anything else (doubling rounds, periodic routes) are gathered as before.
+#define K1_SMASK 0x3FFFFFu
+#define K1_SPACK(s, byte) ((u32)(s) | ((u32)(byte) << 24))
+#define K1C_POS(e) ((u32)(e) & 0xFFFFFu)
+#define K1C_S(e) ((u32)((e) >> 20) & 0xFFFFFu)
+#define K1C_BYTE(e) ((u32)((e) >> 40) & 0xFFu)
+#define K1C_IDX(e) ((u32)((e) >> 48) & 0xFFu)
+#define K1C_LEN(e) (((u32)((e) >> 56) & 0xFFu) + 1u)
+#define K1C_MAKE(len1, idx, byte, s, pos) (((u64)(len1) << 56) | ((u64)(idx) << 48) | ((u64)(byte) << 40) | ((u64)(s) << 20) | (u64)(pos))
+#define K1_CARRY_MAXN (1u << 20)
 // doubling rounds (k1_dbl.hip)
 #define K1D_MAXR 24            // rounds at most (h0 >= 8, n < 2^22: 19 doublings + the tie-break round)
 #ifndef K1D_GS
@@ -145,8 +158,8 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream);
 // k1_front.hip: rotations of every block sorted by their first 8 bytes into B.SA, group heads into B.HN
 // iters: 0 = the bucket sort compares 8 bytes, else K1F_KEYB = 16 (cyclic mode with lists); lists: fill the round lists (0: neither - the
 // K1-deep tile kernel does that work); purerot_max: the predictor threshold (see k1f_bsort)
-int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max);
-int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth);
+int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max, u32 carry);
+int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth, u32 carry);
 // k1_dbl.hip: ranks of every rotation from (SA, HN), then list-driven prefix doubling from depth h0 until every group is resolved
 //   check_h != 0: from the round with that h on the host looks after every round whether anything is left and stops launching if not
 int k1_dbl_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 h0, u32 check_h);

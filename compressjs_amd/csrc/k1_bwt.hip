@@ -101,7 +101,7 @@ __device__ __forceinline__ bool deep_walk(const u8* T, u32 n, const u32* members
 #pragma unroll
     for (int i = 0; i < M; i++) {
         pp[i] = 0;
-        if ((u32)i < gl) { u32 q = members[(u32)i * mstride] + dm; if (q >= n) q -= n; pp[i] = q; }
+        if ((u32)i < gl) { u32 q = (members[(u32)i * mstride] & K1_SMASK) + dm; if (q >= n) q -= n; pp[i] = q; }      // (the members may be packed index words)
     }
     for (;;) {
         u64 k[M][W];
@@ -165,7 +165,7 @@ __device__ __forceinline__ bool deep_pass2_wanted(const K1Buf& B, u32 limit, u32
 }
 
 template <bool PASS2>
-__global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 capd, u32 limit) {
+__global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 capd, u32 limit, u32 carry) {
     if (!deep_pass2_wanted<PASS2>(B, limit, capd)) return;
     // gridDim.x is a multiple of 8 * K1_DEEP_SUB: workgroup -> (XCD region, sub-region, slice of the sub-region)
     const u32 xr = (blockIdx.x & 7u) * K1_DEEP_SUB + ((blockIdx.x >> 3) & (K1_DEEP_SUB - 1u));
@@ -181,12 +181,16 @@ __global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 c
         const u32 n = B.nfront[b];
         const u8* T = B.T + (size_t)b * g.tstride;
         u32* SA = B.SA + (size_t)b * g.stride + start;
+        u8* U = B.U + (size_t)b * g.stride + start;          // (carry mode: the BWT bytes of these positions move with the rotations)
         u32 mem[2];
         u64 keys[2];
         mem[0] = SA[0];
         mem[1] = SA[1];
         if (deep_walk<2, 8>(T, n, mem, 1u, 2u, d, capd, keys, 1u)) {
-            if (keys[0] > keys[1]) { SA[0] = mem[1]; SA[1] = mem[0]; }
+            if (keys[0] > keys[1]) {
+                SA[0] = mem[1]; SA[1] = mem[0];
+                if (carry) { const u8 u0 = U[0], u1 = U[1]; U[0] = u1; U[1] = u0; }
+            }
             atomicOr(&B.HN[(size_t)b * g.hstride + ((start + 1u) >> 5)], 1u << ((start + 1u) & 31u));
         } else if (!PASS2) {
             const u32 idx = atomicAdd(&B.deepCnt[2u * 8u * K1_DEEP_SUB + xr], 1u);
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void k1_deep_pairs(K1Buf B, BatchGeom g, u32 c
 // of all members until a word differs, sorts them by that word, and goes on depth-first with every run of
 // equal keys (own depth per run) until the group is resolved or a run ties up to capd (left as it is).
 template <bool PASS2>
-__global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 capd, u32 limit) {
+__global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 capd, u32 limit, u32 carry) {
     if (!deep_pass2_wanted<PASS2>(B, limit, capd)) return;
     __shared__ u64 lk[K1_DEEP_LANE * 256];
     __shared__ u32 lv[K1_DEEP_LANE * 256];
@@ -220,9 +224,14 @@ __global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 c
         const u32 n = B.nfront[b];
         const u8* T = B.T + (size_t)b * g.tstride;
         u32* SA = B.SA + (size_t)b * g.stride + start;
+        u8* U = B.U + (size_t)b * g.stride + start;
         u32 mem[K1_DEEP_LANE];
 #pragma unroll
         for (int i = 0; i < (int)K1_DEEP_LANE; i++) mem[i] = (u32)i < gl ? SA[i] : 0u;     // all loads in flight together
+        if (carry) {                                                  // the BWT bytes ride in the index words while the group is sorted
+#pragma unroll
+            for (int i = 0; i < (int)K1_DEEP_LANE; i++) if ((u32)i < gl) mem[i] = K1_SPACK(mem[i], U[i]);
+        }
 #pragma unroll
         for (int i = 0; i < (int)K1_DEEP_LANE; i++)
             if ((u32)i < gl) { cv[(u32)i * 256u] = mem[i]; cd[(u32)i * 256u] = (u16)DP_DEPTH(dsc); }
@@ -260,7 +269,11 @@ __global__ __launch_bounds__(256) void k1_deep_small(K1Buf B, BatchGeom g, u32 c
             for (u32 i = a + 1u; i < e; i++) if (ck[i * 256u] != ck[(i - 1u) * 256u]) heads |= 1u << i;
             for (u32 i = a; i < e; i++) cd[i * 256u] = (u16)(d < 0xFFFFu ? d : 0xFFFFu);
         }
-        for (u32 i = 0; i < gl; i++) SA[i] = cv[i * 256u];
+        for (u32 i = 0; i < gl; i++) {
+            const u32 v = cv[i * 256u];
+            SA[i] = v & K1_SMASK;
+            if (carry) U[i] = (u8)(v >> 24);
+        }
         const u64 bits = (u64)(heads & ~1u) << (start & 31u);
         u32* HN = B.HN + (size_t)b * g.hstride + (start >> 5);
         if ((u32)bits) atomicOr(&HN[0], (u32)bits);
@@ -297,7 +310,10 @@ __global__ __launch_bounds__(256) void k1_count_unsorted(K1Buf B, BatchGeom g) {
 // ---------------------------------------------------------------------------------------------
 // Four suffix-array entries per thread: one 16-byte load, four text gathers in flight, one 4-byte store (round 3; one entry per
 // thread was 4x the workgroups and a byte store each).
-__global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g) {
+// Round 5, `carry`: the text stages wrote U next to the suffix array (the byte in front of a rotation travels with it from k1f_scatter on), so a block whose
+// order they finished on their own needs no gather - only origPtr is looked up here (enwik: 0.46 -> 0.0x ms).  A block that the doubling rounds (dtot), the
+// closed form (per) or the three-period reduction (red) had a hand in is gathered as before.
+__global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g, u32 carry) {
     u32 b, tt;
     if (!xcd_block_tile(g.nb, b, tt)) return;
     const u32 n = B.nlen[b];
@@ -306,6 +322,18 @@ __global__ __launch_bounds__(256) void k1_finish(K1Buf B, BatchGeom g) {
     const u8* T = B.T + (size_t)b * g.tstride;
     const u32* SA = (B.red[b] ? B.SB : B.SA) + (size_t)b * g.stride;     // (k1_period.hip: expanded from the reduced block's)
     u8* U = B.U + (size_t)b * g.stride;
+    if (carry && B.dtot[K1_BI(B, b)] == 0u && B.per[b] == 0u && B.red[b] == 0u) {
+        if (p0 + 4u <= n) {
+            const uint4 v = *(const uint4*)(SA + p0);
+            if (v.x == 0u) B.pidx[b] = p0;
+            if (v.y == 0u) B.pidx[b] = p0 + 1u;
+            if (v.z == 0u) B.pidx[b] = p0 + 2u;
+            if (v.w == 0u) B.pidx[b] = p0 + 3u;
+        } else {
+            for (u32 p = p0; p < n; p++) if (SA[p] == 0u) B.pidx[b] = p;
+        }
+        return;
+    }
     if (p0 + 4u <= n) {
         const uint4 v = *(const uint4*)(SA + p0);          // stride is a multiple of 4 entries: 16-byte aligned
         const u32 s[4] = {v.x, v.y, v.z, v.w};
@@ -474,8 +502,11 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     }
     // the text stages: cyclic mode, blocks whose indices fit the list entries' 22 bits
     const bool fused = !B.linear && K.text_bytes > d0 && max_n < (1u << 22);
+    // the byte in front of a rotation travels with it through the text stages (k1_bwt.h: K1_SPACK): blocks below 2^20 bytes (CJS_K1_CARRY=0: off)
+    static const bool carry_on = []() { const char* e = getenv("CJS_K1_CARRY"); return !e || atoi(e) != 0; }();
+    const u32 carry = (fused && carry_on && max_n < K1_CARRY_MAXN) ? 1u : 0u;
     {
-        const int rc = k1_front_run(B, g, max_n, stream, fused ? K.bsort_iters : 0u, fused ? 1u : 0u, (u32)(total_n / K.big_div));
+        const int rc = k1_front_run(B, g, max_n, stream, fused ? K.bsort_iters : 0u, fused ? 1u : 0u, (u32)(total_n / K.big_div), carry);
         if (rc) return rc;
     }
     if (K.trace) {
@@ -504,7 +535,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     if (fused) {
         // the refinement rounds over what k1f_bsort and the task levels listed; a block ends them early when its list stops shrinking
         const u32 depth0 = K.bsort_iters ? K1F_KEYB : d0;           // bytes every listed group shares
-        const int rc = k1_rounds_run(B, g, stream, depth0, K.text_bytes);
+        const int rc = k1_rounds_run(B, g, stream, depth0, K.text_bytes, carry);
         if (rc) return rc;
         if (K.trace) {
             std::vector<u32> rc2((size_t)(K1R_MAXR + 1) * B.rnb8 * K1_RCS);
@@ -528,8 +559,8 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
             const u32 lane_unit = 8u * K1_DEEP_SUB;          // one workgroup per (XCD region, sub-region) at least
             const u32 lane_grid = g.nb * 32u <= lane_unit ? lane_unit : (g.nb * 32u >= 4096u ? 4096u : (g.nb * 32u + lane_unit - 1u) / lane_unit * lane_unit);
             const u32 limit = (u32)(total_n / 256u);
-            hipLaunchKernelGGL(k1_deep_pairs<true>, dim3(lane_grid), dim3(256), 0, stream, B, g, K.lane_cap, limit);
-            hipLaunchKernelGGL(k1_deep_small<true>, dim3(lane_grid), dim3(256), 0, stream, B, g, K.lane_cap, limit);
+            hipLaunchKernelGGL(k1_deep_pairs<true>, dim3(lane_grid), dim3(256), 0, stream, B, g, K.lane_cap, limit, carry);
+            hipLaunchKernelGGL(k1_deep_small<true>, dim3(lane_grid), dim3(256), 0, stream, B, g, K.lane_cap, limit, carry);
         }
     }
     // What still ties (long repeats, identical rotations, groups the text stages did not take; in linear mode everything beyond
@@ -585,7 +616,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         if (rc) return rc;
     }
     if (B.linear) hipLaunchKernelGGL(k1_finish_linear, dim3((max_n + 255) / 256, g.nb), dim3(256), 0, stream, B, g, B.SAout);
-    else hipLaunchKernelGGL(k1_finish, dim3((max_n + 1023) / 1024, (g.nb + 7u) & ~7u), dim3(256), 0, stream, B, g);
+    else hipLaunchKernelGGL(k1_finish, dim3((max_n + 1023) / 1024, (g.nb + 7u) & ~7u), dim3(256), 0, stream, B, g, carry);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

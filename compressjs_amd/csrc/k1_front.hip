@@ -176,7 +176,8 @@ __global__ __launch_bounds__(1024) void k1f_hist(K1Buf B, BatchGeom g, u32 ptile
     const u32* T32 = (const u32*)(T + t0);
     for (u32 i = tid; i < K1F_PT / 4 + 4; i += 1024) tx[i] = i < avail ? T32[i] : 0u;
     __syncthreads();
-    u16* bid = (u16*)(B.KA + (size_t)b * g.stride);
+    u32* bid = B.KA + (size_t)b * g.stride;             // bucket id | byte in front of the rotation << 16 (k1f_scatter packs it into the index word: K1_SPACK)
+    const u32 prev0 = tid == 0 ? (u32)T[t0 ? t0 - 1u : n - 1u] : 0u;
 #pragma unroll
     for (int it = 0; it < K1F_PT / 1024; it++) {
         const u32 q = (u32)it * 1024u + tid, j = t0 + q;
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(1024) void k1f_hist(K1Buf B, BatchGeom g, u32 ptile
             for (u32 l = 0; l < K1F_LOG_NB; l++) node = 2u * node + (sp[node] <= key ? 1u : 0u);
             const u32 pos = node - K1F_NB;
             atomicAdd(&hist[pos], 1u);
-            bid[j] = (u16)pos;
+            const u32 prev = q ? (tx[(q - 1u) >> 2] >> (((q - 1u) & 3u) * 8u)) & 0xFFu : prev0;
+            bid[j] = pos | (prev << 16);
         }
     }
     __syncthreads();
@@ -313,13 +315,15 @@ __global__ __launch_bounds__(1024) void k1f_scatter(K1Buf B, BatchGeom g, u32 pt
     const u32* th = B.tileHist + ((size_t)b * ptiles + t) * K1F_NB;
     for (u32 d = tid; d < K1F_NB; d += 1024) { cnt[d] = 0; base[d] = th[d]; }
     __syncthreads();
-    const u16* bid = (const u16*)(B.KA + (size_t)b * g.stride);
+    const u32* bid = B.KA + (size_t)b * g.stride;
     u32* SB = B.SB + (size_t)b * g.stride;
-    u32 dv[K1F_PT / 1024], rk[K1F_PT / 1024];
+    u32 dv[K1F_PT / 1024], rk[K1F_PT / 1024], pb[K1F_PT / 1024];
 #pragma unroll
     for (int it = 0; it < K1F_PT / 1024; it++) {
         const u32 j = t0 + (u32)it * 1024u + tid;
-        dv[it] = j < n ? bid[j] : 0xFFFFFFFFu;
+        const u32 v = j < n ? bid[j] : 0xFFFFFFFFu;          // bucket | byte in front of rotation j << 16 (k1f_hist): the byte rides in the index word (K1_SPACK) from here on
+        dv[it] = j < n ? (v & 0xFFFFu) : 0xFFFFFFFFu;
+        pb[it] = (v >> 16) & 0xFFu;
     }
 #pragma unroll
     for (int it = 0; it < K1F_PT / 1024; it++)
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(1024) void k1f_scatter(K1Buf B, BatchGeom g, u32 pt
     for (int it = 0; it < K1F_PT / 1024; it++)
         if (dv[it] != 0xFFFFFFFFu) {
             const u32 slot = cnt[dv[it]] + rk[it];
-            stage[slot] = t0 + (u32)it * 1024u + tid;
+            stage[slot] = K1_SPACK(t0 + (u32)it * 1024u + tid, pb[it]);
             sbk[slot] = (u16)dv[it];
         }
     __syncthreads();
@@ -414,7 +418,6 @@ static_assert(K1F_LS <= K1F_BT && K1F_LK <= 64, "one thread per local sample; le
 #define K1F_GBIG 256u                                   // groups up to this size are listed for the refinement rounds (8-bit fields of a list entry)
 #endif
 #define K1F_CAP (K1F_C - 4u)                            // rotations a bucket-sort workgroup takes (four spare key cells behind them: the ranking loops read past a leaf's end)
-#define K1F_LEAFSH 26u                                  // leaf id of a rotation travels in the top bits of its index word (n < 2^26)
 
 // ---- 16-byte keys: four big-endian dwords, x the most significant -------------------------------------------------
 // 16 text bytes at T + p (any alignment): one dwordx4 + one dword load, v_alignbyte.  A random gather from the L2-resident
@@ -545,7 +548,7 @@ __device__ __forceinline__ bool k1f_bit(const u32* bm, u32 q) { return (bm[q >> 
 // LDS of a bucket-sort workgroup (views into the kernel's __shared__ arrays)
 struct K1fL {
     uint4* key;     // [K1F_C]  16-byte keys: arrival order, then leaf order, then sorted
-    u32* sx;        // [K1F_C]  rotation index at every position (leaf order: | leaf << K1F_LEAFSH); before that the local sample sort's scratch:
+    u32* sx;        // [K1F_C]  packed index word (K1_SPACK) at every position; before the leaf order the local sample sort's scratch:
     uint4* smp;     //   [K1F_LS] samples (aliases sx)
     uint4* sp;      //   [K1F_LK] local splitters (aliases sx)
     u32* srank;     //   [K1F_LS] sample ranks (aliases sx)
@@ -553,6 +556,7 @@ struct K1fL {
     u32* off2;      // [K1F_LK + 1]  first position of every leaf | 1 << 31 for a leaf of ONE key
     u32* hb;        // [K1F_HW] group heads (bit 0 and bits >= cnt set)
     u32* lb;        // [K1F_HW] flush: listed positions
+    u8* lf;         // [K1F_C]  leaf of every position (leaf order)
     u32* misc;      // [K1F_E * K1F_NW + 8] workgroup-wide scratch words
 };
 
@@ -560,6 +564,7 @@ struct K1fL {
 // x = block, y = suffix-array position of the slice, z = its length, w = depth (bytes all its rotations share) | K1F_TASK_SB
 // when the indices sit in the slice of SB (not SA).  One atomic per task (they are rare).
 #define K1F_TASK_SB 0x80000000u
+#define K1F_TASK_PLAIN 0x40000000u   // the slice holds plain indices (k1f_flush wrote it): in carry mode the task first packs the BWT bytes of its positions into them
 #define K1F_PS (K1F_C / 2)          // samples a task partition sorts in LDS
 #define K1F_PB (K1F_C / 4)          // sub-buckets of a task partition, at most (<= 256: one byte per id)
 static_assert(K1F_PB <= 256 && K1F_PB >= 64 && (K1F_PB & (K1F_PB - 1)) == 0 && K1F_PS % 4 == 0, "task partition geometry");
@@ -575,7 +580,7 @@ __device__ __forceinline__ void k1f_push_task(const K1Buf& B, u32 level, u32 b, 
 // where a tie outlasts the last round, clear the bits again.  One atomic per workgroup reserves the list slots.  Groups above
 // K1F_GBIG rotations stay marked as groups and become tasks of level `task_level`, `task_depth` deep.
 __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const BatchGeom& g, u32 b, u32 pos0, u32 cnt, bool lists,
-                                          u32 task_level, u32 task_depth) {
+                                          u32 task_level, u32 task_depth, bool carry) {
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     u32* SA = B.SA + (size_t)b * g.stride + pos0;
     u32* HN = B.HN + (size_t)b * g.hstride;
@@ -602,7 +607,7 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
                 listed = gl <= K1F_GBIG;
                 gsv[it] = (q - gs) | ((gl - 1u) << 8);
                 // a group too big for the lists: a task of the next level
-                if (!listed && q == gs) k1f_push_task(B, task_level, b, pos0 + gs, gl, task_depth);
+                if (!listed && q == gs) k1f_push_task(B, task_level, b, pos0 + gs, gl, task_depth | K1F_TASK_PLAIN);
             }
             bal[it] = __ballot(listed);
             if (lane == 0) { lb[q0 >> 5] = (u32)bal[it]; lb[(q0 >> 5) + 1u] = (u32)(bal[it] >> 32); }
@@ -620,7 +625,16 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
             if (lane < K1F_E * K1F_NW) S.misc[lane] = base + inc - c;
         }
     }
-    for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = S.sx[i];
+    // the suffix-array slice (plain indices) and, in carry mode, the BWT bytes of these positions: final where the rotation is settled here,
+    // overwritten by whoever settles it later (k1r_round, the lane kernels)
+    {
+        u8* U = B.U + (size_t)b * g.stride + pos0;
+        for (u32 i = tid; i < cnt; i += K1F_BT) {
+            const u32 v = S.sx[i];
+            SA[i] = v & K1_SMASK;
+            if (carry) U[i] = (u8)(v >> 24);
+        }
+    }
     __syncthreads();
     if (lists) {
         k1f_write_heads(HN, pos0, pos0 + cnt, [&](u32 p) { return k1f_bit(S.hb, p - pos0) || k1f_bit(lb, p - pos0); });
@@ -630,7 +644,10 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
             const u32 q = (u32)it * K1F_BT + tid;
             if ((bal[it] >> lane) & 1ull) {
                 const u32 idx = S.misc[(u32)it * K1F_NW + w] + (u32)__popcll(bal[it] & lt);
-                if (idx < g.stride) L[idx] = ((u64)gsv[it] << 44) | ((u64)S.sx[q] << 22) | (u64)(pos0 + q);
+                const u32 v = S.sx[q];
+                if (idx < g.stride)
+                    L[idx] = carry ? K1C_MAKE(gsv[it] >> 8, gsv[it] & 0xFFu, v >> 24, v & K1_SMASK, pos0 + q)
+                                   : (((u64)gsv[it] << 44) | ((u64)(v & K1_SMASK) << 22) | (u64)(pos0 + q));
             }
         }
     } else {
@@ -683,7 +700,7 @@ __device__ __forceinline__ void k1f_sortk(const K1fL& S, const u8* T, u32 n, con
 #pragma unroll
     for (int it = 0; it < K1F_E; it++) {
         const u32 i = (u32)it * K1F_BT + tid;
-        u32 p = v[it] + dm;
+        u32 p = (v[it] & K1_SMASK) + dm;                   // (index words are packed: K1_SPACK)
         if (p >= n) p -= n;
         k[it] = i < cnt ? KT::load(T, p) : KT::zero();
     }
@@ -769,7 +786,8 @@ __device__ __forceinline__ void k1f_sortk(const K1fL& S, const u8* T, u32 n, con
             if (L[it] != 0xFFFFFFFFu) {
                 const u32 leaf = L[it] >> 16, p = (S.off2[leaf] & 0x7FFFFFFFu) + (L[it] & 0xFFFFu);
                 key[p] = k[it];
-                sx[p] = v[it] | (leaf << K1F_LEAFSH);
+                sx[p] = v[it];
+                S.lf[p] = (u8)leaf;
             }
         __syncthreads();
         K1F_SSTAMP(2);
@@ -779,11 +797,11 @@ __device__ __forceinline__ void k1f_sortk(const K1fL& S, const u8* T, u32 n, con
             const u32 i = (u32)it * K1F_BT + tid;
             q[it] = 0xFFFFFFFFu;
             if (i < cnt) {
-                const u32 vl = sx[i], leaf = vl >> K1F_LEAFSH;
+                const u32 vl = sx[i], leaf = S.lf[i];
                 const u32 oo = S.off2[leaf], o = oo & 0x7FFFFFFFu, e = S.off2[leaf + 1u] & 0x7FFFFFFFu;
                 const KeyT mine = key[i];
                 kk[it] = mine;
-                vv[it] = vl & ((1u << K1F_LEAFSH) - 1u);
+                vv[it] = vl;
                 u32 less = 0;
                 if (!(oo >> 31)) {
                     for (u32 j = o; j < e; j += 4u) {
@@ -851,11 +869,12 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
     __shared__ __attribute__((aligned(16))) u32 sx[K1F_C];                                                                           \
     __shared__ u32 cnt2s[K1F_LK], off2s[K1F_LK + 1];                                                                                 \
     __shared__ u32 hbits[K1F_HW], lbits[K1F_HW];                                                                                     \
+    __shared__ u8 lfs[K1F_C];                                                                                                        \
     __shared__ u32 misc[K1F_E * K1F_NW + 8];                                                                                         \
     static_assert((K1F_LS + K1F_LK) * 16 + K1F_LS * 4 <= K1F_C * 4, "the local sample sort's scratch fits sx[]");                    \
     K1fL S;                                                                                                                          \
     S.key = key128; S.sx = sx; S.smp = (uint4*)sx; S.sp = (uint4*)sx + K1F_LS; S.srank = sx + (K1F_LS + K1F_LK) * 4;                 \
-    S.cnt2 = cnt2s; S.off2 = off2s; S.hb = hbits; S.lb = lbits; S.misc = misc;
+    S.cnt2 = cnt2s; S.off2 = off2s; S.hb = hbits; S.lb = lbits; S.lf = lfs; S.misc = misc;
 
 // One workgroup per bucket (a bucket is a KEY RANGE: everything that ties on its first 8 bytes, or deeper, is inside).
 //   1. k1f_sort128: the bucket sorted by its first 16 bytes in LDS (`wide`; else 8), groups of equal keys marked;
@@ -870,7 +889,7 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
 #define K1F_BG 1u                                       // buckets a bucket-sort workgroup walks (power of two; 1: measured best, see below): neighbours are sorted TOGETHER while they fit
 #endif
 static_assert(K1F_NB % K1F_BG == 0, "bucket groups");
-__global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max) {
+__global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max, u32 carry) {
     u32 b, dg;
     if (!xcd_block_tile(g.nb, b, dg)) return;
     const u32 n = B.nfront[b];
@@ -913,7 +932,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
         if (pure && !deepen && (!wide || cnt > K1F_CAP)) {
             // one 8-byte key, no text stage behind this one, and no 16-byte sort either (linear mode, or beyond LDS): a single group as it stands
             u32* SA = B.SA + (size_t)b * g.stride + start;
-            for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i];
+            for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i] & K1_SMASK;       // (a group: the doubling rounds finish this block, k1_finish gathers its bytes)
             k1f_write_heads(HN, start, start + cnt, [&](u32 p) { return p == start; });
             if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (trace only)
             j++;
@@ -936,7 +955,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
 #ifdef K1F_TRACE
         long long tprev_ = clock64();
 #endif
-        k1f_flush(S, B, g, b, start, cnt, deepen, 0u, wide ? K1F_KEYB : 8u);
+        k1f_flush(S, B, g, b, start, cnt, deepen, 0u, wide ? K1F_KEYB : 8u, carry != 0u);
         K1F_STAMP(5);
         j = je;
     }
@@ -955,7 +974,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
 // groups of 257..1024: rounds 1-2 left all of them to prefix doubling from h = 8 (13 of 22 ms).  `last` (the last level
 // launched): whatever arrives is sorted by 8 bytes at its depth and left at that (the doubling rounds take it from there):
 // in LDS if it fits, else by stable LSD passes through global memory (one digit byte gathered per pass; slow, never seen).
-__global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 level, u32 iters, u32 lists, u32 purerot_max, u32 last) {
+__global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 level, u32 iters, u32 lists, u32 purerot_max, u32 last, u32 carry) {
     K1F_DECLARE_LDS(S)
     // scratch of the partition and of the last level's LSD passes: views into the key cells (K1F_C * 16 bytes)
     u64* key = (u64*)key128;                            // [K1F_PS + K1F_PB] u64
@@ -968,7 +987,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
     for (u32 li = blockIdx.x; li < ntask; li += gridDim.x) {
         __syncthreads();
         const uint4 tk = B.btask[(size_t)level * B.btaskCap + li];
-        const u32 b = tk.x, pos = tk.y, len = tk.z, depth = tk.w & ~K1F_TASK_SB;
+        const u32 b = tk.x, pos = tk.y, len = tk.z, depth = tk.w & ~(K1F_TASK_SB | K1F_TASK_PLAIN);
         const bool inSB = (tk.w & K1F_TASK_SB) != 0u;
         const u32 n = B.nfront[b];
         const u8* T = B.T + (size_t)b * g.tstride;
@@ -977,6 +996,13 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
         u32* HN = B.HN + (size_t)b * g.hstride;
         const u32* src = inSB ? SBs : SAs;
         const u32 dm = depth % n;
+        if (carry && (tk.w & K1F_TASK_PLAIN)) {
+            // a group that k1f_flush left in the suffix array (plain indices, its BWT bytes in U): packed index words from here on, like every other slice
+            const u8* Ub = B.U + (size_t)b * g.stride + pos;
+            for (u32 i = tid; i < len; i += K1F_BT) SAs[i] = K1_SPACK(SAs[i], Ub[i]);
+            __threadfence_block();
+            __syncthreads();
+        }
         const bool widem = lists != 0u && iters != 0u && !last;       // 16-byte keys also without lists behind them (see k1f_bsort)
         if (!deepen && depth && (!widem || len > K1F_CAP)) {
             // no text stages behind this one (linear mode: BWT.bwtransform / suffixsort sort suffixes by the first 8 bytes only; cyclic
@@ -984,19 +1010,24 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             // group, as the one-key buckets of k1f_bsort are.  (Until round 4 the cyclic case went on partitioning such slices 8 bytes
             // deeper, level after level - 0.8 ms per E8S-A sub-batch, one workgroup alone on a 50 000-rotation slice - for an order the
             // doubling rounds do not need.)
-            for (u32 i = tid; i < len; i += K1F_BT) SAs[i] = src[i];
+            for (u32 i = tid; i < len; i += K1F_BT) SAs[i] = src[i] & K1_SMASK;     // (stays a group: the doubling rounds finish this block)
             if (tid == 0) atomicOr(&HN[pos >> 5], 1u << (pos & 31u));
             continue;
         }
         if (len <= K1F_CAP) {
             if (len == 1u) {
-                if (tid == 0) { SAs[0] = src[0]; atomicOr(&HN[pos >> 5], 1u << (pos & 31u)); }
+                if (tid == 0) {
+                    const u32 v = src[0];
+                    SAs[0] = v & K1_SMASK;
+                    if (carry) B.U[(size_t)b * g.stride + pos] = (u8)(v >> 24);
+                    atomicOr(&HN[pos >> 5], 1u << (pos & 31u));
+                }
                 continue;
             }
             const bool go = deepen && !last;
             const bool wide = widem;
             k1f_sort128(S, T, n, src, len, dm, wide);
-            k1f_flush(S, B, g, b, pos, len, go, level + 1u, depth + (wide ? K1F_KEYB : 8u));
+            k1f_flush(S, B, g, b, pos, len, go, level + 1u, depth + (wide ? K1F_KEYB : 8u), carry != 0u);
             continue;
         }
         if (!last) {
@@ -1008,7 +1039,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             if (nbk > K1F_PB - 1u) nbk = K1F_PB - 1u;
             for (u32 i = tid; i < K1F_PS; i += K1F_BT) {
                 const u32 at = (u32)(((u64)i * len + (k1f_hash(i, pos) % len)) / K1F_PS) % len;      // stratified, hashed
-                u32 p = src[at] + dm;
+                u32 p = (src[at] & K1_SMASK) + dm;
                 if (p >= n) p -= n;
                 smp[i] = k1f_load_be64(T, p);
             }
@@ -1047,7 +1078,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             __syncthreads();
             u8* ids = (u8*)(B.KA + (size_t)b * g.stride + pos);       // one byte per rotation of the slice (KA is free after k1f_scatter)
             for (u32 i = tid; i < len; i += K1F_BT) {
-                u32 p = src[i] + dm;
+                u32 p = (src[i] & K1_SMASK) + dm;
                 if (p >= n) p -= n;
                 const u64 kk = k1f_load_be64(T, p);
                 u32 id = 0;
@@ -1097,7 +1128,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
                 if (tid < 256u) dstart[tid] = 0;
                 if (tid == 0) *single = 0;
                 __syncthreads();
-                for (u32 i = tid; i < len; i += K1F_BT) { u32 p = sp[i] + dmp; if (p >= n) p -= n; atomicAdd(&dstart[T[p]], 1u); }
+                for (u32 i = tid; i < len; i += K1F_BT) { u32 p = (sp[i] & K1_SMASK) + dmp; if (p >= n) p -= n; atomicAdd(&dstart[T[p]], 1u); }
                 __syncthreads();
                 const u32 c = tid < 256u ? dstart[tid] : 0u;
                 if (c == len) *single = 1;
@@ -1112,7 +1143,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
                         const u32 i = r0 + lane;
                         const bool valid = i < len;
                         const u32 v = valid ? sp[i] : 0u;
-                        u32 p = v + dmp;
+                        u32 p = (v & K1_SMASK) + dmp;
                         if (p >= n) p -= n;
                         const u32 dg = valid ? T[p] : 0u;
                         const u64 m = match_any(dg, 8, valid);
@@ -1128,8 +1159,13 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
                 __syncthreads();
                 cur ^= 1;
             }
-            if (bufs[cur] != SAs) {
-                for (u32 i = tid; i < len; i += K1F_BT) SAs[i] = bufs[cur][i];
+            {   // packed words -> plain indices in the suffix array (in place when the last pass ended there: a thread rewrites only its own cells)
+                const u32* fin = bufs[cur];
+                for (u32 i = tid; i < len; i += K1F_BT) {
+                    const u32 v = fin[i];
+                    SAs[i] = v & K1_SMASK;
+                    if (carry) B.U[(size_t)b * g.stride + pos + i] = (u8)(v >> 24);
+                }
                 __threadfence_block();
                 __syncthreads();
             }
@@ -1188,7 +1224,13 @@ static_assert(K1R_ROWS % 4u == 0 && K1R_SW <= 64u && K1F_GBIG <= 256u, "rows are
 #endif
 #endif
 
+// CARRY: the entries are in the K1C layout (20-bit fields and the byte in front of the rotation): whoever settles a rotation writes its BWT byte next to the suffix-array entry
+template <bool CARRY>
 __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g, u32 round, u32 depth, u32 final_host) {
+    auto EPOS = [](u64 e) { return CARRY ? K1C_POS(e) : K1E_POS(e); };
+    auto ES = [](u64 e) { return CARRY ? K1C_S(e) : K1E_S(e); };
+    auto EIDX = [](u64 e) { return CARRY ? K1C_IDX(e) : K1E_IDX(e); };
+    auto ELEN = [](u64 e) { return CARRY ? K1C_LEN(e) : K1E_LEN(e); };
     u32 b, t0;
     if (!xcd_block_tile(g.nb, b, t0)) return;
     u32 cnt = K1_RCNT(B, round, b);
@@ -1211,6 +1253,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
     u64* Lout = B.rlist[(round & 1u) ^ 1u] + (size_t)b * g.stride;
     u32* ocnt = &K1_RCNT(B, round + 1u, b);
     u32* SA = B.SA + (size_t)b * g.stride;
+    u8* U = B.U + (size_t)b * g.stride;
     u32* HN = B.HN + (size_t)b * g.hstride;
     __shared__ u64 kA[K1R_N + 2], kB[K1R_N + 2], kC[K1R_N + 2];   // (+2: the ranking loop reads cells in pairs, one past a group's end)
     __shared__ u32 sb[2][K1R_SW], pre[2][K1R_SW + 1];
@@ -1227,7 +1270,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
         }
     };
     // owned: the group starts inside the tile's first K1R_T entries
-    auto own = [&](u64 e, u32 i) { const u32 gs = i - K1R_IDX(e); return K1R_LEN(e) >= 2u && gs < K1R_T; };     // (i < idx wraps to a huge gs)
+    auto own = [&](u64 e, u32 i) { const u32 gs = i - EIDX(e); return ELEN(e) >= 2u && gs < K1R_T; };     // (i < idx wraps to a huge gs)
     // raw text of the owned entries of a tile (7 dwords each, decoded when the tile's turn comes)
     auto gather = [&](const u64 (&e)[K1R_RPW], u32 (&d)[K1R_RPW][7]) {
 #pragma unroll
@@ -1236,7 +1279,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
 #pragma unroll
             for (int j = 0; j < 7; j++) d[it][j] = 0;
             if (own(e[it], i)) {
-                u32 p = K1R_S(e[it]) + dm;
+                u32 p = ES(e[it]) + dm;
                 if (p >= n) p -= n;
                 __builtin_memcpy(d[it], __builtin_assume_aligned(T + (p & ~3u), 4), 28);
             }
@@ -1266,7 +1309,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
             if (own(eC[it], i)) {
-                u32 p = K1R_S(eC[it]) + dm;
+                u32 p = ES(eC[it]) + dm;
                 if (p >= n) p -= n;
                 const u32 sh = p & 3u;
                 u32 x[6];
@@ -1304,7 +1347,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
             const u32 i = (it * 4u + w) * 64u + lane;
             qn[it] = 0xFFFFFFFFu;
             if (own(eC[it], i)) {
-                const u32 gs = i - K1R_IDX(eC[it]), ge = gs + K1R_LEN(eC[it]);
+                const u32 gs = i - EIDX(eC[it]), ge = gs + ELEN(eC[it]);
                 const u64 m0 = kA[i], m1 = kB[i], m2 = kC[i];
                 u32 less = 0, eqb = 0, eqt = 0;
                 for (u32 j = gs; j < ge; j += 2u) {
@@ -1327,14 +1370,17 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
                     }
                 }
                 const u32 q = gs + less + eqb;
-                const u32 s = K1R_S(eC[it]), pos = K1R_POS(eC[it]) + q - i;     // positions inside a group are consecutive
+                const u32 s = ES(eC[it]), pos = EPOS(eC[it]) + q - i;     // positions inside a group are consecutive
                 const bool surv = eqt > 1u;
-                if (!surv || final) SA[pos] = s;
+                if (!surv || final) {
+                    SA[pos] = s;
+                    if (CARRY) U[pos] = (u8)K1C_BYTE(eC[it]);
+                }
                 if (surv) {
                     if (!final) {
                         qn[it] = q;
                         atomicOr(&sb[par][q >> 5], 1u << (q & 31u));
-                        pv_e[it] = K1E_MAKE(eqt - 1u, eqb, s, pos);
+                        pv_e[it] = CARRY ? K1C_MAKE(eqt - 1u, eqb, K1C_BYTE(eC[it]), s, pos) : K1E_MAKE(eqt - 1u, eqb, s, pos);
                     } else if (eqb) {
                         // (not a head: its bit is cleared by the group's first member, below)
                     } else {
@@ -1404,7 +1450,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
 // ---------------------------------------------------------------------------------------------
 size_t k1_front_tilehist_words(const BatchGeom& g) { return (size_t)k1f_ptiles(g) * K1F_NB; }
 
-int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max) {
+int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32 iters, u32 lists, u32 purerot_max, u32 carry) {
     const u32 ptiles = k1f_ptiles(g);
     const u32 nb8 = (g.nb + 7u) & ~7u;
     hipLaunchKernelGGL(k1f_sample, dim3(g.nb), dim3(1024), 0, stream, B, g);
@@ -1413,7 +1459,7 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
     hipLaunchKernelGGL(k1f_scatter, dim3(ptiles, nb8), dim3(1024), 0, stream, B, g, ptiles);
     {
         const u32 slot = k1_prof_begin(B.prof, K1P_BSORT, stream);
-        hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB / K1F_BG, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max);
+        hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB / K1F_BG, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max, carry);
         k1_prof_end(B.prof, slot, stream, (u64)g.nb * max_n);
     }
     // the task levels: what k1f_bsort could not finish in LDS (slices beyond K1F_C, big groups), level after level; an empty
@@ -1421,7 +1467,7 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
     for (u32 lv = 0; lv < K1F_LEVELS; lv++) {
         const u32 slot = k1_prof_begin(B.prof, K1P_TASK, stream);
         hipLaunchKernelGGL(k1f_task, dim3(g.nb * 16u < 2048u ? g.nb * 16u : 2048u), dim3(K1F_BT), 0, stream, B, g, lv, iters, lists, purerot_max,
-                           lv + 1u == K1F_LEVELS ? 1u : 0u);
+                           lv + 1u == K1F_LEVELS ? 1u : 0u, carry);
         k1_prof_end(B.prof, slot, stream, 0);
     }
     HIP_CHECK_RET(hipGetLastError());
@@ -1429,7 +1475,7 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
 }
 
 // the refinement rounds over the lists k1f_bsort filled: depth0 = what the listed groups share, up to max_depth
-int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth) {
+int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u32 max_depth, u32 carry) {
     const u32 nb8 = (g.nb + 7u) & ~7u;
     const u32 full = (g.stride + K1R_T - 1u) / K1R_T;
     u32 rounds = max_depth > depth0 ? (max_depth - depth0 + K1R_STEP - 1u) / K1R_STEP : 1u;
@@ -1447,7 +1493,8 @@ int k1_rounds_run(K1Buf B, const BatchGeom& g, hipStream_t stream, u32 depth0, u
         for (u32 q = 0; q < r; q++) tiles = K1R_SHR == 2u ? tiles / 2u : tiles * 5u / 8u;
         if (tiles < 16u) tiles = 16u;
         const u32 slot = k1_prof_begin(B.prof, K1P_RROUND, stream);
-        hipLaunchKernelGGL(k1r_round, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
+        if (carry) hipLaunchKernelGGL(k1r_round<true>, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
+        else hipLaunchKernelGGL(k1r_round<false>, dim3(tiles, nb8), dim3(256), 0, stream, B, g, r, depth0 + K1R_STEP * r, r + 1u == rounds ? 1u : 0u);
         k1_prof_end(B.prof, slot, stream, 0);
     }
     HIP_CHECK_RET(hipGetLastError());
