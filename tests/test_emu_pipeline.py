@@ -420,7 +420,7 @@ def test_decoder_differential_fuzz_vs_oracle(emu_ctx):
     assert decode_fuzz.fuzz(L, h, seed=20260925, cases=150) == 150
 
 
-@pytest.mark.parametrize("env_add", [{}, {"CJS_TEXT_BYTES": "0"}, {"CJS_TEXT_BYTES": "44", "CJS_DEEP_LANE_CAP": "0"},
+@pytest.mark.parametrize("env_add", [{}, {"CJS_K1_CARRY": "0"}, {"CJS_TEXT_BYTES": "0"}, {"CJS_TEXT_BYTES": "44", "CJS_DEEP_LANE_CAP": "0"},
                                      {"CJS_BSORT_ITERS": "0", "CJS_DEEP_BIG_DIV": "1"}, {"CJS_BSORT_ITERS": "2"},
                                      {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}])
 def test_deep_refinement_of_suffix_sort(env_add):

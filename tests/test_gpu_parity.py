@@ -608,7 +608,7 @@ def test_deep_refinement_variants_same_bytes(ctx):
     outs = []
     for env_add in ({"CJS_TEXT_BYTES": "0"}, {}, {"CJS_TEXT_BYTES": "44", "CJS_DEEP_LANE_CAP": "0", "CJS_STREAMS": "1"},
                     {"CJS_BSORT_ITERS": "0", "CJS_DEEP_BIG_DIV": "1", "CJS_SHARES": "300:700"},
-                    {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}, {"CJS_K1_PERIOD": "0"}):
+                    {"CJS_DEEP_BIG_DIV": "1000000000", "CJS_K1_SYNC": "0"}, {"CJS_K1_PERIOD": "0"}, {"CJS_K1_CARRY": "0", "CJS_NO_SIDE_CRC": "1"}):
         env = dict(os.environ, **env_add)
         outs.append(subprocess.check_output([sys.executable, "-c", code], env=env, timeout=600).decode().split()[-2:])
     assert all(o == outs[0] for o in outs), outs
