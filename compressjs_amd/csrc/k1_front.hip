@@ -11,21 +11,21 @@
 //                LDS; every K1F_OVS-th is a splitter.  A key that fills more than one quantile gets a bucket of
 //                its own ([v, v+1): nothing to sort there), so runs/periodic data cannot overflow a bucket.
 //   k1f_hist     per tile of K1F_PT rotations: key of every rotation from the LDS-staged text, bucket = number
-//                of splitters <= key (branch-free binary search in LDS), per-tile bucket counts, bucket ids (u16).
+//                of splitters <= key (branch-free binary search in LDS), per-tile bucket counts; per rotation the bucket id
+//                and (round 5) the byte in FRONT of the rotation, which travels with it from here on (K1_SPACK).
 //   k1f_scan     per block: bucket starts and per-(tile, bucket) write offsets.
-//   k1f_scatter  rotation indices to their bucket (4 bytes per rotation; order inside a bucket is irrelevant).
-//   k1f_bsort    one workgroup per bucket: gathers the 8-byte keys from the block's text (L2-resident, all tiles
-//                of a block run on one XCD), sorts (key, index) in LDS by a local sample sort into <= 64 leaves and
-//                lane-parallel rank counting inside the leaves, takes K1F_STEP more bytes off what still ties
-//                (in-bucket deepening, round 3), writes the suffix array slice and the group heads once, and one
-//                list entry per rotation that still ties.
+//   k1f_scatter  packed index words (rotation index | byte in front << 24) to their bucket; order inside a bucket is irrelevant.
+//   k1f_bsort    one workgroup per bucket: (round 5) ONE in-LDS sample sort on 16-byte keys gathered from the block's text
+//                (L2-resident, all tiles of a block run on one XCD) - <= 64 leaves, lane-parallel rank counting inside the leaves by a
+//                carry chain -, writes the suffix-array slice, the BWT bytes and the group heads once, and one list entry per
+//                rotation that still ties.
 //   k1f_task     (round 3) slices beyond LDS and groups above K1F_GBIG rotations, level after level: partitioned
-//                like a block, or sorted in LDS 8 bytes deeper.
+//                like a block, or sorted in LDS 16 bytes deeper.
 //   k1r_round    (round 3) list-driven refinement: 24 more text bytes per round off every listed rotation, ranked
 //                inside its group; resolved rotations are final, the others go to the next round's list.
 //
-// HBM traffic per rotation of the 8-byte sort: text 1 + ids 2+2 + indices 4+4 + suffix array 4 + keys gathered from
-// L2 = ~17 bytes (the LSD design moved 7 x 20 = 140).  All integer work.
+// HBM traffic per rotation of the first sort: text 1 + ids 4+4 + indices 4+4 + suffix array 4 + BWT byte 1 + keys gathered from
+// L2 = ~22 bytes (the LSD design moved 7 x 20 = 140).  All integer work.
 #include "k1_bwt.h"
 #include "devutil.h"
 
@@ -885,87 +885,61 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
 // oversize buckets (linear mode; cyclic mode with the text stages off).
 // `purerot_max`: with more rotations than this in one-key buckets (counted by k1f_scan) the text stages are skipped
 // altogether (CJS_DEEP_BIG_DIV = 8: HTML-like input, whose ties of hundreds of bytes prefix doubling settles faster).
-#ifndef K1F_BG
-#define K1F_BG 1u                                       // buckets a bucket-sort workgroup walks (power of two; 1: measured best, see below): neighbours are sorted TOGETHER while they fit
-#endif
-static_assert(K1F_NB % K1F_BG == 0, "bucket groups");
+// One bucket per workgroup.  (Round 5, measured and dropped, ms for the kernel on enwik against 2.08: neighbouring buckets - adjacent key ranges - sorted
+// TOGETHER while they fit the LDS, pairs 3.32, fours 3.20; four buckets one after the other in a persistent workgroup 3.62: what this kernel lives on is the
+// number of INDEPENDENT workgroups in flight, 7 per CU, each a short chain of dependent loads and barriers.)
 __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom g, u32 iters, u32 lists, u32 purerot_max, u32 carry) {
-    u32 b, dg;
-    if (!xcd_block_tile(g.nb, b, dg)) return;
+    u32 b, d;
+    if (!xcd_block_tile(g.nb, b, d)) return;
     const u32 n = B.nfront[b];
     if (n == 0) return;
     const u32* fs = B.fstart + (size_t)b * (K1F_NB + 1);
+    const u32 start = fs[d], end = fs[d + 1];
+    if (end <= start) return;
+    const u32 cnt = end - start;
     const u32 tid = threadIdx.x;
     const u8* T = B.T + (size_t)b * g.tstride;
+    const u32* SB = B.SB + (size_t)b * g.stride + start;
     u32* HN = B.HN + (size_t)b * g.hstride;
     const u64* sp = B.fsplit + (size_t)b * K1F_NB;
+    // a bucket between the splitters v and v+1 holds one key only
+    const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
     // 16-byte keys whenever the caller wants the text stages (cyclic mode) - also when the predictor then skips them (HTML-like input): the
     // doubling rounds start from h = 8 either way, but on groups that are already 16 bytes deep where a bucket fit the LDS (E8S-A: k1f_bsort
     // 1.17 -> 1.41 ms, the doubling stage 7.6 -> 6.4 ms)
     const bool wide = lists != 0u && iters != 0u;
-    K1F_DECLARE_LDS(S)
-    // Buckets are adjacent key ranges: the union of neighbours, sorted, is the neighbours sorted one after the other.  A workgroup
-    // may walk K1F_BG buckets and sort as many of them at once as its LDS holds (a 2048-quantile is 440 rotations, a slot 1020): twice
-    // the rotations per barrier and per dependent load of the sort.  Measured (round 5, enwik, ms for the kernel): one bucket per
-    // workgroup 2.08; pairs sorted together 3.32, fours 3.20; four buckets one after the other 3.62 - what this kernel lives on is
-    // the number of INDEPENDENT workgroups in flight (7 per CU), each a short chain of dependent loads and barriers; K1F_BG stays 1.
-    const u32* fsv = fs + dg * K1F_BG;                  // (wave-uniform: scalar loads)
-    for (u32 j = 0; j < K1F_BG;) {
-        const u32 d = dg * K1F_BG + j;
-        const u32 start = fsv[j];
-        u32 cnt = fsv[j + 1] - start;
-        if (cnt == 0u) { j++; continue; }
-        // a bucket between the splitters v and v+1 holds one key only
-        const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
-        if (cnt > K1F_CAP && (deepen || !pure)) {
-            // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB
-            if (tid == 0) {
-                k1f_push_task(B, 0u, b, start, cnt, (pure ? 8u : 0u) | K1F_TASK_SB);
-                if (!pure) atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
-                atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
-            }
-            j++;
-            continue;
+    if (cnt > K1F_CAP && (deepen || !pure)) {
+        // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB
+        if (tid == 0) {
+            k1f_push_task(B, 0u, b, start, cnt, (pure ? 8u : 0u) | K1F_TASK_SB);
+            if (!pure) atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
+            atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
         }
-        const u32* SB = B.SB + (size_t)b * g.stride + start;
-        if (pure && !deepen && (!wide || cnt > K1F_CAP)) {
-            // one 8-byte key, no text stage behind this one, and no 16-byte sort either (linear mode, or beyond LDS): a single group as it stands
-            u32* SA = B.SA + (size_t)b * g.stride + start;
-            for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i] & K1_SMASK;       // (a group: the doubling rounds finish this block, k1_finish gathers its bytes)
-            k1f_write_heads(HN, start, start + cnt, [&](u32 p) { return p == start; });
-            if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);     // one big group (trace only)
-            j++;
-            continue;
-        }
-        // the neighbours that fit as well (never a one-key bucket that is to stay one group)
-        u32 je = j + 1u;
-#ifndef K1F_MERGE
-#define K1F_MERGE 1
-#endif
-        while (K1F_MERGE && je < K1F_BG && fsv[je + 1] - start <= K1F_CAP) {
-            const u32 d2 = dg * K1F_BG + je;
-            const bool pure2 = d2 < K1F_NB - 1u && sp[d2] == sp[d2 - 1u] + 1u;
-            if (pure2 && !deepen) break;
-            je++;
-        }
-        cnt = fsv[je] - start;
-        if (j) __syncthreads();                         // (the previous sort's flush still reads the LDS arrays)
-        k1f_sort128(S, T, n, SB, cnt, 0u, wide, B.stats);
-#ifdef K1F_TRACE
-        long long tprev_ = clock64();
-#endif
-        k1f_flush(S, B, g, b, start, cnt, deepen, 0u, wide ? K1F_KEYB : 8u, carry != 0u);
-        K1F_STAMP(5);
-        j = je;
+        return;
     }
+    if (pure && !deepen && (!wide || cnt > K1F_CAP)) {
+        // one 8-byte key, no text stage behind this one, and no 16-byte sort either (linear mode, or beyond LDS): a single group as it stands
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i] & K1_SMASK;           // (a group: the doubling rounds finish this block, k1_finish gathers its bytes)
+        k1f_write_heads(HN, start, end, [&](u32 p) { return p == start; });
+        if (tid == 0 && cnt > 64u) atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);         // one big group (trace only)
+        return;
+    }
+    K1F_DECLARE_LDS(S)
+    k1f_sort128(S, T, n, SB, cnt, 0u, wide, B.stats);
+#ifdef K1F_TRACE
+    long long tprev_ = clock64();
+#endif
+    k1f_flush(S, B, g, b, start, cnt, deepen, 0u, wide ? K1F_KEYB : 8u, carry != 0u);
+    K1F_STAMP(5);
 }
 
 // The task levels: slices that a bucket-sort workgroup could not finish in LDS.  Level L reads the tasks level L - 1 (or
 // k1f_bsort) pushed; one workgroup per task:
-//   * a slice of up to K1F_C rotations (sharing `depth` bytes) is sorted in LDS by the 8 bytes at `depth` (k1f_sort_lds),
-//     deepened and flushed like a bucket: what still ties goes to the refinement rounds' lists, groups above K1F_GBIG
-//     rotations become tasks of the next level, 8 bytes deeper;
+//   * a slice of up to K1F_CAP rotations (sharing `depth` bytes) is sorted in LDS by the 16 bytes at `depth` (k1f_sortk)
+//     and flushed like a bucket: what still ties goes to the refinement rounds' lists, groups above K1F_GBIG
+//     rotations become tasks of the next level, 16 bytes deeper;
 //   * a longer slice is PARTITIONED like a block by the front end: K1F_PS = 512 of its own keys at `depth` sorted in LDS, every
 //     k-th a splitter (a key that fills more than one quantile gets a sub-bucket of its own, 8 bytes deeper), bucket ids
 //     (one byte per rotation, in the slice of KA), an LDS histogram, the indices scattered into the other of the two index
@@ -1459,7 +1433,7 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
     hipLaunchKernelGGL(k1f_scatter, dim3(ptiles, nb8), dim3(1024), 0, stream, B, g, ptiles);
     {
         const u32 slot = k1_prof_begin(B.prof, K1P_BSORT, stream);
-        hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB / K1F_BG, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max, carry);
+        hipLaunchKernelGGL(k1f_bsort, dim3(K1F_NB, nb8), dim3(K1F_BT), 0, stream, B, g, iters, lists, purerot_max, carry);
         k1_prof_end(B.prof, slot, stream, (u64)g.nb * max_n);
     }
     // the task levels: what k1f_bsort could not finish in LDS (slices beyond K1F_C, big groups), level after level; an empty
