@@ -16,6 +16,27 @@ __device__ __forceinline__ u64 bitset1_b64(u64 m, u32 b) {
 #endif
 }
 
+// m & ~(1 << (b & 63)) in ONE scalar instruction (b is wave-uniform; "clear the lowest set bit" as m & (m - 1) is three)
+__device__ __forceinline__ u64 bitset0_b64(u64 m, u32 b) {
+#if defined(__AMDGCN__)
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
+    return m;
+#else
+    return m & ~(1ull << (b & 63u));
+#endif
+}
+
+// The big-endian u32 made of the four bytes at byte offset sh (0..3) of the little-endian dword pair hi:lo: v_alignbyte and the byte
+// swap in ONE v_perm_b32 (its selector is computed once per thread and text position: be_sel(sh)).
+__device__ __forceinline__ u32 be_sel(u32 sh) { return 0x00010203u + sh * 0x01010101u; }
+__device__ __forceinline__ u32 be32_at(u32 hi, u32 lo, u32 sel) {
+#if defined(__AMDGCN__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    return __builtin_bswap32((u32)((((u64)hi << 32) | lo) >> (8u * (sel >> 24))));
+#endif
+}
+
 // keeps the compiler from sinking the computation (typically a load) of v below this point
 __device__ __forceinline__ void pin_vgpr(u32& v) {
 #if defined(__AMDGCN__)

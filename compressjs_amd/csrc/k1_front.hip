@@ -33,9 +33,8 @@ __device__ __forceinline__ u64 k1f_load_be64(const u8* T, u32 p) {
     const u32 sh = p & 3u;
     u32 d[3];
     __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 12);
-    const u32 w0 = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
-    const u32 w1 = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
-    return ((u64)__builtin_bswap32(w0) << 32) | (u64)__builtin_bswap32(w1);
+    const u32 sel = be_sel(sh);
+    return ((u64)be32_at(d[1], d[0], sel) << 32) | (u64)be32_at(d[2], d[1], sel);
 }
 
 __device__ __forceinline__ u32 k1f_hash(u32 k, u32 b) {
@@ -183,9 +182,8 @@ __global__ __launch_bounds__(1024) void k1f_hist(K1Buf B, BatchGeom g, u32 ptile
         const u32 q = (u32)it * 1024u + tid, j = t0 + q;
         if (j < n) {
             const u32 sh = q & 3u, wi = q >> 2;
-            const u32 w0 = __builtin_amdgcn_alignbyte(tx[wi + 1], tx[wi], sh);
-            const u32 w1 = __builtin_amdgcn_alignbyte(tx[wi + 2], tx[wi + 1], sh);
-            const u64 key = ((u64)__builtin_bswap32(w0) << 32) | (u64)__builtin_bswap32(w1);
+            const u32 sel = be_sel(sh);
+            const u64 key = ((u64)be32_at(tx[wi + 1], tx[wi], sel) << 32) | (u64)be32_at(tx[wi + 2], tx[wi + 1], sel);
             u32 node = 1;                               // ends at K1F_NB + the number of splitters <= key
 #pragma unroll
             for (u32 l = 0; l < K1F_LOG_NB; l++) node = 2u * node + (sp[node] <= key ? 1u : 0u);
@@ -420,17 +418,18 @@ static_assert(K1F_LS <= K1F_BT && K1F_LK <= 64, "one thread per local sample; le
 #define K1F_CAP (K1F_C - 4u)                            // rotations a bucket-sort workgroup takes (four spare key cells behind them: the ranking loops read past a leaf's end)
 
 // ---- 16-byte keys: four big-endian dwords, x the most significant -------------------------------------------------
-// 16 text bytes at T + p (any alignment): one dwordx4 + one dword load, v_alignbyte.  A random gather from the L2-resident
+// 16 text bytes at T + p (any alignment): one dwordx4 + one dword load, one v_perm_b32 per key dword (alignment and byte order at once).  A random gather from the L2-resident
 // text costs the same at 4 and at 16 bytes (tests/microbench/gather.hip), so the bucket sort takes all 16 at once.
 __device__ __forceinline__ uint4 k1f_load_be128(const u8* T, u32 p) {
     const u32 sh = p & 3u;
     u32 d[5];
     __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 20);
+    const u32 sel = be_sel(sh);
     uint4 k;
-    k.x = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[1], d[0], sh));
-    k.y = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[2], d[1], sh));
-    k.z = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[3], d[2], sh));
-    k.w = __builtin_bswap32(__builtin_amdgcn_alignbyte(d[4], d[3], sh));
+    k.x = be32_at(d[1], d[0], sel);
+    k.y = be32_at(d[2], d[1], sel);
+    k.z = be32_at(d[3], d[2], sel);
+    k.w = be32_at(d[4], d[3], sel);
     return k;
 }
 __device__ __forceinline__ bool k1f_eq128(const uint4& a, const uint4& b) { return ((a.x ^ b.x) | (a.y ^ b.y) | (a.z ^ b.z) | (a.w ^ b.w)) == 0u; }
@@ -469,7 +468,8 @@ __device__ __forceinline__ uint2 k1f_load_be64x2(const u8* T, u32 p) {
     const u32 sh = p & 3u;
     u32 d[3];
     __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 12);
-    return make_uint2(__builtin_bswap32(__builtin_amdgcn_alignbyte(d[1], d[0], sh)), __builtin_bswap32(__builtin_amdgcn_alignbyte(d[2], d[1], sh)));
+    const u32 sel = be_sel(sh);
+    return make_uint2(be32_at(d[1], d[0], sel), be32_at(d[2], d[1], sel));
 }
 __device__ __forceinline__ void k1f_acc_lt64(u32& less, const uint2& c, u32 j, const uint2& m, u32 i) {
 #if defined(__AMDGCN__)
@@ -1178,6 +1178,26 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
 // The LAST round (`final`) writes what still ties (long repeats, identical rotations) to the suffix array, clears the
 // head bits of its non-heads, and hands groups of 2..8 to the second pass of the lane kernels (k1_deep_pairs<true> /
 // k1_deep_small<true>: up to CJS_DEEP_LANE_CAP bytes); what they leave, and bigger groups, the doubling rounds of k1_run take.
+// less += (c < m) for 24-byte keys held as three big-endian u64 (c0 the most significant): the borrow of c - m, one chain
+__device__ __forceinline__ void k1r_acc_lt192(u32& less, u64 c0, u64 c1, u64 c2, u64 m0, u64 m1, u64 m2) {
+#if defined(__AMDGCN__)
+    u32 t;
+    asm("v_sub_co_u32 %1, vcc, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %8, %9, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %11, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %12, %13, vcc\n\t"
+        "v_addc_co_u32 %0, vcc, 0, %0, vcc"
+        : "+v"(less), "=&v"(t)
+        : "v"((u32)c2), "v"((u32)m2), "v"((u32)(c2 >> 32)), "v"((u32)(m2 >> 32)), "v"((u32)c1), "v"((u32)m1), "v"((u32)(c1 >> 32)), "v"((u32)(m1 >> 32)),
+          "v"((u32)c0), "v"((u32)m0), "v"((u32)(c0 >> 32)), "v"((u32)(m0 >> 32))
+        : "vcc");
+#else
+    less += (c0 < m0 || (c0 == m0 && (c1 < m1 || (c1 == m1 && c2 < m2)))) ? 1u : 0u;
+#endif
+}
+
 #ifndef K1R_T
 #define K1R_T 768u           // entries a workgroup owns per step (round 5: 768 - 24.6 KB of LDS, six workgroups per CU instead of five: the two-stream step 7.40 -> 7.24 ms (median of 8), the kernel
                                 // alone 1.78 -> 1.75; round 3: 512 -> 1024: 80 % of the 1280 slots of a step are owned instead of 67 %,
@@ -1285,10 +1305,10 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
             if (own(eC[it], i)) {
                 u32 p = ES(eC[it]) + dm;
                 if (p >= n) p -= n;
-                const u32 sh = p & 3u;
+                const u32 sel = be_sel(p & 3u);
                 u32 x[6];
 #pragma unroll
-                for (int j = 0; j < 6; j++) x[j] = __builtin_bswap32(__builtin_amdgcn_alignbyte(dC[it][j + 1], dC[it][j], sh));
+                for (int j = 0; j < 6; j++) x[j] = be32_at(dC[it][j + 1], dC[it][j], sel);
                 kA[i] = ((u64)x[0] << 32) | x[1];
                 kB[i] = ((u64)x[2] << 32) | x[3];
                 kC[i] = ((u64)x[4] << 32) | x[5];
@@ -1321,27 +1341,23 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
             const u32 i = (it * 4u + w) * 64u + lane;
             qn[it] = 0xFFFFFFFFu;
             if (own(eC[it], i)) {
-                const u32 gs = i - EIDX(eC[it]), ge = gs + ELEN(eC[it]);
+                // (round 5) against the OTHER members of the group, one at a time: a pair - most groups are - costs one comparison per rotation
+                // where the loop over all cells in twos (ds_read2_b64) cost two, one of them with itself; the kernel is bound by its vector
+                // instructions (PMC: 1 900 per wave and tile, half its clocks).  `less` is one borrow chain over the six key dwords.
+                const u32 idx = EIDX(eC[it]), len = ELEN(eC[it]), gs = i - idx;
                 const u64 m0 = kA[i], m1 = kB[i], m2 = kC[i];
-                u32 less = 0, eqb = 0, eqt = 0;
-                for (u32 j = gs; j < ge; j += 2u) {
-                    u64 c0[2], c1[2], c2[2];
-#pragma unroll
-                    for (u32 u = 0; u < 2u; u++) {
-                        c0[u] = kA[j + u];                // pairs (ds_read2_b64); the cell past the group's end is masked below
-                        c1[u] = kB[j + u];
-                        c2[u] = kC[j + u];
-                    }
-#pragma unroll
-                    for (u32 u = 0; u < 2u; u++) {
-                        const bool in = j + u < ge;
-                        const bool eq01 = c0[u] == m0 && c1[u] == m1;
-                        const bool ltk = c0[u] < m0 || (c0[u] == m0 && c1[u] < m1) || (eq01 && c2[u] < m2);
-                        const bool eq = eq01 && c2[u] == m2;
-                        less += (in && ltk) ? 1u : 0u;
-                        eqb += (in && eq && j + u < i) ? 1u : 0u;
-                        eqt += (in && eq) ? 1u : 0u;
-                    }
+                u32 less = 0, eqb = 0, eqt = 1;
+                u32 o = gs + (idx == 0u ? 1u : 0u);
+                u64 c0 = kA[o], c1 = kB[o], c2 = kC[o];
+                for (u32 t = 0; t + 1u < len;) {
+                    t++;
+                    const u32 o2 = gs + t + (t >= idx ? 1u : 0u);          // (one past the last: a cell inside the arrays, read and not used)
+                    const u64 n0 = kA[o2], n1 = kB[o2], n2 = kC[o2];
+                    k1r_acc_lt192(less, c0, c1, c2, m0, m1, m2);
+                    const bool eq = c0 == m0 && c1 == m1 && c2 == m2;
+                    eqt += eq ? 1u : 0u;
+                    eqb += (eq && t <= idx) ? 1u : 0u;                    // (this cell was member t - 1 of the others: in front of me while t - 1 < idx)
+                    c0 = n0; c1 = n1; c2 = n2;
                 }
                 const u32 q = gs + less + eqb;
                 const u32 s = ES(eC[it]), pos = EPOS(eC[it]) + q - i;     // positions inside a group are consecutive

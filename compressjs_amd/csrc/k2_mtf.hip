@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
     const BatchGeom g = P.g;
     const u32 b = blockIdx.y;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    const u32 seg = blockIdx.x * 4u + w;
+    const u32 seg = (u32)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + w));      // (wave-uniform: base, the table updates and the loop bounds below stay scalar)
     const u32 nr = P.nruns[b];
     // whole waves leave together; no block-level barrier below
     if (seg * K2_SEG >= nr) return;
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
         const bool by_lane = (u32)__popcll(need) * 4u < nrest;
         if (by_lane) {
             while (need) {                                 // wave-uniform
-                const int j = __ffsll((long long)need) - 1;
-                need &= need - 1;
+                const int j = __builtin_ctzll(need);
+                need = bitset0_b64(need, (u32)j);
                 const int pj = __builtin_amdgcn_readlane(p, j);
                 u32 c2 = 0;
 #pragma unroll
@@ -240,26 +240,28 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
             for (int k = 0; k < 4; k++) {
                 u64 um = usedw[k] & ~occm[k];
                 while (um) {                               // wave-uniform
-                    const int sl = __ffsll((long long)um) - 1;
-                    um &= um - 1;
+                    const int sl = __builtin_ctzll(um);
+                    um = bitset0_b64(um, (u32)sl);
                     idx += (__builtin_amdgcn_readlane(Lr[k], sl) > p) ? 1u : 0u;
                 }
             }
         }
+        // Symbols that occur in the step: the last occurrence of s before my lane is later than p when s occurs in my WINDOW - the lanes
+        // between my own symbol's previous occurrence in this step (or the step's start) and me - or, for a first occurrence of the step
+        // (p is a table entry then), when s's table entry is.  Round 5: two ANDs, an OR and two compares per symbol instead of the position
+        // of the last occurrence (two v_ffbh, min3, selects: 14 vector instructions -> 9); the table entry of s is replaced by v_writelane.
+        const u64 win = own ? (lt & (~0ull << (64 - __clzll((long long)own)))) : lt;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            // symbols that occur: last occurrence before my lane from the ballot, else the table
             u64 um = occm[k];
             while (um) {
-                const int sl = __ffsll((long long)um) - 1;
-                um &= um - 1;
+                const int sl = __builtin_ctzll(um);
+                um = bitset0_b64(um, (u32)sl);
                 const u32 s = (u32)(k * 64 + sl);
                 const u64 ms = __ballot(c == s);
                 const int Ls = __builtin_amdgcn_readlane(Lr[k], sl);
-                const u64 mlt = ms & lt;
-                const int Lsi = mlt ? base + 63 - __clzll((long long)mlt) : Ls;
-                idx += (Lsi > p) ? 1u : 0u;
-                if ((int)lane == sl) Lr[k] = base + 63 - __clzll((long long)ms);
+                idx += ((ms & win) != 0ull || Ls > p) ? 1u : 0u;
+                Lr[k] = cjs_writelane(base + 63 - __builtin_clzll(ms), sl, Lr[k]);           // (ms != 0: s occurs)
             }
         }
         if (valid) J[r] = (u8)idx;
