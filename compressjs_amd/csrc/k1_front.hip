@@ -486,6 +486,39 @@ __device__ __forceinline__ void k1f_acc_lt64(u32& less, const uint2& c, u32 j, c
     less += (cc < mm || (cc == mm && j < i)) ? 1u : 0u;
 #endif
 }
+// a step of the branch-free binary search over sorted splitters: pos + step when s <= k, else pos - the borrow of k - s picks (one
+// ds_read_b128 and six vector instructions; as `if (!lt(k, s)) pos += step` the compiler read the key's halves one after the other,
+// the second behind a branch: two dependent LDS round trips per step)
+__device__ __forceinline__ u32 k1f_step_ge(u32 pos, u32 step, const uint4& k, const uint4& s) {
+#if defined(__AMDGCN__)
+    u32 t, r = pos + step;
+    asm("v_sub_co_u32 %1, vcc, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %8, %9, vcc\n\t"
+        "v_cndmask_b32 %0, %0, %10, vcc"
+        : "+v"(r), "=&v"(t)
+        : "v"(k.w), "v"(s.w), "v"(k.z), "v"(s.z), "v"(k.y), "v"(s.y), "v"(k.x), "v"(s.x), "v"(pos)
+        : "vcc");
+    return r;
+#else
+    return k1f_lt128(k, s) ? pos : pos + step;
+#endif
+}
+__device__ __forceinline__ u32 k1f_step_ge64(u32 pos, u32 step, const uint2& k, const uint2& s) {
+#if defined(__AMDGCN__)
+    u32 t, r = pos + step;
+    asm("v_sub_co_u32 %1, vcc, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
+        "v_cndmask_b32 %0, %0, %6, vcc"
+        : "+v"(r), "=&v"(t)
+        : "v"(k.y), "v"(s.y), "v"(k.x), "v"(s.x), "v"(pos)
+        : "vcc");
+    return r;
+#else
+    return ((((u64)k.x << 32) | k.y) < (((u64)s.x << 32) | s.y)) ? pos : pos + step;
+#endif
+}
 // the two key widths of the bucket sort behind one interface
 struct K1fK16 {
     typedef uint4 T;
@@ -497,6 +530,7 @@ struct K1fK16 {
     static __device__ __forceinline__ bool is_ones(const T& a) { return k1f_ones128(a); }
     static __device__ __forceinline__ T inc(const T& a) { return k1f_inc128(a); }
     static __device__ __forceinline__ void acc_lt(u32& less, const T& c, u32 j, const T& m, u32 i) { k1f_acc_lt(less, c, j, m, i); }
+    static __device__ __forceinline__ u32 step_ge(u32 pos, u32 step, const T& k, const T& sp) { return k1f_step_ge(pos, step, k, sp); }
 };
 struct K1fK8 {
     typedef uint2 T;
@@ -508,6 +542,7 @@ struct K1fK8 {
     static __device__ __forceinline__ bool is_ones(const T& a) { return (a.x & a.y) == 0xFFFFFFFFu; }
     static __device__ __forceinline__ T inc(T a) { a.y += 1u; if (a.y == 0u) a.x += 1u; return a; }
     static __device__ __forceinline__ void acc_lt(u32& less, const T& c, u32 j, const T& m, u32 i) { k1f_acc_lt64(less, c, j, m, i); }
+    static __device__ __forceinline__ u32 step_ge(u32 pos, u32 step, const T& k, const T& sp) { return k1f_step_ge64(pos, step, k, sp); }
 };
 
 // largest head position <= q / smallest head position > q in an LDS bitmap whose bit 0 and every bit >= cnt are set
@@ -763,8 +798,7 @@ __device__ __forceinline__ void k1f_sortk(const K1fL& S, const u8* T, u32 n, con
             L[it] = 0xFFFFFFFFu;
             if (i < cnt) {
                 u32 pos = 0;
-                for (u32 step = K >> 1; step >= 1u; step >>= 1)
-                    if (!KT::lt(k[it], spk[pos + step - 1u])) pos += step;
+                for (u32 step = K >> 1; step >= 1u; step >>= 1) pos = KT::step_ge(pos, step, k[it], spk[pos + step - 1u]);
                 L[it] = (pos << 16) | atomicAdd(&S.cnt2[pos], 1u);
             }
         }

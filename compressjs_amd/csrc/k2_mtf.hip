@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
         const bool valid = r < nr;
         const u32 c = valid ? RHsym[r] : 0x1FFu;
         // previous occurrence of my own symbol
-        const u64 own = match_any(c, 9, valid) & lt;
+        const u64 own = match_any(c, 8, valid) & lt;          // (the lanes past the end are not `valid`: in nobody's mask, and their own is not used)
         int p;
         {
             const int l0 = __shfl(Lr[0], (int)(c & 63u));
