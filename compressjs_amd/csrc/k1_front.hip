@@ -1294,7 +1294,12 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
-            e[it] = (e0 < cnt && i < cnt - e0) ? Lin[e0 + i] : 0ull;          // beyond the list: a group of one, never owned
+            // beyond the list: a group of one, never owned.  The load itself is UNCONDITIONAL (of entry 0 then): behind a branch the compiler
+            // cannot count the loads in flight, and every s_waitcnt vmcnt of the loop became "all of them" - the entries requested at the
+            // top of a step were waited for a few instructions later, at the first use of the text requested a step earlier (round 5)
+            const bool in = e0 < cnt && i < cnt - e0;
+            const u64 x = Lin[in ? e0 + i : 0u];
+            e[it] = in ? x : 0ull;
         }
     };
     // owned: the group starts inside the tile's first K1R_T entries
@@ -1304,13 +1309,10 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
 #pragma unroll
         for (u32 it = 0; it < K1R_RPW; it++) {
             const u32 i = (it * 4u + w) * 64u + lane;
-#pragma unroll
-            for (int j = 0; j < 7; j++) d[it][j] = 0;
-            if (own(e[it], i)) {
-                u32 p = ES(e[it]) + dm;
-                if (p >= n) p -= n;
-                __builtin_memcpy(d[it], __builtin_assume_aligned(T + (p & ~3u), 4), 28);
-            }
+            u32 p = ES(e[it]) + dm;
+            if (p >= n) p -= n;
+            if (!own(e[it], i)) p = 0u;                 // (unconditional as well: the block's first bytes, one line for the whole wave)
+            __builtin_memcpy(d[it], __builtin_assume_aligned(T + (p & ~3u), 4), 28);
         }
     };
     u64 eC[K1R_RPW], eN[K1R_RPW], eNN[K1R_RPW];
@@ -1339,7 +1341,7 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
             if (own(eC[it], i)) {
                 u32 p = ES(eC[it]) + dm;
                 if (p >= n) p -= n;
-                const u32 sel = be_sel(p & 3u);
+                const u32 sel = be_sel(p);
                 u32 x[6];
 #pragma unroll
                 for (int j = 0; j < 6; j++) x[j] = be32_at(dC[it][j + 1], dC[it][j], sel);
@@ -1439,7 +1441,14 @@ __global__ __launch_bounds__(256, K1R_MINW) void k1r_round(K1Buf B, BatchGeom g,
             const u32 inc = wave_incl_scan_u32(c);
             if (lane < K1R_SW) pre[par][lane] = inc - c;
             const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
-            if (lane == 0) abase = total ? atomicAdd(ocnt, total) : 0u;
+            if (lane == 0) {
+                // the result is first looked at a step later.  Unconditional: no select on it; and through a pointer the compiler takes for
+                // divergent - for a uniform one it rewrites the atomic as a wave reduction whose v_readfirstlane waits for the result
+                // (and for every load in flight) on the spot
+                u32 z = 0;
+                pin_vgpr(z);
+                abase = atomicAdd(ocnt + z, total);
+            }
         }
         K1R_STAMP(3);
 #pragma unroll
