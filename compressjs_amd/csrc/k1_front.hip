@@ -633,12 +633,30 @@ __device__ __forceinline__ void k1f_flush(const K1fL& S, const K1Buf& B, const B
                 if (lane == 0) S.misc[(u32)it * K1F_NW + w] = 0;
                 continue;
             }
-            const u32 q = q0 + lane;
+            // The group around every position of the row from the ROW's 64 head bits (round 5; per lane it was two reads of the bitmap and two
+            // searches with divergent loops - a third of this function's vector instructions were the copies their control flow needs):
+            // the words are the same for all lanes, the heads in front of and behind the row are searched once per row on the scalar unit
+            // (bit 0 and every bit >= cnt are set, behind them two words of ones).
+            const u32 q = q0 + lane, hw = q0 >> 5;
+            const u32 h0 = (u32)__builtin_amdgcn_readfirstlane((int)S.hb[hw]), h1 = (u32)__builtin_amdgcn_readfirstlane((int)S.hb[hw + 1u]);
+            u32 gprev = q0, gnext;
+            if (!(h0 & 1u)) {                           // the row starts inside a group (wave-uniform)
+                u32 ww = hw, m;
+                do { m = (u32)__builtin_amdgcn_readfirstlane((int)S.hb[--ww]); } while (!m);
+                gprev = ww * 32u + 31u - (u32)__builtin_clz(m);
+            }
+            {
+                u32 ww = hw + 2u, m;
+                while (!(m = (u32)__builtin_amdgcn_readfirstlane((int)S.hb[ww]))) ww++;
+                gnext = ww * 32u + (u32)__builtin_ctz(m);
+            }
+            const u64 H = (u64)h0 | ((u64)h1 << 32), le = (lt << 1) | 1ull;
+            const u64 hb_ = H & le, ha_ = H & ~le;
+            const u32 gs = hb_ ? q0 + 63u - (u32)__builtin_clzll(hb_) : gprev;
+            const u32 ge_ = ha_ ? q0 + (u32)__builtin_ctzll(ha_) : gnext;
+            const u32 gl = ge_ - gs;
             bool listed = false;
-            if (q < cnt && k1f_bits2(S.hb, q) != 3u) {
-                u32 gs, ge_;
-                k1f_group(S.hb, q, gs, ge_);
-                const u32 gl = ge_ - gs;
+            if (q < cnt && gl > 1u) {
                 listed = gl <= K1F_GBIG;
                 gsv[it] = (q - gs) | ((gl - 1u) << 8);
                 // a group too big for the lists: a task of the next level
