@@ -21,7 +21,7 @@ SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_lcg_ascii_devic
            "cjs_bz2_decompress", "cjs_bz2_decompress_device", "cjs_bz2_decompress_block", "cjs_bz2_table",
            "cjs_bz2_last_size", "cjs_bz2_fetch", "cjs_shift_bits", "cjs_bwtc_decompress", "cjs_bwtc_last_size", "cjs_bwtc_fetch", "cjs_bz2_last_detail", "cjs_bz2_last_decode_ms",
            "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages", "cjs_dbg_k1_sparse_rounds",
-           "cjs_dbg_k1_rounds", "cjs_dbg_k1_periodic_blocks", "cjs_dbg_rc_div", "cjs_dbg_multi_mallocs"]
+           "cjs_dbg_k1_rounds", "cjs_dbg_k1_periodic_blocks", "cjs_dbg_rc_div", "cjs_dbg_multi_mallocs", "cjs_dbg_multi_fallbacks"]
 
 
 class CompressjsAmdError(RuntimeError):

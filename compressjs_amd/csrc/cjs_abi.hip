@@ -413,6 +413,8 @@ struct cjs_ctx {
 };
 static std::atomic<int> g_multi_mallocs{0};        // hipMalloc calls of cjs_bz2_compress_multi's segment buffers (cjs_dbg_multi_mallocs: none after warm-up)
 extern "C" int cjs_dbg_multi_mallocs(void) { return g_multi_mallocs.load(); }
+static std::atomic<int> g_multi_fallbacks{0};      // calls of cjs_bz2_compress_multi that took the replicated plan (a segment that cannot be planned on its own)
+extern "C" int cjs_dbg_multi_fallbacks(void) { return g_multi_fallbacks.load(); }
 #define CJS_SNAP_SLOTS 4096u
 
 extern "C" void cjs_destroy(cjs_ctx* c);
@@ -1230,7 +1232,7 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
     const u32 cap = (u32)level * 100000u - 19u;
     const uint64_t seg_env = []() -> uint64_t { const char* ev = getenv("CJS_SEG_BYTES"); return ev ? strtoull(ev, nullptr, 10) : 0; }();   // (read per call)
     const uint64_t seg_bytes = seg_env ? seg_env : (uint64_t)ctxs[0]->batch_blocks * cap;
-    const uint64_t nseg = (in_len + seg_bytes - 1) / seg_bytes;
+    uint64_t nseg = (in_len + seg_bytes - 1) / seg_bytes;
     if (n == 1 || nseg <= 1) return cjs_bz2_compress(ctxs[0], in, in_len, level, out, out_cap);
     const uint64_t W = (uint64_t)4 * (cap + 19u);
     std::vector<MSeg> S(nseg);
@@ -1240,7 +1242,7 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
     }
     std::mutex mu;
     const auto t_begin = std::chrono::steady_clock::now();
-    std::atomic<int> err{0};        // first error; 1 = fall back to one device (the workers read it without the lock)
+    std::atomic<int> err{0};        // first error; 1 = take the replicated plan (the workers read it without the lock)
     auto fail = [&](int code) { std::lock_guard<std::mutex> g(mu); if (!err.load()) err.store(code); };
     // phase A of one segment on its context: window into HBM, cost scan
     auto scan_seg = [&](uint64_t k) {
@@ -1267,23 +1269,7 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
         if (nb == CJS_E_SPEC) { fail(1); return; }
         if (nb < 0) { fail((int)nb); return; }
         if (nb == 0) return;
-        g.dseg_cap = ((uint64_t)cjs_bz2_compress_bound(g.e - g.lo + W) + 3) & ~(uint64_t)3;
-        {   // the device's buffer for its segment of this wave: from the context's pool (grow-only, kept across calls: a hipMalloc per segment
-            // and a hipFree - a device-wide sync - per segment in every call was what rounds 2-4 did)
-            if (!c->segpool) c->segpool = new std::vector<std::pair<void*, size_t>>();
-            const size_t slot = (size_t)(k / n);
-            if (c->segpool->size() <= slot) c->segpool->resize(slot + 1, std::pair<void*, size_t>(nullptr, 0));
-            std::pair<void*, size_t>& pr = (*c->segpool)[slot];
-            if (pr.second < g.dseg_cap) {
-                (void)hipFree(pr.first);
-                pr = std::pair<void*, size_t>(nullptr, 0);
-                void* pnew = nullptr;
-                g_multi_mallocs++;
-                if (hipMalloc(&pnew, g.dseg_cap + (g.dseg_cap >> 3)) != hipSuccess) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); return; }
-                pr = std::pair<void*, size_t>(pnew, g.dseg_cap + (g.dseg_cap >> 3));
-            }
-            g.dseg = (u8*)pr.first;
-        }
+        if (!g.dseg) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); return; }
         u32 fold = 0, cnt = 0;
         const int64_t bits = cjs_bz2_encode_blocks(c, 0, (u32)nb, g.dseg, g.dseg_cap, &fold, &cnt);
         if (bits < 0) { fail((int)bits); return; }
@@ -1324,7 +1310,89 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
             run_range(k0, k1, scan_seg);
             if (err) break;
             for (uint64_t k = k0; k < k1; k++) plan_base(pc, S[k], edge_runs(in, S[k].lo, S[k].e), cap);
+            // Every device's buffer for its segment of this wave, from the context's pool (grow-only, kept across calls: a hipMalloc per
+            // segment and a hipFree - a device-wide sync - per segment in every call was what rounds 2-4 did).  Taken HERE, on the calling
+            // thread and for every segment of the wave: inside the workers it depended on which of them saw another one's fallback flag
+            // first, and a slot skipped in one call was a hipMalloc in the next (round 5: the test that counts them failed one run in eight).
+            for (uint64_t k = k0; k < k1 && !err; k++) {
+                cjs_ctx* c = ctxs[k % n];
+                MSeg& g = S[k];
+                g.dseg_cap = ((uint64_t)cjs_bz2_compress_bound(g.e - g.lo + W) + 3) & ~(uint64_t)3;
+                if (!c->segpool) c->segpool = new std::vector<std::pair<void*, size_t>>();
+                const size_t slot = (size_t)(k / n);
+                if (c->segpool->size() <= slot) c->segpool->resize(slot + 1, std::pair<void*, size_t>(nullptr, 0));
+                std::pair<void*, size_t>& pr = (*c->segpool)[slot];
+                if (pr.second < g.dseg_cap) {
+                    if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); break; }
+                    (void)hipFree(pr.first);
+                    pr = std::pair<void*, size_t>(nullptr, 0);
+                    void* pnew = nullptr;
+                    g_multi_mallocs++;
+                    if (hipMalloc(&pnew, g.dseg_cap + (g.dseg_cap >> 3)) != hipSuccess) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); break; }
+                    pr = std::pair<void*, size_t>(pnew, g.dseg_cap + (g.dseg_cap >> 3));
+                }
+                g.dseg = (u8*)pr.first;
+            }
+            if (err) break;
             run_range(k0, k1, encode_seg);
+        }
+    }
+    if (err == 1) {
+        // A segment that cannot be planned on its own - a block boundary inside a run of four or more equal bytes (ordinary text has
+        // them: indentation, rules of '=' or '-'; 0.1 % of the positions of the enwik-shaped streams, one call in twenty-five at 7*10^7
+        // bytes), a block longer than the margin: the REPLICATED plan.  Every device takes the whole input and plans it with the serial
+        // chain (cjs_bz2_plan: 0.5 ms per 10^8 bytes; the uploads run on the devices' own links), then encodes its share of the blocks -
+        // what compressjs_amd/dist.py::sharded_compress does across processes.  Until round 5 such a call went to ONE device.
+        err.store(0);
+        g_multi_fallbacks++;
+        std::vector<int64_t> nbv(n, 0);
+        run_range(0, n, [&](uint64_t d) {
+            cjs_ctx* c = ctxs[d];
+            if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); return; }
+            int rc = grow(&c->din, &c->din_bytes, in_len + 64);
+            if (rc) { fail(rc); return; }
+            hipError_t e2 = hipMemcpyAsync(c->din, in, in_len, hipMemcpyHostToDevice, c->stream);
+            if (e2 != hipSuccess) { fail(CJS_E_HIP - (int)e2); return; }
+            nbv[d] = cjs_bz2_plan(c, c->din, in_len, level);               // (synchronises the stream)
+            if (nbv[d] < 0) { (void)hipStreamSynchronize(c->stream); fail((int)nbv[d]); }
+        });
+        for (u32 d = 1; d < n && !err; d++) if (nbv[d] != nbv[0]) fail(CJS_E_ARG);      // (cannot happen: the same bytes, the same plan)
+        if (!err) {
+            const uint64_t nb = (uint64_t)nbv[0];
+            nseg = n;
+            S.assign(nseg, MSeg());
+            std::vector<u32> first(n), cnt(n);
+            for (u32 d = 0; d < n && !err; d++) {
+                cjs_ctx* c = ctxs[d];
+                first[d] = (u32)(nb * d / n);
+                cnt[d] = (u32)(nb * (d + 1) / n) - first[d];
+                if (!cnt[d]) continue;
+                MSeg& g = S[d];
+                g.dseg_cap = ((uint64_t)cjs_bz2_compress_bound((uint64_t)cnt[d] * (cap + 19u)) + 3) & ~(uint64_t)3;
+                if (!c->segpool) c->segpool = new std::vector<std::pair<void*, size_t>>();
+                if (c->segpool->empty()) c->segpool->resize(1, std::pair<void*, size_t>(nullptr, 0));
+                std::pair<void*, size_t>& pr = (*c->segpool)[0];
+                if (pr.second < g.dseg_cap) {
+                    if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); break; }
+                    (void)hipFree(pr.first);
+                    pr = std::pair<void*, size_t>(nullptr, 0);
+                    void* pnew = nullptr;
+                    g_multi_mallocs++;
+                    if (hipMalloc(&pnew, g.dseg_cap + (g.dseg_cap >> 3)) != hipSuccess) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); break; }
+                    pr = std::pair<void*, size_t>(pnew, g.dseg_cap + (g.dseg_cap >> 3));
+                }
+                g.dseg = (u8*)pr.first;
+            }
+            if (!err)
+                run_range(0, n, [&](uint64_t d) {
+                    if (!cnt[d]) return;
+                    cjs_ctx* c = ctxs[d];
+                    MSeg& g = S[d];
+                    u32 fold = 0, done = 0;
+                    const int64_t bits = cjs_bz2_encode_blocks(c, first[d], cnt[d], g.dseg, g.dseg_cap, &fold, &done);
+                    if (bits < 0) { fail((int)bits); return; }
+                    g.bits = (uint64_t)bits; g.fold = fold; g.count = done;
+                });
         }
     }
     int64_t result = 0;
@@ -1358,7 +1426,6 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
             }
         }
     }
-    if (err == 1) return cjs_bz2_compress(ctxs[0], in, in_len, level, out, out_cap);
     if (err) return err;
     u32 blocks = 0;
     for (uint64_t k = 0; k < nseg; k++) blocks += S[k].count;

@@ -142,6 +142,7 @@ int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen, uint32_t 
 int cjs_dbg_k1_sparse_rounds(void);   /* rounds of the last K1 run that used the sparse phase */
 int cjs_dbg_k1_rounds(void);
 uint32_t cjs_dbg_rc_div(uint32_t range, uint32_t tot);   /* bwtc_host.hip: the range coder's range / tot by reciprocal (boundary test in tests/test_host_api.py) */
+int cjs_dbg_multi_fallbacks(void);    /* calls of cjs_bz2_compress_multi that took the REPLICATED plan (a segment that cannot be planned on its own: every device plans the whole input, encodes its share) */
 int cjs_dbg_multi_mallocs(void);      /* hipMalloc calls cjs_bz2_compress_multi has made for its per-device segment buffers (grow-only pools: none after warm-up) */
 int cjs_dbg_k1_periodic_blocks(void); /* k1_period.hip, last K1 run (counted under CJS_K1_TRACE only): blocks with a period <= 64 (closed form) | blocks sorted through a reduced block << 16 */
 int32_t cjs_dbg_block_stages(const uint8_t* T, const uint32_t* nlen, uint32_t nb, uint32_t cap,

@@ -754,19 +754,24 @@ def _segmented_check():
         for d, lv in ((synth.text_like(330_000, 21), 1), (synth.runs_mixed(300_000, 6), 1), (synth.text_like(185_000, 2), 1)):
             assert _compress((L, h), d, lv) == oracle.bz2_compress(d, lv), (d.size, lv)
         # the same inputs over three contexts (cjs_bz2_compress_multi: segment k on context k mod 3, windows, bit-shifted
-        # placement, seam bytes, trailer); zeros / runs take its fall-back to one device
+        # placement, seam bytes, trailer); zeros / runs take the replicated plan (every context plans the whole input, encodes its share)
         hs = [L.cjs_create(0, 4) for _ in range(3)]
         arr = (C.c_void_p * 3)(*hs)
         runs = synth.text_like(520_000, 8).copy()          # five segments on three contexts (two waves), runs on / across the cuts,
         runs[119_990:120_004] = 65                          # a block boundary (99 981) right where a straddling run starts: refuse or agree
         runs[239_998:240_001] = 66
         runs[359_000:361_500] = 67
+        took = []
+        L.cjs_dbg_multi_fallbacks.restype = C.c_int
         for d, lv in ((np.zeros(260_000, np.uint8), 1), (synth.enwik_like(330_000, 4), 1), (synth.text_like(520_000, 7), 1), (runs, 1),
                       (np.concatenate([synth.lcg_ascii(99_981, 3), np.full(20_030, 65, np.uint8), synth.lcg_ascii(140_000, 4)]), 1)):
             cap = int(L.cjs_bz2_compress_bound(d.size))
             out = np.full(cap, 0xAA, np.uint8)                  # stale bytes: the call must write every byte it returns
+            fb = L.cjs_dbg_multi_fallbacks()
             n = L.cjs_bz2_compress_multi(arr, 3, d.ctypes.data, d.size, lv, out.ctypes.data, cap)
             assert n > 0 and out[:n].tobytes() == oracle.bz2_compress(d, lv), (d.size, lv, n)
+            took.append(L.cjs_dbg_multi_fallbacks() - fb)
+        assert took[0] == 1 and took[1] == 0 and took[2] == 0 and sum(took) >= 2, took     # zeros: replicated; the two text streams: the parallel plan
         for x in hs:
             L.cjs_destroy(x)
     finally:

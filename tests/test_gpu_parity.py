@@ -656,20 +656,27 @@ def test_overlapped_host_path_same_bytes(ctx):
 
 def test_multi_context_fan_out_same_bytes():
     """cjs_bz2_compress_multi (what the Node addon calls with several devices configured): three contexts - here on the
-    same GPU - take the segments round-robin; windows, chained planning, bit-shifted placement, seam bytes, trailer."""
+    same GPU - take the segments round-robin; windows, parallel planning (or the replicated plan), bit-shifted placement, seam bytes, trailer."""
     from compressjs_amd.bzip2 import compress_multi
     cs = [Context(0, 16) for _ in range(3)]
     one = Context(0, 128)
+    L = _lib.load()
+    L.cjs_dbg_multi_mallocs.restype = C.c_int
+    L.cjs_dbg_multi_fallbacks.restype = C.c_int
     try:
-        for d, lv in ((synth.enwik_like(70_000_000, 8), 9), (synth.runs_mixed(40_000_000, 3), 9), (synth.lcg_ascii(9_000_000, 2), 1),
-                      (np.zeros(50_000_000, np.uint8), 9)):
+        # Random ASCII goes through the parallel plan (every context plans its own segment); a block boundary inside a run of four or more
+        # equal bytes - the runs, the zeros, and block 2 of THIS text stream (a run of 4 at byte 1 799 588) - takes the replicated plan:
+        # every context plans the whole input and encodes its share of the blocks.  Either way all three contexts encode.
+        for d, lv, replicated in ((synth.enwik_like(70_000_000, 8), 9, 1), (synth.runs_mixed(40_000_000, 3), 9, None), (synth.lcg_ascii(9_000_000, 2), 1, 0),
+                                  (np.zeros(50_000_000, np.uint8), 9, 1), (synth.enwik_like(40_000_000, 5), 9, None)):
+            fb = L.cjs_dbg_multi_fallbacks()
             assert _sha(compress_multi(cs, d, lv)) == _sha(one.compress(d, lv)), (d.size, lv)
+            if replicated is not None:
+                assert L.cjs_dbg_multi_fallbacks() - fb == replicated, (d.size, lv)
         # the per-device segment buffers are grow-only pools kept across calls: a second pass over the same inputs allocates nothing
-        L = _lib.load()
-        L.cjs_dbg_multi_mallocs.restype = C.c_int
         before = L.cjs_dbg_multi_mallocs()
-        d = synth.enwik_like(70_000_000, 8)
-        assert _sha(compress_multi(cs, d, 9)) == _sha(one.compress(d, 9))
+        for d, lv in ((synth.enwik_like(70_000_000, 8), 9), (np.zeros(50_000_000, np.uint8), 9), (synth.lcg_ascii(9_000_000, 2), 1)):
+            assert _sha(compress_multi(cs, d, lv)) == _sha(one.compress(d, lv))
         assert L.cjs_dbg_multi_mallocs() == before, "cjs_bz2_compress_multi allocated in its hot loop after warm-up"
     finally:
         for c in cs + [one]:
