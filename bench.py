@@ -233,12 +233,20 @@ def main():
             n = ctx.compress_device(d_in, d_out, args.level)
             return d_out[:n]
         seg.zero_()
-        def whole():                                           # only the replicated fall-back (run-heavy input) needs it
+        def whole():
+            # only the replicated fall-back needs the whole stream on every rank (a block boundary inside a run of four or more equal bytes
+            # somewhere in the job - 0.05 % per boundary on the enwik-shaped streams): the ranks' own slices, all_gathered on the devices
+            # (round 5; until then every rank named the whole job on its host again, minutes inside the timed region)
             if on_device:
                 t = torch.empty(total, dtype=torch.uint8, device=dev)
                 ctx.lcg_ascii_device(t, 7, first=0)
                 return t
-            return torch.from_numpy(workloads.world_stream(args.workload, args.size, world)).to(dev)
+            own = d_in[:hi - lo].contiguous()
+            if backend != "nccl":
+                own = own.cpu()                                # (gloo test rigs: collectives on host tensors)
+            parts = [torch.empty_like(own) for _ in range(world)]
+            dist.all_gather(parts, own)
+            return torch.cat(parts).to(dev)
         return sharded_compress_parallel(ctx, d_in, hi - lo, lo, total, args.level, seg=seg,
                                          fallback=lambda: sharded_compress(ctx, whole(), args.level))
 

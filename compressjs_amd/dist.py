@@ -342,9 +342,10 @@ def sharded_compress_parallel(ctx, d_win: torch.Tensor, own_len: int, lo: int, t
          of the block boundaries inside its slice: it plans the blocks that START in its slice (cjs_bz2_plan_phase) and
          encodes them, the margin completing the last one;
       3. one all_reduce of a flag "could not plan on my own" (a boundary inside a run of four or more equal bytes, a block
-         longer than the margin, a boundary run longer than 4 KB, any local error): if any rank raises it, all fall back to
-         `fallback()` (a callable that runs one of the other drivers), else the (bits, CRC fold, block count) all_gather of
-         the other drivers follows and segments are shifted, sent and assembled as before.
+         longer than the margin, a boundary run longer than 4 KB, any local error) BEFORE anything is encoded, and one more
+         after the encoding (local errors): if any rank raises it, all fall back to `fallback()` (a callable that runs one of
+         the other drivers), else the (bits, CRC fold, block count) all_gather of the other drivers follows and segments are
+         shifted, sent and assembled as before.
     Returns the stream on rank 0, None elsewhere."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -379,7 +380,25 @@ def sharded_compress_parallel(ctx, d_win: torch.Tensor, own_len: int, lo: int, t
     try:
         if ok:
             nb = ctx.plan_phase(own_len, phase, lo + own_len >= total)
-        mark("plan")
+    except Exception:                                        # noqa: BLE001
+        if os.environ.get('CJS_DIST_TRACE'):
+            import traceback
+            traceback.print_exc()
+        nb = -1
+    mark("plan")
+    if os.environ.get("CJS_DIST_FORCE_FALLBACK"):            # (tests: the fall-back path on an input that plans fine)
+        nb = -1
+    # the plans' verdict BEFORE anything is encoded (round 5; until then a slice that could not be planned on its own was found out after
+    # every other rank had encoded its blocks for nothing): one more small all_reduce on the good path
+    flag0 = torch.tensor([1 if nb < 0 else 0], dtype=torch.int64, device=cdev)
+    if world > 1:
+        dist.all_reduce(flag0, op=dist.ReduceOp.MAX, group=group)
+    if int(flag0.item()):
+        if fallback is None:
+            raise RuntimeError("this input cannot be planned slice by slice (a block boundary inside a run of four or more equal bytes, or a block "
+                               "longer than the margin); use sharded_compress_sliced / sharded_compress")
+        return fallback()
+    try:
         if nb > 0:
             if seg is None:
                 seg = torch.zeros((own_len + margin_bytes(level)) * 3 // 2 + (1 << 20), dtype=torch.uint8, device=dev)
