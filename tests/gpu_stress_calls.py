@@ -40,10 +40,11 @@ def work(seed, n, out):
         if size and ok != valid: bad += 1; print("DECODER", seed, k, size, level, kind, "libbz2 valid", valid, "gpu round trip", ok, flush=True)
     out.append((bad, n))
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-res = []
-seeds = tuple(int(x) for x in os.environ.get('CJS_STRESS_SEEDS', '1,2').split(','))        # one thread (and context) per seed
-ts = [threading.Thread(target=work, args=(s, n, res)) for s in (seeds if len(sys.argv) < 3 else seeds[:1])]
-for t in ts: t.start()
-for t in ts: t.join()
-print("threads finished", len(res), "calls", sum(r[1] for r in res), "bad", sum(r[0] for r in res))
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    res = []
+    seeds = tuple(int(x) for x in os.environ.get('CJS_STRESS_SEEDS', '1,2').split(','))        # one thread (and context) per seed
+    ts = [threading.Thread(target=work, args=(s, n, res)) for s in (seeds if len(sys.argv) < 3 else seeds[:1])]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    print("threads finished", len(res), "calls", sum(r[1] for r in res), "bad", sum(r[0] for r in res))

@@ -744,3 +744,18 @@ def test_lcg_generator_on_the_device(ctx):
         ctx.lcg_ascii_device(t[:n], 7, first)
         got = t.cpu().numpy()
         assert np.array_equal(got[:n], want[first:first + n]) and (got[n:] == 0xEE).all()
+
+
+def test_mixed_calls_on_two_threads_vs_oracle():
+    """tests/gpu_stress_calls.py, bounded: 2 x 45 calls of mixed sizes (0 .. 5 MB), kinds (text, noise, runs, short periods, enwik-shaped) and
+    levels through two contexts on two host threads at once - every stream up to 2 MB equals the oracle's, every stream decodes back on the
+    GPU with the verdict of the oracle's decoder (libbz2 first; where it refuses - the 4th-byte-of-a-run quirk - the oracle decides)."""
+    import threading
+    import gpu_stress_calls
+    res = []
+    ts = [threading.Thread(target=gpu_stress_calls.work, args=(sd, 45, res)) for sd in (5, 6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(res) == 2 and sum(r[0] for r in res) == 0, res
