@@ -545,39 +545,6 @@ struct K1fK8 {
     static __device__ __forceinline__ u32 step_ge(u32 pos, u32 step, const T& k, const T& sp) { return k1f_step_ge64(pos, step, k, sp); }
 };
 
-// largest head position <= q / smallest head position > q in an LDS bitmap whose bit 0 and every bit >= cnt are set
-__device__ __forceinline__ u32 k1f_prev_head(const u32* hb, u32 q) {
-    u32 w = q >> 5;
-    u32 m = hb[w] & (0xFFFFFFFFu >> (31u - (q & 31u)));
-    while (!m) m = hb[--w];
-    return w * 32u + 31u - (u32)__clz((int)m);
-}
-__device__ __forceinline__ u32 k1f_next_head(const u32* hb, u32 q) {
-    u32 w = q >> 5;
-    u32 m = (q & 31u) == 31u ? 0u : (hb[w] & (0xFFFFFFFEu << (q & 31u)));
-    while (!m) m = hb[++w];
-    return w * 32u + (u32)__ffs((int)m) - 1u;
-}
-
-// bits q and q + 1 of a bitmap (bit 0 / bit 1 of the result) from ONE read of two adjacent words, and the group around q
-// (largest head <= q, smallest head > q) starting from that same read
-__device__ __forceinline__ u32 k1f_bits2(const u32* hb, u32 q) {
-    const u32 w = q >> 5;
-    const u64 v = (u64)hb[w] | ((u64)hb[w + 1u] << 32);
-    return (u32)(v >> (q & 31u)) & 3u;
-}
-__device__ __forceinline__ void k1f_group(const u32* hb, u32 q, u32& gs, u32& ge) {
-    const u32 w = q >> 5;
-    const u32 w0 = hb[w], w1 = hb[w + 1u];
-    u32 m = w0 & (0xFFFFFFFFu >> (31u - (q & 31u)));
-    u32 ww = w;
-    while (!m) m = hb[--ww];
-    gs = ww * 32u + 31u - (u32)__clz((int)m);
-    u32 m2 = (q & 31u) == 31u ? 0u : (w0 & (0xFFFFFFFEu << (q & 31u)));
-    ww = w;
-    if (!m2) { m2 = w1; ww = w + 1u; while (!m2) m2 = hb[++ww]; }
-    ge = ww * 32u + (u32)__ffs((int)m2) - 1u;
-}
 __device__ __forceinline__ bool k1f_bit(const u32* bm, u32 q) { return (bm[q >> 5] >> (q & 31u)) & 1u; }
 
 // LDS of a bucket-sort workgroup (views into the kernel's __shared__ arrays)
