@@ -177,12 +177,12 @@ static napi_value DeviceCount(napi_env env, napi_callback_info) {
 }
 
 // result blocks of Compress: a pool of at most four (what is beyond that is freed when its Buffer is collected)
-struct StageBlock { uint8_t* data; uint64_t cap; };
+struct StageBlock { uint8_t* data; uint64_t cap; int64_t accounted; };   // accounted: bytes V8 was told an external Buffer over this block holds
 static std::vector<StageBlock*> g_stage_pool;
 static StageBlock* stage_take(uint64_t cap) {
     for (size_t i = 0; i < g_stage_pool.size(); i++)
         if (g_stage_pool[i]->cap >= cap) { StageBlock* b = g_stage_pool[i]; g_stage_pool.erase(g_stage_pool.begin() + (long)i); return b; }
-    StageBlock* b = new StageBlock{(uint8_t*)malloc(cap ? cap : 1), cap};
+    StageBlock* b = new StageBlock{(uint8_t*)malloc(cap ? cap : 1), cap, 0};
     if (!b->data) { delete b; return nullptr; }
     return b;
 }
@@ -190,7 +190,12 @@ static void stage_give(StageBlock* b) {
     if (g_stage_pool.size() < 4) g_stage_pool.push_back(b);
     else { free(b->data); delete b; }
 }
-static void stage_finalize(napi_env, void*, void* hint) { stage_give((StageBlock*)hint); }
+static void stage_finalize(napi_env env, void*, void* hint) {
+    StageBlock* b = (StageBlock*)hint;
+    int64_t now;
+    if (b->accounted) { napi_adjust_external_memory(env, -b->accounted, &now); b->accounted = 0; }
+    stage_give(b);
+}
 
 static napi_value Compress(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
@@ -216,6 +221,12 @@ static napi_value Compress(napi_env env, napi_callback_info info) {
         void* dst;                                           // (an embedder without external buffers: copy as before)
         napi_create_buffer_copy(env, (size_t)n, blk->data, &dst, &out);
         stage_give(blk);
+    } else {
+        // V8 sees a Buffer object of a few dozen bytes: tell it what hangs on it, or results pile up uncollected (every call a fresh block
+        // whose pages the D2H copy has to fault in) until the heap of small objects happens to fill
+        int64_t now;
+        blk->accounted = (int64_t)n;
+        napi_adjust_external_memory(env, blk->accounted, &now);
     }
     return out;
 }
