@@ -14,6 +14,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <sys/mman.h>
 
 typedef struct cjs_ctx cjs_ctx;
 static cjs_ctx* (*p_create)(int, uint32_t);
@@ -182,8 +183,13 @@ static std::vector<StageBlock*> g_stage_pool;
 static StageBlock* stage_take(uint64_t cap) {
     for (size_t i = 0; i < g_stage_pool.size(); i++)
         if (g_stage_pool[i]->cap >= cap) { StageBlock* b = g_stage_pool[i]; g_stage_pool.erase(g_stage_pool.begin() + (long)i); return b; }
-    StageBlock* b = new StageBlock{(uint8_t*)malloc(cap ? cap : 1), cap, 0};
-    if (!b->data) { delete b; return nullptr; }
+    // 2 MB-aligned and advised for transparent huge pages: a fresh block's pages are faulted in by the copy that brings the result home
+    // (7 200 small pages for the 29 MB of a 10^8-byte text; results that JavaScript still holds cannot be reused)
+    const uint64_t sz = ((cap ? cap : 1) + ((2u << 20) - 1)) & ~(uint64_t)((2u << 20) - 1);
+    void* mem = nullptr;
+    if (posix_memalign(&mem, 2u << 20, sz) != 0) return nullptr;
+    (void)madvise(mem, sz, MADV_HUGEPAGE);
+    StageBlock* b = new StageBlock{(uint8_t*)mem, cap, 0};
     return b;
 }
 static void stage_give(StageBlock* b) {
