@@ -354,6 +354,24 @@ static napi_value fetch_result(napi_env env, int64_t n) {
     if (n == -21) n = p_lastsize(g_ctx);                       // decoded; the size is known now
     else if (n < 0) return throw_decode(env, n);
     napi_value out; void* dst = nullptr;
+    if (n >= (1 << 20)) {
+        // a large result: fetched into a pooled, huge-page-advised block handed over as an external Buffer (as Compress does) - a fresh
+        // Node Buffer of 10^8 bytes is 24 400 small pages faulted in by the copy
+        StageBlock* blk = stage_take((uint64_t)n);
+        if (blk) {
+            const int64_t m = p_fetch(g_ctx, blk->data, (uint64_t)n);
+            if (m < 0) { stage_give(blk); return throw_code(env, m, "cjs_bz2_fetch"); }
+            if (napi_create_external_buffer(env, (size_t)n, blk->data, stage_finalize, blk, &out) == napi_ok) {
+                int64_t now;
+                blk->accounted = n;
+                napi_adjust_external_memory(env, blk->accounted, &now);
+                return out;
+            }
+            napi_create_buffer_copy(env, (size_t)n, blk->data, &dst, &out);
+            stage_give(blk);
+            return out;
+        }
+    }
     napi_create_buffer(env, (size_t)n, &dst, &out);
     if (n > 0) {
         const int64_t m = p_fetch(g_ctx, (uint8_t*)dst, (uint64_t)n);

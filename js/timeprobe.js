@@ -1,4 +1,4 @@
-// node js/timeprobe.js <raw byte file> [level] : wall time of Bzip2.compressFile through the N-API drop-in (not a test).
+// node js/timeprobe.js <raw byte file> [level] [d] : wall time of Bzip2.compressFile (and, with `d`, of Bzip2.decompressFile of its result) through the N-API drop-in (not a test).
 'use strict';
 var fs = require('fs'), crypto = require('crypto');
 var cjs = require('./index.js');
@@ -14,3 +14,13 @@ for (var i = 0; i < 4; i++) {
 }
 console.log(JSON.stringify({ bytes: buf.length, out: out.length, ms: +best.toFixed(2), mb_per_s: +(buf.length / best / 1e3).toFixed(1),
                              sha256: crypto.createHash('sha256').update(Buffer.from(out)).digest('hex') }));
+if (process.argv[4] === 'd') {
+  var comp = Buffer.from(out.buffer, out.byteOffset, out.length), back = cjs.Bzip2.decompressFile(comp), bd = 1e9;
+  for (var j = 0; j < 3; j++) {
+    var t1 = process.hrtime.bigint();
+    back = cjs.Bzip2.decompressFile(comp);
+    var d2 = Number(process.hrtime.bigint() - t1) / 1e6;
+    if (d2 < bd) bd = d2;
+  }
+  console.log(JSON.stringify({ decompress_ms: +bd.toFixed(2), mb_per_s: +(back.length / bd / 1e3).toFixed(1), equal: Buffer.compare(Buffer.from(back.buffer, back.byteOffset, back.length), buf) === 0 }));
+}
