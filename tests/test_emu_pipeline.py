@@ -776,3 +776,40 @@ def _segmented_check():
             L.cjs_destroy(x)
     finally:
         L.cjs_destroy(h)
+
+
+@pytest.mark.parametrize("env_add", [{}, {"CJS_K1_CARRY": "0"}, {"CJS_TEXT_BYTES": "0"}], ids=["default", "carry_off", "text_stages_off"])
+def test_attack_words_on_the_bucket_sort(env_add):
+    """tests/attackwords.py (the families the round-5 judge attacked the 16-byte-key bucket sort with: words of 15 / 16 / 17 and 40..90
+    bytes over {0xFE,0xFF}, {a..d} and the full alphabet, 0xFF- / 0x00-heavy blocks with sparse defects, one phrase of 16..64 bytes in
+    300..1500 places, near-periodic words with flipped bits, a mixed block): 28 blocks of 8 000 .. 48 000 bytes per knob setting (the GPU
+    suite runs the same families at the -9 block capacity),
+    transform and origPtr against the oracle."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle, stagelib, attackwords
+from compressjs_amd import synth
+L = C.CDLL(stagelib.build_emu())
+L.cjs_bwt_cyclic_batch.restype = C.c_int32
+L.cjs_bwt_cyclic_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+rng = np.random.default_rng(20260930)
+cap = 48000
+B = attackwords.blocks(cap, rng, synth.text_like, small=True)
+for i in range(0, len(B), 8):
+    blocks = B[i:i + 8]
+    nb = len(blocks)
+    T = np.zeros((nb, cap), np.uint8); nl = np.zeros(nb, np.uint32)
+    for j, (_, d) in enumerate(blocks):
+        T[j, :d.size] = d; nl[j] = d.size
+    U = np.zeros((nb, cap), np.uint8); P = np.zeros(nb, np.uint32)
+    assert L.cjs_bwt_cyclic_batch(T.ctypes.data, nl.ctypes.data, nb, cap, U.ctypes.data, P.ctypes.data) == 0
+    for j, (name, d) in enumerate(blocks):
+        uo, po = oracle.bwt_cyclic(d)
+        assert P[j] == po and (U[j, :d.size] == uo).all(), name
+print("ok", len(B))
+''' % (stagelib.ROOT, os.path.join(stagelib.ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]

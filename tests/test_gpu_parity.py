@@ -586,6 +586,40 @@ def test_adversarial_period_words_vs_oracle():
     assert out[0] == "ok" and int(out[1]) >= 5 and int(out[2]) >= 10, out      # closed form / three-period reduction both taken
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_add", [{}, {"CJS_K1_CARRY": "0"}, {"CJS_TEXT_BYTES": "0"}], ids=["default", "carry_off", "text_stages_off"])
+def test_attack_words_on_the_bucket_sort_vs_oracle(env_add):
+    """tests/attackwords.py at the -9 block capacity (n = 899 981; VERDICT r5 item 6: the families the judge attacked the 16-byte-key
+    bucket sort, its all-ones sentinel cells and the carried BWT byte with - words of 15 / 16 / 17 and 40..90 bytes over {0xFE,0xFF},
+    {a..d} and the full alphabet, 0xFF- / 0x00-heavy blocks with 5..400 defects, one phrase of 16..64 bytes in 300..1500 places,
+    near-periodic words with 1..5 flipped bits, a mixed block): 28 blocks per knob setting through cjs_bwt_cyclic_batch, transform and
+    origPtr equal the oracle's."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import numpy as np, oracle, attackwords\n"
+        "from compressjs_amd import _lib, synth\n"
+        "L = _lib.load()\n"
+        "L.cjs_bwt_cyclic_batch.restype = C.c_int32\n"
+        "L.cjs_bwt_cyclic_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]\n"
+        "rng = np.random.default_rng(20260930)\n"
+        "B = attackwords.blocks(899981, rng, synth.text_like)\n"
+        "cap = 899981; nb = len(B)\n"
+        "T = np.zeros((nb, cap), np.uint8); nl = np.zeros(nb, np.uint32)\n"
+        "for i, (_, d) in enumerate(B): T[i, :d.size] = d; nl[i] = d.size\n"
+        "U = np.zeros((nb, cap), np.uint8); P = np.zeros(nb, np.uint32)\n"
+        "assert L.cjs_bwt_cyclic_batch(T.ctypes.data, nl.ctypes.data, nb, cap, U.ctypes.data, P.ctypes.data) == 0\n"
+        "for i, (name, d) in enumerate(B):\n"
+        "    uo, po = oracle.bwt_cyclic(d)\n"
+        "    assert P[i] == po and np.array_equal(U[i, :d.size], uo), name\n"
+        "print('ok', nb)\n"
+    ) % (ROOT, ROOT)
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, **env_add), timeout=1500,
+                                  stderr=subprocess.DEVNULL).decode().split()
+    assert out[0] == "ok" and int(out[1]) == 28, out
+
+
 def test_deep_refinement_variants_same_bytes(ctx):
     """The text stages in front of the doubling rounds are a faster route to the same order.  K1's knobs (k1_bwt.hip,
     k1_knobs) must all give the same bytes on phrase-reuse text + runs + periodic + tiled input, and those bytes must be the
