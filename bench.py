@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--full-verify", action="store_true", help="N > 1: rebuild the whole job stream on rank 0 and decode / compare it even when a pinned digest exists")
     ap.add_argument("--batch", type=int, default=128, help="bzip2 blocks in flight (over all streams)")
+    ap.add_argument("--force-fallback", action="store_true", help="N > 1, test rigs: take the replicated fall-back plan on an input that plans slice by slice")
     ap.add_argument("--codec", default="bz2", choices=["bz2", "bwtc"],
                     help="bwtc: BWTC.compressFile -9 (BASELINE.json configs[4]; N = 1, host buffers in and out: its range coder is serial "
                          "host code, lib/RangeCoder.js; BWT, MTF/RLE2 and the adaptive FenwickModel run on the GPU)")
@@ -248,7 +249,7 @@ def main():
             dist.all_gather(parts, own)
             return torch.cat(parts).to(dev)
         return sharded_compress_parallel(ctx, d_in, hi - lo, lo, total, args.level, seg=seg,
-                                         fallback=lambda: sharded_compress(ctx, whole(), args.level))
+                                         fallback=lambda: sharded_compress(ctx, whole(), args.level), force_fallback=args.force_fallback)
 
     for _ in range(args.warmup):
         out = step()

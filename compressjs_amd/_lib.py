@@ -13,7 +13,7 @@ _lib = None
 
 # every symbol include/compressjs_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_lcg_ascii_device", "cjs_bz2_compress_bound", "cjs_bz2_compress",
-           "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_plan_block_start", "cjs_bwtc_last_times", "cjs_bz2_plan_scan", "cjs_bz2_plan_cost", "cjs_bz2_plan_phase", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
+           "cjs_bz2_compress_device", "cjs_bz2_compress_multi", "cjs_bz2_plan", "cjs_bz2_plan_block_start", "cjs_bwtc_last_times", "cjs_bz2_plan_scan", "cjs_bz2_plan_cost", "cjs_bz2_plan_phase", "cjs_bz2_plan_chain", "cjs_bz2_encode_blocks", "cjs_bwtc_compress",
            "cjs_bwtc_compress_bound",
            "cjs_last_device_ms", "cjs_last_block_count", "cjs_stream", "cjs_profile_enable",
            "cjs_profile_read", "cjs_profile_read_class", "cjs_bwt_cyclic", "cjs_bwt_cyclic_batch", "cjs_bwt_linear",
@@ -21,7 +21,7 @@ SYMBOLS = ["cjs_create", "cjs_destroy", "cjs_device_count", "cjs_lcg_ascii_devic
            "cjs_bz2_decompress", "cjs_bz2_decompress_device", "cjs_bz2_decompress_block", "cjs_bz2_table",
            "cjs_bz2_last_size", "cjs_bz2_fetch", "cjs_shift_bits", "cjs_bwtc_decompress", "cjs_bwtc_last_size", "cjs_bwtc_fetch", "cjs_bz2_last_detail", "cjs_bz2_last_decode_ms",
            "cjs_dbg_bwt_batch_time", "cjs_dbg_block_stages", "cjs_dbg_k1_sparse_rounds",
-           "cjs_dbg_k1_rounds", "cjs_dbg_k1_periodic_blocks", "cjs_dbg_rc_div", "cjs_dbg_multi_mallocs", "cjs_dbg_multi_fallbacks"]
+           "cjs_dbg_k1_rounds", "cjs_dbg_k1_periodic_blocks", "cjs_dbg_rc_div", "cjs_dbg_multi_mallocs", "cjs_dbg_multi_fallbacks", "cjs_dbg_multi_replans"]
 
 
 class CompressjsAmdError(RuntimeError):
@@ -77,6 +77,8 @@ def load(path: str | None = None):
     L.cjs_bz2_plan_cost.argtypes = [vp, C.c_uint64]
     L.cjs_bz2_plan_phase.restype = C.c_int64
     L.cjs_bz2_plan_phase.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int]
+    L.cjs_bz2_plan_chain.restype = C.c_int64
+    L.cjs_bz2_plan_chain.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]
     L.cjs_bz2_encode_blocks.restype = C.c_int64
     L.cjs_bz2_encode_blocks.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_uint64,
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]

@@ -161,6 +161,15 @@ class Context:
             return -1
         return _lib.check(n, "cjs_bz2_plan_phase")
 
+    def plan_chain(self, own_len: int, t0: int, last: bool):
+        """The slice's plan as a link of a chain (round 6): (blocks that start in [0, own_len), target of the first boundary at or
+        beyond own_len in this input's own cost prefix), or (-1, t0) when the slice cannot be planned on its own (CJS_E_SPEC)."""
+        tn = C.c_uint64(0)
+        n = self.L.cjs_bz2_plan_chain(self.h, int(own_len), int(t0), 1 if last else 0, C.byref(tn))
+        if n == -25:
+            return -1, int(t0)
+        return _lib.check(n, "cjs_bz2_plan_chain"), int(tn.value)
+
     def plan_block_start(self, k: int) -> int:
         """First input byte (relative to the planned input) of block k of the current plan."""
         return _lib.check(self.L.cjs_bz2_plan_block_start(self.h, int(k)), "cjs_bz2_plan_block_start")

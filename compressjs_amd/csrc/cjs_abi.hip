@@ -413,6 +413,8 @@ struct cjs_ctx {
 };
 static std::atomic<int> g_multi_mallocs{0};        // hipMalloc calls of cjs_bz2_compress_multi's segment buffers (cjs_dbg_multi_mallocs: none after warm-up)
 extern "C" int cjs_dbg_multi_mallocs(void) { return g_multi_mallocs.load(); }
+static std::atomic<int> g_multi_replans{0};        // segments of cjs_bz2_compress_multi planned a second time (the chain carried a shift to them)
+extern "C" int cjs_dbg_multi_replans(void) { return g_multi_replans.load(); }
 static std::atomic<int> g_multi_fallbacks{0};      // calls of cjs_bz2_compress_multi that took the replicated plan (a segment that cannot be planned on its own)
 extern "C" int cjs_dbg_multi_fallbacks(void) { return g_multi_fallbacks.load(); }
 #define CJS_SNAP_SLOTS 4096u
@@ -901,7 +903,12 @@ namespace {
 struct MSeg {
     uint64_t lo = 0, e = 0;         // the segment's bytes [lo, e) (absolute input offsets)
     uint64_t cost = 0;              // RLE1 cost of its bytes, scanned as an input of its own
-    u32 phase = 0;                  // block boundaries lie where the slice's own cost prefix reaches phase + m * cap
+    u32 phase = 0;                  // block boundaries lie where the slice's own cost prefix reaches phase + m * cap - while no boundary in front of the segment moved
+    uint64_t base = 0;              // origin of the segment's own cost prefix in the stream's: G(lo + i) = base + C_own(i) beyond the head run
+    bool has_span = false;          // a run of four or more bytes straddles the segment's start: its cost span [c0, c1] from the run's first byte
+    uint64_t c0 = 0, c1 = 0;        //   (the own prefix is wrong inside it: a boundary target in there cannot be planned by this segment)
+    uint64_t t0 = 0, tnext = 0;     // round 6, the chained plan: the target the segment was planned from, the one it hands on
+    int64_t nb = 0;                 // blocks that start in the segment
     bool ok = true;                 // can be planned on its own
     uint64_t bits = 0, off = 0;
     u32 fold = 0, count = 0;
@@ -936,11 +943,14 @@ static void plan_base(PlanChain& P, MSeg& g, const EdgeRuns& r, u32 cap) {
         delta = (int64_t)rle1_g(P.ink + r.lh) - (int64_t)rle1_g(P.ink) - (int64_t)rle1_g(r.lh);      // the head run costs what the tail of a longer run costs
         if (P.ink + r.lh >= 4) {
             // a run of four or more bytes straddles the cut: no block boundary may fall into its cost span, measured from the run's first byte
-            const uint64_t c0 = P.G - rle1_g(P.ink), c1 = P.G + rle1_g(P.ink + r.lh) - rle1_g(P.ink);
-            if (c0 / cap != c1 / cap || c0 % cap == 0 || c1 % cap == 0) g.ok = false;
+            // (round 6: checked against the target the chain actually carries to this segment - seg_target - not against multiples of cap)
+            g.has_span = true;
+            g.c0 = P.G - rle1_g(P.ink);
+            g.c1 = P.G + rle1_g(P.ink + r.lh) - rle1_g(P.ink);
         }
     }
     const uint64_t base = (uint64_t)((int64_t)P.G + delta);
+    g.base = base;
     g.phase = (u32)((cap - base % cap) % cap);
     if (n) {
         if (r.lh == n && P.inb == r.hb && P.ink > 0) P.ink += n;       // the whole segment continues the incoming run
@@ -948,6 +958,14 @@ static void plan_base(PlanChain& P, MSeg& g, const EdgeRuns& r, u32 cap) {
         else { P.inb = r.tb; P.ink = r.lt; }
     }
     P.G = (uint64_t)((int64_t)P.G + (int64_t)g.cost + delta);
+}
+// The chained plan (compressjs_amd/dist.py: chain_step): tau = the stream-wide target of the first block boundary at or behind the
+// segment's start (what the segment before it handed on; 0 for the first).  Sets g.t0, the same target under the segment's own origin;
+// false when the boundary falls into a run that straddles the segment's start (the segment cannot plan it: the caller falls back).
+static bool seg_target(MSeg& g, uint64_t tau) {
+    if (g.has_span && tau >= g.c0 && tau <= g.c1) return false;
+    g.t0 = tau > g.base ? tau - g.base : 0;
+    return true;
 }
 }
 
@@ -1142,6 +1160,7 @@ static int64_t compress_overlapped(cjs_ctx* c, const uint8_t* in, uint64_t in_le
         if (!rc && hipEventRecord(c->evReady, st) != hipSuccess) rc = CJS_E_HIP;
         if (rc) fail(rc);
         PlanChain pc;
+        uint64_t tau = 0;                                   // stream-wide target of the next block boundary (round 6: carried from slice to slice)
         for (u32 k = 0; k < ns && !rc; k++) {
             OvSlice& sl = S[k];
             sl.evScan = (*c->evPool)[2 * k];
@@ -1165,12 +1184,14 @@ static int64_t compress_overlapped(cjs_ctx* c, const uint8_t* in, uint64_t in_le
             ms.lo = sl.lo; ms.e = sl.e;
             ms.cost = own < wlen ? tot[1] : tot[0];
             plan_base(pc, ms, edge_runs(in, sl.lo, sl.e), cap);
-            if (!ms.ok) { fallback = true; break; }
-            rc = k0_phase_plan(sl.K, cap, ms.phase, own, sl.e >= in_len ? 1u : 0u, tot[0], st);
+            if (!ms.ok || !seg_target(ms, tau)) { fallback = true; break; }
+            rc = k0_phase_plan(sl.K, cap, ms.t0, own, sl.wend >= in_len ? 1u : 0u, tot[0], st);
             if (rc) break;
-            u32 nb = 0;
-            if (hipMemcpyAsync(&nb, sl.K.nBlocks, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CJS_E_HIP; break; }
+            u64 nbt[2] = {0, 0};                            // blocks, the target handed on (k0_phase_chain)
+            if (hipMemcpyAsync(nbt, sl.K.nBlocks, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = CJS_E_HIP; break; }
+            const u32 nb = (u32)nbt[0];
             if (nb == K0_PHASE_FAIL || nb > c->sub_blocks) { fallback = true; break; }
+            tau = ms.base + nbt[1];                         // the slices are planned in order: the chain needs no speculation here
             sl.nblocks = nb;
             sl.t_plan = now_ms();
             std::lock_guard<std::mutex> gq(mu);
@@ -1259,19 +1280,29 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
         if (v < 0) { (void)hipStreamSynchronize(c->stream); fail((int)v); return; }     // (the window's upload reads the caller's buffer: not left pending - ADVICE r4)
         g.cost = (uint64_t)v;
     };
-    // phase B: the blocks that start in the segment, planned from its phase and encoded from bit 0
+    // phase B1: the blocks that START in the segment, planned from the target g.t0 (round 6: a link of the chain - cjs_bz2_plan_chain;
+    // the segments of a wave plan at once from speculative targets, the calling thread validates the chain and plans a segment whose
+    // target was wrong again)
+    auto plan_seg = [&](uint64_t k) {
+        cjs_ctx* c = ctxs[k % n];
+        MSeg& g = S[k];
+        if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); return; }
+        const uint64_t we = g.e + W < in_len ? g.e + W : in_len;
+        uint64_t tn = g.t0;
+        const int64_t nb = cjs_bz2_plan_chain(c, g.e - g.lo, g.t0, we >= in_len ? 1 : 0, &tn);
+        if (nb == CJS_E_SPEC) { fail(1); return; }
+        if (nb < 0) { fail((int)nb); return; }
+        g.nb = nb; g.tnext = tn;
+    };
+    // phase B2: encoded from bit 0
     auto encode_seg = [&](uint64_t k) {
         cjs_ctx* c = ctxs[k % n];
         MSeg& g = S[k];
-        if (!g.ok) { fail(1); return; }
+        if (g.nb == 0) return;
         if (hipSetDevice(c->device) != hipSuccess) { fail(CJS_E_NOGPU); return; }
-        const int64_t nb = cjs_bz2_plan_phase(c, g.e - g.lo, g.phase, g.e >= in_len ? 1 : 0);
-        if (nb == CJS_E_SPEC) { fail(1); return; }
-        if (nb < 0) { fail((int)nb); return; }
-        if (nb == 0) return;
         if (!g.dseg) { fail(CJS_E_HIP - (int)hipErrorOutOfMemory); return; }
         u32 fold = 0, cnt = 0;
-        const int64_t bits = cjs_bz2_encode_blocks(c, 0, (u32)nb, g.dseg, g.dseg_cap, &fold, &cnt);
+        const int64_t bits = cjs_bz2_encode_blocks(c, 0, (u32)g.nb, g.dseg, g.dseg_cap, &fold, &cnt);
         if (bits < 0) { fail((int)bits); return; }
         g.bits = (uint64_t)bits; g.fold = fold; g.count = cnt;
     };
@@ -1292,24 +1323,52 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
         if (e2 == hipSuccess && span > 2) e2 = hipMemcpy(out + fb + 1, (u8*)c->dout + 1, span - 2, hipMemcpyDeviceToHost);
         if (e2 != hipSuccess) fail(CJS_E_HIP - (int)e2);
     };
+    // one PERSISTENT worker thread per device (the context's io[0] helper: created at its first job, kept until cjs_destroy) - until
+    // round 5 a std::thread per device per phase per wave
     auto run_range = [&](uint64_t k0, uint64_t k1, const std::function<void(uint64_t)>& fn) {
 #ifdef CJS_CPU_DEBUG_BUILD
         for (uint64_t k = k0; k < k1 && !err; k++) fn(k);             // the CPU logic-debug build runs kernels on one thread
 #else
-        std::vector<std::thread> th;
-        for (u32 d = 0; d < n; d++)
-            th.emplace_back([&, d]() { for (uint64_t k = k0 + d; k < k1 && !err; k += n) fn(k); });
-        for (auto& t : th) t.join();
+        const u32 nw = k1 - k0 < n ? (u32)(k1 - k0) : n;
+        for (u32 d = 1; d < nw; d++) {
+            cjs_ctx* c = ctxs[(k0 + d) % n];
+            if (!c->io[0]) c->io[0] = new CjsHelper();
+            c->io[0]->post([&, d]() { for (uint64_t k = k0 + d; k < k1 && !err; k += n) fn(k); });
+        }
+        for (uint64_t k = k0; k < k1 && !err; k += n) fn(k);          // (the calling thread takes the first device's share)
+        for (u32 d = 1; d < nw; d++) ctxs[(k0 + d) % n]->io[0]->wait();
 #endif
     };
     auto run_all = [&](const std::function<void(uint64_t)>& fn) { run_range(0, nseg, fn); };
     {
         PlanChain pc;
+        uint64_t tau = 0;                                             // stream-wide target of the next block boundary (the chain)
+        int64_t shift = 0;                                            // what the boundaries in front of the wave have moved by so far (a guess for its later segments)
         for (uint64_t k0 = 0; k0 < nseg && !err; k0 += n) {           // a wave: one segment per device
             const uint64_t k1 = k0 + n < nseg ? k0 + n : nseg;
             run_range(k0, k1, scan_seg);
             if (err) break;
-            for (uint64_t k = k0; k < k1; k++) plan_base(pc, S[k], edge_runs(in, S[k].lo, S[k].e), cap);
+            for (uint64_t k = k0; k < k1; k++) {
+                plan_base(pc, S[k], edge_runs(in, S[k].lo, S[k].e), cap);
+                if (!S[k].ok) fail(1);
+                const int64_t guess = (int64_t)S[k].phase + shift;
+                S[k].t0 = (uint64_t)(guess < 0 ? guess + (int64_t)cap : guess);
+            }
+            if (!err && !seg_target(S[k0], tau)) fail(1);             // (the wave's first segment: its target is known)
+            if (err) break;
+            run_range(k0, k1, plan_seg);
+            if (err) break;
+            // the chain through the wave's segments: a segment planned from a wrong target (a boundary inside a run of four or more equal
+            // bytes in a segment before it: ordinary text has them) is planned again, here and now - 0.1 ms, one job in some dozens
+            for (uint64_t k = k0; k < k1 && !err; k++) {
+                const uint64_t planned = S[k].t0;
+                if (!seg_target(S[k], tau)) { fail(1); break; }
+                if (S[k].t0 != planned) { g_multi_replans++; plan_seg(k); }
+                if (err) break;
+                shift = (int64_t)S[k].t0 - (int64_t)S[k].phase;
+                tau = S[k].base + S[k].tnext;
+            }
+            if (err) break;
             // Every device's buffer for its segment of this wave, from the context's pool (grow-only, kept across calls: a hipMalloc per
             // segment and a hipFree - a device-wide sync - per segment in every call was what rounds 2-4 did).  Taken HERE, on the calling
             // thread and for every segment of the wave: inside the workers it depended on which of them saw another one's fallback flag
@@ -1337,13 +1396,15 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
             run_range(k0, k1, encode_seg);
         }
     }
+    bool replicated = false;
     if (err == 1) {
-        // A segment that cannot be planned on its own - a block boundary inside a run of four or more equal bytes (ordinary text has
-        // them: indentation, rules of '=' or '-'; 0.1 % of the positions of the enwik-shaped streams, one call in twenty-five at 7*10^7
-        // bytes), a block longer than the margin: the REPLICATED plan.  Every device takes the whole input and plans it with the serial
-        // chain (cjs_bz2_plan: 0.5 ms per 10^8 bytes; the uploads run on the devices' own links), then encodes its share of the blocks -
-        // what compressjs_amd/dist.py::sharded_compress does across processes.  Until round 5 such a call went to ONE device.
+        // A segment that cannot be planned on its own - a block longer than the margin, a run that fills a block or reaches beyond 4 KB at a
+        // cut, a boundary inside a run that straddles a cut (round 5 also: any block boundary inside a run of four or more equal bytes - one
+        // call in twenty-five at 7*10^7 bytes of text; round 6 carries those through the chain): the REPLICATED plan.  Every device takes
+        // the whole input and plans it with the serial chain (cjs_bz2_plan: 0.5 ms per 10^8 bytes; the uploads run on the devices' own
+        // links), then encodes its share of the blocks - what compressjs_amd/dist.py::sharded_compress does across processes.
         err.store(0);
+        replicated = true;
         g_multi_fallbacks++;
         std::vector<int64_t> nbv(n, 0);
         run_range(0, n, [&](uint64_t d) {
@@ -1395,6 +1456,9 @@ extern "C" int64_t cjs_bz2_compress_multi(cjs_ctx** ctxs, uint32_t n, const uint
                 });
         }
     }
+    // the replicated plan needs the whole input and its K0 workspace on EVERY device: when that does not fit (a HIP / out-of-memory
+    // error), the call degrades to one device's segmented path, whose device memory is bounded
+    if (replicated && err.load() <= CJS_E_HIP) return cjs_bz2_compress(ctxs[0], in, in_len, level, out, out_cap);
     int64_t result = 0;
     if (!err) {
         uint64_t pos = 32;
@@ -1521,26 +1585,48 @@ extern "C" int64_t cjs_bz2_plan_cost(cjs_ctx* c, uint64_t pos) {
 #undef TRYR
 }
 
-extern "C" int64_t cjs_bz2_plan_phase(cjs_ctx* c, uint64_t own_len, uint64_t phase, int last) {
+// Round 6: the slice's plan as a link of a CHAIN.  t0 = the value this input's own cost prefix reaches at the slice's first block boundary
+// (the previous slice's *t_next after a change of origin; phase = (-G(lo)) mod cap when nothing in front of the slice moved a boundary).
+// A block boundary inside a run of four or more equal bytes no longer refuses: the slice goes on serially from there (k0_phase_chain)
+// and *t_next - the target of the first boundary at or beyond own_len - carries the shift to the slices behind it.  CJS_E_SPEC is left
+// for what a slice cannot do on its own: a block longer than the margin, a run that fills a block.
+extern "C" int64_t cjs_bz2_plan_chain(cjs_ctx* c, uint64_t own_len, uint64_t t0, int last, uint64_t* t_next) {
     if (!c || !c->scan_level || own_len > c->plan.in_len) return CJS_E_ARG;
     hipError_t e;
 #define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
     TRYR(hipSetDevice(c->device));
     const u32 cap = (u32)c->scan_level * 100000u - 19u;
-    if (phase >= cap) return CJS_E_ARG;
     c->plan_level = 0;
     c->plan_blocks = 0;
+    if (t_next) *t_next = t0;
     if (c->plan.in_len == 0) { c->plan_level = c->scan_level; return 0; }
-    const int rc = k0_phase_plan(c->plan, cap, phase, own_len, last ? 1u : 0u, c->scan_total, c->stream);
+    const int rc = k0_phase_plan(c->plan, cap, t0, own_len, last ? 1u : 0u, c->scan_total, c->stream);
     if (rc) return rc;
-    u32 nblocks = 0;
-    TRYR(hipMemcpyAsync(&nblocks, c->plan.nBlocks, 4, hipMemcpyDeviceToHost, c->stream));
+    // (pinned: a pageable read-back costs tens of microseconds more; pin[0] is free here - no sub-batch is running on this context)
+    TRYR(hipMemcpyAsync(c->pin[0], c->plan.nBlocks, 16, hipMemcpyDeviceToHost, c->stream));
     TRYR(hipStreamSynchronize(c->stream));
+    const u32 nblocks = c->pin[0][0];
+    uint64_t tn = 0;
+    memcpy(&tn, c->pin[0] + 2, 8);
     if (nblocks == K0_PHASE_FAIL) return CJS_E_SPEC;
+    if (t_next) *t_next = tn;
     c->plan_blocks = nblocks;
     c->plan_level = c->scan_level;
     return (int64_t)nblocks;
 #undef TRYR
+}
+
+// The round-3 entry: boundaries where the prefix reaches phase + m * cap and NOTHING carried - a slice whose plan moves the
+// boundaries behind it (a boundary inside a long run) is refused, as before, unless the stream ends in it.
+extern "C" int64_t cjs_bz2_plan_phase(cjs_ctx* c, uint64_t own_len, uint64_t phase, int last) {
+    if (!c || !c->scan_level) return CJS_E_ARG;
+    const u32 cap = (u32)c->scan_level * 100000u - 19u;
+    if (phase >= cap) return CJS_E_ARG;
+    uint64_t tn = 0;
+    const int64_t nb = cjs_bz2_plan_chain(c, own_len, phase, last, &tn);
+    if (nb < 0) return nb;
+    if (!last && tn >= phase && (tn - phase) % cap != 0) { c->plan_level = 0; c->plan_blocks = 0; return CJS_E_SPEC; }
+    return nb;
 }
 
 // first input byte (relative to the planned input) of block k of the current plan; k == number of blocks: the input length

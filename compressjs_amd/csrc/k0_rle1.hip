@@ -672,18 +672,25 @@ int k0_prepass(K0Buf K, u32 cap, hipStream_t stream) {
 // With G(i) the cost prefix of the WHOLE stream, block k of the stream starts at min{ i : G(i) >= k cap } wherever the
 // speculation of k0_chain_spec holds.  A rank that holds bytes [lo, lo + in_len) knows G(lo) from one all_gather of per-slice
 // totals and boundary runs (compressjs_amd/dist.py), and G(lo + i) = G(lo) + delta + C(i) with this input's own prefix C
-// beyond its first run: its boundaries are the positions where C reaches phase + m cap, phase = (-(G(lo) + delta)) mod cap.
-//   k0_phase_spec    boundary m = min{ i : C(i) >= phase + m cap }, one workgroup each; flags what k0_chain_spec flags
-//   k0_phase_accept  the blocks that START before own_len (the rest of the input is the margin that completes the last of
-//                    them); *nBlocks = their number, or K0_PHASE_FAIL when a boundary is flagged or the margin too short
-//                    (the caller falls back to the chained / replicated drivers).  `last`: the input ends where the stream
-//                    ends - the final block may be short (lib/Bzip2.js:922) or absent (:916).
-__global__ __launch_bounds__(256) void k0_phase_spec(K0Buf K, u32 cap, u64 phase) {
+// beyond its first run.  Round 6: a slice is planned from the TARGET t0 of its first boundary - the value its own prefix C has to
+// reach there - instead of a phase modulo cap, so that what the speculation cannot express is CARRIED instead of refused: a block
+// boundary inside a run of four or more equal bytes (ordinary text has them: indentation, rules of '=' or '-') restarts the run in
+// the new block, which moves every later boundary by a few output bytes - on one device k0_chain resumes serially from such a
+// boundary, and so does a slice here; what it hands to the next slice is the target of the first boundary it does not own.
+//   k0_phase_spec    boundary m = min{ i : C(i) >= t0 + m cap }, one workgroup each; flags what k0_chain_spec flags
+//   k0_phase_chain   one workgroup: the blocks that START before own_len (the rest of the input is the margin that completes the
+//                    last of them), straight from the speculation up to the first flagged boundary and by the serial chain of
+//                    k0_chain from there; *nBlocks = their number, or K0_PHASE_FAIL when the margin is too short for a block or a
+//                    run fills a whole block (the caller falls back to the replicated plan); ((u64*)nBlocks)[1] = the target
+//                    (in this input's own prefix C) of the first boundary at or beyond own_len - the next slice's t0 after a change of
+//                    origin.  `last`: the input ends where the stream ends - the final block may be short (lib/Bzip2.js:922) or
+//                    absent (:916).
+__global__ __launch_bounds__(256) void k0_phase_spec(K0Buf K, u32 cap, u64 t0) {
     __shared__ u64 sh[256];
     __shared__ u32 sh32[4];
     const u64 total = K.tileC[K.ntiles];
     const u64 m = blockIdx.x;
-    const u64 t = phase + m * (u64)cap;
+    const u64 t = t0 + m * (u64)cap;
     if (t > total) { if (threadIdx.x == 0) { K.specEnd[m] = K.in_len + 1; K.specC[m] = 0; } return; }
     u64 ce = 0, e = 0;
     if (t) e = k0_searchC(K, t, 0, sh, sh32, &ce);
@@ -702,34 +709,89 @@ __global__ __launch_bounds__(256) void k0_phase_spec(K0Buf K, u32 cap, u64 phase
     }
 }
 
-__global__ __launch_bounds__(256) void k0_phase_accept(K0Buf K, u32 cap, u64 phase, u64 own_len, u32 last, u32 nbound) {
-    __shared__ u32 nb, fail;
-    if (threadIdx.x == 0) { nb = 0; fail = 0; }
+__global__ __launch_bounds__(256) void k0_phase_chain(K0Buf K, u32 cap, u64 t0, u64 own_len, u32 last, u32 nbound) {
+    __shared__ u64 sh[256];
+    __shared__ u32 sh32[4];
+    __shared__ u32 nb, fail, stop;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) { nb = 0; fail = 0; stop = nbound; }
     __syncthreads();
     const u64 total = K.tileC[K.ntiles];
-    const u64 bad = *K.specBad;
-    for (u32 m = threadIdx.x; m < nbound; m += 256u) {
-        const u64 t = phase + (u64)m * cap;
-        if (t > total) continue;
-        const u64 s = K.specEnd[m];
-        if (s >= own_len) continue;                               // starts in the margin (or at the very end): the next rank's
+    const u64 badraw = *K.specBad;
+    const u32 bad = badraw < (u64)nbound ? (u32)badraw : nbound;          // first boundary the speculation does not carry past
+    // ---- the speculated prefix: boundary m starts block m while m < bad, the boundary lies in the window and in front of own_len
+    for (u32 m = tid; m < nbound; m += 256u) {
+        const u64 t = t0 + (u64)m * cap;
+        const u64 s = t > total ? K.in_len + 1 : K.specEnd[m];
+        if (m >= bad || t > total || s >= own_len) { atomicMin(&stop, m); continue; }
         if (m >= K.maxBlocks) { atomicOr(&fail, 1u); continue; }
         u64 e, n = cap;
-        u64 used = m;                                             // highest boundary this block relies on
-        if (t + cap <= total && m + 1u < nbound) { e = K.specEnd[m + 1u]; used = m + 1u; }
-        else if (last) { e = K.in_len; n = total - t; }           // the stream ends inside this block
-        else { atomicOr(&fail, 1u); continue; }                   // the margin does not reach the end of the block
-        if (bad <= used) { atomicOr(&fail, 1u); continue; }
-        if (n == 0) continue;                                     // (last) nothing after the boundary: no block (lib/Bzip2.js:916)
+        if (t + cap <= total && m + 1u < nbound) e = K.specEnd[m + 1u];     // (boundary m + 1 <= bad: its position is right even if it is flagged)
+        else if (last) { e = K.in_len; n = total - t; }                  // the stream ends inside this block
+        else { atomicOr(&fail, 1u); continue; }                          // the margin does not reach the end of the block
+        if (n == 0) continue;                                            // (last) nothing after the boundary: no block (lib/Bzip2.js:916)
         K.blkStart[m] = s;
         K.blkEnd[m] = e;
         K.blkN[m] = (u32)n;
-        K.blkAdj[m] = t;                                          // = C(s)
+        K.blkAdj[m] = t;                                                 // = C(s)
         K.blkRe[m] = s;
         atomicMax(&nb, m + 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) *K.nBlocks = fail ? K0_PHASE_FAIL : nb;
+    const u32 m0 = stop;
+    u64 tnext = t0 + (u64)m0 * cap;                                      // the target of the first boundary this slice does not own
+    bool failed = fail != 0u;
+    u32 kb = nb;
+    __syncthreads();
+    // ---- a flagged boundary in front of own_len: the serial chain of k0_chain from there to the end of the slice
+    if (!failed && m0 < nbound && m0 == bad && tnext <= total && K.specEnd[m0] < own_len) {
+        u64 s = K.specEnd[m0], cnext = K.specC[m0];
+        bool have_cnext = true;
+        kb = m0;
+        for (;;) {
+            if (s >= own_len) break;                                      // the next slice's (tnext is the target that found s)
+            if (kb >= K.maxBlocks) { failed = true; break; }
+            const bool cut = s > 0 && K.in[s - 1] == K.in[s];
+            u64 e = s, adj = 0, re = s, pre = 0;
+            u32 n = 0;
+            bool ends = false;                                            // the stream ends inside this block
+            if (cut) {
+                re = k0_run_end(K, s, sh);
+                const u64 gL = k0_g(re - s);
+                if (gL >= cap) { failed = true; break; }                  // a run that fills a block: not a slice's business
+                if (re >= K.in_len) {
+                    if (!last) { failed = true; break; }
+                    e = K.in_len; n = (u32)gL; re = e; ends = true;
+                } else pre = gL;
+            }
+            if (!ends) {
+                const u64 cbase = (!cut && have_cnext) ? cnext : k0_evalC(K, re, sh, sh32);
+                adj = cbase - pre;
+                const u64 target = adj + cap;
+                u64 ce = 0;
+                e = k0_searchC(K, target, re, sh, sh32, &ce);
+                if (e > K.in_len) {
+                    if (!last) { failed = true; break; }                  // the margin does not reach the end of the block
+                    e = K.in_len; n = (u32)(total - adj); ends = true;
+                } else {
+                    n = cap;
+                    cnext = ce;
+                    have_cnext = true;
+                    tnext = target;
+                }
+            }
+            if (n) {
+                if (tid == 0) { K.blkStart[kb] = s; K.blkEnd[kb] = e; K.blkN[kb] = n; K.blkAdj[kb] = adj; K.blkRe[kb] = re; }
+                kb++;
+            }
+            if (ends) { tnext = total + cap; break; }                    // no boundary behind the stream's last block: a target no window reaches
+            s = e;
+        }
+    }
+    if (tid == 0) {
+        *K.nBlocks = failed ? K0_PHASE_FAIL : kb;
+        ((u64*)K.nBlocks)[1] = tnext;
+    }
 }
 
 __global__ __launch_bounds__(256) void k0_eval_at(K0Buf K, u64 pos) {
@@ -745,12 +807,12 @@ int k0_eval(K0Buf K, u64 pos, hipStream_t stream) {
     return CJS_OK;
 }
 
-int k0_phase_plan(K0Buf K, u32 cap, u64 phase, u64 own_len, u32 last, u64 total, hipStream_t stream) {
-    u64 nb = total >= phase ? (total - phase) / cap + 2 : 1;
+int k0_phase_plan(K0Buf K, u32 cap, u64 t0, u64 own_len, u32 last, u64 total, hipStream_t stream) {
+    u64 nb = total >= t0 ? (total - t0) / cap + 2 : 1;
     if (nb > (u64)K.maxBlocks + 1) nb = (u64)K.maxBlocks + 1;
     HIP_CHECK_RET(hipMemsetAsync(K.specBad, 0xFF, 8, stream));
-    hipLaunchKernelGGL(k0_phase_spec, dim3((u32)nb), dim3(256), 0, stream, K, cap, phase);
-    hipLaunchKernelGGL(k0_phase_accept, dim3(1), dim3(256), 0, stream, K, cap, phase, own_len, last, (u32)nb);
+    hipLaunchKernelGGL(k0_phase_spec, dim3((u32)nb), dim3(256), 0, stream, K, cap, t0);
+    hipLaunchKernelGGL(k0_phase_chain, dim3(1), dim3(256), 0, stream, K, cap, t0, own_len, last, (u32)nb);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }

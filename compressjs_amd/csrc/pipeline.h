@@ -94,7 +94,7 @@ int k0_prepass(K0Buf K, u32 cap, hipStream_t stream);
 #define K0_PHASE_FAIL 0xFFFFFFFFu
 int k0_scans(K0Buf K, hipStream_t stream);
 int k0_eval(K0Buf K, u64 pos, hipStream_t stream);
-int k0_phase_plan(K0Buf K, u32 cap, u64 phase, u64 own_len, u32 last, u64 total, hipStream_t stream);
+int k0_phase_plan(K0Buf K, u32 cap, u64 t0, u64 own_len, u32 last, u64 total, hipStream_t stream);   // t0: target of the slice's first boundary (round 6: carried from slice to slice; *K.nBlocks, ((u64*)K.nBlocks)[1] = blocks, the next slice's target)
 
 int k6_unbwt_linear(const u8* dT, u8* dU, u32 n, u32 pidx, void* ws, hipStream_t stream);
 int k2_run(Pipe P, u32 max_n, hipStream_t stream);

@@ -331,21 +331,81 @@ def plan_bases(meta, level: int):
     return out
 
 
+def plan_origins(meta, level: int):
+    """plan_bases for the CHAINED plan (round 6): per slice (base, span, long_run) - base = G(lo) + head-run correction, the origin
+    of the slice's own cost prefix in the stream's (G(lo + i) = base + C_own(i) beyond the head run); span = (c0, c1), the cost span
+    of a run of four or more bytes that straddles the slice start, measured from the run's first byte (the slice's own prefix is
+    wrong inside it: a boundary target in there cannot be planned by this slice), or None."""
+    out = []
+    G = 0
+    inb, ink = -1, 0
+    for n, cost, hb, lh, tb, lt, long_run in meta:
+        delta, span = 0, None
+        if n and inb == hb and ink > 0:
+            delta = _g(ink + lh) - _g(ink) - _g(lh)
+            if ink + lh >= 4:
+                span = (G - _g(ink), G + _g(ink + lh) - _g(ink))
+        out.append((G + delta, span, bool(long_run)))
+        if n:
+            if lh == n and inb == hb and ink > 0:
+                ink += n
+            elif lh == n:
+                inb, ink = hb, n
+            else:
+                inb, ink = tb, lt
+        G += cost + delta
+    return out
+
+
+def chain_step(origins, assumed, results, cap: int, ends=None):
+    """One validation pass over the slices' speculative plans - pure integer arithmetic on gathered values, identical on every rank.
+    origins: plan_origins(); assumed[r]: the t0 slice r planned with; results[r] = (t_next, ok) of that plan; ends: index of the
+    slice in which the stream ends (the walk stops there).
+    Returns (status, assumed'): status 'done' (every slice planned from its true target), 'refuse' (a slice cannot be planned on
+    its own: fall back), or 'again' with the targets to plan from next: the first slice whose assumption was wrong gets its true
+    target, the slices behind it the same shift as a guess."""
+    tau = 0                                   # the stream's first boundary: G = 0
+    for r, (base, span, long_run) in enumerate(origins):
+        if ends is not None and r > ends:
+            break                             # (slices behind the end of the stream: nothing to plan, nothing to agree on)
+        if long_run:
+            return "refuse", assumed
+        if span is not None and span[0] <= tau <= span[1]:
+            return "refuse", assumed          # the boundary falls into a run that straddles this slice's start
+        true_t0 = max(0, tau - base)
+        if assumed[r] != true_t0:
+            shift = true_t0 - assumed[r]
+            nxt = list(assumed)
+            nxt[r] = true_t0
+            for q in range(r + 1, len(origins)):
+                g = assumed[q] + shift
+                nxt[q] = g if g >= 0 else g + cap
+            return "again", nxt
+        t_next, ok = results[r]
+        if not ok:
+            return "refuse", assumed
+        tau = base + t_next
+    return "done", assumed
+
+
 def sharded_compress_parallel(ctx, d_win: torch.Tensor, own_len: int, lo: int, total: int, level: int, group=None,
-                              seg: torch.Tensor = None, fallback=None):
+                              seg: torch.Tensor = None, fallback=None, force_fallback: bool = False):
     """The stream of sharded_compress with every rank holding its slice and a margin of what FOLLOWS it - d_win = stream
     bytes [lo, min(total, lo + own_len + margin_bytes(level))) - and no chain between the ranks' plans (the reference's
     `do { readBlock } while`, lib/Bzip2.js:913-922, is serial; the round-2 driver kept it serial across ranks):
 
       1. every rank scans its own window (K0's cost prefix) and summarises its slice: cost total, first and last run;
-      2. ONE all_gather (7 integers per rank) gives every rank the stream's cost prefix at its slice start, hence the phase
-         of the block boundaries inside its slice: it plans the blocks that START in its slice (cjs_bz2_plan_phase) and
-         encodes them, the margin completing the last one;
-      3. one all_reduce of a flag "could not plan on my own" (a boundary inside a run of four or more equal bytes, a block
-         longer than the margin, a boundary run longer than 4 KB, any local error) BEFORE anything is encoded, and one more
-         after the encoding (local errors): if any rank raises it, all fall back to `fallback()` (a callable that runs one of
-         the other drivers), else the (bits, CRC fold, block count) all_gather of the other drivers follows and segments are
-         shifted, sent and assembled as before.
+      2. ONE all_gather (7 integers per rank) gives every rank the stream's cost prefix at its slice start, hence the target
+         of the first block boundary inside its slice: it plans the blocks that START in its slice (cjs_bz2_plan_chain), the
+         margin completing the last one;
+      3. one all_gather of (target planned from, target handed on, ok) BEFORE anything is encoded: every rank walks the chain of
+         targets (chain_step).  Round 6: a boundary inside a run of four or more equal bytes no longer sends the job to the
+         replicated plan - it shifts the targets behind it, the ranks behind it plan again (one more small all_gather) and the job
+         stays sharded; what still falls back to `fallback()` (a callable that runs one of the other drivers): a block longer than
+         the margin, a run that fills a block, a boundary run longer than 4 KB at a slice edge, a boundary inside a run that
+         straddles a cut, any local error;
+      4. the blocks are encoded; one all_reduce of a flag carries local errors of the encoding (then all fall back); else the
+         (bits, CRC fold, block count) all_gather of the other drivers follows and segments are shifted, sent and assembled as before.
     Returns the stream on rank 0, None elsewhere."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -372,31 +432,49 @@ def sharded_compress_parallel(ctx, d_win: torch.Tensor, own_len: int, lo: int, t
     else:
         meta = [tuple(int(x) for x in mine.cpu().tolist())]
     mark("all_gather summaries")
-    phase, ok = plan_bases([(m[0], m[1], m[2], m[3], m[4], m[5], bool(m[6])) for m in meta], level)[rank]
-    nb = -1
+    # ---- the chained plan (round 6): every rank plans from the target it EXPECTS its first boundary to have (no boundary in front of
+    # it moved: the round-3 phase); one all_gather of (assumed target, target handed on, ok) lets every rank walk the chain - the same
+    # integer arithmetic everywhere (chain_step).  A boundary inside a run of four or more equal bytes somewhere in the job moves the
+    # targets behind it by a few bytes: the ranks behind it plan again from the corrected targets (one more small all_gather per such
+    # boundary; ordinary text: one job in four at 8 x 10^8 bytes has one), instead of all ranks falling back to the replicated plan.
+    cap = level * 100000 - 19
+    origins = plan_origins([(m[0], m[1], m[2], m[3], m[4], m[5], bool(m[6])) for m in meta], level)
+    assumed = [(-o[0]) % cap for o in origins]
+    last = lo + d_win.numel() >= total                         # the WINDOW ends where the stream ends: the final block may be short (a slice-level flag refused jobs whose last block starts in the slice before the last)
+    nb, t_next, okp, planned_with = -1, 0, False, None
     bits, fold, cnt = 0, 0, 0
-    # a local failure of any kind becomes the fall-back flag: every rank must reach the collective below, or the others hang
-    # (ADVICE r3); the fall-back driver then raises the same error on this rank where every rank sees it
-    try:
-        if ok:
-            nb = ctx.plan_phase(own_len, phase, lo + own_len >= total)
-    except Exception:                                        # noqa: BLE001
-        if os.environ.get('CJS_DIST_TRACE'):
-            import traceback
-            traceback.print_exc()
-        nb = -1
+    status = "again"
+    for _it in range(world + 2):
+        # a local failure of any kind becomes the fall-back flag: every rank must reach the collective below, or the others hang
+        # (ADVICE r3); the fall-back driver then raises the same error on this rank where every rank sees it
+        if planned_with != assumed[rank]:
+            planned_with = assumed[rank]
+            try:
+                nb, t_next = ctx.plan_chain(own_len, planned_with, last)
+                okp = nb >= 0
+            except Exception:                                    # noqa: BLE001
+                if os.environ.get('CJS_DIST_TRACE'):
+                    import traceback
+                    traceback.print_exc()
+                nb, t_next, okp = -1, planned_with, False
+        if force_fallback:                                       # (tests: the fall-back path on an input that plans fine)
+            okp = False
+        mine3 = torch.tensor([planned_with, t_next, 1 if okp else 0], dtype=torch.int64, device=cdev)
+        if world > 1:
+            all3 = [torch.zeros(3, dtype=torch.int64, device=cdev) for _ in range(world)]
+            dist.all_gather(all3, mine3, group=group)
+            res = [tuple(int(x) for x in v.cpu().tolist()) for v in all3]
+        else:
+            res = [tuple(int(x) for x in mine3.cpu().tolist())]
+        status, assumed = chain_step(origins, [r[0] for r in res], [(r[1], bool(r[2])) for r in res], cap,
+                                     ends=max([r for r, m in enumerate(meta) if m[0] > 0], default=None))
+        if status != "again":
+            break
     mark("plan")
-    if os.environ.get("CJS_DIST_FORCE_FALLBACK"):            # (tests: the fall-back path on an input that plans fine)
-        nb = -1
-    # the plans' verdict BEFORE anything is encoded (round 5; until then a slice that could not be planned on its own was found out after
-    # every other rank had encoded its blocks for nothing): one more small all_reduce on the good path
-    flag0 = torch.tensor([1 if nb < 0 else 0], dtype=torch.int64, device=cdev)
-    if world > 1:
-        dist.all_reduce(flag0, op=dist.ReduceOp.MAX, group=group)
-    if int(flag0.item()):
+    if status != "done":
         if fallback is None:
-            raise RuntimeError("this input cannot be planned slice by slice (a block boundary inside a run of four or more equal bytes, or a block "
-                               "longer than the margin); use sharded_compress_sliced / sharded_compress")
+            raise RuntimeError("this input cannot be planned slice by slice (a block longer than the margin, a run that fills a block or reaches "
+                               "beyond 4 KB at a slice edge, a boundary inside a run that straddles a cut); use sharded_compress_sliced / sharded_compress")
         return fallback()
     try:
         if nb > 0:

@@ -67,11 +67,20 @@ int64_t cjs_bz2_plan_block_start(cjs_ctx* ctx, uint32_t k);
  *                       (phase = (-(G(lo) + head-run correction)) mod cap; last != 0: d_in ends where the stream ends, the final
  *                       block may be short or absent, lib/Bzip2.js:916,922).  Returns their number - they are blocks 0 .. n-1
  *                       for cjs_bz2_encode_blocks - or CJS_E_SPEC when the slice cannot be planned on its own (a boundary in a
- *                       long run, a block longer than the margin): the caller falls back to cjs_bz2_plan on more of the stream. */
+ *                       long run, a block longer than the margin): the caller falls back to cjs_bz2_plan on more of the stream.
+ *   cjs_bz2_plan_chain  (round 6) the same plan as a link of a chain: t0 = the value the own prefix reaches at the slice's FIRST
+ *                       block boundary (the slice before it hands it on; phase when nothing in front of the slice moved a
+ *                       boundary).  A boundary inside a run of four or more equal bytes - ordinary text has them - restarts the
+ *                       run in the new block (lib/Bzip2.js:636-667) and moves every later boundary by a few bytes: the slice goes
+ *                       on serially from there instead of refusing, and *t_next = the target of the first boundary at or beyond
+ *                       own_len carries the shift to the slices behind it (the next slice's t0 = *t_next + G(lo) - G(lo') under
+ *                       its own origin, not below 0).  CJS_E_SPEC only for a block longer than the margin or a run that fills a
+ *                       block. */
 #define CJS_E_SPEC (-25)
 int64_t cjs_bz2_plan_scan(cjs_ctx* ctx, const void* d_in, uint64_t in_len, int level);
 int64_t cjs_bz2_plan_cost(cjs_ctx* ctx, uint64_t pos);
 int64_t cjs_bz2_plan_phase(cjs_ctx* ctx, uint64_t own_len, uint64_t phase, int last);
+int64_t cjs_bz2_plan_chain(cjs_ctx* ctx, uint64_t own_len, uint64_t t0, int last, uint64_t* t_next);
 int64_t cjs_bz2_encode_blocks(cjs_ctx* ctx, uint32_t first, uint32_t count, void* d_seg,
                               uint64_t seg_cap, uint32_t* crc_fold, uint32_t* n_done);
 /* Device time (HIP events on the context's stream) and block count of the last compress call. */
@@ -142,6 +151,7 @@ int32_t cjs_dbg_bwt_batch_time(const uint8_t* T, const uint32_t* nlen, uint32_t 
 int cjs_dbg_k1_sparse_rounds(void);   /* rounds of the last K1 run that used the sparse phase */
 int cjs_dbg_k1_rounds(void);
 uint32_t cjs_dbg_rc_div(uint32_t range, uint32_t tot);   /* bwtc_host.hip: the range coder's range / tot by reciprocal (boundary test in tests/test_host_api.py) */
+int cjs_dbg_multi_replans(void);      /* segments of cjs_bz2_compress_multi planned a second time: the chain carried a boundary shift to them (round 6: such calls used to take the replicated plan) */
 int cjs_dbg_multi_fallbacks(void);    /* calls of cjs_bz2_compress_multi that took the REPLICATED plan (a segment that cannot be planned on its own: every device plans the whole input, encodes its share) */
 int cjs_dbg_multi_mallocs(void);      /* hipMalloc calls cjs_bz2_compress_multi has made for its per-device segment buffers (grow-only pools: none after warm-up) */
 int cjs_dbg_k1_periodic_blocks(void); /* k1_period.hip, last K1 run (counted under CJS_K1_TRACE only): blocks with a period <= 64 (closed form) | blocks sorted through a reduced block << 16 */

@@ -772,6 +772,29 @@ def _segmented_check():
             assert n > 0 and out[:n].tobytes() == oracle.bz2_compress(d, lv), (d.size, lv, n)
             took.append(L.cjs_dbg_multi_fallbacks() - fb)
         assert took[0] == 1 and took[1] == 0 and took[2] == 0 and sum(took) >= 2, took     # zeros: replicated; the two text streams: the parallel plan
+        # round 6: a block boundary inside a run of 4..9 equal bytes (ordinary text has them) is CARRIED through the segments' chain - the
+        # segments behind it are planned again from the moved target - instead of sending the call to the replicated plan
+        import torch
+        from compressjs_amd.bzip2 import Context
+        L.cjs_dbg_multi_replans.restype = C.c_int
+        carried = synth.text_like(520_000, 7).copy()
+        saved = _lib._lib
+        _lib._lib = L
+        try:
+            pc = Context(0, 2)
+            nser = pc.plan(torch.from_numpy(carried), 1)
+            bnd = [pc.plan_block_start(k) for k in range(nser)]
+            pc.close()
+        finally:
+            _lib._lib = saved
+        carried[bnd[1] - 3:bnd[1] + 3] = 66                 # boundary 1 (segment 0) inside a run of 6; boundary 3 inside a run of 9
+        carried[bnd[3] - 2:bnd[3] + 7] = 67
+        cap = int(L.cjs_bz2_compress_bound(carried.size))
+        out = np.full(cap, 0xAA, np.uint8)
+        fb, rp = L.cjs_dbg_multi_fallbacks(), L.cjs_dbg_multi_replans()
+        n = L.cjs_bz2_compress_multi(arr, 3, carried.ctypes.data, carried.size, 1, out.ctypes.data, cap)
+        assert n > 0 and out[:n].tobytes() == oracle.bz2_compress(carried, 1)
+        assert L.cjs_dbg_multi_fallbacks() == fb and L.cjs_dbg_multi_replans() > rp, (L.cjs_dbg_multi_fallbacks() - fb, L.cjs_dbg_multi_replans() - rp)
         for x in hs:
             L.cjs_destroy(x)
     finally:

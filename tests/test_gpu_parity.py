@@ -698,15 +698,19 @@ def test_multi_context_fan_out_same_bytes():
     L.cjs_dbg_multi_mallocs.restype = C.c_int
     L.cjs_dbg_multi_fallbacks.restype = C.c_int
     try:
-        # Random ASCII goes through the parallel plan (every context plans its own segment); a block boundary inside a run of four or more
-        # equal bytes - the runs, the zeros, and block 2 of THIS text stream (a run of 4 at byte 1 799 588) - takes the replicated plan:
-        # every context plans the whole input and encodes its share of the blocks.  Either way all three contexts encode.
-        for d, lv, replicated in ((synth.enwik_like(70_000_000, 8), 9, 1), (synth.runs_mixed(40_000_000, 3), 9, None), (synth.lcg_ascii(9_000_000, 2), 1, 0),
-                                  (np.zeros(50_000_000, np.uint8), 9, 1), (synth.enwik_like(40_000_000, 5), 9, None)):
-            fb = L.cjs_dbg_multi_fallbacks()
+        # Random ASCII goes through the parallel plan (every context plans its own segment).  Block 2 of THIS text stream ends inside a run
+        # of 4 (byte 1 799 588): round 5 sent the call to the replicated plan for that; round 6 carries the moved boundary through the
+        # segments' chain (the segments behind it are planned again: cjs_dbg_multi_replans) - no fall-back.  The zeros (a run that fills
+        # blocks) still take the replicated plan: every context plans the whole input and encodes its share.  Either way all three encode.
+        L.cjs_dbg_multi_replans.restype = C.c_int
+        for d, lv, replicated in ((synth.enwik_like(70_000_000, 8), 9, 0), (synth.runs_mixed(40_000_000, 3), 9, None), (synth.lcg_ascii(9_000_000, 2), 1, 0),
+                                  (np.zeros(50_000_000, np.uint8), 9, 1), (synth.enwik_like(40_000_000, 5), 9, 0)):
+            fb, rp = L.cjs_dbg_multi_fallbacks(), L.cjs_dbg_multi_replans()
             assert _sha(compress_multi(cs, d, lv)) == _sha(one.compress(d, lv)), (d.size, lv)
             if replicated is not None:
                 assert L.cjs_dbg_multi_fallbacks() - fb == replicated, (d.size, lv)
+            if d.size == 70_000_000:
+                assert L.cjs_dbg_multi_replans() > rp, "the boundary inside the run at byte 1 799 588 moved nothing?"
         # the per-device segment buffers are grow-only pools kept across calls: a second pass over the same inputs allocates nothing
         before = L.cjs_dbg_multi_mallocs()
         for d, lv in ((synth.enwik_like(70_000_000, 8), 9), (np.zeros(50_000_000, np.uint8), 9), (synth.lcg_ascii(9_000_000, 2), 1)):
