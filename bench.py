@@ -17,7 +17,8 @@ are gathered to rank 0 (compressjs_amd/dist.py).  Prints ONE JSON line (rank 0).
 What the line carries besides the driver's contract:
   config.bit_exact_vs_reference_digest   sha256 of the WHOLE stream == what the reference itself (node 12) produced
                                          on the same bytes (tests/golden/golden_big.json), all 112 blocks
-  config.pcie_inclusive_mb_s             the same step through cjs_bz2_compress (host buffer in, host buffer out)
+  config.pcie_inclusive_mb_s             the same step through cjs_bz2_compress (host buffer in, host buffer out), mean of the same number of steps
+  config.sample5_mb_s / sample5_ms       BASELINE.json configs[1]: test/sample5.ref (2 MB, three blocks) -9, one host-to-host call
   roofline                               the kernel with the largest total time ON THIS WORKLOAD, found and timed with HIP
                                          events around every launch of K1's main kernels on the library's stream in a
                                          single-stream pass after the timed region (kernel_ms_per_step lists them all);
@@ -329,16 +330,18 @@ def main():
                 nbytes = (32 + pref) // 8
                 verified = verified and comp[:nbytes] == ref[:nbytes]
             if world == 1:
-                # host buffer in -> .bz2 in host memory through the C ABI (SURVEY.md 8d's end-to-end definition)
+                # host buffer in -> .bz2 in host memory through the C ABI (SURVEY.md 8d's end-to-end definition): the MEAN of the same
+                # number of steps as the headline (round 6; until then the minimum of three calls - not the estimator `value` is)
                 hbuf = np.zeros(bound, dtype=np.uint8)             # caller-owned output buffer, pages touched
-                tt, nn = [], 0
-                for _ in range(4):
-                    a = time.perf_counter()
+                nn = 0
+                for _ in range(max(1, args.warmup // 2)):
                     nn = int(ctx.L.cjs_bz2_compress(ctx.h, host.ctypes.data, host.size, args.level, hbuf.ctypes.data, hbuf.size))
-                    tt.append(time.perf_counter() - a)
+                a = time.perf_counter()
+                for _ in range(args.steps):
+                    nn = int(ctx.L.cjs_bz2_compress(ctx.h, host.ctypes.data, host.size, args.level, hbuf.ctypes.data, hbuf.size))
+                pcie_dt = (time.perf_counter() - a) / args.steps
                 assert nn == len(comp) and hashlib.sha256(hbuf[:nn].tobytes()).hexdigest() == sha
-                tt = tt[1:]
-                pcie = round(total / min(tt) / 1e6, 1)
+                pcie = round(total / pcie_dt / 1e6, 1)
         # ---- roofline leg: K1's main kernels alone on the GPU (one stream), HIP events around every launch; the one with the
         #      largest total on this workload is the line's dominant kernel -----------------------------------------------
         prof_steps, kms, dom = 3, {}, None
@@ -384,19 +387,36 @@ def main():
         if world == 1 and args.workload != "e8sa" and workloads.have_fixtures() and not args.no_verify:
             h2 = workloads.stream("e8sa", args.size)
             d2 = torch.from_numpy(h2).to(dev)
-            for _ in range(3):
+            for _ in range(args.warmup):                       # (the headline's own warm-up and step counts)
                 n2 = ctx.compress_device(d2, d_out, args.level)
             torch.cuda.synchronize()
             a = time.perf_counter()
-            for _ in range(10):
+            for _ in range(args.steps):
                 n2 = ctx.compress_device(d2, d_out, args.level)
             torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - a) / 10
+            dt2 = (time.perf_counter() - a) / args.steps
             o2 = d_out[:n2].cpu().numpy().tobytes()
             g2 = gold.get("e8sa:%d:bz2:%d" % (args.size, args.level))
             e8 = {"mb_s": round(args.size / dt2 / 1e6, 2), "ms": round(dt2 * 1e3, 3),
                   "exact": None if g2 is None else bool(hashlib.sha256(o2).hexdigest() == g2["out_sha256"] and len(o2) == g2["out_len"])}
             del d2, h2
+        # ---- BASELINE.json configs[1]: test/sample5.ref (2 130 640 bytes, three blocks), bzip2 -9, ONE call through cjs_bz2_compress
+        #      (host buffer in, host buffer out): the small-input rate, bound by the latency of the kernel chain, not by throughput
+        s5 = {"mb_s": None, "ms": None, "exact": None}
+        s5path = os.path.join(ROOT, "oracle", "_ref", "fixtures", "sample5.ref")
+        if world == 1 and os.path.exists(s5path) and not args.no_verify:
+            h5 = np.fromfile(s5path, dtype=np.uint8)
+            b5 = np.zeros(int(ctx.L.cjs_bz2_compress_bound(h5.size)), dtype=np.uint8)
+            n5 = 0
+            for _ in range(3):
+                n5 = int(ctx.L.cjs_bz2_compress(ctx.h, h5.ctypes.data, h5.size, args.level, b5.ctypes.data, b5.size))
+            a = time.perf_counter()
+            for _ in range(args.steps):
+                n5 = int(ctx.L.cjs_bz2_compress(ctx.h, h5.ctypes.data, h5.size, args.level, b5.ctypes.data, b5.size))
+            dt5 = (time.perf_counter() - a) / args.steps
+            # the reference's own output for sample5.ref at -9 is 274 768 bytes, sha256 236be53b...
+            s5 = {"mb_s": round(h5.size / dt5 / 1e6, 2), "ms": round(dt5 * 1e3, 3),
+                  "exact": bool(args.level == 9 and n5 == 274768 and hashlib.sha256(b5[:n5].tobytes()).hexdigest().startswith("236be53b"))}
         wall = elapsed / args.steps
         ref_line = None
         if world == 1 and not args.no_verify:
@@ -442,6 +462,7 @@ def main():
                        "bit_exact_vs_oracle_prefix_and_roundtrip": verified,
                        "libbz2_prefix_roundtrip": prefix_ok,
                        "pcie_inclusive_mb_s": pcie,
+                       "sample5_mb_s": s5["mb_s"], "sample5_ms": s5["ms"], "sample5_bit_exact_vs_reference_digest": s5["exact"],
                        "gpu_decode_mb_s": decode_mb_s,
                        "sha256": sha},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 2),

@@ -616,7 +616,12 @@ static int issue_blocks(cjs_ctx* c, const K0Buf& K, u32 cap, u32 first, u32 coun
         worker(0);
         for (u32 i = 1; i < ns; i++) c->helper[i]->wait();
     }
-    if (err.load()) return err.load();
+    if (err.load()) {
+        // (the block CRCs run on c->side and only k5_run joins them back: on an error between the two, k0_crc may still be reading the input and
+        // XOR-ing into the workspace when the call returns - ADVICE r5)
+        if (c->side) (void)hipStreamSynchronize(c->side);
+        return err.load();
+    }
     for (u32 i = 0; i < ns; i++) {
         HIP_CHECK_RET(hipEventRecord(c->evDone[i], c->sub[i]));
         HIP_CHECK_RET(hipStreamWaitEvent(c->stream, c->evDone[i], 0));
@@ -842,6 +847,7 @@ done:
 #ifndef CJS_CPU_DEBUG_BUILD
 static int64_t compress_overlapped(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out, uint64_t out_cap, u32 slice_blocks);
 #endif
+#define CJS_OV_NOT_STARTED (-1000)   // compress_overlapped: the input does not cut into slices - nothing was uploaded (internal: never returned by the ABI)
 extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_len, int level, uint8_t* out,
                                     uint64_t out_cap) {
     if (!c || (!in && in_len) || !out) return CJS_E_ARG;
@@ -870,8 +876,8 @@ extern "C" int64_t cjs_bz2_compress(cjs_ctx* c, const uint8_t* in, uint64_t in_l
         const u32 cap = (u32)level * 100000u - 19u;
         if (slice_blocks && !seg_env && in_len >= (uint64_t)slice_blocks * cap * 3 / 2) {
             const int64_t r = compress_overlapped(c, in, in_len, level, out, out_cap, slice_blocks);
-            if (r != CJS_E_SPEC) return r;
-            resident = true;                                // a slice refused its plan (rare): the input is in HBM by now, one piece from here
+            if (r != CJS_E_SPEC && r != CJS_OV_NOT_STARTED) return r;
+            resident = r == CJS_E_SPEC;                     // a slice refused its plan (rare): the uploader has run to its end, the input is in HBM - one piece from here
         }
     }
 #endif
@@ -1022,7 +1028,7 @@ static int64_t compress_overlapped(cjs_ctx* c, const uint8_t* in, uint64_t in_le
         }
     }
     const u32 ns = (u32)S.size();
-    if (ns < 2 || ns > CJS_SNAP_SLOTS) return CJS_E_SPEC;
+    if (ns < 2 || ns > CJS_SNAP_SLOTS) return CJS_OV_NOT_STARTED;      // (nothing uploaded: the caller must not take the input for resident - ADVICE r5)
     hipError_t e;
 #define TRYR(x) if ((e = (x)) != hipSuccess) return CJS_E_HIP - (int)e
     if (!c->sIn) TRYR(hipStreamCreateWithFlags(&c->sIn, hipStreamNonBlocking));
@@ -1129,9 +1135,12 @@ static int64_t compress_overlapped(cjs_ctx* c, const uint8_t* in, uint64_t in_le
                     r2 = k5_run(P, cap, c->sub[si], k ? S[k - 1].evScan : nullptr, sl.evScan, c->side ? c->evCrc[si] : nullptr);
                 } else {
                     // (a slice in which no block starts: the cursor stays where it is)
+                    // (the cursor is carried IN STREAM ORDER behind the previous slice's k5_blockscan: read on the host at issue time, slot k - 1
+                    // may not have been written yet, and the downloader would take stale bytes for final - ADVICE r5)
                     if (k && hipStreamWaitEvent(c->sub[si], S[k - 1].evScan, 0) != hipSuccess) r2 = CJS_E_HIP;
+                    if (!k) c->snapPin[0] = 32u;
+                    else if (!r2 && hipMemcpyAsync(c->snapPin + k, c->snapPin + k - 1, 8, hipMemcpyHostToHost, c->sub[si]) != hipSuccess) r2 = CJS_E_HIP;
                     if (!r2 && hipEventRecord(sl.evScan, c->sub[si]) != hipSuccess) r2 = CJS_E_HIP;
-                    c->snapPin[k] = k ? c->snapPin[k - 1] : 32u;
                 }
             }
             if (!r2 && hipEventRecord(sl.evDone, c->sub[si]) != hipSuccess) r2 = CJS_E_HIP;

@@ -23,6 +23,15 @@
 #define K1_STAT_RTRACE 128      // stats[128..135]: K1F_TRACE builds, stage clocks of k1r_round
 #define K1_MED_MAX 4096     // doubling rounds: largest group a workgroup sorts in LDS
 #define K1_STATS 144
+// Round 6: with 16-byte keys in the bucket sort every group the front end leaves is at least 16 bytes deep - also on the path
+// without text stages (HTML-like input), where a bucket of ONE 8-byte key beyond LDS used to stay a single 8-deep group and kept
+// the doubling rounds at h = 8: such a bucket is now partitioned by its next 8 bytes (one task level) and sorted 16 bytes deeper in
+// LDS, and the rounds start at h = 16 (the round with h = 8 was the most expensive one: 1.9 of 10.8 ms per E8S-A step).  Whoever
+// leaves a shallower group after all (the last task level on adversarial input) says so here, and the host starts the rounds at 8.
+#ifndef K1_DEEP_START
+#define K1_DEEP_START 1
+#endif
+#define K1D_SHALLOW(B) ((B).dbn[(K1D_MAXR + 1u) * 4u])      // (a word of dbn's last row, which no round uses: read back together with dtot)
 // list entries of the refinement rounds (k1r_round) and the doubling rounds (k1_dbl.hip): one per rotation that still ties,
 // a group = consecutive entries:  (group length - 1) << 52 | index in the group << 44 | rotation index << 22 | suffix-array position
 #define K1E_POS(e) ((u32)(e) & 0x3FFFFFu)

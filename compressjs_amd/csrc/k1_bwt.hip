@@ -573,6 +573,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     // (The same look tells whether any block was reduced by k1_period.hip: if none, the expansion's launches are left out too - empty
     // kernels are only cheap on an idle GPU: next to the other stream's k2_mtf one of them sat 190 us in the queue.)
     bool any_group = true, any_red = true;
+    u32 h0 = d0;                                           // depth the doubling rounds start from
     if (K.sync && !B.linear) {
         // (ONE copy - dtot, dbn and dred lie behind one another -, into pinned memory when the caller has some: a second pageable copy was
         // issued 65 us after the first on the kernel timeline)
@@ -585,9 +586,11 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         any_group = any_red = false;
         const u32* dr = tt + (B.dred - B.dtot);
         for (u32 bb = 0; bb < B.rstride; bb++) { any_group = any_group || tt[bb] != 0u; any_red = any_red || dr[bb] != 0u; }   // (any order: K1_BI)
+        // round 6: 16-byte keys in every bucket sort and nobody left a shallower group (k1_bwt.h: K1_DEEP_START): the rounds start at h = 16
+        if (K1_DEEP_START && fused && K.bsort_iters && tt[&K1D_SHALLOW(B) - B.dtot] == 0u) h0 = K1F_KEYB;
     }
     if (any_group) {
-        const int rc = k1_dbl_run(B, g, max_n, stream, d0, K.sync ? K.check_h : 0u);
+        const int rc = k1_dbl_run(B, g, max_n, stream, h0, K.sync ? K.check_h : 0u);
         if (rc) return rc;
     }
     if (K.trace) {
@@ -599,7 +602,7 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         HIP_CHECK_RET(hipStreamSynchronize(stream));
         u64 un = 0;
         for (u32 bb = 0; bb < B.rstride; bb++) un += tt[bb];
-        fprintf(stderr, "[k1] rotations in unsorted groups before the doubling rounds: %llu (of %llu); per round entries / medium (<= 1024 + larger) / large / chunks:", (unsigned long long)un, (unsigned long long)total_n);
+        fprintf(stderr, "[k1] rotations in unsorted groups before the doubling rounds: %llu (of %llu), rounds from h = %u; per round entries / medium (<= 1024 + larger) / large / chunks:", (unsigned long long)un, (unsigned long long)total_n, h0);
         for (u32 r = 0; r < K1D_MAXR + 1u; r++) {
             u64 e = 0;
             for (u32 bb = 0; bb < B.rstride; bb++) e += cn[(size_t)r * B.rstride + bb];

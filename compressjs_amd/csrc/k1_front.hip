@@ -928,8 +928,9 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     // doubling rounds start from h = 8 either way, but on groups that are already 16 bytes deep where a bucket fit the LDS (E8S-A: k1f_bsort
     // 1.17 -> 1.41 ms, the doubling stage 7.6 -> 6.4 ms)
     const bool wide = lists != 0u && iters != 0u;
-    if (cnt > K1F_CAP && (deepen || !pure)) {
-        // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB
+    if (cnt > K1F_CAP && (deepen || !pure || (K1_DEEP_START && wide))) {
+        // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB.  (Round 6: a one-key bucket beyond LDS also
+        // without text stages behind it - partitioned by its next 8 bytes and sorted in LDS it enters the doubling rounds 16 or 24 bytes deep)
         if (tid == 0) {
             k1f_push_task(B, 0u, b, start, cnt, (pure ? 8u : 0u) | K1F_TASK_SB);
             if (!pure) atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
         }
         return;
     }
-    if (pure && !deepen && (!wide || cnt > K1F_CAP)) {
+    if (pure && !deepen && (!wide || (!K1_DEEP_START && cnt > K1F_CAP))) {
         // one 8-byte key, no text stage behind this one, and no 16-byte sort either (linear mode, or beyond LDS): a single group as it stands
         u32* SA = B.SA + (size_t)b * g.stride + start;
         for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i] & K1_SMASK;           // (a group: the doubling rounds finish this block, k1_finish gathers its bytes)
@@ -997,7 +998,8 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             __syncthreads();
         }
         const bool widem = lists != 0u && iters != 0u && !last;       // 16-byte keys also without lists behind them (see k1f_bsort)
-        if (!deepen && depth && (!widem || len > K1F_CAP)) {
+        const bool wide_any = K1_DEEP_START && lists != 0u && iters != 0u;   // the doubling rounds want to start at h = 16: no group shallower than that
+        if (!deepen && depth && (!widem || (len > K1F_CAP && (!wide_any || depth >= K1F_KEYB)))) {
             // no text stages behind this one (linear mode: BWT.bwtransform / suffixsort sort suffixes by the first 8 bytes only; cyclic
             // mode with the predictor on: HTML-like input, the doubling rounds take over from 8 bytes): a sub-bucket of ONE key is one
             // group, as the one-key buckets of k1f_bsort are.  (Until round 4 the cyclic case went on partitioning such slices 8 bytes
@@ -1005,6 +1007,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             // doubling rounds do not need.)
             for (u32 i = tid; i < len; i += K1F_BT) SAs[i] = src[i] & K1_SMASK;     // (stays a group: the doubling rounds finish this block)
             if (tid == 0) atomicOr(&HN[pos >> 5], 1u << (pos & 31u));
+            if (tid == 0 && wide_any && depth < K1F_KEYB && len > 1u) K1D_SHALLOW(B) = 1u;
             continue;
         }
         if (len <= K1F_CAP) {
@@ -1019,6 +1022,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             }
             const bool go = deepen && !last;
             const bool wide = widem;
+            if (tid == 0 && wide_any && !wide && depth + 8u < K1F_KEYB) K1D_SHALLOW(B) = 1u;     // (the last level sorts by 8 bytes)
             k1f_sort128(S, T, n, src, len, dm, wide);
             k1f_flush(S, B, g, b, pos, len, go, level + 1u, depth + (wide ? K1F_KEYB : 8u), carry != 0u);
             continue;
@@ -1028,19 +1032,27 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             u64* smp = key;                                 // [K1F_PS]
             u64* spl = key + K1F_PS;                        // [K1F_PB] sub-bucket j holds the keys in [spl[j-1], spl[j])
             u32* rk = key1;                                 // [K1F_PS] ranks; then [K1F_PB] histogram, [K1F_PB] cursors
-            u32 nbk = (len + 319u) / 320u;
+#ifndef K1F_SUBT
+#define K1F_SUBT 320u                                       // rotations per sub-bucket a partition aims at
+#endif
+            u32 nbk = (len + K1F_SUBT - 1u) / K1F_SUBT;
             if (nbk > K1F_PB - 1u) nbk = K1F_PB - 1u;
-            for (u32 i = tid; i < K1F_PS; i += K1F_BT) {
-                const u32 at = (u32)(((u64)i * len + (k1f_hash(i, pos) % len)) / K1F_PS) % len;      // stratified, hashed
+            // samples: ~26 per sub-bucket, at most K1F_PS (round 6: always K1F_PS = 512 until then - ranking 512 samples against 512 was most of
+            // what a slice of 2 000 rotations cost, and E8S-A's one-key buckets beyond LDS are 9 900 such slices per 10^8 bytes)
+            u32 ns = (len / 12u + 3u) & ~3u;
+            if (ns < 64u) ns = 64u;
+            if (ns > K1F_PS) ns = K1F_PS;
+            for (u32 i = tid; i < ns; i += K1F_BT) {
+                const u32 at = (u32)(((u64)i * len + (k1f_hash(i, pos) % len)) / ns) % len;      // stratified, hashed
                 u32 p = (src[at] & K1_SMASK) + dm;
                 if (p >= n) p -= n;
                 smp[i] = k1f_load_be64(T, p);
             }
             __syncthreads();
-            for (u32 i = tid; i < K1F_PS; i += K1F_BT) {
+            for (u32 i = tid; i < ns; i += K1F_BT) {
                 const u64 mine = smp[i];
                 u32 r = 0;
-                for (u32 j = 0; j < K1F_PS; j += 4u) {
+                for (u32 j = 0; j < ns; j += 4u) {
                     u64 c[4];
 #pragma unroll
                     for (u32 u = 0; u < 4u; u++) c[u] = smp[j + u];
@@ -1051,16 +1063,16 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             }
             __syncthreads();
             u64 mine2[(K1F_PS + K1F_BT - 1) / K1F_BT];
-            for (u32 i = tid, k = 0; i < K1F_PS; i += K1F_BT, k++) mine2[k] = smp[i];
+            for (u32 i = tid, k = 0; i < ns; i += K1F_BT, k++) mine2[k] = smp[i];
             __syncthreads();
-            for (u32 i = tid, k = 0; i < K1F_PS; i += K1F_BT, k++) smp[rk[i]] = mine2[k];
+            for (u32 i = tid, k = 0; i < ns; i += K1F_BT, k++) smp[rk[i]] = mine2[k];
             __syncthreads();
             for (u32 j = tid; j < K1F_PB; j += K1F_BT) {
                 u64 v = ~0ull;
                 if (j + 1u < nbk) {
-                    const u64 q = smp[(u32)(((u64)(j + 1u) * K1F_PS) / nbk)];
+                    const u64 q = smp[(u32)(((u64)(j + 1u) * ns) / nbk)];
                     v = q;
-                    if (j >= 1u && smp[(u32)(((u64)j * K1F_PS) / nbk)] == q && q != ~0ull) v = q + 1u;     // heavy key: [q, q+1) is a sub-bucket of its own
+                    if (j >= 1u && smp[(u32)(((u64)j * ns) / nbk)] == q && q != ~0ull) v = q + 1u;     // heavy key: [q, q+1) is a sub-bucket of its own
                 }
                 spl[j] = v;
             }
@@ -1070,16 +1082,35 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             for (u32 j = tid; j < K1F_PB; j += K1F_BT) hist[j] = 0;
             __syncthreads();
             u8* ids = (u8*)(B.KA + (size_t)b * g.stride + pos);       // one byte per rotation of the slice (KA is free after k1f_scatter)
-            for (u32 i = tid; i < len; i += K1F_BT) {
-                u32 p = (src[i] & K1_SMASK) + dm;
-                if (p >= n) p -= n;
-                const u64 kk = k1f_load_be64(T, p);
-                u32 id = 0;
+            // K1F_PU rotations per thread and step, all their loads in flight together (round 6): a slice of 50 000 rotations is ONE workgroup's
+            // work, two dependent global round trips per rotation - as a plain loop 200 of them one after the other, and the launch of a level
+            // lasts as long as its longest task (E8S-A, level 0: 1.30 ms for 22.8 M rotations while most of the GPU idles)
+#ifndef K1F_PU
+#define K1F_PU 8u
+#endif
+            for (u32 i0 = tid; i0 < len; i0 += K1F_BT * K1F_PU) {
+                u32 pp[K1F_PU];
+                u64 kq[K1F_PU];
 #pragma unroll
-                for (u32 step = K1F_PB / 2u; step >= 1u; step >>= 1)
-                    if (id + step - 1u < K1F_PB - 1u && spl[id + step - 1u] <= kk) id += step;      // spl[K1F_PB - 1] is never read
-                ids[i] = (u8)id;
-                atomicAdd(&hist[id], 1u);
+                for (u32 u = 0; u < K1F_PU; u++) {
+                    const u32 i = i0 + u * K1F_BT;
+                    u32 p = (src[i < len ? i : tid] & K1_SMASK) + dm;
+                    if (p >= n) p -= n;
+                    pp[u] = p;
+                }
+#pragma unroll
+                for (u32 u = 0; u < K1F_PU; u++) kq[u] = k1f_load_be64(T, pp[u]);
+#pragma unroll
+                for (u32 u = 0; u < K1F_PU; u++) {
+                    const u32 i = i0 + u * K1F_BT;
+                    if (i >= len) break;
+                    u32 id = 0;
+#pragma unroll
+                    for (u32 step = K1F_PB / 2u; step >= 1u; step >>= 1)
+                        if (id + step - 1u < K1F_PB - 1u && spl[id + step - 1u] <= kq[u]) id += step;      // spl[K1F_PB - 1] is never read
+                    ids[i] = (u8)id;
+                    atomicAdd(&hist[id], 1u);
+                }
             }
             __syncthreads();
             {
@@ -1090,10 +1121,20 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             __syncthreads();
             u32* dst = inSB ? SAs : SBs;
             __threadfence_block();
-            for (u32 i = tid; i < len; i += K1F_BT) {
-                const u32 id = ids[i];
-                const u32 at = atomicAdd(&cur[id], 1u);
-                dst[at] = src[i];
+            for (u32 i0 = tid; i0 < len; i0 += K1F_BT * K1F_PU) {
+                u32 idv[K1F_PU], sv2[K1F_PU];
+#pragma unroll
+                for (u32 u = 0; u < K1F_PU; u++) {
+                    const u32 i = i0 + u * K1F_BT, ic = i < len ? i : tid;
+                    idv[u] = ids[ic];
+                    sv2[u] = src[ic];
+                }
+#pragma unroll
+                for (u32 u = 0; u < K1F_PU; u++) {
+                    if (i0 + u * K1F_BT >= len) break;
+                    const u32 at = atomicAdd(&cur[idv[u]], 1u);
+                    dst[at] = sv2[u];
+                }
             }
             __threadfence_block();
             __syncthreads();
@@ -1108,6 +1149,7 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
             continue;
         }
         // ---- last level, beyond LDS: stable LSD passes on the 8 bytes at `depth`, heads by comparing them
+        if (tid == 0 && wide_any && depth + 8u < K1F_KEYB) K1D_SHALLOW(B) = 1u;
         {
             u32* dstart = (u32*)key;                        // [256]
             u32* sh = dstart + 256;                         // [256]

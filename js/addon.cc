@@ -14,6 +14,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <mutex>
 #include <sys/mman.h>
 
 typedef struct cjs_ctx cjs_ctx;
@@ -177,24 +178,33 @@ static napi_value DeviceCount(napi_env env, napi_callback_info) {
     return r;
 }
 
-// result blocks of Compress: a pool of at most four (what is beyond that is freed when its Buffer is collected)
-struct StageBlock { uint8_t* data; uint64_t cap; int64_t accounted; };   // accounted: bytes V8 was told an external Buffer over this block holds
+// result blocks of Compress: a pool of at most four (what is beyond that is freed when its Buffer is collected).  The pool is shared by
+// every environment of the process (worker_threads load the same addon): guarded by a mutex.
+struct StageBlock { uint8_t* data; uint64_t cap; uint64_t size; int64_t accounted; };   // size: bytes allocated; accounted: bytes V8 was told an external Buffer over this block holds
 static std::vector<StageBlock*> g_stage_pool;
+static std::mutex g_stage_mu;
 static StageBlock* stage_take(uint64_t cap) {
-    for (size_t i = 0; i < g_stage_pool.size(); i++)
-        if (g_stage_pool[i]->cap >= cap) { StageBlock* b = g_stage_pool[i]; g_stage_pool.erase(g_stage_pool.begin() + (long)i); return b; }
+    {
+        std::lock_guard<std::mutex> g(g_stage_mu);
+        for (size_t i = 0; i < g_stage_pool.size(); i++)
+            if (g_stage_pool[i]->cap >= cap) { StageBlock* b = g_stage_pool[i]; g_stage_pool.erase(g_stage_pool.begin() + (long)i); return b; }
+    }
     // 2 MB-aligned and advised for transparent huge pages: a fresh block's pages are faulted in by the copy that brings the result home
     // (7 200 small pages for the 29 MB of a 10^8-byte text; results that JavaScript still holds cannot be reused)
     const uint64_t sz = ((cap ? cap : 1) + ((2u << 20) - 1)) & ~(uint64_t)((2u << 20) - 1);
     void* mem = nullptr;
     if (posix_memalign(&mem, 2u << 20, sz) != 0) return nullptr;
     (void)madvise(mem, sz, MADV_HUGEPAGE);
-    StageBlock* b = new StageBlock{(uint8_t*)mem, cap, 0};
+    StageBlock* b = new StageBlock{(uint8_t*)mem, cap, sz, 0};
     return b;
 }
 static void stage_give(StageBlock* b) {
-    if (g_stage_pool.size() < 4) g_stage_pool.push_back(b);
-    else { free(b->data); delete b; }
+    {
+        std::lock_guard<std::mutex> g(g_stage_mu);
+        if (g_stage_pool.size() < 4) { g_stage_pool.push_back(b); return; }
+    }
+    free(b->data);
+    delete b;
 }
 static void stage_finalize(napi_env env, void*, void* hint) {
     StageBlock* b = (StageBlock*)hint;
@@ -202,6 +212,11 @@ static void stage_finalize(napi_env env, void*, void* hint) {
     if (b->accounted) { napi_adjust_external_memory(env, -b->accounted, &now); b->accounted = 0; }
     stage_give(b);
 }
+// A result goes to JavaScript as an EXTERNAL Buffer over its block only when that pays and costs little: at least 1 MB (below that a copy
+// is microseconds) and at least an eighth of the block (the block is sized for the worst case, 1.5 x the input + 24 KB per 100 KB: a few KB
+// of result must not pin 2 MB, nor 20 MB of result 175 MB).  Everything else is copied into an exact-size Buffer and the block goes
+// straight back to the pool.
+static bool stage_external(const StageBlock* b, uint64_t n) { return n >= (1u << 20) && n * 8u >= b->size; }
 
 static napi_value Compress(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
@@ -223,15 +238,16 @@ static napi_value Compress(napi_env env, napi_callback_info info) {
                                         : p_compress(g_ctx, in, len, level, blk->data, cap);
     if (n < 0) { stage_give(blk); return throw_code(env, n, "cjs_bz2_compress"); }
     napi_value out;
-    if (napi_create_external_buffer(env, (size_t)n, blk->data, stage_finalize, blk, &out) != napi_ok) {
-        void* dst;                                           // (an embedder without external buffers: copy as before)
+    if (!stage_external(blk, (uint64_t)n) || napi_create_external_buffer(env, (size_t)n, blk->data, stage_finalize, blk, &out) != napi_ok) {
+        void* dst;                                           // (small results, and embedders without external buffers: a copy)
         napi_create_buffer_copy(env, (size_t)n, blk->data, &dst, &out);
         stage_give(blk);
     } else {
-        // V8 sees a Buffer object of a few dozen bytes: tell it what hangs on it, or results pile up uncollected (every call a fresh block
-        // whose pages the D2H copy has to fault in) until the heap of small objects happens to fill
+        // V8 sees a Buffer object of a few dozen bytes: tell it what hangs on it - the whole block, not the n bytes of the result -, or
+        // results pile up uncollected (every call a fresh block whose pages the D2H copy has to fault in) until the heap of small objects
+        // happens to fill
         int64_t now;
-        blk->accounted = (int64_t)n;
+        blk->accounted = (int64_t)blk->size;
         napi_adjust_external_memory(env, blk->accounted, &now);
     }
     return out;
@@ -358,12 +374,13 @@ static napi_value fetch_result(napi_env env, int64_t n) {
         // a large result: fetched into a pooled, huge-page-advised block handed over as an external Buffer (as Compress does) - a fresh
         // Node Buffer of 10^8 bytes is 24 400 small pages faulted in by the copy
         StageBlock* blk = stage_take((uint64_t)n);
+        if (blk && !stage_external(blk, (uint64_t)n)) { stage_give(blk); blk = nullptr; }     // (a pooled block many times the result: not pinned for it)
         if (blk) {
             const int64_t m = p_fetch(g_ctx, blk->data, (uint64_t)n);
             if (m < 0) { stage_give(blk); return throw_code(env, m, "cjs_bz2_fetch"); }
             if (napi_create_external_buffer(env, (size_t)n, blk->data, stage_finalize, blk, &out) == napi_ok) {
                 int64_t now;
-                blk->accounted = n;
+                blk->accounted = (int64_t)blk->size;
                 napi_adjust_external_memory(env, blk->accounted, &now);
                 return out;
             }
