@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void k0_tile_last(K0Buf K) {
             u64 last = K0_NONE;
             for (u32 ww = 0; ww < 4u; ww++) if (wl[tid][ww] != K0_NONE) last = wl[tid][ww];
             K.tileA[t] = last;
+            K.tileB[t] = last;                              // (the unscanned copy k0_run_end reads: a device-to-device copy of its own until round 6)
         }
     }
 }
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void k0_scan_local(u64* data, u64* chunkTot, u
 }
 
 template <bool MAX>
-__global__ __launch_bounds__(1024) void k0_scan_chunks(u64* chunkTot, u64 nchunks, u64* total) {
+__global__ __launch_bounds__(1024) void k0_scan_chunks(u64* chunkTot, u64 nchunks, u64* total, u64* reset) {
     __shared__ u64 sh[1024];
     __shared__ u64 carry;
     const u32 tid = threadIdx.x;
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(1024) void k0_scan_chunks(u64* chunkTot, u64 nchunk
         __syncthreads();
     }
     if (tid == 0 && total) *total = carry;
+    if (tid == 0 && reset) *reset = ~0ull;                  // (k0_scans: "no boundary flagged yet" for the chain kernels - a fill launch of its own until round 6)
 }
 
 template <bool MAX>
@@ -395,22 +397,6 @@ __global__ __launch_bounds__(256) void k0_chain_spec(K0Buf K, u32 cap) {
     }
 }
 
-// blocks 0 .. kb0-1 straight from the speculation; kb0 = first flagged boundary (or nfull)
-__global__ __launch_bounds__(256) void k0_chain_accept(K0Buf K, u32 cap) {
-    const u64 total = K.tileC[K.ntiles];
-    const u64 nfull = total / cap;
-    u64 kb0 = *K.specBad < nfull ? *K.specBad : nfull;    // block k ends at boundary k+1 <= kb0
-    if (kb0 > K.maxBlocks) kb0 = K.maxBlocks;
-    for (u64 k = (u64)blockIdx.x * 256u + threadIdx.x; k < kb0; k += (u64)gridDim.x * 256u) {
-        const u64 s = k ? K.specEnd[k] : 0;
-        K.blkStart[k] = s;
-        K.blkEnd[k] = K.specEnd[k + 1];
-        K.blkN[k] = cap;
-        K.blkAdj[k] = k * (u64)cap;                       // = C(s)
-        K.blkRe[k] = s;
-    }
-}
-
 __global__ __launch_bounds__(256) void k0_chain(K0Buf K, u32 cap) {
     __shared__ u64 sh[256];
     __shared__ u32 sh32[4];
@@ -419,6 +405,15 @@ __global__ __launch_bounds__(256) void k0_chain(K0Buf K, u32 cap) {
     const u64 nfull = total / cap;
     u64 kb0 = *K.specBad < nfull ? *K.specBad : nfull;
     if (kb0 > K.maxBlocks) kb0 = K.maxBlocks;
+    // blocks 0 .. kb0-1 straight from the speculation (k0_chain_accept, a launch of its own until round 6)
+    for (u64 k = threadIdx.x; k < kb0; k += 256u) {
+        const u64 s0 = k ? K.specEnd[k] : 0;
+        K.blkStart[k] = s0;
+        K.blkEnd[k] = K.specEnd[k + 1];
+        K.blkN[k] = cap;
+        K.blkAdj[k] = k * (u64)cap;                       // = C(s0)
+        K.blkRe[k] = s0;
+    }
     u64 s = kb0 ? K.specEnd[kb0] : 0, cnext = kb0 ? K.specC[kb0] : 0;
     bool have_cnext = true;                               // C(s) is known (C(0) = 0)
     u32 kb = (u32)kb0;
@@ -639,15 +634,13 @@ void k0_carve(K0Buf& K, const u8* d_in, u64 in_len, u32 cap, void* ws) {
 int k0_scans(K0Buf K, hipStream_t stream) {
     const u32 nt = (u32)K.ntiles, nc = (u32)K.nchunks;
     hipLaunchKernelGGL(k0_tile_last, dim3((nt + K0_TPW - 1u) / K0_TPW), dim3(256), 0, stream, K);
-    HIP_CHECK_RET(hipMemcpyAsync(K.tileB, K.tileA, K.ntiles * 8, hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(k0_scan_local<true>, dim3(nc), dim3(256), 0, stream, K.tileA, K.chunk, K.ntiles);
-    hipLaunchKernelGGL(k0_scan_chunks<true>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, (u64*)nullptr);
+    hipLaunchKernelGGL(k0_scan_chunks<true>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, (u64*)nullptr, (u64*)nullptr);
     hipLaunchKernelGGL(k0_scan_apply<true>, dim3(nc), dim3(256), 0, stream, K.tileA, (const u64*)K.chunk, K.ntiles);
     hipLaunchKernelGGL(k0_tile_cost, dim3(nt), dim3(256), 0, stream, K);
     hipLaunchKernelGGL(k0_scan_local<false>, dim3(nc), dim3(256), 0, stream, K.tileC, K.chunk, K.ntiles);
-    hipLaunchKernelGGL(k0_scan_chunks<false>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, K.tileC + K.ntiles);
+    hipLaunchKernelGGL(k0_scan_chunks<false>, dim3(1), dim3(1024), 0, stream, K.chunk, K.nchunks, K.tileC + K.ntiles, K.specBad);
     hipLaunchKernelGGL(k0_scan_apply<false>, dim3(nc), dim3(256), 0, stream, K.tileC, (const u64*)K.chunk, K.ntiles);
-    HIP_CHECK_RET(hipMemsetAsync(K.specBad, 0xFF, 8, stream));
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;
 }
@@ -662,7 +655,6 @@ int k0_prepass(K0Buf K, u32 cap, hipStream_t stream) {
     if (rc) return rc;
     const u32 nspec = (u32)(K.in_len * 5 / 4 / cap + 2 < K.maxBlocks ? K.in_len * 5 / 4 / cap + 2 : K.maxBlocks);
     hipLaunchKernelGGL(k0_chain_spec, dim3(nspec), dim3(256), 0, stream, K, cap);
-    hipLaunchKernelGGL(k0_chain_accept, dim3((nspec + 255) / 256), dim3(256), 0, stream, K, cap);
     hipLaunchKernelGGL(k0_chain, dim3(1), dim3(256), 0, stream, K, cap);
     HIP_CHECK_RET(hipGetLastError());
     return CJS_OK;

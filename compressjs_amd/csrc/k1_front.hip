@@ -1526,7 +1526,10 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
     // level costs its launch (~2 us: the workgroups read one counter and leave)
     for (u32 lv = 0; lv < K1F_LEVELS; lv++) {
         const u32 slot = k1_prof_begin(B.prof, K1P_TASK, stream);
-        hipLaunchKernelGGL(k1f_task, dim3(g.nb * 16u < 2048u ? g.nb * 16u : 2048u), dim3(K1F_BT), 0, stream, B, g, lv, iters, lists, purerot_max,
+#ifndef K1F_TASK_WGS
+#define K1F_TASK_WGS 16u
+#endif
+        hipLaunchKernelGGL(k1f_task, dim3(g.nb * K1F_TASK_WGS < 128u * K1F_TASK_WGS ? g.nb * K1F_TASK_WGS : 128u * K1F_TASK_WGS), dim3(K1F_BT), 0, stream, B, g, lv, iters, lists, purerot_max,
                            lv + 1u == K1F_LEVELS ? 1u : 0u, carry);
         k1_prof_end(B.prof, slot, stream, 0);
     }

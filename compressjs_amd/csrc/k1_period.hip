@@ -475,7 +475,9 @@ int k1_period_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u3
     if (max_n == 0u) max_n = 1u;                                              // (a batch of empty blocks: the grids below must not be empty)
     hipLaunchKernelGGL(k1p_detect, dim3(g.nb), dim3(256), 0, stream, B, g, enable);
     for (u32 stage = 0; stage < 2u; stage++) {
-        hipLaunchKernelGGL(k1p_find, dim3(K1P_GRID / 2u, g.nb), dim3(256), 0, stream, B, g, enable, stage);
+        // (round 6: 32 workgroups per block instead of 8 - a block's n / 4 candidate distances are 55 tiles, and with 7 of them per workgroup, one after
+        // the other, the kernel sat 62-67 us on every sub-batch's critical path for a route text never takes)
+        hipLaunchKernelGGL(k1p_find, dim3(K1P_GRID * 2u, g.nb), dim3(256), 0, stream, B, g, enable, stage);
         hipLaunchKernelGGL(k1p_verify, dim3(K1P_GRID, g.nb), dim3(256), 0, stream, B, g, stage);
     }
     hipLaunchKernelGGL(k1p_tables, dim3(g.nb), dim3(256), 0, stream, B, g);
