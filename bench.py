@@ -22,7 +22,7 @@ What the line carries besides the driver's contract:
   roofline                               the kernel with the largest total time ON THIS WORKLOAD, found and timed with HIP
                                          events around every launch of K1's main kernels on the library's stream in a
                                          single-stream pass after the timed region (kernel_ms_per_step lists them all);
-                                         traffic from the PMC passes of profiles/r05_pmc_traffic.json (stamped with the
+                                         traffic from the PMC passes of profiles/r06_pmc_traffic.json (stamped with the
                                          build they were collected on; null when none for this workload), e2e = 16 B/B
   cpu_baseline                           kind "reference": Bzip2.compressFile of cscott/compressjs under node, timed ON THIS
                                          BOX IN THIS RUN on the first 10^7 bytes of the same stream (staged copy under
@@ -371,11 +371,11 @@ def main():
             avg_ms = tot_ms / max(launches, 1)
         alg_bytes = None if (alg_per_el is None or not launches) else alg_per_el * elements / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if (alg_bytes and avg_ms > 0) else None
-        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE passes of this workload (separate --pmc runs, tests/gpu_r5_traffic.sh;
-        # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), committed as profiles/r05_pmc_traffic.json together with
+        # HBM traffic per launch: FETCH_SIZE / WRITE_SIZE passes of this workload (separate --pmc runs, tests/gpu_r6_traffic.sh;
+        # FETCH_SIZE doubled as the MI355X guide prescribes for gfx950), committed as profiles/r06_pmc_traffic.json together with
         # the build they were collected on.  null when no pass for this workload / size / kernel is committed.
         traffic, traffic_build = None, None
-        tpath = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
         if os.path.exists(tpath) and dom:
             tj = json.load(open(tpath))
             ent = tj.get("%s:%d" % (args.workload, args.size), {}).get(dom)
