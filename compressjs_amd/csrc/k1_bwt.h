@@ -149,8 +149,8 @@ struct K1Buf {
     u32* dtot;        // [rstride]                positions in unsorted groups per block before the doubling rounds (k1_count_unsorted)
     u32* dbn;         // [K1D_MAXR + 2][4]        per round: descriptors of medium groups (1025..), of large groups, chunks, medium groups (..1024)
     u32* dred;        // [rstride]                != 0: the block was reduced by k1_period.hip (behind dbn: read back together with dtot)
-    uint4* btask;     // [K1F_LEVELS][btaskCap]  task levels of the front end (k1f_task): (block, position, length, depth | flag)
-    u32* bcnt;        // [K1F_LEVELS]            tasks per level
+    uint4* btask;     // [K1F_LEVELS][8][btaskCap]  task levels of the front end (k1f_task): (block, position, length, depth | flag), one list per level and XCD (block mod 8)
+    u32* bcnt;        // [K1F_LEVELS][8]         tasks per level and XCD
     u32 btaskCap;
     u8* U;            // [nb][stride]   BWT output
     u32* pidx;        // [nb]           origPtr

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void k1_init(K1Buf B, BatchGeom g) {
     if (b == 0 && gid < K1_STATS) B.stats[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 4u * 8u * K1_DEEP_SUB; i += gridDim.x * blockDim.x) B.deepCnt[i] = 0;
     if (b == 0) for (u32 i = gid; i < (K1R_MAXR + 1u) * B.rnb8 * K1_RCS; i += gridDim.x * blockDim.x) B.rcnt[i] = 0;
-    if (b == 0 && gid < K1F_LEVELS) B.bcnt[gid] = 0;
+    if (b == 0 && gid < K1F_LEVELS * 8u) B.bcnt[gid] = 0;
     if (b == 0) for (u32 i = gid; i < 2u * (K1D_MAXR + 2u) * B.rstride + 2u * B.rstride + (K1D_MAXR + 2u) * 4u; i += gridDim.x * blockDim.x) B.dcnt[i] = 0;   // dcnt, dchg, dtot, dbn, dred (contiguous)
     if (gid < g.hstride) {
         const u32 lo = gid * 32u;
@@ -396,7 +396,7 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     B.listSCap = g.nb * (g.stride / 8u);                    // lane kernels' lists (8 XCD regions x K1_DEEP_SUB sub-regions); chunks of large groups
     B.listMCap = g.nb * (g.stride / 1024u + 1u);            // descriptors of groups of 1025 .. K1_MED_MAX
     B.listLCap = g.nb * (g.stride / K1_MED_MAX + 1u);       // ... of larger ones
-    B.btaskCap = g.nb * (g.stride / 256u);
+    B.btaskCap = ((g.nb + 7u) / 8u) * (g.stride / 256u) * 2u;      // tasks per level AND XCD list (block mod 8): twice what its blocks' rotations make at 256 per task
     take((void**)&B.SA, e * 4);
     take((void**)&B.SB, e * 4);
     take((void**)&B.ISA, e * 4);
@@ -415,7 +415,7 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     for (int k = 0; k < 2; k++) take((void**)&B.rlist[k], e * 8);
     take((void**)&B.rcnt, (size_t)(K1R_MAXR + 1) * nb8 * K1_RCS * 4);
     take((void**)&B.dcnt, ((size_t)(2u * (K1D_MAXR + 2u) + 2u) * rs + (K1D_MAXR + 2u) * 4u) * 4);      // dcnt, dchg, dtot, dbn, dred (contiguous: zeroed as one; dtot .. dred read back as one)
-    take((void**)&B.btask, (size_t)K1F_LEVELS * B.btaskCap * sizeof(uint4));
+    take((void**)&B.btask, (size_t)K1F_LEVELS * 8u * B.btaskCap * sizeof(uint4));
     take((void**)&B.bcnt, 256);
     take((void**)&B.nfront, (size_t)nb8 * 4);
     take((void**)&B.per, (size_t)nb8 * 4);
@@ -527,16 +527,20 @@ int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
         u64 bg = 0;
         for (u32 i = 0; i < 8u; i++) bg += fs[K1_STAT_BIGROT - K1_STAT_FRONT_BIG + i];
         {   // task levels: tasks, the longest one and its depth
-            std::vector<u32> bc(K1F_LEVELS);
-            HIP_CHECK_RET(hipMemcpy(bc.data(), B.bcnt, K1F_LEVELS * 4, hipMemcpyDeviceToHost));
+            std::vector<u32> bc(K1F_LEVELS * 8u);
+            HIP_CHECK_RET(hipMemcpy(bc.data(), B.bcnt, K1F_LEVELS * 8u * 4, hipMemcpyDeviceToHost));
             fprintf(stderr, "[k1] task levels (tasks / longest / its depth):");
+            const u32 cap8 = B.btaskCap;
             for (u32 lv = 0; lv < K1F_LEVELS; lv++) {
-                const u32 nt = bc[lv] < B.btaskCap ? bc[lv] : B.btaskCap;
-                std::vector<uint4> tk(nt);
-                if (nt) HIP_CHECK_RET(hipMemcpy(tk.data(), B.btask + (size_t)lv * B.btaskCap, (size_t)nt * sizeof(uint4), hipMemcpyDeviceToHost));
-                u32 ml = 0, md = 0;
-                for (const uint4& t : tk) if (t.z > ml) { ml = t.z; md = t.w & 0x7FFFFFFFu; }
-                fprintf(stderr, " [%u] %u/%u/%u", lv, nt, ml, md);
+                u32 ntot = 0, ml = 0, md = 0;
+                for (u32 x = 0; x < 8u; x++) {               // (one list per level and XCD)
+                    const u32 nt = bc[lv * 8u + x] < cap8 ? bc[lv * 8u + x] : cap8;
+                    std::vector<uint4> tk(nt);
+                    if (nt) HIP_CHECK_RET(hipMemcpy(tk.data(), B.btask + (size_t)(lv * 8u + x) * cap8, (size_t)nt * sizeof(uint4), hipMemcpyDeviceToHost));
+                    for (const uint4& t : tk) if (t.z > ml) { ml = t.z; md = t.w & 0x3FFFFFFFu; }
+                    ntot += nt;
+                }
+                fprintf(stderr, " [%u] %u/%u/%u", lv, ntot, ml, md);
             }
             fprintf(stderr, "\n");
         }

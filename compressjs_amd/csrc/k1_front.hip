@@ -572,8 +572,11 @@ struct K1fL {
 static_assert(K1F_PB <= 256 && K1F_PB >= 64 && (K1F_PB & (K1F_PB - 1)) == 0 && K1F_PS % 4 == 0, "task partition geometry");
 __device__ __forceinline__ void k1f_push_task(const K1Buf& B, u32 level, u32 b, u32 pos, u32 len, u32 depth_flag) {
     if (level >= K1F_LEVELS) return;
-    const u32 idx = atomicAdd(&B.bcnt[level], 1u);
-    if (idx < B.btaskCap) B.btask[(size_t)level * B.btaskCap + idx] = make_uint4(b, pos, len, depth_flag);
+    // (round 6: one list per level AND XCD - b mod 8, where every other kernel works on block b: a task's random key gathers then hit the L2 that
+    // holds the block's text; one list per level, walked by all workgroups, had 32 % L2 hits and 150 bytes of fetch traffic per rotation)
+    const u32 li = level * 8u + (b & 7u), cap8 = B.btaskCap;
+    const u32 idx = atomicAdd(&B.bcnt[li], 1u);
+    if (idx < cap8) B.btask[(size_t)li * cap8 + idx] = make_uint4(b, pos, len, depth_flag);
 }
 
 // Results of positions [0, cnt) of the slice that starts at suffix-array position `pos0` of block b: the suffix indices and the
@@ -975,12 +978,14 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
     u32* key1 = (u32*)(key + K1F_PS + K1F_PB);          // [K1F_PS] u32
     static_assert((K1F_PS + K1F_PB) * 8 + K1F_PS * 4 <= K1F_C * 16 && 512 * 4 <= K1F_C * 16, "task scratch fits the key cells");
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    u32 ntask = B.bcnt[level];
-    if (ntask > B.btaskCap) ntask = B.btaskCap;
+    // the workgroups the dispatcher places on XCD x (blockIdx.x mod 8, as in xcd_block_tile) walk the tasks of the blocks x, x + 8, ...
+    const u32 tli = level * 8u + (blockIdx.x & 7u), cap8 = B.btaskCap;
+    u32 ntask = B.bcnt[tli];
+    if (ntask > cap8) ntask = cap8;
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
-    for (u32 li = blockIdx.x; li < ntask; li += gridDim.x) {
+    for (u32 li = blockIdx.x >> 3; li < ntask; li += gridDim.x >> 3) {
         __syncthreads();
-        const uint4 tk = B.btask[(size_t)level * B.btaskCap + li];
+        const uint4 tk = B.btask[(size_t)tli * cap8 + li];
         const u32 b = tk.x, pos = tk.y, len = tk.z, depth = tk.w & ~(K1F_TASK_SB | K1F_TASK_PLAIN);
         const bool inSB = (tk.w & K1F_TASK_SB) != 0u;
         const u32 n = B.nfront[b];
@@ -1529,7 +1534,7 @@ int k1_front_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream, u32
 #ifndef K1F_TASK_WGS
 #define K1F_TASK_WGS 16u
 #endif
-        hipLaunchKernelGGL(k1f_task, dim3(g.nb * K1F_TASK_WGS < 128u * K1F_TASK_WGS ? g.nb * K1F_TASK_WGS : 128u * K1F_TASK_WGS), dim3(K1F_BT), 0, stream, B, g, lv, iters, lists, purerot_max,
+        hipLaunchKernelGGL(k1f_task, dim3(((g.nb * K1F_TASK_WGS < 128u * K1F_TASK_WGS ? g.nb * K1F_TASK_WGS : 128u * K1F_TASK_WGS) + 7u) & ~7u), dim3(K1F_BT), 0, stream, B, g, lv, iters, lists, purerot_max,
                            lv + 1u == K1F_LEVELS ? 1u : 0u, carry);
         k1_prof_end(B.prof, slot, stream, 0);
     }
