@@ -31,6 +31,16 @@
 #ifndef K1_DEEP_START
 #define K1_DEEP_START 1
 #endif
+// Round 6: a key that fills m >= 3 quantiles of the sample used to get ONE bucket [v, v + 1) and leave m - 2 EMPTY ones behind it (the equal splitters); on
+// HTML-like input such buckets hold a quarter of the rotations and most are beyond LDS (E8S-A: 22.8 M rotations in 9 900 buckets of 2 300 on average - the
+// task levels' work, 1.0 ms per step).  k1f_hist now spreads a heavy key's rotations over its own bucket AND the empty ones behind it by the bucket of their
+// NEXT 8 bytes - against sub-splitters that k1f_sample takes from the key's OWN samples (the next 8 bytes of the sampled rotations that start with the key,
+// sorted: quantiles of the conditional distribution; the global buckets of the next 8 bytes were tried first and split nothing - what follows `<td clas` is
+// nearly always the same bucket) - monotone in bytes 8..16: the order between the sub-buckets is the order of the rotations, and k1f_bsort sorts them like
+// any other bucket.
+#ifndef K1F_SUBBUCKETS
+#define K1F_SUBBUCKETS 1
+#endif
 #define K1D_SHALLOW(B) ((B).dbn[(K1D_MAXR + 1u) * 4u])      // (a word of dbn's last row, which no round uses: read back together with dtot)
 // list entries of the refinement rounds (k1r_round) and the doubling rounds (k1_dbl.hip): one per rotation that still ties,
 // a group = consecutive entries:  (group length - 1) << 52 | index in the group << 44 | rotation index << 22 | suffix-array position
@@ -131,6 +141,10 @@ struct K1Buf {
     u32* red;         // [nb]           period p > 64 of a block that is sorted through its first 3 p + (n mod p) bytes (k1_period.hip), else 0
     u32* tileHist;    // [nb][ptiles][K1F_NB]  front end: per-tile bucket counts
     u64* fsplit;      // [nb][K1F_NB]       front end: bucket d holds the keys in [fsplit[d-1], fsplit[d])
+    u8* fsub;         // [nb][K1F_NB]       round 6, heavy 8-byte keys: 0 = an ordinary bucket; n = 1 .. 254: the bucket of ONE key, the first of n that share the key's
+                      //                    rotations by their NEXT 8 bytes; 255: another one of those n
+    u64* fsplit2;     // [nb][K1F_NB]       ... bucket d of such a run holds the rotations whose next 8 bytes are below fsplit2[d] (and not below fsplit2[d - 1])
+    u8* fp16;         // [nb][K1F_NB]       ... 1: bucket d holds ONE 16-byte key (sub-splitters x, x + 1: a heavy continuation of the heavy key): beyond LDS it is a group as it stands
     u32* fstart;      // [nb][K1F_NB+1]     front end: first suffix-array position of every bucket
     u32* stats;       // [K1_STATS]
     u32* deepCnt;     // [2 passes][2 classes][8 XCD regions][K1_DEEP_SUB]  entries in each list sub-region of the lane kernels

@@ -405,6 +405,9 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     take((void**)&B.HN, (size_t)g.nb * g.hstride * 4);
     take((void**)&B.tileHist, (size_t)g.nb * k1_front_tilehist_words(g) * 4);
     take((void**)&B.fsplit, (size_t)g.nb * K1F_NB * 8);
+    take((void**)&B.fsub, (size_t)g.nb * K1F_NB);
+    take((void**)&B.fsplit2, (size_t)g.nb * K1F_NB * 8);
+    take((void**)&B.fp16, (size_t)g.nb * K1F_NB);
     take((void**)&B.fstart, (size_t)g.nb * (K1F_NB + 1) * 4);
     take((void**)&B.stats, K1_STATS * 4);
     take((void**)&B.deepCnt, 4 * 8 * K1_DEEP_SUB * 4);

@@ -59,13 +59,30 @@ __device__ __forceinline__ void k1f_cmpx(u64& a, u64& c, bool up) {
     if ((a > c) == up) { const u64 t = a; a = c; c = t; }
 }
 
+// less += ((c, j) < (m, i)): 8-byte keys as two big-endian dwords, ties by the slot numbers - one borrow chain (see k1f_acc_lt below)
+__device__ __forceinline__ void k1f_acc_lt64(u32& less, const uint2& c, u32 j, const uint2& m, u32 i) {
+#if defined(__AMDGCN__)
+    u32 t;
+    asm("v_cmp_lt_u32 vcc, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
+        "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
+        "v_addc_co_u32 %0, vcc, 0, %0, vcc"
+        : "+v"(less), "=&v"(t)
+        : "v"(j), "v"(i), "v"(c.y), "v"(m.y), "v"(c.x), "v"(m.x)
+        : "vcc");
+#else
+    const u64 cc = ((u64)c.x << 32) | c.y, mm = ((u64)m.x << 32) | m.y;
+    less += (cc < mm || (cc == mm && j < i)) ? 1u : 0u;
+#endif
+}
 __global__ __launch_bounds__(1024) void k1f_sample(K1Buf B, BatchGeom g) {
     const u32 b = blockIdx.x;
     const u32 n = B.nfront[b];
     const u32 tid = threadIdx.x;
     u64* sp = B.fsplit + (size_t)b * K1F_NB;
+    u8* fsub = B.fsub + (size_t)b * K1F_NB;
     if (n <= K1F_C) {                                   // one bucket holds the whole block
-        for (u32 j = tid; j < K1F_NB; j += 1024) sp[j] = ~0ull;
+        for (u32 j = tid; j < K1F_NB; j += 1024) { sp[j] = ~0ull; fsub[j] = 0; B.fp16[(size_t)b * K1F_NB + j] = 0; }
         return;
     }
     __shared__ u64 s[K1F_S + K1F_S / 16u];
@@ -133,6 +150,24 @@ __global__ __launch_bounds__(1024) void k1f_sample(K1Buf B, BatchGeom g) {
         }
         __syncthreads();
     }
+#if K1F_SUBBUCKETS
+    constexpr u32 K1F_HK = 512u;                        // heavy keys that get sub-splitters, at most (more: the rest keep their one bucket)
+#ifndef K1F_HRANK
+#define K1F_HRANK 1024u
+#endif
+    constexpr u32 K1F_HR = K1F_HRANK;                   // entries of a heavy key's list that are ranked, at most (a key with more samples is thinned)
+    __shared__ u64 hk[K1F_HK];                          // the heavy keys, ascending
+    __shared__ u16 hlo[K1F_HK], hcn[K1F_HK], hbk[K1F_HK], hst[K1F_HK];   // first cell / entries of the key's list (cells of the sorted sample array), its first bucket, thinning stride
+    __shared__ u32 hrun[K1F_HK];                        // samples of the key seen by the second pass
+    __shared__ u8 mk[K1F_NB];
+    __shared__ u32 scansh[20];
+    __shared__ u32 anyh;
+    if (tid == 0) anyh = 0;
+    for (u32 i = tid; i < K1F_HK; i += 1024) hrun[i] = 0;
+    u32 myhead[K1F_NB / 1024u], mylb[K1F_NB / 1024u], mycn[K1F_NB / 1024u];
+    u64 myq[K1F_NB / 1024u];
+    __syncthreads();
+#endif
     for (u32 j = tid; j < K1F_NB; j += 1024) {
         u64 v = ~0ull;                                  // sp[K1F_NB-1] is padding (never compared)
         if (j + 1u < K1F_NB) {
@@ -141,7 +176,184 @@ __global__ __launch_bounds__(1024) void k1f_sample(K1Buf B, BatchGeom g) {
             if (j >= 1u && s[K1F_SPAD(j * K1F_OVS)] == q && q != ~0ull) v = q + 1u;   // heavy key: [q, q+1) becomes a bucket of its own
         }
         sp[j] = v;
+        // heavy keys (K1F_SUBBUCKETS, k1_bwt.h): with Q_j = the (j + 1)-th quantile of the sample, a run Q_(d-1) = Q_d = .. = q makes bucket d the bucket of the ONE
+        // key q (splitters q, q + 1) and the buckets behind it, up to the run's end, empty (splitters q + 1, q + 1): bucket d is marked with their number
+        // (k1f_hist spreads the key's rotations over all of them), the others as members
+        u32 mark = 0;
+        if (K1F_SUBBUCKETS && j >= 1u && j + 1u < K1F_NB) {
+            const u64 q = s[K1F_SPAD((j + 1u) * K1F_OVS)];
+            if (q != ~0ull && s[K1F_SPAD(j * K1F_OVS)] == q) {
+                if (j >= 2u && s[K1F_SPAD((j - 1u) * K1F_OVS)] == q) mark = 255u;             // (not the first of the run)
+                else {
+                    u32 cnt = 1u;
+                    while (cnt < 254u && j + cnt + 1u < K1F_NB && s[K1F_SPAD((j + cnt + 1u) * K1F_OVS)] == q) cnt++;
+                    mark = cnt;
+                }
+            }
+        }
+        fsub[j] = (u8)mark;
+#if K1F_SUBBUCKETS
+        mk[j] = (u8)mark;
+        const u32 slotj = j / 1024u;
+        myhead[slotj] = 0;
+        if (mark >= 2u && mark != 255u) {
+            // the key's samples in the sorted array: [first >= q, first > q)
+            const u64 q = s[K1F_SPAD((j + 1u) * K1F_OVS)];
+            u32 lb = 0, ub = 0;
+#pragma unroll
+            for (u32 step = K1F_S / 2u; step >= 1u; step >>= 1) {
+                if (s[K1F_SPAD(lb + step - 1u)] < q) lb += step;
+                if (s[K1F_SPAD(ub + step - 1u)] <= q) ub += step;
+            }
+            myhead[slotj] = 1u; mylb[slotj] = lb; mycn[slotj] = ub - lb; myq[slotj] = q;
+            anyh = 1u;
+        }
+#endif
     }
+#if K1F_SUBBUCKETS
+    // ---- sub-splitters of the heavy keys: quantiles of the NEXT 8 bytes of the sampled rotations that start with the key.
+    u64* sp2 = B.fsplit2 + (size_t)b * K1F_NB;
+    u8* fp16 = B.fp16 + (size_t)b * K1F_NB;
+    __syncthreads();
+    if (!anyh) {                                        // (uniform) no key fills three quantiles: nothing to spread
+        for (u32 j = tid; j < K1F_NB; j += 1024) { sp2[j] = ~0ull; fp16[j] = 0; }
+        return;
+    }
+    // the heavy keys in bucket order (= ascending): index by two block scans over the threads' heads (buckets tid, then tid + 1024)
+    u32 nh = 0;
+#pragma unroll
+    for (u32 sl = 0; sl < K1F_NB / 1024u; sl++) {
+        u32 tot;
+        const u32 ex = block_excl_scan_1024(myhead[sl], scansh, &tot);
+        if (myhead[sl] && nh + ex < K1F_HK) {
+            const u32 i = nh + ex;
+            hk[i] = myq[sl]; hlo[i] = (u16)mylb[sl]; hbk[i] = (u16)(tid + sl * 1024u);
+            // a key with more samples than K1F_HR is thinned: every stride-th sample is listed
+            const u32 stride = (mycn[sl] + K1F_HR - 1u) / K1F_HR;
+            hst[i] = (u16)stride;
+            hcn[i] = (u16)((mycn[sl] + stride - 1u) / stride);
+        }
+        nh += tot;
+    }
+    if (nh > K1F_HK) nh = K1F_HK;
+    // the lists take the cells of the sorted array (not needed any more): list of key i = cells [hlo[i], hlo[i] + hcn[i]); ~0 = empty
+    u64* lst = s;
+    for (u32 i = tid; i < K1F_S; i += 1024) lst[i] = ~0ull;
+    __syncthreads();
+    // second pass over the samples: a sample whose key is a heavy one puts its NEXT 8 bytes into the key's list (eight samples per step, their loads in
+    // flight together: as a plain loop it was sixteen dependent pairs of gathers per thread, 40 us on every sub-batch's critical path)
+    for (u32 k0 = tid; k0 < K1F_S; k0 += 1024u * 8u) {
+        u32 pp[8], hi8[8];
+        u64 kq[8];
+#pragma unroll
+        for (u32 u = 0; u < 8u; u++) {
+            const u32 k = k0 + u * 1024u;
+            const u32 lo = (u32)((u64)k * n / K1F_S), hi = (u32)((u64)(k + 1u) * n / K1F_S);
+            pp[u] = hi > lo + 1u ? lo + k1f_hash(k, b) % (hi - lo) : lo;
+        }
+#pragma unroll
+        for (u32 u = 0; u < 8u; u++) kq[u] = k1f_load_be64(T, pp[u]);
+#pragma unroll
+        for (u32 u = 0; u < 8u; u++) {
+            u32 i = 0;                                  // heavy keys below the sample's key
+#pragma unroll
+            for (u32 step = K1F_HK / 2u; step >= 1u; step >>= 1) if (i + step <= nh && hk[i + step - 1u] < kq[u]) i += step;
+            hi8[u] = (i < nh && hk[i] == kq[u]) ? i : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (u32 u = 0; u < 8u; u++) kq[u] = hi8[u] != 0xFFFFFFFFu ? k1f_load_be64(T, pp[u] + 8u) : 0ull;     // (p + 15 < n + 64: inside the wrap-around bytes)
+#pragma unroll
+        for (u32 u = 0; u < 8u; u++)
+            if (hi8[u] != 0xFFFFFFFFu) {
+                const u32 i = hi8[u];
+                const u32 seen = atomicAdd(&hrun[i], 1u), stride = hst[i];
+                if (seen % stride == 0u && seen / stride < hcn[i]) lst[hlo[i] + seen / stride] = kq[u];     // (every stride-th sample of the key, in arrival order)
+            }
+    }
+    __syncthreads();
+    // every listed entry ranks itself inside its list by counting (strict order by value, then cell); the entries whose ranks are the wanted quantiles
+    // drop their values into sp2 (global scratch for now: the final thresholds below read their neighbours')
+    for (u32 j = tid; j < K1F_NB; j += 1024) sp2[j] = ~0ull;
+    __threadfence_block();
+    __syncthreads();
+    for (u32 c = tid; c < K1F_S; c += 1024) {
+        const u64 v = lst[c];
+        if (v == ~0ull) continue;
+        u32 i = 0;                                      // the list the cell belongs to: the last one that starts at or before it
+#pragma unroll
+        for (u32 step = K1F_HK / 2u; step >= 1u; step >>= 1) if (i + step <= nh && hlo[i + step - 1u] <= c) i += step;
+        if (i == 0u) continue;
+        i--;
+        const u32 lo = hlo[i], cn = hcn[i];
+        if (c >= lo + cn) continue;
+        // rank = cells of the list that are smaller in the strict order (value, cell): one borrow chain per candidate (k1f_acc_lt64 - 64-bit compares run
+        // at a quarter of the rate), K1F_RU cells per step, their reads in flight
+        // together; cells behind the list's end (other lists', spare cells) count as (all ones, all ones): below nothing
+#ifndef K1F_RU
+#define K1F_RU 16u                                      // cells per step of the ranking loop: a step is a dependent LDS round trip, ~100 clocks for a kernel of four waves per SIMD
+#endif
+        u32 r = 0;
+        const uint2 mv = make_uint2((u32)(v >> 32), (u32)v);
+        for (u32 e = lo; e < lo + cn; e += K1F_RU) {
+            u64 x[K1F_RU];
+#pragma unroll
+            for (u32 u = 0; u < K1F_RU; u++) x[u] = lst[e + u];
+#pragma unroll
+            for (u32 u = 0; u < K1F_RU; u++) {
+                const bool in = e + u < lo + cn;
+                k1f_acc_lt64(r, make_uint2(in ? (u32)(x[u] >> 32) : 0xFFFFFFFFu, in ? (u32)x[u] : 0xFFFFFFFFu), in ? e + u : 0xFFFFFFFFu, mv, c);
+            }
+        }
+        // wanted: rank (t + 1) * cn / nsub for t = 0 .. nsub - 2 (empty cells - ~0 - rank last and are never wanted while the list is mostly full)
+        const u32 h = hbk[i], nsub = mk[h];
+        u32 t = (r * nsub) / cn;                        // (32-bit: r, cn <= K1F_HR, nsub <= 254 - a 64-bit division is a subroutine of hundreds of instructions)
+        t = t ? t - 1u : 0u;
+        for (; t + 1u < nsub; t++) {
+            const u32 want = ((t + 1u) * cn) / nsub;
+            if (want > r) break;
+            if (want == r) sp2[h + t] = v;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // thresholds: bucket h + t of a run of nsub buckets (head h) ends below q_t; two equal quantiles q_(t-1) = q_t = x - a continuation that is heavy itself -
+    // become the thresholds x, x + 1: bucket h + t holds ONE 16-byte key (fp16)
+    u64 fin[K1F_NB / 1024u];
+    u32 fin16[K1F_NB / 1024u];
+#pragma unroll
+    for (u32 sl = 0; sl < K1F_NB / 1024u; sl++) {
+        const u32 j = tid + sl * 1024u;
+        u64 v2 = ~0ull;
+        u32 p16 = 0;
+        u32 h = j, t = 0;
+        const u32 mj = mk[j];
+        bool run = mj >= 2u && mj != 255u;
+        if (mj == 255u) {                               // a member: its head is the nearest bucket to the left with a count
+            while (h > 0u && mk[h] == 255u) h--;
+            t = j - h;
+            run = mk[h] >= 2u && mk[h] != 255u && t < mk[h];
+        }
+        if (run) {
+            const u32 nsub = mk[h];
+            if (t + 1u < nsub) {
+                u64 qt = sp2[h + t];
+                const u64 qp = t >= 1u ? sp2[h + t - 1u] : 0ull;
+                if (qt < qp) qt = qp;                       // (cannot happen - ranks order the values -; the sub-buckets' order depends on ascending thresholds)
+                v2 = qt;
+                if (t >= 1u && qp == qt && qt != ~0ull) v2 = qt + 1u;
+                // [x, x + 1): my lower threshold is an unincremented x and my upper one x + 1
+                if (t >= 1u && qp == qt && qt != ~0ull) {
+                    const bool lower_plain = t == 1u || sp2[h + t - 2u] != qp;
+                    if (lower_plain) p16 = 1u;
+                }
+            }
+        }
+        fin[sl] = v2; fin16[sl] = p16;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 sl = 0; sl < K1F_NB / 1024u; sl++) { sp2[tid + sl * 1024u] = fin[sl]; fp16[tid + sl * 1024u] = (u8)fin16[sl]; }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -159,12 +371,17 @@ __global__ __launch_bounds__(1024) void k1f_hist(K1Buf B, BatchGeom g, u32 ptile
     __shared__ u64 sp[K1F_NB];
     __shared__ u32 hist[K1F_NB];
     __shared__ u32 tx[K1F_PT / 4 + 4];
+    __shared__ u8 fs[K1F_NB];                           // heavy-key marks of the buckets (k1f_sample)
+    __shared__ u64 sp2[K1F_NB];                         // ... and their sub-splitters (bucket order)
     // The splitters in breadth-first order (node i: children 2i, 2i + 1; level k = cells [2^k, 2^(k+1))): the sorted array
     // put the 2^k nodes of the upper levels 2^(11-k) * 8 bytes apart, i.e. all in ONE pair of LDS banks - the six upper
     // levels of every search cost 2 + 4 + .. + 64 cycles (86 % of the kernel's LDS cycles were bank conflicts).
     const u64* gsp = B.fsplit + (size_t)b * K1F_NB;
+    const u8* gfs = B.fsub + (size_t)b * K1F_NB;
     for (u32 d = tid; d < K1F_NB; d += 1024) {
         hist[d] = 0;
+        fs[d] = gfs[d];
+        sp2[d] = B.fsplit2[(size_t)b * K1F_NB + d];
         if (d) {
             const u32 k = 31u - (u32)__clz((int)d), j = d - (1u << k);
             sp[d] = gsp[(((2u * j + 1u) << (K1F_LOG_NB - 1u - k))) - 1u];
@@ -187,7 +404,20 @@ __global__ __launch_bounds__(1024) void k1f_hist(K1Buf B, BatchGeom g, u32 ptile
             u32 node = 1;                               // ends at K1F_NB + the number of splitters <= key
 #pragma unroll
             for (u32 l = 0; l < K1F_LOG_NB; l++) node = 2u * node + (sp[node] <= key ? 1u : 0u);
-            const u32 pos = node - K1F_NB;
+            u32 pos = node - K1F_NB;
+            const u32 nsb = fs[pos];
+            if (K1F_SUBBUCKETS && nsb > 1u && nsb != 255u) {
+                // the bucket of ONE heavy key with nsb - 1 empty buckets behind it: which of them, by the rotation's NEXT 8 bytes against the key's own
+                // sub-splitters sp2[pos .. pos + nsb - 2] (the number of them that are <= the next 8 bytes)
+                const u64 key2 = ((u64)be32_at(tx[wi + 3], tx[wi + 2], sel) << 32) | (u64)be32_at(tx[wi + 4], tx[wi + 3], sel);
+                u32 lo2 = 0, len2 = nsb - 1u;
+                while (len2) {
+                    const u32 half = len2 >> 1;
+                    if (sp2[pos + lo2 + half] <= key2) { lo2 += half + 1u; len2 -= half + 1u; }
+                    else len2 = half;
+                }
+                pos += lo2;
+            }
             atomicAdd(&hist[pos], 1u);
             const u32 prev = q ? (tx[(q - 1u) >> 2] >> (((q - 1u) & 3u) * 8u)) & 0xFFu : prev0;
             bid[j] = pos | (prev << 16);
@@ -227,7 +457,7 @@ __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptile
         B.fstart[(size_t)b * (K1F_NB + 1) + tid] = excl;
         if (tid == 0) B.fstart[(size_t)b * (K1F_NB + 1) + K1F_NB] = n;
         const u64* sp = B.fsplit + (size_t)b * K1F_NB;
-        const bool pure = tid > 0u && tid < K1F_NB - 1u && sp[tid] == sp[tid - 1u] + 1u;
+        const bool pure = K1F_SUBBUCKETS ? B.fsub[(size_t)b * K1F_NB + tid] != 0u : (tid > 0u && tid < K1F_NB - 1u && sp[tid] == sp[tid - 1u] + 1u);
         if ((pure && tot > 64u) || tot > K1F_C) atomicAdd(&B.stats[K1_STAT_PUREROT], tot);
     }
     __syncthreads();
@@ -275,7 +505,7 @@ __global__ __launch_bounds__(1024) void k1f_scan(K1Buf B, BatchGeom g, u32 ptile
 #pragma unroll
         for (u32 r = 0; r < R; r++) {
             const u32 d = tid + r * 1024u;
-            const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
+            const bool pure = K1F_SUBBUCKETS ? B.fsub[(size_t)b * K1F_NB + d] != 0u : (d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u);
             if ((pure && sum[r] > 64u) || sum[r] > K1F_C) pr += sum[r];
         }
         u32 total;
@@ -470,21 +700,6 @@ __device__ __forceinline__ uint2 k1f_load_be64x2(const u8* T, u32 p) {
     __builtin_memcpy(d, __builtin_assume_aligned(T + (p - sh), 4), 12);
     const u32 sel = be_sel(sh);
     return make_uint2(be32_at(d[1], d[0], sel), be32_at(d[2], d[1], sel));
-}
-__device__ __forceinline__ void k1f_acc_lt64(u32& less, const uint2& c, u32 j, const uint2& m, u32 i) {
-#if defined(__AMDGCN__)
-    u32 t;
-    asm("v_cmp_lt_u32 vcc, %2, %3\n\t"
-        "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
-        "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
-        "v_addc_co_u32 %0, vcc, 0, %0, vcc"
-        : "+v"(less), "=&v"(t)
-        : "v"(j), "v"(i), "v"(c.y), "v"(m.y), "v"(c.x), "v"(m.x)
-        : "vcc");
-#else
-    const u64 cc = ((u64)c.x << 32) | c.y, mm = ((u64)m.x << 32) | m.y;
-    less += (cc < mm || (cc == mm && j < i)) ? 1u : 0u;
-#endif
 }
 // a step of the branch-free binary search over sorted splitters: pos + step when s <= k, else pos - the borrow of k - s picks (one
 // ds_read_b128 and six vector instructions; as `if (!lt(k, s)) pos += step` the compiler read the key's halves one after the other,
@@ -925,17 +1140,26 @@ __global__ __launch_bounds__(K1F_BT, K1F_MINW) void k1f_bsort(K1Buf B, BatchGeom
     u32* HN = B.HN + (size_t)b * g.hstride;
     const u64* sp = B.fsplit + (size_t)b * K1F_NB;
     // a bucket between the splitters v and v+1 holds one key only
-    const bool pure = d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u;
+    // (K1F_SUBBUCKETS: the bucket of a heavy key and the - formerly empty - ones behind it that share its rotations, marked by k1f_sample)
+    const bool pure = K1F_SUBBUCKETS ? B.fsub[(size_t)b * K1F_NB + d] != 0u : (d > 0u && d < K1F_NB - 1u && sp[d] == sp[d - 1u] + 1u);
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
     // 16-byte keys whenever the caller wants the text stages (cyclic mode) - also when the predictor then skips them (HTML-like input): the
     // doubling rounds start from h = 8 either way, but on groups that are already 16 bytes deep where a bucket fit the LDS (E8S-A: k1f_bsort
     // 1.17 -> 1.41 ms, the doubling stage 7.6 -> 6.4 ms)
     const bool wide = lists != 0u && iters != 0u;
+    const bool pure16 = K1F_SUBBUCKETS && B.fp16[(size_t)b * K1F_NB + d] != 0u;     // ONE 16-byte key (a heavy continuation of a heavy key)
+    if (pure16 && !deepen && wide && cnt > K1F_CAP) {
+        // beyond LDS, all rotations share 16 bytes, no text stage behind this one: a single group as it stands, as deep as the doubling rounds' first step
+        u32* SA = B.SA + (size_t)b * g.stride + start;
+        for (u32 i = tid; i < cnt; i += K1F_BT) SA[i] = SB[i] & K1_SMASK;
+        k1f_write_heads(HN, start, end, [&](u32 p) { return p == start; });
+        return;
+    }
     if (cnt > K1F_CAP && (deepen || !pure || (K1_DEEP_START && wide))) {
         // beyond LDS: a level-0 task (a one-key bucket starts 8 bytes deep); its indices stay in SB.  (Round 6: a one-key bucket beyond LDS also
         // without text stages behind it - partitioned by its next 8 bytes and sorted in LDS it enters the doubling rounds 16 or 24 bytes deep)
         if (tid == 0) {
-            k1f_push_task(B, 0u, b, start, cnt, (pure ? 8u : 0u) | K1F_TASK_SB);
+            k1f_push_task(B, 0u, b, start, cnt, (pure16 ? 16u : (pure ? 8u : 0u)) | K1F_TASK_SB);
             if (!pure) atomicAdd(&B.stats[K1_STAT_FRONT_BIG], 1u);
             atomicAdd(&B.stats[K1_STAT_BIGROT + (d & 7u)], cnt);
         }

@@ -587,7 +587,8 @@ def test_adversarial_period_words_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env_add", [{}, {"CJS_K1_CARRY": "0"}, {"CJS_TEXT_BYTES": "0"}], ids=["default", "carry_off", "text_stages_off"])
+@pytest.mark.parametrize("env_add", [{}, {"CJS_K1_CARRY": "0"}, {"CJS_TEXT_BYTES": "0"}, {"CJS_DEEP_BIG_DIV": "1073741824"}],
+                         ids=["default", "carry_off", "text_stages_off", "doubling_path_from_16"])
 def test_attack_words_on_the_bucket_sort_vs_oracle(env_add):
     """tests/attackwords.py at the -9 block capacity (n = 899 981; VERDICT r5 item 6: the families the judge attacked the 16-byte-key
     bucket sort, its all-ones sentinel cells and the carried BWT byte with - words of 15 / 16 / 17 and 40..90 bytes over {0xFE,0xFF},
