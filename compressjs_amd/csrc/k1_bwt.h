@@ -166,6 +166,7 @@ struct K1Buf {
     uint4* btask;     // [K1F_LEVELS][8][btaskCap]  task levels of the front end (k1f_task): (block, position, length, depth | flag), one list per level and XCD (block mod 8)
     u32* bcnt;        // [K1F_LEVELS][8]         tasks per level and XCD
     u32 btaskCap;
+    u32 btaskLists;   // task lists in use per level: min(8, blocks of the batch)
     u8* U;            // [nb][stride]   BWT output
     u32* pidx;        // [nb]           origPtr
     u32* hpin;        // host side only: pinned memory for K1's small read-backs (null: pageable), hpinWords u32 long

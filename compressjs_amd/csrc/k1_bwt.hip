@@ -396,6 +396,7 @@ static void k1_layout(K1Buf& B, const BatchGeom& g, F&& take) {
     B.listSCap = g.nb * (g.stride / 8u);                    // lane kernels' lists (8 XCD regions x K1_DEEP_SUB sub-regions); chunks of large groups
     B.listMCap = g.nb * (g.stride / 1024u + 1u);            // descriptors of groups of 1025 .. K1_MED_MAX
     B.listLCap = g.nb * (g.stride / K1_MED_MAX + 1u);       // ... of larger ones
+    B.btaskLists = g.nb < 8u ? (g.nb ? g.nb : 1u) : 8u;
     B.btaskCap = ((g.nb + 7u) / 8u) * (g.stride / 256u) * 2u;      // tasks per level AND XCD list (block mod 8): twice what its blocks' rotations make at 256 per task
     take((void**)&B.SA, e * 4);
     take((void**)&B.SB, e * 4);
@@ -493,6 +494,7 @@ static const K1Knobs& k1_knobs() {
 //   4. the BWT gather.
 int k1_run(K1Buf B, const BatchGeom& g, u32 max_n, hipStream_t stream) {
     const K1Knobs& K = k1_knobs();
+    B.btaskLists = g.nb < 8u ? (g.nb ? g.nb : 1u) : 8u;   // (the batch at hand, not the geometry the workspace was carved for)
     const u32 d0 = 8u;                                     // bytes every group shares after the front end
     const u64 total_n = (u64)g.nb * max_n;
     int rounds_with_work = 0;

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(1024) void k1f_sample(K1Buf B, BatchGeom g) {
 #if K1F_SUBBUCKETS
     constexpr u32 K1F_HK = 512u;                        // heavy keys that get sub-splitters, at most (more: the rest keep their one bucket)
 #ifndef K1F_HRANK
-#define K1F_HRANK 1024u
+#define K1F_HRANK 256u      // (1024: a block of a few equally heavy keys - RLE1 output of zeros - spent 1.6 ms ranking five lists of 1024: the work is quadratic; 256 entries still give every one of up to 254 sub-buckets its quantile)
 #endif
     constexpr u32 K1F_HR = K1F_HRANK;                   // entries of a heavy key's list that are ranked, at most (a key with more samples is thinned)
     __shared__ u64 hk[K1F_HK];                          // the heavy keys, ascending
@@ -789,7 +789,7 @@ __device__ __forceinline__ void k1f_push_task(const K1Buf& B, u32 level, u32 b, 
     if (level >= K1F_LEVELS) return;
     // (round 6: one list per level AND XCD - b mod 8, where every other kernel works on block b: a task's random key gathers then hit the L2 that
     // holds the block's text; one list per level, walked by all workgroups, had 32 % L2 hits and 150 bytes of fetch traffic per rotation)
-    const u32 li = level * 8u + (b & 7u), cap8 = B.btaskCap;
+    const u32 li = level * 8u + (b & 7u) % B.btaskLists, cap8 = B.btaskCap;
     const u32 idx = atomicAdd(&B.bcnt[li], 1u);
     if (idx < cap8) B.btask[(size_t)li * cap8 + idx] = make_uint4(b, pos, len, depth_flag);
 }
@@ -1203,11 +1203,12 @@ __global__ __launch_bounds__(K1F_BT) void k1f_task(K1Buf B, BatchGeom g, u32 lev
     static_assert((K1F_PS + K1F_PB) * 8 + K1F_PS * 4 <= K1F_C * 16 && 512 * 4 <= K1F_C * 16, "task scratch fits the key cells");
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     // the workgroups the dispatcher places on XCD x (blockIdx.x mod 8, as in xcd_block_tile) walk the tasks of the blocks x, x + 8, ...
-    const u32 tli = level * 8u + (blockIdx.x & 7u), cap8 = B.btaskCap;
+    const u32 tli = level * 8u + (blockIdx.x & 7u) % B.btaskLists, cap8 = B.btaskCap;      // (batches of fewer than 8 blocks: the idle XCDs' workgroups share the lists in use)
+    const u32 tshare = (8u + B.btaskLists - 1u - (blockIdx.x & 7u) % B.btaskLists) / B.btaskLists;     // XCDs that walk this list
     u32 ntask = B.bcnt[tli];
     if (ntask > cap8) ntask = cap8;
     const bool deepen = lists != 0u && B.stats[K1_STAT_PUREROT] <= purerot_max;
-    for (u32 li = blockIdx.x >> 3; li < ntask; li += gridDim.x >> 3) {
+    for (u32 li = (blockIdx.x >> 3) * tshare + (blockIdx.x & 7u) / B.btaskLists; li < ntask; li += (gridDim.x >> 3) * tshare) {
         __syncthreads();
         const uint4 tk = B.btask[(size_t)tli * cap8 + li];
         const u32 b = tk.x, pos = tk.y, len = tk.z, depth = tk.w & ~(K1F_TASK_SB | K1F_TASK_PLAIN);
