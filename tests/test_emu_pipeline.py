@@ -499,7 +499,7 @@ def _front_blocks():
             np.full(5000, 255, np.uint8), synth.text_like(4097, 1), synth.text_like(4096, 2)]
 
 
-@pytest.mark.parametrize("variant", ["default", "tiny_buckets"])
+@pytest.mark.parametrize("variant", ["default", "tiny_buckets", "doubling_forced"])
 def test_sample_sort_front_end(variant):
     """k1_front.hip (sample-sort front end of the suffix sort) on blocks large enough to be partitioned: text,
     random, periodic (pure buckets), runs, a moderately heavy key; `tiny_buckets` is a build with a 256-rotation
@@ -507,6 +507,11 @@ def test_sample_sort_front_end(variant):
     above ~1.1 MB take as a matter of course (test_bwt_entry_points_above_one_megabyte).  BWT + origPtr of every block
     against the oracle."""
     env = dict(os.environ)
+    if variant == "doubling_forced":
+        # round 6: the predictor forced on (no text stages) with 16-byte keys - heavy keys spread over sub-buckets by their own samples' sub-splitters,
+        # buckets of one 16-byte key left as groups, task levels in front of doubling rounds that start at h = 16
+        env["CJS_DEEP_BIG_DIV"] = "1073741824"
+        variant = "default"
     code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'));"
             "sys.path.insert(0, os.path.join(%r, 'tests', 'golden'));"
             "import test_emu_pipeline as t; t._front_check(%r)" % (ROOT, ROOT, ROOT, variant))
