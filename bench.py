@@ -11,7 +11,7 @@ when the timed region starts, complete .bz2 stream resident in HBM (rank 0) when
 (tests/workloads.py): enwik (default: synthetic enwik8-shaped text with phrase reuse), e8sa (SURVEY.md 8d E8S-A:
 the reference's test/sample5.ref || sample4.ref tiled), lcg (configs[3]: random printable ASCII), text, e8sb.
 Weak scaling: N GPUs compress an N x 10^8-byte stream; every rank holds its 10^8-byte slice (+ a 3.6 MB margin) only,
-every rank plans its own slice (one all_gather of per-slice RLE1 totals, no chain through the ranks), the encoded segments
+every rank plans its own slice (one all_gather of per-slice RLE1 totals, one of the boundary targets the slices hand on: no rank waits for another rank's plan), the encoded segments
 are gathered to rank 0 (compressjs_amd/dist.py).  Prints ONE JSON line (rank 0).
 
 What the line carries besides the driver's contract:
@@ -453,7 +453,7 @@ def main():
                        "input_bytes": total, "compressed_bytes": len(comp),
                        "blocks_in_flight": args.batch,
                        "sharding": "blocks/%d" % world if world == 1 else
-                                   "one %d-byte document per GPU, one .bz2 stream of the %d documents; every rank holds its document + %d bytes of the next one (parallel plan: one all_gather of per-slice RLE1 totals, no chain)"
+                                   "one %d-byte document per GPU, one .bz2 stream of the %d documents; every rank holds its document + %d bytes of the next one (parallel plan: one all_gather of per-slice RLE1 totals, one of the slices' boundary targets; no rank waits for another rank's plan)"
                                    % (args.size, world, margin_bytes(args.level)),
                        "device_ms_per_step": round(dev_ms / args.steps, 3),
                        "bit_exact_vs_reference_digest": vs_ref,
