@@ -9,7 +9,9 @@
 //
 //   k1f_sample   per block: K1F_S keys (8 text bytes each) at stratified, hashed positions, bitonic-sorted in
 //                LDS; every K1F_OVS-th is a splitter.  A key that fills more than one quantile gets a bucket of
-//                its own ([v, v+1): nothing to sort there), so runs/periodic data cannot overflow a bucket.
+//                its own ([v, v+1): nothing to sort there), so runs/periodic data cannot overflow a bucket.  Round 6: a key that fills
+//                three quantiles or more shares its rotations with the (empty) buckets behind its own, by their NEXT 8 bytes against
+//                sub-splitters from the key's own samples (fsub / fsplit2 / fp16: K1F_SUBBUCKETS in k1_bwt.h).
 //   k1f_hist     per tile of K1F_PT rotations: key of every rotation from the LDS-staged text, bucket = number
 //                of splitters <= key (branch-free binary search in LDS), per-tile bucket counts; per rotation the bucket id
 //                and (round 5) the byte in FRONT of the rotation, which travels with it from here on (K1_SPACK).
@@ -229,7 +231,11 @@ __global__ __launch_bounds__(1024) void k1f_sample(K1Buf B, BatchGeom g) {
             const u32 i = nh + ex;
             hk[i] = myq[sl]; hlo[i] = (u16)mylb[sl]; hbk[i] = (u16)(tid + sl * 1024u);
             // a key with more samples than K1F_HR is thinned: every stride-th sample is listed
-            const u32 stride = (mycn[sl] + K1F_HR - 1u) / K1F_HR;
+#ifndef K1F_HTHIN
+#define K1F_HTHIN 1u
+#endif
+            u32 stride = (mycn[sl] + K1F_HR - 1u) / K1F_HR;
+            if (stride < K1F_HTHIN) stride = K1F_HTHIN;
             hst[i] = (u16)stride;
             hcn[i] = (u16)((mycn[sl] + stride - 1u) / stride);
         }
@@ -1118,8 +1124,10 @@ __device__ __forceinline__ void k1f_sort128(const K1fL& S, const u8* T, u32 n, c
 //   2. k1f_flush: suffix-array slice and head bits written ONCE; what still ties goes to the refinement rounds' lists, and
 //      what could not be handled here (groups above K1F_GBIG rotations) to the task levels.
 // Buckets beyond LDS (cnt > K1F_CAP: an unlucky sample, a moderately heavy key) and buckets of ONE 8-byte key beyond LDS
-// (HTML-like input: a quarter of all rotations) are level-0 tasks.  `lists` = 0: 8-byte keys, no lists, no tasks but the
-// oversize buckets (linear mode; cyclic mode with the text stages off).
+// (HTML-like input: a quarter of all rotations; round 6: fewer and smaller - a heavy key's rotations are spread over several
+// buckets by k1f_hist) are level-0 tasks, also when no text stage follows (round 6: every group is to be 16 bytes deep, the
+// doubling rounds start there); a bucket of ONE 16-byte key beyond LDS (fp16) is a group as it stands.  `lists` = 0: 8-byte
+// keys, no lists, no tasks but the oversize buckets (linear mode; cyclic mode with the text stages off).
 // `purerot_max`: with more rotations than this in one-key buckets (counted by k1f_scan) the text stages are skipped
 // altogether (CJS_DEEP_BIG_DIV = 8: HTML-like input, whose ties of hundreds of bytes prefix doubling settles faster).
 // One bucket per workgroup.  (Round 5, measured and dropped, ms for the kernel on enwik against 2.08: neighbouring buckets - adjacent key ranges - sorted
