@@ -180,7 +180,7 @@ static napi_value DeviceCount(napi_env env, napi_callback_info) {
 
 // result blocks of Compress: a pool of at most four (what is beyond that is freed when its Buffer is collected).  The pool is shared by
 // every environment of the process (worker_threads load the same addon): guarded by a mutex.
-struct StageBlock { uint8_t* data; uint64_t cap; uint64_t size; int64_t accounted; };   // size: bytes allocated; accounted: bytes V8 was told an external Buffer over this block holds
+struct StageBlock { uint8_t* data; uint64_t cap; uint64_t size; int64_t accounted; uint64_t hw; };   // size: bytes of address space; accounted: bytes V8 was told an external Buffer over this block holds; hw: bytes ever written (resident pages)
 static std::vector<StageBlock*> g_stage_pool;
 static std::mutex g_stage_mu;
 static StageBlock* stage_take(uint64_t cap) {
@@ -195,7 +195,7 @@ static StageBlock* stage_take(uint64_t cap) {
     void* mem = nullptr;
     if (posix_memalign(&mem, 2u << 20, sz) != 0) return nullptr;
     (void)madvise(mem, sz, MADV_HUGEPAGE);
-    StageBlock* b = new StageBlock{(uint8_t*)mem, cap, sz, 0};
+    StageBlock* b = new StageBlock{(uint8_t*)mem, cap, sz, 0, 0};
     return b;
 }
 static void stage_give(StageBlock* b) {
@@ -212,11 +212,17 @@ static void stage_finalize(napi_env env, void*, void* hint) {
     if (b->accounted) { napi_adjust_external_memory(env, -b->accounted, &now); b->accounted = 0; }
     stage_give(b);
 }
-// A result goes to JavaScript as an EXTERNAL Buffer over its block only when that pays and costs little: at least 1 MB (below that a copy
-// is microseconds) and at least an eighth of the block (the block is sized for the worst case, 1.5 x the input + 24 KB per 100 KB: a few KB
-// of result must not pin 2 MB, nor 20 MB of result 175 MB).  Everything else is copied into an exact-size Buffer and the block goes
-// straight back to the pool.
-static bool stage_external(const StageBlock* b, uint64_t n) { return n >= (1u << 20) && n * 8u >= b->size; }
+// A result of at least 1 MB goes to JavaScript as an EXTERNAL Buffer over its block (below that a copy is microseconds, and a few KB must not pin a
+// block).  A block is sized for the worst case (1.5 x the input + 24 KB per 100 KB: 175 MB of ADDRESS SPACE for a 10^8-byte input), but only the
+// pages a result was written into are resident; what an earlier, larger result left resident behind the current one is given back to the system
+// before the Buffer is handed over (madvise DONTNEED), and V8 is told the resident size (a retained 29 MB result holds 30 MB, not 175).
+static bool stage_external(const StageBlock*, uint64_t n) { return n >= (1u << 20); }
+static uint64_t stage_trim(StageBlock* b, uint64_t n) {
+    const uint64_t keep = (n + ((2u << 20) - 1)) & ~(uint64_t)((2u << 20) - 1);
+    if (b->hw > keep) (void)madvise(b->data + keep, (size_t)(b->hw - keep), MADV_DONTNEED);
+    b->hw = keep < b->size ? keep : b->size;
+    return b->hw;
+}
 
 static napi_value Compress(napi_env env, napi_callback_info info) {
     size_t argc = 2; napi_value argv[2];
@@ -238,16 +244,16 @@ static napi_value Compress(napi_env env, napi_callback_info info) {
                                         : p_compress(g_ctx, in, len, level, blk->data, cap);
     if (n < 0) { stage_give(blk); return throw_code(env, n, "cjs_bz2_compress"); }
     napi_value out;
+    if ((uint64_t)n > blk->hw) blk->hw = (uint64_t)n;
     if (!stage_external(blk, (uint64_t)n) || napi_create_external_buffer(env, (size_t)n, blk->data, stage_finalize, blk, &out) != napi_ok) {
         void* dst;                                           // (small results, and embedders without external buffers: a copy)
         napi_create_buffer_copy(env, (size_t)n, blk->data, &dst, &out);
         stage_give(blk);
     } else {
-        // V8 sees a Buffer object of a few dozen bytes: tell it what hangs on it - the whole block, not the n bytes of the result -, or
-        // results pile up uncollected (every call a fresh block whose pages the D2H copy has to fault in) until the heap of small objects
-        // happens to fill
+        // V8 sees a Buffer object of a few dozen bytes: tell it what hangs on it - the block's resident pages -, or results pile up
+        // uncollected (every call a fresh block whose pages the D2H copy has to fault in) until the heap of small objects happens to fill
         int64_t now;
-        blk->accounted = (int64_t)blk->size;
+        blk->accounted = (int64_t)stage_trim(blk, (uint64_t)n);
         napi_adjust_external_memory(env, blk->accounted, &now);
     }
     return out;
@@ -374,13 +380,13 @@ static napi_value fetch_result(napi_env env, int64_t n) {
         // a large result: fetched into a pooled, huge-page-advised block handed over as an external Buffer (as Compress does) - a fresh
         // Node Buffer of 10^8 bytes is 24 400 small pages faulted in by the copy
         StageBlock* blk = stage_take((uint64_t)n);
-        if (blk && !stage_external(blk, (uint64_t)n)) { stage_give(blk); blk = nullptr; }     // (a pooled block many times the result: not pinned for it)
         if (blk) {
             const int64_t m = p_fetch(g_ctx, blk->data, (uint64_t)n);
             if (m < 0) { stage_give(blk); return throw_code(env, m, "cjs_bz2_fetch"); }
+            if ((uint64_t)n > blk->hw) blk->hw = (uint64_t)n;
             if (napi_create_external_buffer(env, (size_t)n, blk->data, stage_finalize, blk, &out) == napi_ok) {
                 int64_t now;
-                blk->accounted = (int64_t)blk->size;
+                blk->accounted = (int64_t)stage_trim(blk, (uint64_t)n);
                 napi_adjust_external_memory(env, blk->accounted, &now);
                 return out;
             }
