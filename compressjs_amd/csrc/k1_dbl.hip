@@ -330,6 +330,11 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
     __shared__ __attribute__((aligned(16))) u32 kk[K1D_N + 8];
     __shared__ u32 tpre[K1D_NBW + 1], scr[256];
     __shared__ u32 s_cnt[K1D_NBW], s_n[K1D_NBW], s_hm[K1D_NBW], s_mode[K1D_NBW];     // per slot (block): what a tile needs of its block
+    // Round 6, blocks that k1_period.hip reduced to three periods (red[b] = p): two rotations of the SAME phase (s mod p) never need a comparison - they agree
+    // until the later one wraps, and then ONE sign decides for the whole block (k1_period.hip: W_r0 against W_0, K1P_RASC).  A tiled input keeps every
+    // rotation in such groups (three copies of everything) for log2(p) rounds; a group whose members all share a phase is settled by index order on the spot.
+    __shared__ u32 s_per[K1D_NBW], s_asc[K1D_NBW];
+    __shared__ u32 ks[K1D_N + 8], kp[K1D_N + 8];                                      // rotation / phase of every owned cell (periodic blocks only)
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u32 linear = B.linear;
     const u32* cnt_row = B.dcnt + (size_t)r * B.rstride;
@@ -344,13 +349,15 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
             s_n[tid] = nn;
             s_hm[tid] = nn ? (h >> 32 ? (u32)(h % nn) : (u32)h % nn) : 0u;
             s_mode[tid] = k1d_mode(B, r, bb, final_h);
+            s_per[tid] = linear ? 0u : B.red[bb];
+            s_asc[tid] = B.ptab[(size_t)bb * 256u + 202u];          // K1P_RASC (k1_period.hip)
         }
         __syncthreads();
         // a tile of the flat sequence: block, first entry, entries of the block's list
-        struct Tile { u32 b, e0, cnt, n, hm, mode; };
+        struct Tile { u32 b, e0, cnt, n, hm, mode, per, asc; };
         auto tile_of = [&](u32 f) {
             Tile t;
-            t.b = 0; t.e0 = 0; t.cnt = 0; t.n = 1; t.hm = 0; t.mode = 0;
+            t.b = 0; t.e0 = 0; t.cnt = 0; t.n = 1; t.hm = 0; t.mode = 0; t.per = 0; t.asc = 0;
             if (f < ntile) {
                 const u32 i = k1d_tile_block(tpre, q.slots, f);
                 t.b = q.first + q.step * i;
@@ -359,6 +366,8 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
                 t.n = s_n[i];
                 t.hm = s_hm[i];
                 t.mode = s_mode[i];
+                t.per = s_per[i];
+                t.asc = s_asc[i];
             }
             return t;
         };
@@ -395,7 +404,10 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
 #pragma unroll
             for (u32 it = 0; it < K1D_RPT; it++) {
                 const u32 i = (it * 4u + w) * 64u + lane;
-                if (own(eC[it], i)) kk[i] = pack ? (kC[it] << 11) | i : kC[it];
+                if (own(eC[it], i)) {
+                    kk[i] = pack ? (kC[it] << 11) | i : kC[it];
+                    if (tC.per) { const u32 sx_ = K1E_S(eC[it]); ks[i] = sx_; kp[i] = sx_ % tC.per; }     // (uniform per tile)
+                }
             }
             lds_barrier();
             u32 kN[K1D_RPT];
@@ -413,6 +425,21 @@ __global__ __launch_bounds__(256, K1D_MINW) void k1d_round(K1Buf B, BatchGeom g,
                     Lt[tC.e0 + i] = K1E_MAKE(0u, 0u, K1E_S(eC[it]), tpos) | K1E_KEEP;      // final; k1d_update has nothing to do for it
                 } else if (own(eC[it], i)) {
                     const u32 gs = i - K1E_IDX(eC[it]), ge = gs + K1E_LEN(eC[it]);
+                    if (tC.per) {
+                        // a group of ONE phase: index order with the block's sign, every member final
+                        const u32 sx_ = K1E_S(eC[it]), myph = kp[i];
+                        u32 diff = 0, lt = 0;
+                        for (u32 j = gs; j < ge; j++) { diff |= kp[j] ^ myph; lt += ks[j] < sx_ ? 1u : 0u; }
+                        if (diff == 0u) {
+                            const u32 q = gs + (tC.asc ? lt : ge - gs - 1u - lt);
+                            const u32 pos = K1E_POS(eC[it]) + q - i;
+                            const bool keep = pos == K1E_POS(eC[it]) - K1E_IDX(eC[it]);
+                            Lt[tC.e0 + q] = K1E_MAKE(0u, 0u, sx_, pos) | (keep ? K1E_KEEP : 0ull);
+                            SA[pos] = sx_;
+                            changed |= 1u;
+                            continue;
+                        }
+                    }
                     const u32 m = kC[it];
                     u32 less = 0, eqb = 0, eqt = 0;
                     if (pack) {
