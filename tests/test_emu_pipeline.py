@@ -644,6 +644,20 @@ print("ok", seen)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("env_add", [{}, {"CJS_DEEP_BIG_DIV": "1073741824"}], ids=["default", "doubling_forced"])
+def test_long_period_words_same_phase_groups(env_add):
+    """k1d_round's shortcut for blocks reduced to three periods (a group whose members share s mod p is settled by index order with the
+    block's sign): tests/period_stress.py - period words that are text, binary noise, Q^m with defects (groups of several phases), one
+    phrase planted many times, 0xFF-heavy, and tests/periodwords.py's families; p from 65 to n / 4, n = 0, 1, p - 1 or anything (mod p) -
+    16 blocks per setting against the oracle's cyclic BWT; with the doubling path forced every triple of the reduced block goes through it."""
+    import subprocess
+    import sys
+    stagelib.build_emu()
+    r = subprocess.run([sys.executable, os.path.join(stagelib.ROOT, "tests", "period_stress.py"), "31", "16"],
+                       env=dict(os.environ, **env_add), capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0 and r.stdout.startswith("ok 16"), r.stdout + r.stderr[-3000:]
+
+
 def test_long_period_blocks_sorted_through_three_periods():
     """k1_period.hip, periods beyond 64: a block T of period p (n >= 16384, 3 p + n mod p <= 0.8 n) is sorted as its first
     n' = 3 p + (n mod p) bytes (n' = p when p divides n) and expanded - every phase's missing members next to the first one the

@@ -587,6 +587,18 @@ def test_adversarial_period_words_vs_oracle():
 
 
 @pytest.mark.gpu
+def test_long_period_words_same_phase_groups_vs_oracle():
+    """tests/period_stress.py at the -9 block capacity: 48 blocks of period 65 .. n / 4 (text, binary noise, Q^m with defects, planted
+    phrases, 0xFF-heavy words, tests/periodwords.py's families; n = 0, 1, p - 1 or anything mod p) through cjs_bwt_cyclic_batch - the
+    three-period reduction and, behind it, k1d_round's same-phase shortcut - transform and origPtr equal the oracle's."""
+    import subprocess
+    import sys
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tests", "period_stress.py"), "41", "48"],
+                                  env=dict(os.environ, CJS_STRESS_GPU="1", CJS_K1_TRACE="1"), timeout=1500, stderr=subprocess.DEVNULL).decode().split()
+    assert out[0] == "ok" and out[1] == "48" and int(out[-1]) >= 4, out     # the last batch of eight went through the reduction
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env_add", [{}, {"CJS_K1_CARRY": "0"}, {"CJS_TEXT_BYTES": "0"}, {"CJS_DEEP_BIG_DIV": "1073741824"}],
                          ids=["default", "carry_off", "text_stages_off", "doubling_path_from_16"])
 def test_attack_words_on_the_bucket_sort_vs_oracle(env_add):
