@@ -4,7 +4,8 @@ run for all shapes at once on the host's cores); libbz2's verdict is only a thir
 run gets no count byte from the reference (lib/Bzip2.js:640-644, mirrored on purpose), and libbz2 rejects such streams."""
 import sys, os, time, bz2, hashlib
 from concurrent.futures import ProcessPoolExecutor
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 
 N = 50_000_000
@@ -22,7 +23,7 @@ def shapes(N=N):
     base = synth.text_like(200_000, 5)
     out.append(('200k text tiled', np.tile(base, N // base.size)))
     for f in ('sample5.ref', 'sample4.ref', 'sample3.ref', 'sample2.ref'):
-        p = os.path.join('oracle', '_ref', 'fixtures', f)
+        p = os.path.join(ROOT, 'oracle', '_ref', 'fixtures', f)
         if os.path.exists(p):
             d = np.fromfile(p, dtype=np.uint8)
             out.append((f + ' tiled', np.tile(d, max(1, N // d.size))))

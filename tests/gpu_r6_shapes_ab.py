@@ -1,6 +1,7 @@
 """A/B of variant libraries on a few data shapes (not a test): COMPRESSJS_AMD_LIB=... python tests/gpu_r6_shapes_ab.py [names...]"""
 import sys, os, hashlib
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 import gpu_perf_probe as P
 from compressjs_amd.bzip2 import Context
