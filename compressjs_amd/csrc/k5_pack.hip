@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64) void k5_blockscan(Pipe P) {
     if (P.snap) *P.snap = bits;
 }
 
+#define K5_STAGE_WORDS ((K1_RT * 20u + 62u) / 32u + 2u)    // a tile of K1_RT symbols, at most 20 bits each, starting anywhere in a word
 __device__ __forceinline__ void or_word(u32* out, u64 wi, u32 word) {
     if (word) atomicOr(&out[wi], bswap32(word));
 }
@@ -301,19 +302,20 @@ __global__ __launch_bounds__(256) void k5_pack(Pipe P) {
         }
     }
     if (t0 >= pos) return;
-    __shared__ u8 lens[CJS_MAX_GROUPS][CJS_LEN_PITCH];
-    __shared__ u32 codes[CJS_MAX_GROUPS][CJS_LEN_PITCH];
+    // The tile's bits are assembled in LDS and leave as whole words: only the first and the last word of a tile are shared with its neighbours
+    // (or the header) and need the atomic OR - one per output word from every thread was what the kernel's time went into (round 6: 31-36 ps per word).
+    __shared__ u32 codes[CJS_MAX_GROUPS][CJS_LEN_PITCH];       // code | length << 24 (lengths <= 20): ONE lookup per symbol, kept for the second walk
     __shared__ u32 sh[256];
+    __shared__ u32 stage[K5_STAGE_WORDS];
+    __shared__ u32 s_tot;
     const u32 G = P.ngroups[b];
-    for (u32 i = tid; i < G * CJS_LEN_PITCH; i += 256) {
-        (&lens[0][0])[i] = P.lens[(size_t)b * CJS_MAX_GROUPS * CJS_LEN_PITCH + i];
-        (&codes[0][0])[i] = P.codes[(size_t)b * CJS_MAX_GROUPS * CJS_LEN_PITCH + i];
-    }
+    for (u32 i = tid; i < G * CJS_LEN_PITCH; i += 256)
+        (&codes[0][0])[i] = P.codes[(size_t)b * CJS_MAX_GROUPS * CJS_LEN_PITCH + i] | ((u32)P.lens[(size_t)b * CJS_MAX_GROUPS * CJS_LEN_PITCH + i] << 24);
     __syncthreads();
     const u16* A = P.A + (size_t)b * g.stride;
     const u8* sel = P.sel + (size_t)b * P.selPitch;
     const u32 i0 = t0 + tid * 16u;
-    // The thread's 16 symbols in two 16-byte loads and its (at most two) selectors in two byte loads, kept for both walks
+    // The thread's 16 symbols in two 16-byte loads and its (at most two) selectors in two byte loads
     // (round 3: 16 + 16 two-byte loads 32 bytes apart from lane to lane, twice over, were 64 requests per load instruction).
     u32 aw[8];
 #pragma unroll
@@ -326,33 +328,47 @@ __global__ __launch_bounds__(256) void k5_pack(Pipe P) {
         s0 = sel[g0];
         if (gb < i0 + 16u && gb < pos) s1 = sel[g0 + 1u];
     }
+    u32 e[16];                                                       // 0 behind the block's end: no bits
     u32 mine = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 i = i0 + k;
-        if (i < pos) mine += lens[i < gb ? s0 : s1][(aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+        e[k] = i < pos ? codes[i < gb ? s0 : s1][(aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu] : 0u;
+        mine += e[k] >> 24;
     }
     const u32 ex = block_excl_scan_256(mine, sh);
-    if (i0 >= pos) return;
-    const u64 bitpos = boff + P.tileBits[(size_t)b * g.rtiles + t] + ex;
-    u64 wi = bitpos >> 5;
-    u32 nacc = (u32)(bitpos & 31u);        // bits of the current word that belong to earlier symbols
-    u64 acc = 0;
-    for (int k = 0; k < 16; k++) {
-        const u32 i = i0 + k;
-        if (i >= pos) break;
-        const u32 gsel = i < gb ? s0 : s1, sym = (aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-        const u32 l = lens[gsel][sym];
-        acc = (acc << l) | codes[gsel][sym];
-        nacc += l;
-        if (nacc >= 32u) {
-            nacc -= 32u;
-            or_word(P.out, wi, (u32)(acc >> nacc));
-            wi++;
-            acc &= (1ull << nacc) - 1ull;
+    if (tid == 255) s_tot = ex + mine;
+    __syncthreads();
+    const u64 tbit = boff + P.tileBits[(size_t)b * g.rtiles + t];     // where the tile's first bit goes
+    const u64 w0 = tbit >> 5;
+    const u32 nw = ((u32)(tbit & 31u) + s_tot + 31u) >> 5;           // words the tile touches (<= K5_STAGE_WORDS)
+    for (u32 j = tid; j < nw; j += 256) stage[j] = 0;
+    __syncthreads();
+    if (mine) {
+        const u32 rel = (u32)(tbit & 31u) + ex;                      // the thread's first bit, from the top of word w0
+        u32 wi = rel >> 5;
+        u32 nacc = rel & 31u;                                        // bits of the current word that belong to earlier symbols
+        u64 acc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u32 l = e[k] >> 24;
+            acc = (acc << l) | (e[k] & 0xFFFFFFu);
+            nacc += l;
+            if (nacc >= 32u) {
+                nacc -= 32u;
+                atomicOr(&stage[wi], (u32)(acc >> nacc));
+                wi++;
+                acc &= (1ull << nacc) - 1ull;
+            }
         }
+        if (nacc) atomicOr(&stage[wi], (u32)(acc << (32u - nacc)));
     }
-    if (nacc) or_word(P.out, wi, (u32)(acc << (32u - nacc)));
+    __syncthreads();
+    for (u32 j = tid; j < nw; j += 256) {
+        const u32 v = stage[j];
+        if (j == 0u || j + 1u == nw) or_word(P.out, w0 + j, v);
+        else P.out[w0 + j] = bswap32(v);
+    }
 }
 
 // 'B','Z','h','0'+level (lib/Bzip2.js:903-906); resets the running stream state
