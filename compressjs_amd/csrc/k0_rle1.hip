@@ -174,33 +174,41 @@ __global__ __launch_bounds__(256) void k0_scan_apply(u64* data, const u64* chunk
 // ---- in-tile helper: every thread owns 16 consecutive bytes of tile t ----------------------------
 // Returns, for the thread's first byte, the start of its run (global, uncut), given the tile's
 // incoming run start rs_in.  `sh` is 256 u64 of LDS.  Also returns the bytes in b[16].
-__device__ __forceinline__ u64 tile_runstarts(const K0Buf& K, u64 t, u64 rs_in, u8* b, u64* sh) {
+// hm: bit k = the thread's k-th byte exists (is below in_len) and starts a run.  Everything inside is tile-relative and 32 bits wide
+// (round 6: 64-bit positions per byte - compares, the max-scan's shuffles - were a third of the instructions of the kernels that call it).
+__device__ __forceinline__ u64 tile_runstarts(const K0Buf& K, u64 t, u64 rs_in, u8* b, u64* sh, u32& hm) {
     const u32 tid = threadIdx.x;
     const u64 j0 = t * K0_TILE + tid * 16u;
-    u64 lastb = K0_NONE;
     u8 prev = 0;
     if (j0 > 0 && j0 - 1 < K.in_len) prev = K.in[j0 - 1];
     load16(K, j0, b);
+    const u32 nv = j0 >= K.in_len ? 0u : (K.in_len - j0 < 16u ? (u32)(K.in_len - j0) : 16u);   // bytes of the thread that exist
+    u32 heads = (j0 == 0 || b[0] != prev) ? 1u : 0u;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u64 j = j0 + k;
-        if (j < K.in_len && (j == 0 || b[k] != (k ? b[k - 1] : prev))) lastb = j + 1;
-    }
-    // exclusive max-scan over the 256 threads: shuffles inside a wave, one LDS hop across the 4 waves
-    u64 v = lastb;
+    for (int k = 1; k < 16; k++) heads |= b[k] != b[k - 1] ? 1u << k : 0u;
+    heads &= (1u << nv) - 1u;
+    hm = heads;
+    // 1 + tile-relative index of the thread's last run start, 0 = none; exclusive max-scan over the 256 threads: shuffles inside a wave, one LDS hop across the 4 waves
+    u32 v = heads ? tid * 16u + 32u - (u32)__clz((int)heads) : 0u;
     const u32 lane = tid & 63u, w = tid >> 6;
+    u32* sh32 = (u32*)sh;
     for (u32 off = 1; off < 64; off <<= 1) {
-        const u64 u = __shfl_up(v, off);
+        const u32 u = (u32)__shfl_up((int)v, off);
         if (lane >= off && u > v) v = u;
     }
-    if (lane == 63u) sh[w] = v;
+    if (lane == 63u) sh32[w] = v;
     __syncthreads();
-    u64 before = __shfl_up(v, 1u);                        // inclusive of the previous lane = exclusive here
-    if (lane == 0) before = K0_NONE;
-    for (u32 ww = 0; ww < w; ww++) if (sh[ww] > before) before = sh[ww];
+    u32 before = (u32)__shfl_up((int)v, 1u);              // inclusive of the previous lane = exclusive here
+    if (lane == 0) before = 0;
+    for (u32 ww = 0; ww < w; ww++) if (sh32[ww] > before) before = sh32[ww];
     __syncthreads();
-    return before != K0_NONE ? before - 1 : rs_in;
+    return before ? t * K0_TILE + before - 1u : rs_in;
 }
+__device__ __forceinline__ u64 tile_runstarts(const K0Buf& K, u64 t, u64 rs_in, u8* b, u64* sh) {
+    u32 hm;
+    return tile_runstarts(K, t, rs_in, b, sh, hm);
+}
+__device__ __forceinline__ u32 k0_mod255(u64 d) { return (d >> 32) ? (u32)(d % 255u) : (u32)d % 255u; }
 
 // ---- per-tile cost with uncut runs ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void k0_tile_cost(K0Buf K) {
@@ -211,18 +219,19 @@ __global__ __launch_bounds__(256) void k0_tile_cost(K0Buf K) {
     u8 b[16];
     const u64 rsin_raw = K.tileA[t];                        // exclusive max-scan: last boundary (+1) before the tile
     const u64 rs_in = rsin_raw != K0_NONE ? rsin_raw - 1 : 0;
-    u64 rs = tile_runstarts(K, t, rs_in, b, sh);
+    u32 hm;
+    const u64 rs = tile_runstarts(K, t, rs_in, b, sh, hm);
     const u64 j0 = t * K0_TILE + threadIdx.x * 16u;
+    const u32 nv = j0 >= K.in_len ? 0u : (K.in_len - j0 < 16u ? (u32)(K.in_len - j0) : 16u);
     u32 c = 0, sub = 0;                                   // sub = (j - rs) mod 255, kept incrementally: one division per thread
+    if (nv) {
+        sub = (hm & 1u) ? 0u : k0_mod255(j0 - rs);
+        c = sub < 3u ? 1u : (sub == 3u ? 2u : 0u);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const u64 j = j0 + k;
-        if (j >= K.in_len) break;
-        const bool head = k == 0 ? (j == 0 || K.in[j - 1] != b[0]) : (b[k] != b[k - 1]);
-        if (head) { rs = j; sub = 0; }
-        else if (k == 0) sub = (u32)((j - rs) % 255u);
-        else sub = sub == 254u ? 0u : sub + 1u;
-        c += sub < 3u ? 1u : (sub == 3u ? 2u : 0u);
+        for (u32 k = 1; k < 16; k++) {
+            sub = ((hm >> k) & 1u) ? 0u : (sub == 254u ? 0u : sub + 1u);
+            c += k < nv ? (sub < 3u ? 1u : (sub == 3u ? 2u : 0u)) : 0u;
+        }
     }
     const u32 wsum = wave_incl_scan_dpp(c);               // lane 63: the wave's sum (256 lanes on one LDS atomic queued)
     if ((threadIdx.x & 63u) == 63u) atomicAdd(&tot, wsum);
@@ -497,24 +506,26 @@ __global__ __launch_bounds__(256) void k0_materialize(K0Buf K, Pipe P, u32 first
         const u64 rsin_raw = K.tileA[t];
         const u64 rs_in = rsin_raw != K0_NONE ? rsin_raw - 1 : 0;
         u8 by[16];
-        u64 rs = tile_runstarts(K, t, rs_in, by, sh);
+        u32 hm;
+        const u64 rs = tile_runstarts(K, t, rs_in, by, sh, hm);
         const u64 j0 = t * K0_TILE + tid * 16u;
+        // the thread's bytes inside the block: k in [sR, eR)
+        const u64 eend = e < K.in_len ? e : K.in_len;
+        const u32 sR = s <= j0 ? 0u : (s - j0 >= 16u ? 16u : (u32)(s - j0));
+        const u32 eR = eend <= j0 ? 0u : (eend - j0 >= 16u ? 16u : (u32)(eend - j0));
         // output position of the thread's first byte
         u32 cs[16], mine = 0, sub = 0;
-        bool have = false;                                // sub = (j - rss) mod 255 is valid
+        if (sR < eR) {                                    // (j - start of the run, cut by the block start) mod 255 at the first byte inside: one division per thread
+            const u32 m = hm & ((2u << sR) - 1u);
+            const u64 rsa = m ? j0 + (31u - (u32)__clz((int)m)) : rs;
+            const u64 rss = rsa > s ? rsa : s;
+            sub = k0_mod255(j0 + sR - rss);
+        }
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const u64 j = j0 + k;
+        for (u32 k = 0; k < 16; k++) {
             cs[k] = 0;
-            if (j >= K.in_len) continue;
-            const bool head = k == 0 ? (j == 0 || K.in[j - 1] != by[0]) : (by[k] != by[k - 1]);
-            if (head) rs = j;
-            if (j >= s && j < e) {
-                const u64 rss = rs > s ? rs : s;          // the block start cuts the run
-                if (j == rss) sub = 0;
-                else if (!have) sub = (u32)((j - rss) % 255u);      // one division per thread
-                else sub = sub == 254u ? 0u : sub + 1u;
-                have = true;
+            if (k >= sR && k < eR) {
+                if (k > sR) sub = ((hm >> k) & 1u) ? 0u : (sub == 254u ? 0u : sub + 1u);
                 cs[k] = sub < 3u ? 1u : (sub == 3u ? 2u : 0u);
                 mine += cs[k];
             }
@@ -525,10 +536,10 @@ __global__ __launch_bounds__(256) void k0_materialize(K0Buf K, Pipe P, u32 first
         // output bytes before the first in-block byte of this tile
         const u64 tb = t * K0_TILE > s ? t * K0_TILE : s;
         const u64 ob0 = tb <= re ? (u64)k0_g(tb - s) : K.tileC[t] - adj;   // tb > re implies tile-aligned tb
-        u64 ob = ob0 + excl;
-        for (int k = 0; k < 16; k++) {
+        u32 ob = (u32)(ob0 + excl);                       // (inside the block: below its capacity)
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) {
             const u64 j = j0 + k;
-            if (j < s || j >= e || j >= K.in_len) continue;
             if (cs[k]) {
                 if (ob < n) T[ob] = by[k];
                 if (cs[k] == 2 && ob + 1 < n) {
