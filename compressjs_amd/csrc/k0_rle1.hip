@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256) void k0_materialize(K0Buf K, Pipe P, u32 first
         const u32 eR = eend <= j0 ? 0u : (eend - j0 >= 16u ? 16u : (u32)(eend - j0));
         // output position of the thread's first byte
         u32 cs[16], mine = 0, sub = 0;
+        bool plain = true;                                // all sixteen bytes are inside the block and none is the 4th .. 255th of a run
         if (sR < eR) {                                    // (j - start of the run, cut by the block start) mod 255 at the first byte inside: one division per thread
             const u32 m = hm & ((2u << sR) - 1u);
             const u64 rsa = m ? j0 + (31u - (u32)__clz((int)m)) : rs;
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(256) void k0_materialize(K0Buf K, Pipe P, u32 first
                 cs[k] = sub < 3u ? 1u : (sub == 3u ? 2u : 0u);
                 mine += cs[k];
             }
+            plain = plain && cs[k] == 1u;
         }
         u32 tile_total;
         const u32 excl = block_excl_scan_1024(mine, (u32*)sh, &tile_total);   // wave shuffles + one LDS hop
@@ -537,6 +539,9 @@ __global__ __launch_bounds__(256) void k0_materialize(K0Buf K, Pipe P, u32 first
         const u64 tb = t * K0_TILE > s ? t * K0_TILE : s;
         const u64 ob0 = tb <= re ? (u64)k0_g(tb - s) : K.tileC[t] - adj;   // tb > re implies tile-aligned tb
         u32 ob = (u32)(ob0 + excl);                       // (inside the block: below its capacity)
+        // sixteen bytes that all stand for themselves: one (unaligned) 16-byte store
+        if (plain && ob + 16u <= n) __builtin_memcpy(T + ob, by, 16);
+        else
 #pragma unroll
         for (u32 k = 0; k < 16; k++) {
             const u64 j = j0 + k;
