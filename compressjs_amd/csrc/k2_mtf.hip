@@ -27,33 +27,57 @@ __device__ __forceinline__ u32 popc_below(const u32* used8, u32 s) {
 }
 
 // ---- run heads -------------------------------------------------------------------------------
+// A wave walks its 1024 bytes of the tile 256 at a time, FOUR per lane in one dword (round 6: two byte loads per element and pass were what k2_count and
+// k2_compact spent their instructions on): the byte in front of a lane's four comes from the lane below, in front of lane 0 from the step before.
+// Returns the lane's dword and, in hb, bit k = byte k exists and starts a run.
+__device__ __forceinline__ u32 k2_heads4(const u8* U, u32 n, u32 i, u32 lane, u32& carry, u32& hb) {
+    const u32 wv = i < n ? *(const u32*)(U + i) : 0u;
+    u32 pb = (u32)__shfl_up((int)wv, 1u) >> 24;
+    if (lane == 0) pb = carry;
+    carry = (u32)__builtin_amdgcn_readlane((int)wv, 63) >> 24;
+    const u32 x = wv ^ ((wv << 8) | pb);
+    u32 h = ((x & 0xFFu) ? 1u : 0u) | ((x & 0xFF00u) ? 2u : 0u) | ((x & 0xFF0000u) ? 4u : 0u) | ((x & 0xFF000000u) ? 8u : 0u);
+    if (i == 0) h |= 1u;
+    const u32 nv = i >= n ? 0u : (n - i < 4u ? n - i : 4u);
+    hb = h & ((1u << nv) - 1u);
+    return wv;
+}
+
 __global__ __launch_bounds__(256) void k2_count(Pipe P) {
     const BatchGeom g = P.g;
     const u32 b = blockIdx.y, t = blockIdx.x;
     const u32 n = P.nlen[b];
     const u32 t0 = t * K1_RT;
     if (t0 >= n) { if (threadIdx.x == 0) P.tileCnt[(size_t)b * g.rtiles + t] = 0; return; }
-    __shared__ u32 usedw[8];
+    __shared__ u32 flag[256];                             // byte value seen (plain stores of 1: the eight words of the map took one LDS atomic per run head, 64 lanes on eight addresses)
     __shared__ u32 cnt;
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
-    if (tid < 8) usedw[tid] = 0;
-    if (tid == 8) cnt = 0;
+    flag[tid] = 0;
+    if (tid == 0) cnt = 0;
     __syncthreads();
     const u8* U = P.U + (size_t)b * g.stride;
+    const u32 base = t0 + w * 1024u;
+    u32 carry = base ? (u32)U[base - 1u] : 0u;
     u32 c = 0;
-    for (int it = 0; it < 16; it++) {
-        const u32 i = t0 + w * 1024u + it * 64u + lane;
-        bool head = false;
-        if (i < n) {
-            const u32 s = U[i];
-            head = (i == 0) || (U[i - 1] != s);
-            if (head) atomicOr(&usedw[s >> 5], 1u << (s & 31u));
-        }
-        c += (u32)__popcll(__ballot(head));
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const u32 i = base + it * 256u + lane * 4u;
+        u32 hb;
+        const u32 wv = k2_heads4(U, n, i, lane, carry, hb);
+        if (hb & 1u) flag[wv & 0xFFu] = 1u;
+        if (hb & 2u) flag[(wv >> 8) & 0xFFu] = 1u;
+        if (hb & 4u) flag[(wv >> 16) & 0xFFu] = 1u;
+        if (hb & 8u) flag[wv >> 24] = 1u;
+        c += (u32)__popc(hb);
     }
+    c = wave_sum_dpp(c);
     if (lane == 0) atomicAdd(&cnt, c);
     __syncthreads();
-    if (tid < 8 && usedw[tid]) atomicOr(&P.used[(size_t)b * 8 + tid], usedw[tid]);
+    const u64 seen = __ballot(flag[tid] != 0u);
+    if (lane < 2u) {                                      // (looking first at what the map already holds costs a round trip at the end of a workgroup that lives for a few microseconds: 0.114 -> 0.244 ms)
+        const u32 mine = (u32)(seen >> (32u * lane));
+        if (mine) atomicOr(&P.used[(size_t)b * 8 + 2u * w + lane], mine);
+    }
     if (tid == 0) P.tileCnt[(size_t)b * g.rtiles + t] = cnt;
 }
 
@@ -96,30 +120,32 @@ __global__ __launch_bounds__(256) void k2_compact(Pipe P) {
     __shared__ u32 wtot[4];
     const u32 tid = threadIdx.x, w = tid >> 6, lane = tid & 63u;
     const u8* U = P.U + (size_t)b * g.stride;
-    u32 c = 0;
-    for (int it = 0; it < 16; it++) {
-        const u32 i = t0 + w * 1024u + it * 64u + lane;
-        const bool head = i < n && (i == 0 || U[i - 1] != U[i]);
-        c += (u32)__popcll(__ballot(head));
+    const u32 base = t0 + w * 1024u;
+    u32 carry = base ? (u32)U[base - 1u] : 0u;
+    u32 wv[4], hb[4], inc[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        wv[it] = k2_heads4(U, n, base + it * 256u + lane * 4u, lane, carry, hb[it]);
+        inc[it] = wave_incl_scan_dpp((u32)__popc(hb[it]));          // run heads of the lanes up to this one
     }
-    if (lane == 0) wtot[w] = c;
+    if (lane == 63u) wtot[w] = inc[0] + inc[1] + inc[2] + inc[3];
     __syncthreads();
     u32 run = P.tileCnt[(size_t)b * g.rtiles + t];
     for (u32 i = 0; i < w; i++) run += wtot[i];
-    const u64 lt = lanemask_lt();
     u8* RHsym = P.RHsym + (size_t)b * g.stride;
     u32* RHpos = P.RHpos + (size_t)b * (g.stride + 1);
-    for (int it = 0; it < 16; it++) {
-        const u32 i = t0 + w * 1024u + it * 64u + lane;
-        const u32 s = i < n ? U[i] : 0u;
-        const bool head = i < n && (i == 0 || U[i - 1] != s);
-        const u64 bal = __ballot(head);
-        if (head) {
-            const u32 r = run + (u32)__popcll(bal & lt);
-            RHsym[r] = (u8)s;
-            RHpos[r] = i;
-        }
-        run += (u32)__popcll(bal);
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const u32 i = base + it * 256u + lane * 4u;
+        u32 r = run + inc[it] - (u32)__popc(hb[it]);
+#pragma unroll
+        for (u32 k = 0; k < 4; k++)
+            if ((hb[it] >> k) & 1u) {
+                RHsym[r] = (u8)(wv[it] >> (8u * k));
+                RHpos[r] = i + k;
+                r++;
+            }
+        run += (u32)__builtin_amdgcn_readlane((int)inc[it], 63);
     }
 }
 
