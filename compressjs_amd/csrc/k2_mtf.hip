@@ -14,7 +14,7 @@
 //       previous occurrence of the head's own symbol.  One wave per segment, 64 run heads per
 //       step; last occurrences inside the step come from wave ballots, older ones from a
 //       per-lane register table (4 symbols per lane), read with v_readlane.
-//   k2_symcount / k2_scan_syms / k2_emit : each run emits (index+1 if index>0) followed by the
+//   k2_mtf (symbol counts per tile) / k2_scan_tiles / k2_emit : each run emits (index+1 if index>0) followed by the
 //       bijective base-2 digits of its zero count (lib/Bzip2.js:783-794); exclusive scan gives
 //       the output offsets; freq[] by LDS histogram.  EOB appended (lib/Bzip2.js:813-814).
 #include "pipeline.h"
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void k2_count(Pipe P) {
     const u32 b = blockIdx.y, t = blockIdx.x;
     const u32 n = P.nlen[b];
     const u32 t0 = t * K1_RT;
+    if (threadIdx.x == 0) P.symCnt[(size_t)b * g.rtiles + t] = 0;            // (k2_mtf adds its waves' symbol counts)
     if (t0 >= n) { if (threadIdx.x == 0) P.tileCnt[(size_t)b * g.rtiles + t] = 0; return; }
     __shared__ u32 flag[256];                             // byte value seen (plain stores of 1: the eight words of the map took one LDS atomic per run head, 64 lanes on eight addresses)
     __shared__ u32 cnt;
@@ -186,6 +187,13 @@ __global__ __launch_bounds__(256) void k2_lastscan(Pipe P) {
     }
 }
 
+__device__ __forceinline__ u32 run_symbols(u32 j, u32 len, u32& zeros) {
+    zeros = len - (j ? 1u : 0u);
+    const u32 nd = zeros ? 31u - (u32)__clz((int)(zeros + 1u)) : 0u;
+    return (j ? 1u : 0u) + nd;
+}
+
+static_assert(K2_SEG * 4u == K1_RT, "a workgroup of k2_mtf = the runs of one symbol-count tile");
 // ---- MTF index of every run head ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
     const BatchGeom g = P.g;
@@ -205,6 +213,8 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
     for (int k = 0; k < 4; k++) usedw[k] = (u64)used8[2 * k] | ((u64)used8[2 * k + 1] << 32);
     const u8* RHsym = P.RHsym + (size_t)b * g.stride;
     u8* J = P.J + (size_t)b * g.stride;
+    const u32* RHpos = P.RHpos + (size_t)b * (g.stride + 1);
+    u32 nsym = 0;
     const u64 lt = lanemask_lt();
     __shared__ u8 occ[4][256];
     for (u32 i = lane; i < 256; i += 64) occ[w][i] = 0;
@@ -290,40 +300,18 @@ __global__ __launch_bounds__(256) void k2_mtf(Pipe P) {
                 Lr[k] = cjs_writelane(base + 63 - __builtin_clzll(ms), sl, Lr[k]);           // (ms != 0: s occurs)
             }
         }
-        if (valid) J[r] = (u8)idx;
+        if (valid) {
+            J[r] = (u8)idx;
+            u32 z;
+            nsym += run_symbols(idx, RHpos[r + 1u] - RHpos[r], z);         // (RHpos[nr] is the sentinel k2_scan_tiles wrote)
+        }
     }
+    // RLE2 symbols of the wave's runs into the tile's count (four waves = the 4096 runs of a tile; a kernel of its own until round 6)
+    nsym = wave_sum_dpp(nsym);
+    if (lane == 0) atomicAdd(&P.symCnt[(size_t)b * g.rtiles + blockIdx.x], nsym);
 }
 
 // ---- RLE2 symbol counts, offsets, emission ---------------------------------------------------
-__device__ __forceinline__ u32 run_symbols(u32 j, u32 len, u32& zeros) {
-    zeros = len - (j ? 1u : 0u);
-    const u32 nd = zeros ? 31u - (u32)__clz((int)(zeros + 1u)) : 0u;
-    return (j ? 1u : 0u) + nd;
-}
-
-__global__ __launch_bounds__(256) void k2_symcount(Pipe P) {
-    const BatchGeom g = P.g;
-    const u32 b = blockIdx.y, t = blockIdx.x;
-    const u32 nr = P.nruns[b];
-    const u32 t0 = t * K1_RT;
-    if (t0 >= nr) { if (threadIdx.x == 0) P.symCnt[(size_t)b * g.rtiles + t] = 0; return; }
-    __shared__ u32 tot;
-    if (threadIdx.x == 0) tot = 0;
-    __syncthreads();
-    const u8* J = P.J + (size_t)b * g.stride;
-    const u32* RHpos = P.RHpos + (size_t)b * (g.stride + 1);
-    u32 c = 0;
-    for (int k = 0; k < 16; k++) {
-        const u32 r = t0 + k * 256u + threadIdx.x;
-        if (r < nr) { u32 z; c += run_symbols(J[r], RHpos[r + 1] - RHpos[r], z); }
-    }
-    {   // one LDS atomic per wave (256 lanes on one word queued)
-        const u32 ws = wave_sum_dpp(c);
-        if ((threadIdx.x & 63u) == 0u) atomicAdd(&tot, ws);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) P.symCnt[(size_t)b * g.rtiles + t] = tot;
-}
 
 // A tile of 4096 runs emits at most 4096 * 21 symbols; the common case fits the LDS stage and is
 // written out with consecutive lanes on consecutive addresses, the rest goes straight to memory.
@@ -371,6 +359,7 @@ __global__ __launch_bounds__(256) void k2_emit(Pipe P) {
     const bool staged = total <= K2_STAGE;
     const u32 tile_off = P.symCnt[(size_t)b * g.rtiles + t];
     u32 off = ex;                                                      // tile-relative
+    u64 hot = 0;                                                       // (a thread emits at most 16 * 21 + 1 symbols, a wave 64 times that: the fields do not carry)
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const u32 r = r0 + k;
@@ -378,7 +367,10 @@ __global__ __launch_bounds__(256) void k2_emit(Pipe P) {
         const u32 j = jb[k];
         u32 z;
         run_symbols(j, rp[k + 1] - rp[k], z);
-#define K2_PUT(sym) do { if (staged) stage[off] = (u16)(sym); else A[tile_off + off] = (u16)(sym); off++; atomicAdd(&hist[(sym)], 1u); } while (0)
+        // (symbols 0 .. 3 - RUNA, RUNB and the two nearest list places, most of what a block emits - are counted in four 16-bit fields of a register and reach the
+        // histogram as one sum per wave: as LDS atomics they were dozens of lanes queueing on four addresses)
+#define K2_PUT(sym) do { if (staged) stage[off] = (u16)(sym); else A[tile_off + off] = (u16)(sym); off++; \
+                         if ((sym) < 4u) hot += 1ull << (16u * (sym)); else atomicAdd(&hist[(sym)], 1u); } while (0)
         if (j) K2_PUT(j + 1u);
         while (z) {                                   // lib/Bzip2.js:783-794
             if (z & 1u) { K2_PUT(0u); z -= 1u; }
@@ -390,6 +382,15 @@ __global__ __launch_bounds__(256) void k2_emit(Pipe P) {
             K2_PUT(eob);
         }
 #undef K2_PUT
+    }
+    {
+        const u32 lo = wave_sum_dpp((u32)hot), hi = wave_sum_dpp((u32)(hot >> 32));
+        if ((tid & 63u) == 0u) {
+            if (lo & 0xFFFFu) atomicAdd(&hist[0], lo & 0xFFFFu);
+            if (lo >> 16) atomicAdd(&hist[1], lo >> 16);
+            if (hi & 0xFFFFu) atomicAdd(&hist[2], hi & 0xFFFFu);
+            if (hi >> 16) atomicAdd(&hist[3], hi >> 16);
+        }
     }
     __syncthreads();
     if (staged) for (u32 i = tid; i < total; i += 256) A[tile_off + i] = stage[i];
@@ -410,7 +411,6 @@ int k2_run(Pipe P, u32 max_n, hipStream_t stream) {
     hipLaunchKernelGGL(k2_lastocc, dim3(segs, g.nb), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k2_lastscan, dim3(g.nb), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k2_mtf, dim3((segs + 3) / 4, g.nb), dim3(256), 0, stream, P);
-    hipLaunchKernelGGL(k2_symcount, dim3(g.rtiles, g.nb), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k2_scan_tiles, dim3(g.nb), dim3(256), 0, stream, P, P.symCnt, P.pos, 0);
     hipLaunchKernelGGL(k2_emit, gridT, dim3(256), 0, stream, P);
     HIP_CHECK_RET(hipGetLastError());
