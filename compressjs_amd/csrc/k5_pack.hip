@@ -43,6 +43,7 @@ __device__ __forceinline__ u32 mtf6_front(u32 list, u32 j, u32 s) {
     return keep | ((list & lowmask) << 4) | s;
 }
 
+#define K5_MAX_SEL 18432         // (= K34_MAX_SEL)
 __global__ __launch_bounds__(256) void k5_header(Pipe P) {
     const u32 b = blockIdx.x;
     const u32 n = P.nlen[b];
@@ -56,7 +57,14 @@ __global__ __launch_bounds__(256) void k5_header(Pipe P) {
     __syncthreads();
     const u32 alpha = P.alpha[b], G = P.ngroups[b], nSel = P.nsel[b];
     const int S = (int)alpha + 2;
-    const u8* sel = P.sel + (size_t)b * P.selPitch;
+    // the block's selectors in LDS (k34_run: selPitch <= 18432): each thread walks its chunk of them three times, one after the other - as
+    // global byte loads that was 200 dependent round trips per thread (round 6: 75 us of a step's tail for 56 workgroups)
+    __shared__ __attribute__((aligned(16))) u8 sel[K5_MAX_SEL];
+    {
+        const u8* gsel = P.sel + (size_t)b * P.selPitch;
+        const u32 nw4 = ((nSel < K5_MAX_SEL ? nSel : K5_MAX_SEL) + 3u) >> 2;
+        for (u32 i = tid; i < nw4; i += 256) ((u32*)sel)[i] = ((const u32*)gsel)[i];
+    }
     if (tid == 0) {
         // magic, CRC (lib/Bzip2.js:918-919); randomised bit + origPtr (:740-741)
         put_bits_lds(hw, 0, 24, 0x314159u);
