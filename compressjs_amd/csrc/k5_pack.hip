@@ -9,7 +9,7 @@
 //
 //   k5_header    one workgroup per block builds the header bits in LDS (selectors: parallel MTF over
 //                <= 6 tables + unary codes; tables: per-symbol delta codes + scan) -> hdr[b], hbits[b]
-//   k5_lensum    code bits per 4096-symbol tile
+//   k5_tilescan  code bits per tile of 4000 symbols (80 groups: the sum of the optimiser's group costs), scanned
 //   k5_blockscan per block: tile offsets; across blocks: absolute bit offsets, combined CRC
 //   k5_pack      every thread packs 16 consecutive symbols into 32-bit words and ORs them into the
 //                stream at its absolute bit position; tile 0 also shifts the header in.
@@ -212,51 +212,34 @@ __global__ __launch_bounds__(256) void k5_header(Pipe P) {
     if (tid == 0) P.hbits[b] = cursor;
 }
 
-// selector of symbol i inside a tile: staged table of the tile's selectors
-__global__ __launch_bounds__(256) void k5_lensum(Pipe P) {
-    const BatchGeom g = P.g;
-    const u32 b = blockIdx.y, t = blockIdx.x;
-    const u32 pos = P.nlen[b] ? P.pos[b] : 0u;
-    const u32 t0 = t * K1_RT;
-    if (t0 >= pos) { if (threadIdx.x == 0) P.tileBits[(size_t)b * g.rtiles + t] = 0; return; }
-    __shared__ u8 lens[CJS_MAX_GROUPS][CJS_LEN_PITCH];
-    __shared__ u32 tot;
-    const u32 tid = threadIdx.x;
-    const u32 G = P.ngroups[b];
-    for (u32 i = tid; i < G * CJS_LEN_PITCH; i += 256)
-        (&lens[0][0])[i] = P.lens[(size_t)b * CJS_MAX_GROUPS * CJS_LEN_PITCH + i];
-    if (tid == 0) tot = 0;
-    __syncthreads();
-    const u16* A = P.A + (size_t)b * g.stride;
-    const u8* sel = P.sel + (size_t)b * P.selPitch;
-    u32 c = 0;
-    for (int k = 0; k < 16; k++) {
-        const u32 i = t0 + k * 256u + tid;
-        if (i < pos) c += lens[sel[i / CJS_GROUP]][A[i]];
-    }
-    {   // one LDS atomic per wave (256 lanes on one word queued)
-        const u32 ws = wave_sum_dpp(c);
-        if ((threadIdx.x & 63u) == 0u) atomicAdd(&tot, ws);
-    }
-    __syncthreads();
-    if (tid == 0) P.tileBits[(size_t)b * g.rtiles + t] = tot;
-}
-
-// per block: exclusive scan of tileBits with the header length as base -> bitlen[b]
+// per block: code bits of every tile of K5_TILE symbols = 80 groups of 50 - the sum of the groups' costs under their tables, which the optimiser's
+// last k34_assign left in selCost (round 6: k5_lensum, a pass over the symbols and their selectors that looked every length up again, is gone) -
+// and their exclusive scan with the header length as base -> tileBits, bitlen[b]
 __global__ __launch_bounds__(256) void k5_tilescan(Pipe P) {
     const BatchGeom g = P.g;
     const u32 b = blockIdx.x, tid = threadIdx.x;
     __shared__ u32 sh[256];
     __shared__ u32 carry;
+    const u32 nSel = P.nlen[b] ? P.nsel[b] : 0u;
     if (tid == 0) carry = P.nlen[b] ? P.hbits[b] : 0u;
     __syncthreads();
-    u32* cnt = P.tileBits + (size_t)b * g.rtiles;
-    for (u32 t0 = 0; t0 < g.rtiles; t0 += 256) {
+    const u16* cost = P.selCost + (size_t)b * P.selPitch;
+    u32* cnt = P.tileBits + (size_t)b * K5_TILES(g);
+    for (u32 t0 = 0; t0 < K5_TILES(g); t0 += 256) {
         const u32 t = t0 + tid;
-        const u32 v = t < g.rtiles ? cnt[t] : 0;
+        u32 v = 0;
+        const u32 g0 = t * K5_TGROUPS;
+        if (g0 + K5_TGROUPS <= nSel) {
+            const uint4* c4 = (const uint4*)(cost + g0);           // 80 costs = ten 16-byte loads (g0 * 2 bytes is a multiple of 32)
+#pragma unroll
+            for (u32 k = 0; k < K5_TGROUPS / 8u; k++) {
+                const uint4 q = c4[k];
+                v += (q.x & 0xFFFFu) + (q.x >> 16) + (q.y & 0xFFFFu) + (q.y >> 16) + (q.z & 0xFFFFu) + (q.z >> 16) + (q.w & 0xFFFFu) + (q.w >> 16);
+            }
+        } else for (u32 gi = g0; gi < nSel; gi++) v += cost[gi];
         const u32 ex = block_excl_scan_256(v, sh);
         const u32 base = carry;
-        if (t < g.rtiles) cnt[t] = base + ex;
+        if (t < K5_TILES(g)) cnt[t] = base + ex;
         __syncthreads();
         if (tid == 255) carry = base + ex + v;
         __syncthreads();
@@ -282,7 +265,7 @@ __global__ __launch_bounds__(64) void k5_blockscan(Pipe P) {
     if (P.snap) *P.snap = bits;
 }
 
-#define K5_STAGE_WORDS ((K1_RT * 20u + 62u) / 32u + 2u)    // a tile of K1_RT symbols, at most 20 bits each, starting anywhere in a word
+#define K5_STAGE_WORDS ((K5_TILE * 20u + 62u) / 32u + 2u)    // a tile of K5_TILE symbols, at most 20 bits each, starting anywhere in a word
 __device__ __forceinline__ void or_word(u32* out, u64 wi, u32 word) {
     if (word) atomicOr(&out[wi], bswap32(word));
 }
@@ -292,7 +275,7 @@ __global__ __launch_bounds__(256) void k5_pack(Pipe P) {
     const u32 b = blockIdx.y, t = blockIdx.x;
     if (P.nlen[b] == 0 || P.ss->overflow) return;
     const u32 pos = P.pos[b];
-    const u32 t0 = t * K1_RT;
+    const u32 t0 = t * K5_TILE;
     const u32 tid = threadIdx.x;
     const u64 boff = P.bitoff[b];
     if (t == 0) {
@@ -322,7 +305,7 @@ __global__ __launch_bounds__(256) void k5_pack(Pipe P) {
     __syncthreads();
     const u16* A = P.A + (size_t)b * g.stride;
     const u8* sel = P.sel + (size_t)b * P.selPitch;
-    const u32 i0 = t0 + tid * 16u;
+    const u32 i0 = tid * 16u < K5_TILE ? t0 + tid * 16u : pos;         // (250 of the 256 threads own symbols)
     // The thread's 16 symbols in two 16-byte loads and its (at most two) selectors in two byte loads
     // (round 3: 16 + 16 two-byte loads 32 bytes apart from lane to lane, twice over, were 64 requests per load instruction).
     u32 aw[8];
@@ -347,7 +330,7 @@ __global__ __launch_bounds__(256) void k5_pack(Pipe P) {
     const u32 ex = block_excl_scan_256(mine, sh);
     if (tid == 255) s_tot = ex + mine;
     __syncthreads();
-    const u64 tbit = boff + P.tileBits[(size_t)b * g.rtiles + t];     // where the tile's first bit goes
+    const u64 tbit = boff + P.tileBits[(size_t)b * K5_TILES(g) + t];  // where the tile's first bit goes
     const u64 w0 = tbit >> 5;
     const u32 nw = ((u32)(tbit & 31u) + s_tot + 31u) >> 5;           // words the tile touches (<= K5_STAGE_WORDS)
     for (u32 j = tid; j < nw; j += 256) stage[j] = 0;
@@ -422,10 +405,9 @@ int k5_stream_end(Pipe P, hipStream_t stream) {
 // batches; `done` (optional) is recorded right after this batch's k5_blockscan.
 int k5_run(Pipe P, u32 max_n, hipStream_t stream, hipEvent_t after, hipEvent_t done, hipEvent_t crc_ready) {
     const BatchGeom g = P.g;
-    const u32 tiles = (max_n + 1 + K1_RT - 1) / K1_RT;
+    const u32 tiles = (max_n + 1 + K5_TILE - 1) / K5_TILE;
     if (crc_ready) HIP_CHECK_RET(hipStreamWaitEvent(stream, crc_ready, 0));
     hipLaunchKernelGGL(k5_header, dim3(g.nb), dim3(256), 0, stream, P);
-    hipLaunchKernelGGL(k5_lensum, dim3(g.rtiles, g.nb), dim3(256), 0, stream, P);
     hipLaunchKernelGGL(k5_tilescan, dim3(g.nb), dim3(256), 0, stream, P);
     if (after) HIP_CHECK_RET(hipStreamWaitEvent(stream, after, 0));
     hipLaunchKernelGGL(k5_blockscan, dim3(1), dim3(64), 0, stream, P);

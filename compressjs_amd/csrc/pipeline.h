@@ -13,6 +13,9 @@
 #define CJS_LEN_PITCH 264    // bytes per table in lens[], u32 per table in codes[]
 
 #define K5_NONE (-0x40000000)
+#define K5_TGROUPS 80u       // groups of 50 symbols per K5 tile: a tile's code bits are a sum of the optimiser's group costs
+#define K5_TILE (K5_TGROUPS * CJS_GROUP)
+#define K5_TILES(g) ((g).stride / K5_TILE + 2u)              // >= ceil((symbols of a block + EOB) / K5_TILE)
 #define K5_HDR_WORDS 6144     // >= worst-case header: 18001 selectors x 6 bits + 6 tables x 10067 bits
 
 struct StreamState {
@@ -57,7 +60,7 @@ struct Pipe {
     // ---- K5
     u32* hdr;          // [nb][K5_HDR_WORDS] block header bits (magic .. code-length tables)
     u32* hbits;        // [nb]           header length in bits
-    u32* tileBits;     // [nb][rtiles]   code bits per 4096-symbol tile -> exclusive offsets
+    u32* tileBits;     // [nb][K5_TILES] code bits per tile of K5_TILE symbols -> exclusive offsets
     u64* bitlen;       // [nb]           bits of the encoded block
     u64* bitoff;       // [nb]           absolute bit offset of the block in the stream
     StreamState* ss;   // running stream state (bit cursor, combined CRC), device resident

@@ -24,7 +24,7 @@ size_t pipe_bytes(const BatchGeom& g) {
     tot += al256((size_t)g.nb * selPitch * 2);              // selCost
     tot += al256((size_t)g.nb * 2 * CJS_MAX_GROUPS * CJS_LEN_PITCH * 4);   // fr2
     tot += al256((size_t)g.nb * K5_HDR_WORDS * 4);          // hdr
-    tot += al256((size_t)g.nb * g.rtiles * 4);              // tileBits
+    tot += al256((size_t)g.nb * K5_TILES(g) * 4);           // tileBits
     tot += 4 * al256((size_t)g.nb * 8);                     // hbits bitlen bitoff ss
     tot += k1_workspace_bytes(g);
     return tot;
@@ -64,7 +64,7 @@ void pipe_carve(Pipe& P, const BatchGeom& g, void* base) {
     TAKE(selCost, u16*, (size_t)g.nb * P.selPitch * 2);
     TAKE(fr2, u32*, (size_t)g.nb * 2 * CJS_MAX_GROUPS * CJS_LEN_PITCH * 4);
     TAKE(hdr, u32*, (size_t)g.nb * K5_HDR_WORDS * 4);
-    TAKE(tileBits, u32*, (size_t)g.nb * g.rtiles * 4);
+    TAKE(tileBits, u32*, (size_t)g.nb * K5_TILES(g) * 4);
     TAKE(hbits, u32*, (size_t)g.nb * 4);
     TAKE(ss, StreamState*, sizeof(StreamState));
 #undef TAKE
