@@ -1,4 +1,4 @@
-"""Reads a rocprofv3 kernel_trace.csv of the two-stream flow (tests/gpu_timeline.sh) and prints, for the LAST compress call in it,
+"""Reads a rocprofv3 kernel_trace.csv of the two-stream flow (tests/gpu_timeline.sh) and prints, for the SHORTEST compress call in it,
 one line per kernel launch (start relative to the call's first kernel, duration, stream/queue, grid) plus how much of the
 call's span had 0 / 1 / 2+ kernels in flight.  python tests/timeline_report.py gpurun_out/timeline/tl_enwik_kernel_trace.csv [--all]"""
 import csv, sys
@@ -18,7 +18,7 @@ for k in K:
         steps.append(cur); cur = []
     cur.append(k); last_end = max(last_end or 0, k[1])
 if cur: steps.append(cur)
-S = [st for st in steps if any(k[2] == 'k1f_bsort' for k in st)][-1]
+S = min((st for st in steps if any(k[2] == 'k1f_bsort' for k in st)), key=lambda st: max(k[1] for k in st) - st[0][0])   # the shortest of the traced calls (the tracer's own hiccups lengthen some)
 ends = [i for i, k in enumerate(S) if k[2] == 'k5_end']       # the call ends with k5_end (+ the read-back of the stream state)
 if ends: S = S[:min(len(S), ends[0] + 2)]
 t0 = S[0][0]
