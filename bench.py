@@ -284,7 +284,7 @@ def main():
         gkey = "%s:%d:bz2:%d" % (args.workload, total, args.level)
         g = gold.get(gkey)
         vs_ref = None
-        # N > 1 with a pinned digest (tests/golden/make_golden_jobs.py: reference-made at N = 2, oracle-made at N = 4, 8): the digest
+        # N > 1 with a pinned digest (tests/golden/make_golden_jobs.py: reference-made at N = 2, 4 and 8 since round 6 - the line says which in reference_digest_made_by): the digest
         # IS the check; naming the whole N-document stream on rank 0's host again takes minutes and is only done without one
         digest_only = world > 1 and g is not None and not args.full_verify
         if host is None and not digest_only:
